@@ -1,0 +1,547 @@
+"""CPU ORACLE (test infrastructure, NOT product code).
+
+A NumPy restatement of the explicit Runge-Kutta hot path of the reference
+package extensisq v0.6.0 (pure Python/NumPy, `/root/reference`):
+
+    RungeKutta.__init__/_step_impl/...   extensisq/common.py:187-368
+    BS5 (two error estimates)            extensisq/bogacki.py:217-346
+    Ts5 / Pr7 / Pr8 / Pr9 (data only)    extensisq/tsitouras.py:83-115,
+                                         extensisq/prince.py:79-128,205-372,449-746
+    h_start (first step size)            extensisq/common.py:519-763
+    SSV2stab (RKC)                       see oracle/rkc_oracle.py
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
+may import this module; the product (`extensisq_amd`) never does.
+
+Parity pinned: this oracle is checked against golden vectors produced by the
+real reference imported in the build container (`tools/gen_golden.py` ->
+`tests/golden/*.npz|json`, test `tests/test_oracle_golden.py`) and against the
+reference's published known answers (README example, Duffing nfev counts).
+
+The arithmetic keeps the reference's operation order: `K[:i].T @ a` (BLAS gemv)
+first, then `* h`, then `+ y` (common.py:355-356, 343); error `h * (K.T @ E)`
+then `/ scale` (common.py:335-339).
+"""
+from math import copysign, sqrt
+import json
+import os
+
+import numpy as np
+from scipy.integrate._ivp.base import DenseOutput, OdeSolver
+from scipy.integrate._ivp.common import (validate_first_step,
+                                         validate_max_step, warn_extraneous)
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                     "extensisq_amd", "data", "tableaus.json")
+
+# module-level failed-step counter, like common.py:14
+NFS = np.array(0)
+
+SHRINK_FLOOR = 0.2        # common.py:18  MIN_FACTOR
+GROW_CAP = 4.0            # common.py:19  MAX_FACTOR
+GROW_CAP_INITIAL = 10     # common.py:20  MAX_FACTOR0
+
+_CONTROLLERS = {          # common.py:167-169
+    "G": (0.7, -0.4, 0, 0.9),
+    "S": (0.6, -0.2, 0, 0.9),
+    "standard": (1, 0, 0, 0.9),
+}
+
+
+# --------------------------------------------------------------------------
+# tableau data (numbers only; bit-identical to the reference, see
+# tools/gen_tableaus.py)
+# --------------------------------------------------------------------------
+def _unhex_vec(v):
+    return np.array([float.fromhex(s) for s in v])
+
+
+def _unhex_mat(d):
+    M = np.zeros(d["shape"])
+    for i, j, s in d["nz"]:
+        M[i, j] = float.fromhex(s)
+    return M
+
+
+def load_tableau(name):
+    with open(_DATA) as fh:
+        raw = json.load(fh)[name]
+    tab = {}
+    for key, val in raw.items():
+        if isinstance(val, dict):
+            tab[key] = _unhex_mat(val)
+        elif isinstance(val, list):
+            tab[key] = _unhex_vec(val)
+        else:
+            tab[key] = val
+    return tab
+
+
+# --------------------------------------------------------------------------
+# free helpers
+# --------------------------------------------------------------------------
+def check_tolerances(rtol, atol, y):
+    """common.py:30-54 -- RKSuite-style bounds, applied silently."""
+    atol = np.asarray(atol)
+    if atol.ndim > 0 and atol.shape != (y.size,):
+        raise ValueError("`atol` has wrong shape.")
+    if np.any(atol < 0):
+        raise ValueError("`atol` must be positive.")
+    if not isinstance(rtol, float):
+        raise ValueError("`rtol` must be a float.")
+    if rtol < 0:
+        raise ValueError("`rtol` must be positive.")
+    info = np.finfo(y.dtype)
+    atol = np.maximum(atol, sqrt(info.tiny))
+    rtol = np.minimum(np.maximum(rtol, 10 * info.epsneg), 0.1)
+    return rtol, atol
+
+
+def error_scale(atol, rtol, y_a, y_b):
+    """common.py:57-61 (max variant)."""
+    return atol + rtol * np.maximum(np.abs(y_a), np.abs(y_b))
+
+
+def rms(x):
+    """common.py:64-66."""
+    return (np.real(x @ x.conjugate()) / x.size) ** 0.5
+
+
+def first_step_size(fun, a, b, y, yprime, morder, rtol, atol):
+    """Watts' starting step (SLATEC dhstrt), as restated in common.py:519-763
+    (J=None, T=None branch only: the only one the ERK ctor uses, :210-212)."""
+    if y.size == 0:                                          # :585-586
+        return np.inf
+    neq = y.size
+    info = np.finfo(y.dtype)
+    etol = atol + rtol * np.abs(y)                           # :592
+    big = sqrt(info.max)                                     # :606
+    small = np.nextafter(info.epsneg, 1.0)                   # :607
+    dx = b - a
+    absdx = abs(dx)
+    relper = small ** 0.375                                  # :612
+
+    # bound on df/dt and on |f|                              # :617-628
+    da = copysign(max(min(relper * abs(a), absdx), 100. * small * abs(a)), dx)
+    da = da or relper * dx
+    sf = fun(a + da, y)
+    yp = sf - yprime
+    delf = rms(yp)
+    dfdxb = big
+    if delf < big * abs(da):
+        dfdxb = delf / abs(da)
+    fbnd = rms(sf)
+
+    # local Lipschitz estimate by differences               # :649-715
+    dely = relper * rms(y)
+    dely = dely or relper
+    dely = copysign(dely, dx)
+    delf = rms(yprime)
+    fbnd = max(fbnd, delf)
+    spy = np.empty_like(y)
+    pv = np.empty_like(y)
+    if delf:
+        spy[:] = yprime
+        yp[:] = yprime
+    else:
+        spy[:] = 0.0
+        yp[:] = 1.0
+        delf = rms(yp)
+    dfdub = 0.0
+    lk = min(neq + 1, 3)
+    for k in range(1, lk + 1):
+        pv[:] = y + dely / delf * yp                         # :673
+        if k == 2:
+            yp[:] = fun(a + da, pv)
+            pv[:] = yp - sf
+        else:
+            yp[:] = fun(a, pv)
+            pv[:] = yp - yprime
+        fbnd = max(fbnd, rms(yp))
+        delf = rms(pv)
+        if delf >= big * abs(dely):
+            dfdub = big
+            break
+        dfdub = max(dfdub, delf / abs(dely))
+        if k == lk:
+            break
+        delf = delf or 1.0
+        if k == 2:
+            dy = y.copy()
+            dy[:] = np.where(dy, dy, dely / relper)          # :704
+        else:
+            dy = pv.copy()
+            dy[:] = np.where(dy, dy, delf)                   # :707
+        spy[:] = np.where(spy, spy, yp)                      # :708
+        yp[:] = np.where(spy, np.copysign(dy.real, spy.real), dy.real)
+        if np.issubdtype(y.dtype, np.complexfloating):
+            yp[:] += 1j * np.where(spy, np.copysign(dy.imag, spy.imag),
+                                   dy.imag)
+        delf = rms(yp)
+
+    ydpb = dfdxb + dfdub * fbnd                              # :721
+    tolexp = np.log10(etol)                                  # :725-728
+    tolsum = tolexp.sum()
+    tolmin = min(tolexp.min(), big)
+    tolp = 10.0 ** (0.5 * (tolsum / neq + tolmin) / (morder + 1))
+
+    h = absdx                                                # :735-749
+    if ydpb == 0.0 and fbnd == 0.0:
+        if tolp < 1.0:
+            h = absdx * tolp
+    elif ydpb == 0.0:
+        if tolp < fbnd * absdx:
+            h = tolp / fbnd
+    else:
+        srydpb = sqrt(0.5 * ydpb)
+        if tolp < srydpb * absdx:
+            h = tolp / srydpb
+    if dfdub:                                                # :752-753
+        h = min(h, 1.0 / dfdub)
+    h = max(h, 100.0 * small * abs(a))                       # :758-759
+    h = h or small * abs(b)
+    return copysign(h, dx)
+
+
+class HornerInterpolant(DenseOutput):
+    """common.py:766-790."""
+
+    def __init__(self, t_old, t, y_old, Q):
+        super().__init__(t_old, t)
+        self.h = t - t_old
+        self.Q = Q * self.h
+        self.y_old = y_old
+
+    def _call_impl(self, t):
+        x = (t - self.t_old) / self.h
+        acc = self.Q.T[-1, :, np.newaxis] * x
+        for q in reversed(self.Q.T[:-1]):
+            acc += q[:, np.newaxis]
+            acc *= x
+        acc += self.y_old[:, np.newaxis]
+        return acc if t.shape else acc[:, 0]
+
+
+class HermiteInterpolant(DenseOutput):
+    """common.py:793-821."""
+
+    def __init__(self, t_old, t, y_old, y, f_old, f):
+        super().__init__(t_old, t)
+        self.h = t - t_old
+        self.y_old, self.y, self.f_old, self.f = y_old, y, f_old, f
+
+    def _call_impl(self, t):
+        x = (t - self.t_old) / self.h
+        h00 = (1.0 + 2.0 * x) * (1.0 - x) ** 2
+        h10 = x * (1.0 - x) ** 2 * self.h
+        h01 = x ** 2 * (3.0 - 2.0 * x)
+        h11 = x ** 2 * (x - 1.0) * self.h
+        out = (h00 * self.y_old[:, np.newaxis] + h10 * self.f_old[:, np.newaxis]
+               + h01 * self.y[:, np.newaxis] + h11 * self.f[:, np.newaxis])
+        return out if t.shape else out[:, 0]
+
+
+# --------------------------------------------------------------------------
+# generic adaptive ERK
+# --------------------------------------------------------------------------
+class OracleERK(OdeSolver):
+    """Generic adaptive explicit RK step (common.py:69-368).  Stiffness
+    detection (common.py:370-516) is NOT restated: only its failed-step counter
+    is kept; fixtures are generated with `nfev_stiff_detect=0` or stay below
+    the trigger thresholds."""
+
+    tableau_name = None
+    max_factor = GROW_CAP_INITIAL
+    min_factor = SHRINK_FLOOR
+
+    @classmethod
+    def _install(cls, name):
+        tab = load_tableau(name)
+        cls.tableau_name = name
+        for key, val in tab.items():
+            setattr(cls, key, val)
+
+    def __init__(self, fun, t0, y0, t_bound, max_step=np.inf, rtol=1e-3,
+                 atol=1e-6, vectorized=False, first_step=None,
+                 nfev_stiff_detect=5000, sc_params=None, support_complex=True,
+                 **extraneous):
+        warn_extraneous(extraneous)
+        super().__init__(fun, t0, y0, t_bound, vectorized,
+                         support_complex=support_complex)
+        self.max_step = validate_max_step(max_step)
+        self.rtol, self.atol = check_tolerances(rtol, atol, self.y)
+        self.f = self.fun(self.t, self.y)                    # :196
+        if self.f.dtype != self.y.dtype:
+            raise TypeError('dtypes of solution and derivative do not match')
+        self.error_exponent = -1 / (min(self.order_secondary, self.order) + 1)
+        if not (isinstance(nfev_stiff_detect, int) and nfev_stiff_detect >= 0):
+            raise ValueError(
+                "`nfev_stiff_detect` must be a non-negative integer.")
+        self.jflstp = 0
+        # min-step rule, common.py:123-148
+        cdiff = 1.
+        for c1 in self.C:
+            for c2 in self.C:
+                d = abs(c1 - c2)
+                if d:
+                    cdiff = min(cdiff, d)
+        cdiff = max(cdiff, 1e-3)
+        info = np.finfo(self.y.dtype)
+        self.h_min_a = 10 * info.epsneg / cdiff
+        self.h_min_b = sqrt(info.tiny)
+        self.tiny_err = self.h_min_b                         # :203
+        # controller, common.py:166-185
+        sc = sc_params or self.sc_params
+        if isinstance(sc, str) and sc in _CONTROLLERS:
+            kb1, kb2, a, g = _CONTROLLERS[sc]
+        elif isinstance(sc, tuple) and len(sc) == 4:
+            kb1, kb2, a, g = sc
+        else:
+            raise ValueError('sc_params should be a tuple of length 4 or one '
+                             'of the strings "G", "S", "W" or "standard"')
+        self.minbeta1 = kb1 * self.error_exponent
+        self.minbeta2 = kb2 * self.error_exponent
+        self.minalpha = -a
+        self.safety = g
+        self.safety_sc = g ** (kb1 + kb2)
+        self.standard_sc = True
+        # first step, common.py:207-214
+        if first_step is None:
+            b = self.t + self.direction * min(abs(self.t_bound - self.t),
+                                              self.max_step)
+            self.h_abs = abs(first_step_size(
+                self.fun, self.t, b, self.y, self.f, self.order_secondary,
+                self.rtol, self.atol))
+        else:
+            self.h_abs = validate_first_step(first_step, t0, t_bound)
+        self.K = np.empty((self.n_stages + 1, self.n), self.y.dtype)
+        self.FSAL = 1 if self.E[self.n_stages] else 0
+        self.h_previous = None
+        self.y_old = None
+        NFS[()] = 0
+        self.trace = []       # (t_new, h, error_norm, accepted) per attempt
+
+    # -- step-size bookkeeping, common.py:310-331
+    def _limit_step(self, t):
+        h_abs = self.h_abs
+        min_step = max(self.h_min_a * (abs(t) + h_abs), self.h_min_b)
+        if h_abs < min_step or h_abs > self.max_step:
+            h_abs = min(self.max_step, max(min_step, h_abs))
+            self.standard_sc = True
+        d = abs(self.t_bound - t)
+        if d < 2 * h_abs:
+            if d > h_abs:
+                h_abs = max(0.5 * d, min_step)
+                self.standard_sc = True
+            else:
+                h_abs = d
+        return h_abs, min_step
+
+    # -- accept-branch factor, common.py:252-276
+    def _growth_after_accept(self, error_norm, h, had_reject):
+        if error_norm < self.tiny_err:
+            factor = self.max_factor
+            self.standard_sc = True
+        elif self.standard_sc:
+            factor = self.safety * error_norm ** self.error_exponent
+            self.standard_sc = False
+        else:
+            h_ratio = h / self.h_previous
+            factor = self.safety_sc * (
+                error_norm ** self.minbeta1 *
+                self.error_norm_old ** self.minbeta2 *
+                h_ratio ** self.minalpha)
+            factor = min(self.max_factor, max(self.min_factor, factor))
+        if had_reject:
+            factor = min(1, factor)
+        if factor < GROW_CAP:
+            self.max_factor = GROW_CAP
+        return factor
+
+    def _stage(self, h, i):                                  # :353-356
+        dy = h * (self.K[:i, :].T @ self.A[i, :i])
+        self.K[i] = self.fun(self.t + self.C[i] * h, self.y + dy)
+
+    def _estimate_error(self, K, h):                         # :333-336
+        m = self.n_stages + self.FSAL
+        return h * (K[:m].T @ self.E[:m])
+
+    def _estimate_error_norm(self, K, h, scale):             # :338-339
+        return rms(self._estimate_error(K, h) / scale)
+
+    def _solution_and_error(self, y, h):                     # :341-351
+        y_new = y + h * (self.K[:self.n_stages].T @ self.B)
+        scale = error_scale(self.atol, self.rtol, y, y_new)
+        if self.FSAL:
+            self.K[self.n_stages, :] = self.fun(self.t + h, y_new)
+        return y_new, self._estimate_error_norm(self.K, h, scale)
+
+    def _step_impl(self):                                    # :222-308
+        t, y = self.t, self.y
+        h_abs, min_step = self._limit_step(t)
+        had_reject = False
+        while True:
+            if h_abs < min_step:
+                return False, self.TOO_SMALL_STEP
+            h = h_abs * self.direction
+            t_new = t + h
+            self.K[0] = self.f
+            for i in range(1, self.n_stages):
+                self._stage(h, i)
+            y_new, error_norm = self._solution_and_error(y, h)
+            self.trace.append((t_new, h, float(error_norm), error_norm < 1))
+            if error_norm < 1:
+                h_abs *= self._growth_after_accept(error_norm, h, had_reject)
+                break
+            had_reject = True
+            h_abs *= max(self.min_factor,
+                         self.safety * error_norm ** self.error_exponent)
+            NFS[()] += 1
+            self.jflstp += 1
+            if np.isnan(error_norm) or np.isinf(error_norm):
+                return False, "Overflow or underflow encountered."
+        if not self.FSAL:
+            self.K[self.n_stages] = self.fun(t + h, y_new)   # :289-291
+        self.h_previous = h
+        self.y_old = y
+        self.h_abs = h_abs
+        self.f_old = self.f
+        self.f = self.K[self.n_stages].copy()
+        self.error_norm_old = error_norm
+        self.t = t_new
+        self.y = y_new
+        return True, None
+
+    def _dense_output_impl(self):                            # :358-368
+        if isinstance(self.P, np.ndarray):
+            return HornerInterpolant(self.t_old, self.t, self.y_old,
+                                     self.K.T @ self.P)
+        return HermiteInterpolant(self.t_old, self.t, self.y_old, self.y,
+                                  self.f_old, self.f)
+
+
+class Ts5(OracleERK):
+    pass
+
+
+class Pr7(OracleERK):
+    pass
+
+
+class Pr8(OracleERK):
+    pass
+
+
+class Pr9(OracleERK):
+    pass
+
+
+class BS5(OracleERK):
+    """bogacki.py:217-393: early (pre) error estimate after 6 stages."""
+
+    def __init__(self, fun, t0, y0, t_bound, nfev_stiff_detect=5000,
+                 sc_params='standard', interpolant='low', **extraneous):
+        super().__init__(fun, t0, y0, t_bound,
+                         nfev_stiff_detect=nfev_stiff_detect,
+                         sc_params=sc_params, **extraneous)
+        if interpolant not in ('best', 'low', 'free'):
+            raise ValueError(
+                "interpolant should be one of: 'best', 'low', 'free'")
+        self.interpolant = interpolant
+        rows = {'best': self.n_stages + self.n_extra_stages + 1,
+                'low': self.n_stages + 2}.get(interpolant)
+        if rows:
+            self.K_extended = np.zeros((rows, self.n), dtype=self.y.dtype)
+            self.K = self.K_extended[:self.n_stages + 1]
+        else:
+            self.K_extended = self.K
+
+    def _pre_error_norm(self, y, h):                         # :340-346
+        y_pre = y + h * (self.K[:6].T @ self.B_scale_pre)
+        scale = error_scale(self.atol, self.rtol, y, y_pre)
+        err = h * (self.K[:6, :].T @ self.E_pre)
+        return rms(err / scale)
+
+    def _step_impl(self):                                    # :238-338
+        t, y = self.t, self.y
+        h_abs, min_step = self._limit_step(t)
+        had_reject = False
+        while True:
+            if h_abs < min_step:
+                return False, self.TOO_SMALL_STEP
+            h = h_abs * self.direction
+            t_new = t + h
+            self.K[0] = self.f
+            for i in range(1, self.n_stages - 1):
+                self._stage(h, i)
+            pre = self._pre_error_norm(y, h)
+            if pre > 1:                                      # :266-275
+                self.trace.append((t_new, h, float(pre), False))
+                had_reject = True
+                h_abs *= max(self.min_factor,
+                             self.safety * pre ** self.error_exponent)
+                NFS[()] += 1
+                continue
+            self._stage(h, self.n_stages - 1)
+            y_new, error_norm = self._solution_and_error(y, h)
+            self.trace.append((t_new, h, float(error_norm), error_norm < 1))
+            if error_norm < 1:
+                h_abs *= self._growth_after_accept(error_norm, h, had_reject)
+                break
+            if np.isnan(error_norm) or np.isinf(error_norm):  # :314-315
+                return False, "Overflow or underflow encountered."
+            had_reject = True
+            h_abs *= max(self.min_factor,
+                         self.safety * error_norm ** self.error_exponent)
+            NFS[()] += 1
+            self.jflstp += 1
+        self.h_previous = h
+        self.y_old = y
+        self.h_abs = h_abs
+        self.f = self.K[self.n_stages].copy()
+        self.error_norm_old = error_norm
+        self.t = t_new
+        self.y = y_new
+        return True, None
+
+    def _dense_output_impl(self):                            # :348-393
+        h = self.h_previous
+        K = self.K_extended
+        if self.interpolant == 'free':
+            return HornerInterpolant(self.t_old, self.t, self.y_old,
+                                     K.T @ self.P)
+        if self.interpolant == 'low':
+            s = self.n_stages + 1
+            dy = K[:s, :].T @ self.A_extra[0, :s] * h
+            K[s] = self.fun(self.t_old + self.C_extra[0] * h, self.y_old + dy)
+            return HornerInterpolant(self.t_old, self.t, self.y_old,
+                                     K.T @ self.Plow)
+        for s, (a, c) in enumerate(zip(self.A_extra, self.C_extra),
+                                   start=self.n_stages + 1):
+            dy = K[:s, :].T @ a[:s] * h
+            K[s] = self.fun(self.t_old + c * h, self.y_old + dy)
+        # RKSUITE's grouped summation, bogacki.py:372-388
+        groups = (
+            None,
+            lambda T: (T[4] + ((T[5] + T[7]) + T[0]) + ((T[2] + T[8]) + T[9])
+                       + ((T[3] + T[10]) + T[6])),
+            lambda T: (T[4] + T[5] + ((T[2] + T[8]) + (T[9] + T[7]) + T[0])
+                       + ((T[3] + T[10]) + T[6])),
+            lambda T: (((T[3] + T[7]) + (T[6] + T[5]) + T[4])
+                       + ((T[9] + T[8]) + (T[2] + T[10]) + T[0])),
+            lambda T: ((T[9] + T[8]) + ((T[6] + T[5]) + T[4])
+                       + ((T[3] + T[7]) + (T[2] + T[10]) + T[0])),
+            lambda T: (T[4] + ((T[9] + T[7]) + (T[6] + T[5]))
+                       + ((T[3] + T[8]) + (T[2] + T[10]) + T[0])),
+        )
+        Q = np.empty((K.shape[1], self.Pbest.shape[1]), dtype=K.dtype)
+        Q[:, 0] = self.K[7]
+        for col in range(1, 6):
+            Q[:, col] = groups[col](K * self.Pbest[:, col, np.newaxis])
+        return HornerInterpolant(self.t, self.t + h, self.y, Q)
+
+
+for _cls in (Ts5, BS5, Pr7, Pr8, Pr9):
+    _cls._install(_cls.__name__)
+
+METHODS = {c.__name__: c for c in (BS5, Ts5, Pr7, Pr8, Pr9)}

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Dump the Butcher-tableau constants of the in-scope methods as IEEE-754 hex.
+
+Runs ONLY in the build container: it imports the reference package from
+/root/reference (read-only) and evaluates the published coefficient sets
+(Bogacki-Shampine 1996 / RKSUITE; Tsitouras 2011; Prince 2018) exactly as the
+reference holds them in memory after import (e.g. Ts5's derived first column,
+`E = bhat - b`).  The output, extensisq_amd/data/tableaus.json, stores every
+float as `float.hex()` so the product's class attributes are bit-identical to
+the reference's (reference: extensisq/tsitouras.py:83-115, bogacki.py:103-215,
+prince.py:79-128, 205-372, 449-746).  Nothing but numbers is written.
+
+Usage:  python tools/gen_tableaus.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, "/root/reference")
+import extensisq as ref  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(__file__), "..", "extensisq_amd", "data",
+                   "tableaus.json")
+
+
+def vec(x):
+    return [float(v).hex() for v in np.asarray(x, dtype=float).ravel()]
+
+
+def sparse(M):
+    M = np.asarray(M, dtype=float)
+    ent = [[int(i), int(j), float(M[i, j]).hex()]
+           for i in range(M.shape[0]) for j in range(M.shape[1]) if M[i, j] != 0.0]
+    return {"shape": list(M.shape), "nz": ent}
+
+
+def dump(cls, extra=()):
+    d = {
+        "n_stages": int(cls.n_stages),
+        "order": int(cls.order),
+        "order_secondary": int(cls.order_secondary),
+        "tanang": float(cls.tanang),
+        "stbrad": float(cls.stbrad),
+        "sc_params": cls.sc_params,
+        "A": sparse(cls.A), "B": vec(cls.B), "C": vec(cls.C), "E": vec(cls.E),
+        "P": sparse(cls.P),
+    }
+    for name in extra:
+        val = getattr(cls, name)
+        if np.ndim(val) == 2:
+            d[name] = sparse(val)
+        elif np.ndim(val) == 1:
+            d[name] = vec(val)
+        else:
+            d[name] = int(val)
+    return d
+
+
+def main():
+    out = {
+        "Ts5": dump(ref.Ts5),
+        "BS5": dump(ref.BS5, ("n_extra_stages", "E_pre", "B_scale_pre",
+                              "C_extra", "A_extra", "Pbest", "Plow")),
+        "Pr7": dump(ref.Pr7),
+        "Pr8": dump(ref.Pr8),
+        "Pr9": dump(ref.Pr9),
+    }
+    with open(OUT, "w") as fh:
+        json.dump(out, fh, indent=0, separators=(",", ":"))
+    print("wrote", os.path.normpath(OUT), os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
