@@ -1,0 +1,125 @@
+"""ctypes binding of libextensisq_amd.so (the C ABI in include/extensisq_amd.h).
+
+The library is the ONLY compute back end of this package: if it is missing or
+a call fails, an exception is raised -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libextensisq_amd.so")
+
+SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
+PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC = range(4)
+
+RHS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                     C.c_size_t, C.c_void_p)
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/extensisq_amd.h declares
+SIGNATURES = {
+    "esq_abi_version": (C.c_int, []),
+    "esq_create": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int]),
+    "esq_destroy": (C.c_int, [_vp]),
+    "esq_last_error": (C.c_char_p, [_vp]),
+    "esq_synchronize": (C.c_int, [_vp]),
+    "esq_vector_len": (C.c_size_t, [_vp]),
+    "esq_upload": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "esq_download": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "esq_copy": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "esq_rk_set_tableau": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
+    "esq_set_tol": (C.c_int, [_vp, C.c_double, _vp, C.c_size_t]),
+    "esq_set_rhs": (C.c_int, [_vp, _vp, _vp]),
+    "esq_rk_stage_accumulate": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "esq_rk_eval_rhs": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int, C.c_int]),
+    "esq_rk_stages": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "esq_rk_solution": (C.c_int, [_vp, C.c_double]),
+    "esq_rk_error_norm": (C.c_int, [_vp, C.c_double, _dp]),
+    "esq_rk_solution_error": (C.c_int, [_vp, C.c_double, C.c_double, _dp]),
+    "esq_rk_pre_error": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _dp]),
+    "esq_rk_accept": (C.c_int, [_vp, C.c_double, C.c_int]),
+    "esq_rk_error_vector": (C.c_int, [_vp, C.c_double, C.c_int]),
+    "esq_rk_download_last_K": (C.c_int, [_vp, C.c_int, _vp]),
+    "esq_rk_dense_coefficients": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
+    "esq_rk_dense_stage": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double]),
+    "esq_rk_dense_eval": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "esq_rk_upload_last_K": (C.c_int, [_vp, C.c_int, _vp]),
+    "esq_rkc_first_stage": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "esq_rkc_stage": (C.c_int, [_vp] + [C.c_int] * 6 + [C.c_double] * 4),
+    "esq_rkc_stages": (C.c_int, [_vp] + [C.c_int] * 5 + [C.c_double, C.c_int, _vp,
+                                                         C.POINTER(C.c_int)]),
+    "esq_rkc_error_norm": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, _dp]),
+    "esq_rkc_eval_rhs": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
+    "esq_vec_sumsq": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "esq_vec_axpbmc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]),
+    "esq_vec_wdiff_sumsq": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+    "esq_set_comm": (C.c_int, [_vp, _vp]),
+    "esq_comm_unique_id": (C.c_int, [_vp]),
+    "esq_comm_init_rank": (C.c_int, [_vpp, C.c_int, _vp, C.c_int, C.c_int]),
+    "esq_comm_destroy": (C.c_int, [_vp]),
+    "esq_rhs_diag_create": (C.c_int, [_vpp, C.c_int, _vp, C.c_size_t, C.c_double]),
+    "esq_rhs_heat2d_create": (C.c_int, [_vpp, C.c_int]),
+    "esq_rhs_bruss2d_create": (C.c_int, [_vpp, C.c_int, C.c_double, C.c_double,
+                                         C.c_double]),
+    "esq_rhs_diff3d_create": (C.c_int, [_vpp, C.c_int]),
+    "esq_rhs_free": (C.c_int, [_vp]),
+    "esq_rhs_diag": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
+    "esq_rhs_heat2d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
+    "esq_rhs_bruss2d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
+    "esq_rhs_diff3d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
+    "esq_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "esq_profile_read": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_long), _dp]),
+    "esq_profile_reset": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+class DeviceError(RuntimeError):
+    """A call into libextensisq_amd.so failed (HIP/RCCL error or misuse)."""
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DeviceError(
+            f"{LIB_PATH} not found: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C extensisq_amd/csrc`.  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.esq_abi_version() != 1:
+        raise DeviceError("libextensisq_amd.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code, ctx=None, what=""):
+    if code == 0:
+        return
+    msg = ""
+    if ctx:
+        raw = load().esq_last_error(ctx)
+        msg = raw.decode(errors="replace") if raw else ""
+    raise DeviceError(f"{what or 'libextensisq_amd'} failed with code {code}"
+                      + (f": {msg}" if msg else ""))
+
+
+def as_ptr(arr):
+    """borrowed pointer to a C-contiguous float64 / complex128 ndarray"""
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def contiguous(x, dtype):
+    return np.ascontiguousarray(x, dtype=dtype)

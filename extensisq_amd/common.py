@@ -1,0 +1,612 @@
+"""Adaptive explicit Runge-Kutta solvers whose state lives in MI355X HBM.
+
+Host side of the hot path: `RungeKutta` keeps the scipy `OdeSolver` plugin
+surface and the Butcher-tableau class attributes of the reference
+(extensisq/common.py:69-368) -- so `solve_ivp(fun, t_span, y0, method=Pr8)` and
+user-defined `class Heun(RungeKutta)` tableaux work unchanged -- but every
+vector operation of a step is a HIP kernel launched through the C ABI
+(include/extensisq_amd.h).  The step-size controller, the accept/reject
+decision and the end-of-interval logic are scalar arithmetic and stay here on
+the host; one double (the weighted error sum of squares) comes back per
+attempt.
+
+There is no CPU implementation of the step in this package: without the built
+library and a GPU the constructor raises `DeviceError`.
+"""
+import logging
+from math import copysign, sqrt
+from warnings import warn
+
+import numpy as np
+from scipy.integrate._ivp.base import DenseOutput, OdeSolver
+from scipy.integrate._ivp.common import (validate_first_step,
+                                         validate_max_step, warn_extraneous)
+
+from ._lib import (SLOT_K, SLOT_WORK, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, as_ptr)
+from .device import DeviceContext, DeviceRHS
+
+# failed-step counter shared with the RKC module (reference: common.py:14)
+NFS = np.array(0)
+NFI = np.array(0)     # kept for import compatibility (implicit methods: unused)
+NLS = np.array(0)
+
+MIN_FACTOR = 0.2      # reference common.py:18-20
+MAX_FACTOR = 4.0
+MAX_FACTOR0 = 10
+
+_SC_PRESETS = {"G": (0.7, -0.4, 0, 0.9),       # Gustafsson
+               "S": (0.6, -0.2, 0, 0.9),       # Soederlind
+               "standard": (1, 0, 0, 0.9)}
+
+
+def validate_tol(rtol, atol, y):
+    """RKSuite-style tolerance bounds, applied silently (ref common.py:30-54):
+    atol >= sqrt(tiny), 10*epsneg <= rtol <= 0.1."""
+    atol = np.asarray(atol)
+    if atol.ndim > 0 and atol.shape != (y.size,):
+        raise ValueError("`atol` has wrong shape.")
+    if np.any(atol < 0):
+        raise ValueError("`atol` must be positive.")
+    if not isinstance(rtol, float):
+        raise ValueError("`rtol` must be a float.")
+    if rtol < 0:
+        raise ValueError("`rtol` must be positive.")
+    fi = np.finfo(y.dtype)
+    return (np.minimum(np.maximum(rtol, 10 * fi.epsneg), 0.1),
+            np.maximum(atol, sqrt(fi.tiny)))
+
+
+def calculate_scale(atol, rtol, y, y_new, _mean=False):
+    """host helper with the reference's signature (common.py:57-61); the hot
+    path computes the same weights inside the error kernels."""
+    if _mean:
+        return atol + rtol * 0.5 * (np.abs(y) + np.abs(y_new))
+    return atol + rtol * np.maximum(np.abs(y), np.abs(y_new))
+
+
+def norm(x):
+    """RMS norm of a host vector (ref common.py:64-66)."""
+    return (np.real(x @ x.conjugate()) / x.size) ** 0.5
+
+
+def h_start(df, a, b, y, yprime, morder, rtol, atol):
+    """Starting step size after H.A. Watts (SLATEC `dhstrt`), the procedure the
+    reference runs once per integration (common.py:519-763, called at :210).
+    Off the per-step hot path: host NumPy on vectors
+    fetched through `df`."""
+    if y.size == 0:
+        return np.inf
+    fi = np.finfo(y.dtype)
+    big = sqrt(fi.max)
+    small = np.nextafter(fi.epsneg, 1.0)
+    relper = small ** 0.375
+    etol = atol + rtol * np.abs(y)
+    dx = b - a
+    absdx = abs(dx)
+
+    # (1) bound on the t-derivative of f and on |f|
+    da = copysign(max(min(relper * abs(a), absdx), 100. * small * abs(a)), dx)
+    if da == 0.0:
+        da = relper * dx
+    sf = df(a + da, y)
+    yp = sf - yprime
+    delf = norm(yp)
+    dfdxb = delf / abs(da) if delf < big * abs(da) else big
+    fbnd = norm(sf)
+
+    # (2) local Lipschitz constant from up to three perturbations
+    dely = relper * norm(y)
+    if dely == 0.0:
+        dely = relper
+    dely = copysign(dely, dx)
+    delf = norm(yprime)
+    fbnd = max(fbnd, delf)
+    spy = np.empty_like(y)
+    pv = np.empty_like(y)
+    if delf:
+        spy[:] = yprime
+        yp[:] = yprime
+    else:
+        spy[:] = 0.0
+        yp[:] = 1.0
+        delf = norm(yp)
+    dfdub = 0.0
+    n_iter = min(y.size + 1, 3)
+    for k in range(1, n_iter + 1):
+        pv[:] = y + dely / delf * yp
+        if k == 2:
+            yp[:] = df(a + da, pv)
+            pv[:] = yp - sf
+        else:
+            yp[:] = df(a, pv)
+            pv[:] = yp - yprime
+        fbnd = max(fbnd, norm(yp))
+        delf = norm(pv)
+        if delf >= big * abs(dely):
+            dfdub = big
+            break
+        dfdub = max(dfdub, delf / abs(dely))
+        if k == n_iter:
+            break
+        if delf == 0.0:
+            delf = 1.0
+        if k == 2:
+            dy = np.where(y, y, dely / relper)
+        else:
+            dy = np.where(pv, pv, delf)
+        spy[:] = np.where(spy, spy, yp)
+        yp[:] = np.where(spy, np.copysign(dy.real, spy.real), dy.real)
+        if np.iscomplexobj(y):
+            yp[:] += 1j * np.where(spy, np.copysign(dy.imag, spy.imag), dy.imag)
+        delf = norm(yp)
+
+    # (3) step from the second-derivative bound and the tolerances
+    ydpb = dfdxb + dfdub * fbnd
+    tolexp = np.log10(etol)
+    tolp = 10.0 ** (0.5 * (tolexp.sum() / y.size + min(tolexp.min(), big))
+                    / (morder + 1))
+    h = absdx
+    if ydpb == 0.0 and fbnd == 0.0:
+        if tolp < 1.0:
+            h = absdx * tolp
+    elif ydpb == 0.0:
+        if tolp < fbnd * absdx:
+            h = tolp / fbnd
+    else:
+        srydpb = sqrt(0.5 * ydpb)
+        if tolp < srydpb * absdx:
+            h = tolp / srydpb
+    if dfdub:
+        h = min(h, 1.0 / dfdub)
+    h = max(h, 100.0 * small * abs(a))
+    if h == 0.0:
+        h = small * abs(b)
+    return copysign(h, dx)
+
+
+class HornerDenseOutput(DenseOutput):
+    """Polynomial interpolant y_old + sum_c Q[:, c] x^(c+1), evaluated with
+    Horner's rule (ref common.py:766-790)."""
+
+    def __init__(self, t_old, t, y_old, Q):
+        super().__init__(t_old, t)
+        self.h = t - t_old
+        self.Q = Q * self.h
+        self.y_old = y_old
+
+    def _call_impl(self, t):
+        x = (t - self.t_old) / self.h
+        cols = self.Q.T
+        acc = cols[-1, :, np.newaxis] * x
+        for q in cols[-2::-1]:
+            acc += q[:, np.newaxis]
+            acc *= x
+        acc += self.y_old[:, np.newaxis]
+        return acc if t.shape else acc[:, 0]
+
+
+class CubicDenseOutput(DenseOutput):
+    """C1 cubic Hermite interpolant (ref common.py:793-821)."""
+
+    def __init__(self, t_old, t, y_old, y, f_old, f):
+        super().__init__(t_old, t)
+        self.h = t - t_old
+        self.y_old, self.y, self.f_old, self.f = y_old, y, f_old, f
+
+    def _call_impl(self, t):
+        x = (t - self.t_old) / self.h
+        omx2 = (1.0 - x) ** 2
+        out = ((1.0 + 2.0 * x) * omx2 * self.y_old[:, np.newaxis]
+               + x * omx2 * self.h * self.f_old[:, np.newaxis]
+               + x ** 2 * (3.0 - 2.0 * x) * self.y[:, np.newaxis]
+               + x ** 2 * (x - 1.0) * self.h * self.f[:, np.newaxis])
+        return out if t.shape else out[:, 0]
+
+
+class LockstepGroup:
+    """Membership of this solver in a lock-step batch (one rank per GPU):
+    `comm` is an ncclComm_t handle (see extensisq_amd.lockstep), `n_total` the
+    summed state dimension of all ranks.  The C library all-reduces the error
+    sum of squares, so every rank takes the same accept/reject decision."""
+
+    def __init__(self, comm, n_total):
+        self.comm = comm
+        self.n_total = int(n_total)
+
+
+class RungeKutta(OdeSolver):
+    """Base class of the device-resident explicit Runge-Kutta methods.
+
+    Subclasses provide the tableau as class attributes exactly like the
+    reference (common.py:88-121): `n_stages, order, order_secondary, A, B, C,
+    E` and optionally `P, stbrad, tanang, sc_params`.
+
+    `fun` may be a `DeviceRHS` (state stays in HBM for the whole step) or any
+    Python callable (host-RHS mode: the stage argument is downloaded, `fun` is
+    called, the derivative is uploaded -- all RK arithmetic still runs on the
+    GPU).  Extra keyword arguments beyond the reference's: `device` (GPU
+    ordinal) and `lockstep` (a `LockstepGroup`).
+    """
+
+    n_stages: int = NotImplemented
+    order: int = NotImplemented
+    order_secondary: int = NotImplemented
+    A: np.ndarray = NotImplemented
+    B: np.ndarray = NotImplemented
+    C: np.ndarray = NotImplemented
+    E: np.ndarray = NotImplemented
+    P: np.ndarray = NotImplemented
+    stbrad: float = NotImplemented
+    tanang: float = NotImplemented
+    sc_params = "standard"
+    max_factor = MAX_FACTOR0
+    min_factor = MIN_FACTOR
+
+    _extra_rows = 0           # BS5 asks for more K rows
+
+    # ------------------------------------------------------------------ ctor
+    def __init__(self, fun, t0, y0, t_bound, max_step=np.inf, rtol=1e-3,
+                 atol=1e-6, vectorized=False, first_step=None,
+                 nfev_stiff_detect=5000, sc_params=None, support_complex=True,
+                 device=0, lockstep=None, **extraneous):
+        warn_extraneous(extraneous)
+        self._dev = None
+        self._y_host = None
+        self._device_rhs = fun if isinstance(fun, DeviceRHS) else None
+        super().__init__(fun, t0, y0, t_bound, vectorized,
+                         support_complex=support_complex)
+        self.max_step = validate_max_step(max_step)
+        self.rtol, self.atol = validate_tol(rtol, atol, self._y_host)
+        self.error_exponent = -1 / (min(self.order_secondary, self.order) + 1)
+        self._init_stiffness_detection(nfev_stiff_detect)
+        self.h_min_a, self.h_min_b = self._init_min_step_parameters()
+        self.tiny_err = self.h_min_b
+        self._init_sc_control(sc_params)
+        self.FSAL = 1 if self.E[self.n_stages] else 0
+
+        # ---- device state
+        y_host = self._y_host
+        is_cplx = np.iscomplexobj(y_host)
+        if self._device_rhs is not None and is_cplx != self._device_rhs.is_complex:
+            raise TypeError('dtypes of solution and derivative do not match')
+        self._dev = DeviceContext(self.n, self.n_stages + 1 + self._extra_rows,
+                                  is_cplx, device)
+        self._lib = self._dev.lib
+        self._ctx = self._dev.handle
+        self._dev.set_tableau(self.A, self.B, self.C, self.E, self.FSAL)
+        self._dev.set_tol(self.rtol, self.atol)
+        self._dev.upload(SLOT_Y, 0, y_host)
+        self._lockstep = lockstep
+        self._n_norm = self.n
+        if lockstep is not None:
+            self._dev._chk(self._lib.esq_set_comm(self._ctx, lockstep.comm),
+                           "esq_set_comm")
+            self._n_norm = lockstep.n_total
+        self._f_host = None
+        self._K_host = None
+        self._y_old_host = None
+        if self._device_rhs is not None:
+            self._dev.set_rhs(self._device_rhs)
+            self._chk(self._lib.esq_rk_eval_rhs(self._ctx, 0, float(self.t),
+                                                SLOT_Y, 0), "esq_rk_eval_rhs")
+            self.nfev += 1
+        else:
+            f0 = self.fun(self.t, y_host)
+            if f0.dtype != y_host.dtype:
+                raise TypeError('dtypes of solution and derivative do not match')
+            self._dev.upload(SLOT_K, 0, f0)
+            self._f_host = f0
+
+        # ---- first step
+        if first_step is None:
+            b = self.t + self.direction * min(abs(self.t_bound - self.t),
+                                              self.max_step)
+            self.h_abs = abs(h_start(self.fun, self.t, b, y_host, self.f,
+                                     self.order_secondary, self.rtol, self.atol))
+        else:
+            self.h_abs = validate_first_step(first_step, t0, t_bound)
+        self.h_previous = None
+        self.error_norm_old = None
+        NFS[()] = 0
+
+    def _chk(self, code, what):
+        self._dev._chk(code, what)
+
+    # ------------------------------------------------- lazy host mirrors
+    @property
+    def y(self):
+        """current state; downloaded from HBM on first access after a step
+        (a fresh array each step, as scipy stores it by reference)"""
+        if self._y_host is None:
+            self._y_host = self._dev.download(SLOT_Y)
+        return self._y_host
+
+    @y.setter
+    def y(self, value):
+        self._y_host = value
+        if self._dev is not None and value is not None:
+            self._dev.upload(SLOT_Y, 0, value)
+
+    @property
+    def f(self):
+        """derivative at (t, y): logical K row 0"""
+        if self._f_host is None:
+            self._f_host = self._dev.download(SLOT_K, 0)
+        return self._f_host
+
+    @f.setter
+    def f(self, value):
+        self._f_host = value
+
+    @property
+    def K(self):
+        """stage derivatives of the last accepted step, shape (s+1, n)"""
+        if self._K_host is None:
+            rows = self.n_stages + 1
+            K = np.empty((rows, self.n), dtype=self._dev.dtype)
+            for r in range(rows):
+                K[r] = self._dev.download_last_K(r)
+            self._K_host = K
+        return self._K_host
+
+    @property
+    def y_old(self):
+        if self.t_old is None:
+            return None
+        if self._y_old_host is None:
+            # after the accept swap the previous state sits in the YNEW slot
+            self._y_old_host = self._dev.download(SLOT_YNEW)
+        return self._y_old_host
+
+    @y_old.setter
+    def y_old(self, value):
+        self._y_old_host = value
+
+    @property
+    def f_old(self):
+        return self._dev.download_last_K(0)
+
+    def _invalidate_mirrors(self):
+        self._y_host = None
+        self._f_host = None
+        self._K_host = None
+        self._y_old_host = None
+
+    # ------------------------------------------------------- initialisation
+    def _init_min_step_parameters(self):
+        """min_step = max(h_min_a*(|t|+h), h_min_b), RKSuite's rule with the
+        smallest gap between distinct abscissae (ref common.py:123-148)."""
+        c = np.unique(np.asarray(self.C, dtype=float))
+        gaps = np.diff(c)
+        cdiff = min(1.0, gaps.min()) if gaps.size else 1.0
+        if cdiff < 1e-3:
+            cdiff = 1e-3
+            logging.warning(
+                'Some C-values of this Runge Kutta method are nearly the same '
+                'but not identical. This limits the minimum stepsize. You may '
+                'want to check the implementation of this method.')
+        fi = np.finfo(self._y_host.dtype)
+        return 10 * fi.epsneg / cdiff, sqrt(fi.tiny)
+
+    def _init_stiffness_detection(self, nfev_stiff_detect):
+        if not (isinstance(nfev_stiff_detect, int) and nfev_stiff_detect >= 0):
+            raise ValueError(
+                "`nfev_stiff_detect` must be a non-negative integer.")
+        self.nfev_stiff_detect = nfev_stiff_detect
+        if NotImplemented in (self.stbrad, self.tanang):
+            if nfev_stiff_detect not in (5000, 0):
+                warn("This method does not implement stiffness detection. "
+                     "Changing the value of nfev_stiff_detect does nothing.")
+            self.nfev_stiff_detect = 0
+        self.jflstp = 0
+        self.okstp = 0
+        self.havg = 0.0
+
+    def _init_sc_control(self, sc_params):
+        """(k*b1, k*b2, a2, g) of the PI-like controller, ref common.py:166-185"""
+        spec = sc_params or self.sc_params
+        if isinstance(spec, str) and spec in _SC_PRESETS:
+            kb1, kb2, a, g = _SC_PRESETS[spec]
+        elif isinstance(spec, tuple) and len(spec) == 4:
+            kb1, kb2, a, g = spec
+        else:
+            raise ValueError('sc_params should be a tuple of length 4 or one '
+                             'of the strings "G", "S", "W" or "standard"')
+        self.minbeta1 = kb1 * self.error_exponent
+        self.minbeta2 = kb2 * self.error_exponent
+        self.minalpha = -a
+        self.safety = g
+        self.safety_sc = g ** (kb1 + kb2)
+        self.standard_sc = True
+
+    # ------------------------------------------------------- host controller
+    def _reassess_stepsize(self, t, y=None):
+        """clip to [min_step, max_step]; look ahead over the last two steps
+        (ref common.py:310-331)"""
+        h_abs = self.h_abs
+        min_step = max(self.h_min_a * (abs(t) + h_abs), self.h_min_b)
+        if not (min_step <= h_abs <= self.max_step):
+            h_abs = min(self.max_step, max(min_step, h_abs))
+            self.standard_sc = True
+        remaining = abs(self.t_bound - t)
+        if remaining < 2 * h_abs:
+            if remaining > h_abs:
+                h_abs = max(0.5 * remaining, min_step)
+                self.standard_sc = True
+            else:
+                h_abs = remaining
+        return h_abs, min_step
+
+    def _accept_factor(self, error_norm, h, rejected_before):
+        """step-size factor after an accepted attempt (ref common.py:252-276)"""
+        if error_norm < self.tiny_err:
+            factor = self.max_factor
+            self.standard_sc = True
+        elif self.standard_sc:
+            factor = self.safety * error_norm ** self.error_exponent
+            self.standard_sc = False
+        else:
+            factor = self.safety_sc * (
+                error_norm ** self.minbeta1
+                * self.error_norm_old ** self.minbeta2
+                * (h / self.h_previous) ** self.minalpha)
+            factor = min(self.max_factor, max(self.min_factor, factor))
+        if rejected_before:
+            factor = min(1, factor)
+        if factor < MAX_FACTOR:
+            self.max_factor = MAX_FACTOR
+        return factor
+
+    def _reject_factor(self, error_norm):
+        return max(self.min_factor,
+                   self.safety * error_norm ** self.error_exponent)
+
+    def _rms_from_sumsq(self, sumsq):
+        return (sumsq / self._n_norm) ** 0.5 if self._n_norm else np.nan
+
+    # ------------------------------------------------------- device launches
+    def _run_stages(self, i_from, i_to, t, h):
+        """stages i_from .. i_to-1 (ref common.py:241-242, 353-356)"""
+        if self._device_rhs is not None:
+            self._chk(self._lib.esq_rk_stages(self._ctx, i_from, i_to, t, h),
+                      "esq_rk_stages")
+            self.nfev += i_to - i_from
+            return
+        for i in range(i_from, i_to):
+            self._chk(self._lib.esq_rk_stage_accumulate(self._ctx, i, h),
+                      "esq_rk_stage_accumulate")
+            y_stage = self._dev.download(SLOT_YSTAGE)
+            self._dev.upload(SLOT_K, i, self.fun(t + self.C[i] * h, y_stage))
+
+    def _solution_and_error(self, t, h):
+        """`_comp_sol_err` (ref common.py:341-351): returns the error norm,
+        leaves y_new in the YNEW slot"""
+        if self._device_rhs is not None:
+            sumsq = self._dev.rk_solution_error_sumsq(t, h)
+            self.nfev += self.FSAL
+        elif self.FSAL:
+            self._chk(self._lib.esq_rk_solution(self._ctx, h), "esq_rk_solution")
+            y_new = self._dev.download(SLOT_YNEW)
+            self._dev.upload(SLOT_K, self.n_stages, self.fun(t + h, y_new))
+            sumsq = self._dev.rk_error_norm_sumsq(h)
+        else:
+            sumsq = self._dev.rk_solution_error_sumsq(t, h)
+        return self._rms_from_sumsq(sumsq)
+
+    def _finish_step(self, t_new, h):
+        """end-point derivative of non-FSAL pairs, then pointer rotation on the
+        device (ref common.py:289-303)"""
+        end_eval = 0
+        if not self.FSAL:
+            if self._device_rhs is not None:
+                end_eval = 1
+                self.nfev += 1
+            else:
+                y_new = self._dev.download(SLOT_YNEW)
+                self._dev.upload(SLOT_K, self.n_stages, self.fun(t_new, y_new))
+        self._chk(self._lib.esq_rk_accept(self._ctx, t_new, end_eval),
+                  "esq_rk_accept")
+        self._invalidate_mirrors()
+
+    # ----------------------------------------------------------------- step
+    def _step_impl(self):
+        t = self.t
+        h_abs, min_step = self._reassess_stepsize(t)
+        rejected = False
+        while True:
+            if h_abs < min_step:
+                return False, self.TOO_SMALL_STEP
+            h = h_abs * self.direction
+            t_new = t + h
+            self._run_stages(1, self.n_stages, t, h)
+            error_norm = self._solution_and_error(t, h)
+            if error_norm < 1:
+                h_abs *= self._accept_factor(error_norm, h, rejected)
+                break
+            rejected = True
+            h_abs *= self._reject_factor(error_norm)
+            NFS[()] += 1
+            self.jflstp += 1
+            if np.isnan(error_norm) or np.isinf(error_norm):
+                return False, "Overflow or underflow encountered."
+        self._finish_step(t_new, h)
+        self.h_previous = h
+        self.h_abs = h_abs
+        self.error_norm_old = error_norm
+        self.t = t_new
+        self._diagnose_stiffness()
+        return True, None
+
+    # ------------------------------------------------- public-ish helpers
+    def _estimate_error(self, K, h):
+        """h * (K.T @ E) as a host vector (ref common.py:333-336), evaluated on
+        the device.  `K` is normally `self.K`; any other (s+1, n) array is
+        pushed through a scratch context."""
+        if K is self._K_host and K is not None:
+            self._chk(self._lib.esq_rk_error_vector(self._ctx, float(h), 1),
+                      "esq_rk_error_vector")
+            return self._dev.download(SLOT_WORK)
+        K = np.asarray(K)
+        tmp = DeviceContext(self.n, self.n_stages + 1,
+                            np.iscomplexobj(K), self._dev.device)
+        try:
+            tmp.set_tableau(self.A, self.B, self.C, self.E, self.FSAL)
+            for r in range(self.n_stages + self.FSAL):
+                tmp.upload(SLOT_K, r, K[r])
+            tmp._chk(tmp.lib.esq_rk_error_vector(tmp.handle, float(h), 0),
+                     "esq_rk_error_vector")
+            return tmp.download(SLOT_WORK)
+        finally:
+            tmp.close()
+
+    def _estimate_error_norm(self, K, h, scale):
+        return norm(self._estimate_error(K, h) / scale)
+
+    # ---------------------------------------------------------- dense output
+    def _dense_coefficients(self, P, rows=None):
+        """Q = K.T @ P evaluated on the device (ref common.py:363); returns the
+        (n, p) matrix as a transposed view of the (p, n) download"""
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        rows = P.shape[0] if rows is None else rows
+        Qt = np.empty((P.shape[1], self.n), dtype=self._dev.dtype)
+        self._chk(self._lib.esq_rk_dense_coefficients(
+            self._ctx, as_ptr(P), rows, P.shape[1], as_ptr(Qt)),
+            "esq_rk_dense_coefficients")
+        return Qt.T
+
+    def _dense_output_impl(self):
+        if isinstance(self.P, np.ndarray):
+            return HornerDenseOutput(self.t_old, self.t, self.y_old,
+                                     self._dense_coefficients(self.P))
+        return CubicDenseOutput(self.t_old, self.t, self.y_old, self.y,
+                                self.f_old, self.f)
+
+    # ---------------------------------------------------- stiffness detection
+    def _diagnose_stiffness(self):
+        """Bookkeeping of RKSuite's stiffness check (ref common.py:370-410).
+        The diagnosis itself (`stiff_a`, a nonlinear power iteration run every
+        `nfev_stiff_detect` evaluations) is a SURVEY.md §8f "next" row and is
+        not implemented yet: when it would trigger, an INFO record is logged
+        instead of a warning."""
+        if self.nfev_stiff_detect == 0:
+            return
+        self.okstp += 1
+        h = self.h_previous
+        self.havg = 0.9 * self.havg + 0.1 * h
+        if self.okstp == 20:
+            self.havg = h
+            self.jflstp = 0
+        lotsfl = False
+        if self.okstp % 40 == 39:
+            lotsfl = self.jflstp >= 10
+            self.jflstp = 0
+        many_steps = self.nfev_stiff_detect // self.n_stages
+        toomch = self.okstp % many_steps == many_steps - 1
+        if toomch or lotsfl:
+            logging.info('extensisq_amd: stiffness check point reached '
+                         '(diagnosis not implemented on the device path)')
+
+    def __del__(self):
+        dev = getattr(self, "_dev", None)
+        if dev is not None:
+            dev.close()

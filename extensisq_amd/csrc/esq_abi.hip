@@ -1,0 +1,826 @@
+// esq_abi.hip -- the C ABI of libextensisq_amd.so (see include/extensisq_amd.h).
+//
+// Host side of the device path: a context owns one HIP stream and ONE HBM slab
+// holding every vector of the step (K rows, y, y_new, y_stage, atol, work), all
+// 4-KiB aligned and padded to a multiple of 512 doubles so that kernels run
+// without tail code.  Rotation of K rows and the y <-> y_new exchange are
+// pointer swaps on the host; kernels receive row pointers and coefficients by
+// value in their kernel arguments.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/extensisq_amd.h"
+#include "esq_kernels.hpp"
+
+using namespace esq;
+
+namespace {
+
+constexpr size_t kPadDoubles = 512;   // 4 KiB
+constexpr int kFixedSlots = 5;        // Y, YNEW, YSTAGE, ATOL, WORK
+
+struct ProfEvent {
+    hipEvent_t start, stop;
+    int klass;
+    double bytes;
+};
+
+}  // namespace
+
+struct esq_ctx {
+    int device = 0;
+    size_t n = 0;          // state dimension as the user counts it
+    size_t len = 0;        // doubles per vector (n or 2n)
+    size_t len_pad = 0;    // padded doubles per vector
+    size_t stride = 0;     // doubles between consecutive vectors in the slab
+    int n_rows = 0;
+    bool cplx = false;
+    hipStream_t stream = nullptr;
+    double *slab = nullptr;
+    std::vector<double *> krow;       // physical K rows
+    std::vector<int> kmap;            // logical -> physical (step in flight)
+    std::vector<int> kmap_last;       // mapping of the step just accepted
+    double *y = nullptr, *ynew = nullptr, *ystage = nullptr, *atolv = nullptr,
+           *work = nullptr;
+    double *partials = nullptr;       // kMaxPartials doubles
+    double *d_result = nullptr;       // 1 double (device)
+    double *h_result = nullptr;       // 1 double (pinned host)
+    // method
+    int s = 0, fsal = 0;
+    std::vector<double> A, B, C, E;
+    bool have_tab = false;
+    double rtol = 1e-3, atol_s = 1e-6;
+    bool atol_is_vec = false;
+    esq_rhs_fn rhs = nullptr;
+    void *rhs_user = nullptr;
+    // launch geometry
+    unsigned grid_stream = 0;         // grid for streaming kernels
+    unsigned grid_reduce = 0;
+    // lock-step
+    void *comm = nullptr;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfEvent> prof_live;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[ESQ_PROF_NCLASS] = {0};
+    long prof_cnt[ESQ_PROF_NCLASS] = {0};
+    double prof_bytes[ESQ_PROF_NCLASS] = {0};
+    char err[512] = {0};
+};
+
+namespace {
+
+int fail(esq_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof(c->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+#define HIPCHK(c, call)                                                         \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess)                                                   \
+            return fail((c), (int)e_, "%s failed: %s (%s:%d)", #call,           \
+                        hipGetErrorString(e_), __FILE__, __LINE__);             \
+    } while (0)
+
+double *slot_ptr(esq_ctx *c, int slot, int row, bool logical = true) {
+    switch (slot) {
+        case ESQ_SLOT_K:
+            if (row < 0 || row >= c->n_rows) return nullptr;
+            return c->krow[logical ? c->kmap[row] : row];
+        case ESQ_SLOT_Y: return c->y;
+        case ESQ_SLOT_YNEW: return c->ynew;
+        case ESQ_SLOT_YSTAGE: return c->ystage;
+        case ESQ_SLOT_ATOL: return c->atolv;
+        case ESQ_SLOT_WORK: return c->work;
+        default: return nullptr;
+    }
+}
+
+// ---- profiling -------------------------------------------------------------
+struct Prof {
+    esq_ctx *c;
+    bool on;
+    ProfEvent ev;
+    Prof(esq_ctx *ctx, int klass, double bytes) : c(ctx), on(ctx->prof_on) {
+        if (!on) return;
+        auto take = [&]() {
+            hipEvent_t e;
+            if (!c->prof_pool.empty()) {
+                e = c->prof_pool.back();
+                c->prof_pool.pop_back();
+            } else {
+                (void)hipEventCreate(&e);
+            }
+            return e;
+        };
+        ev.start = take();
+        ev.stop = take();
+        ev.klass = klass;
+        ev.bytes = bytes;
+        (void)hipEventRecord(ev.start, c->stream);
+    }
+    ~Prof() {
+        if (!on) return;
+        (void)hipEventRecord(ev.stop, c->stream);
+        c->prof_live.push_back(ev);
+    }
+};
+
+void prof_drain(esq_ctx *c) {
+    if (c->prof_live.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &ev : c->prof_live) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) {
+            c->prof_ms[ev.klass] += ms;
+            c->prof_cnt[ev.klass] += 1;
+            c->prof_bytes[ev.klass] += ev.bytes;
+        }
+        c->prof_pool.push_back(ev.start);
+        c->prof_pool.push_back(ev.stop);
+    }
+    c->prof_live.clear();
+}
+
+// ---- launch helpers ----------------------------------------------------------
+template <int NT>
+void launch_lincomb_n(esq_ctx *c, double *out, const double *base,
+                      const Terms &tm, double h) {
+    hipLaunchKernelGGL(k_lincomb<NT>, dim3(c->grid_stream), dim3(kBlock), 0,
+                       c->stream, out, base, tm, h, c->len_pad / 2);
+}
+int launch_lincomb(esq_ctx *c, double *out, const double *base, const Terms &tm,
+                   int nt, double h) {
+#define CASE(N) case N: launch_lincomb_n<N>(c, out, base, tm, h); break;
+    switch (nt) {
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+        CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
+        CASE(17) CASE(18) CASE(19) CASE(20)
+        default: return fail(c, ESQ_EINVAL, "too many terms: %d", nt);
+    }
+#undef CASE
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+template <int NT>
+void launch_solerr_n(esq_ctx *c, const Terms2 &tm, double h) {
+    const double *av = c->atol_is_vec ? c->atolv : nullptr;
+    if (c->cplx)
+        hipLaunchKernelGGL((k_solution_error<NT, true>), dim3(c->grid_reduce),
+                           dim3(kBlock), 0, c->stream, c->ynew, c->y, tm, h, av,
+                           c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
+    else
+        hipLaunchKernelGGL((k_solution_error<NT, false>), dim3(c->grid_reduce),
+                           dim3(kBlock), 0, c->stream, c->ynew, c->y, tm, h, av,
+                           c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
+}
+template <int NT>
+void launch_errnorm_n(esq_ctx *c, const Terms &tm, double h) {
+    const double *av = c->atol_is_vec ? c->atolv : nullptr;
+    if (c->cplx)
+        hipLaunchKernelGGL((k_error_norm<NT, true>), dim3(c->grid_reduce),
+                           dim3(kBlock), 0, c->stream, c->y, c->ynew, tm, h, av,
+                           c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
+    else
+        hipLaunchKernelGGL((k_error_norm<NT, false>), dim3(c->grid_reduce),
+                           dim3(kBlock), 0, c->stream, c->y, c->ynew, tm, h, av,
+                           c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
+}
+template <int NT>
+void launch_preerr_n(esq_ctx *c, const Terms2 &tm, double h) {
+    const double *av = c->atol_is_vec ? c->atolv : nullptr;
+    if (c->cplx)
+        hipLaunchKernelGGL((k_pre_error<NT, true>), dim3(c->grid_reduce),
+                           dim3(kBlock), 0, c->stream, c->y, tm, h, av, c->atol_s,
+                           c->rtol, c->len_pad / 2, c->n, c->partials);
+    else
+        hipLaunchKernelGGL((k_pre_error<NT, false>), dim3(c->grid_reduce),
+                           dim3(kBlock), 0, c->stream, c->y, tm, h, av, c->atol_s,
+                           c->rtol, c->len_pad / 2, c->n, c->partials);
+}
+#define DISPATCH_1_20(FN, nt, ...)                                              \
+    switch (nt) {                                                               \
+        case 1: FN<1>(__VA_ARGS__); break;   case 2: FN<2>(__VA_ARGS__); break;   \
+        case 3: FN<3>(__VA_ARGS__); break;   case 4: FN<4>(__VA_ARGS__); break;   \
+        case 5: FN<5>(__VA_ARGS__); break;   case 6: FN<6>(__VA_ARGS__); break;   \
+        case 7: FN<7>(__VA_ARGS__); break;   case 8: FN<8>(__VA_ARGS__); break;   \
+        case 9: FN<9>(__VA_ARGS__); break;   case 10: FN<10>(__VA_ARGS__); break; \
+        case 11: FN<11>(__VA_ARGS__); break; case 12: FN<12>(__VA_ARGS__); break; \
+        case 13: FN<13>(__VA_ARGS__); break; case 14: FN<14>(__VA_ARGS__); break; \
+        case 15: FN<15>(__VA_ARGS__); break; case 16: FN<16>(__VA_ARGS__); break; \
+        case 17: FN<17>(__VA_ARGS__); break; case 18: FN<18>(__VA_ARGS__); break; \
+        case 19: FN<19>(__VA_ARGS__); break; case 20: FN<20>(__VA_ARGS__); break; \
+        default: return fail(c, ESQ_EINVAL, "bad term count %d", nt);           \
+    }
+
+// ---- RCCL, loaded lazily so that single-GPU use never pays for it -----------
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    void *CommInitRank = nullptr;   // int (*)(ncclComm_t*, int, ncclUniqueId, int)
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+struct UniqueId { char bytes[128]; };
+typedef int (*init_rank_fn)(void **, int, UniqueId, int);
+
+Rccl g_rccl;
+int rccl_load() {
+    if (g_rccl.lib) return 0;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return ESQ_ESTATE;
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = dlsym(lib, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *,
+                                hipStream_t))dlsym(lib, "ncclAllReduce");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy ||
+        !g_rccl.AllReduce)
+        return ESQ_ESTATE;
+    g_rccl.lib = lib;
+    return 0;
+}
+constexpr int kNcclFloat64 = 8;   // ncclDouble
+constexpr int kNcclSum = 0;       // ncclSum
+
+// partials -> one double on the host (all-reduced over the communicator if set)
+int finish_reduction(esq_ctx *c, double *out) {
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(1024), 0, c->stream,
+                       c->partials, (int)c->grid_reduce, c->d_result);
+    HIPCHK(c, hipGetLastError());
+    if (c->comm) {
+        int r = g_rccl.AllReduce(c->d_result, c->d_result, 1, kNcclFloat64,
+                                 kNcclSum, c->comm, c->stream);
+        if (r != 0)
+            return fail(c, 1000 + r, "ncclAllReduce failed: %s",
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_result, c->d_result, sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out) *out = *c->h_result;
+    return 0;
+}
+
+int call_rhs(esq_ctx *c, double t, const double *src, double *dst) {
+    if (!c->rhs) return fail(c, ESQ_ESTATE, "no device RHS set (esq_set_rhs)");
+    Prof p(c, ESQ_PROF_RHS, 16.0 * (double)c->len);
+    int r = c->rhs(c->rhs_user, t, src, dst, c->len, (void *)c->stream);
+    if (r != 0) return fail(c, ESQ_ERHS, "RHS plugin returned %d", r);
+    return 0;
+}
+
+int build_row_terms(esq_ctx *c, const double *coef, int count, Terms &tm,
+                    const std::vector<int> &map) {
+    int nt = 0;
+    for (int j = 0; j < count; ++j) {
+        if (coef[j] == 0.0) continue;
+        if (nt >= kMaxTerms) return -1;
+        tm.p[nt] = c->krow[map[j]];
+        tm.c[nt] = coef[j];
+        ++nt;
+    }
+    for (int j = nt; j < kMaxTerms; ++j) { tm.p[j] = nullptr; tm.c[j] = 0.0; }
+    return nt;
+}
+int build_row_terms2(esq_ctx *c, const double *b, int nb, const double *e, int ne,
+                     Terms2 &tm, const std::vector<int> &map) {
+    int nt = 0;
+    const int count = nb > ne ? nb : ne;
+    for (int j = 0; j < count; ++j) {
+        const double bj = j < nb ? b[j] : 0.0, ej = j < ne ? e[j] : 0.0;
+        if (bj == 0.0 && ej == 0.0) continue;
+        if (nt >= kMaxTerms) return -1;
+        tm.p[nt] = c->krow[map[j]];
+        tm.b[nt] = bj;
+        tm.e[nt] = ej;
+        ++nt;
+    }
+    for (int j = nt; j < kMaxTerms; ++j) { tm.p[j] = nullptr; tm.b[j] = tm.e[j] = 0.0; }
+    return nt;
+}
+
+unsigned env_uint(const char *name, unsigned dflt) {
+    const char *s = getenv(name);
+    if (!s || !*s) return dflt;
+    long v = strtol(s, nullptr, 10);
+    return v > 0 ? (unsigned)v : dflt;
+}
+
+}  // namespace
+
+extern "C" {
+
+int esq_abi_version(void) { return ESQ_ABI_VERSION; }
+
+int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) {
+    if (!out || n_rows < 1 || n_rows > 64) return ESQ_EINVAL;
+    esq_ctx *c = new (std::nothrow) esq_ctx();
+    if (!c) return ESQ_ENOMEM;
+    *out = c;   // returned even on failure so the caller can read the message
+    c->device = device;
+    c->n = n;
+    c->cplx = is_complex != 0;
+    c->len = c->cplx ? 2 * n : n;
+    c->len_pad = ((c->len + kPadDoubles - 1) / kPadDoubles) * kPadDoubles;
+    if (c->len_pad == 0) c->len_pad = kPadDoubles;
+    // ESQ_ROW_STAGGER: extra bytes between consecutive vectors (HBM channel
+    // de-aliasing experiments); must be a multiple of 16
+    const size_t stagger = (env_uint("ESQ_ROW_STAGGER", 0) / 16) * 2;
+    c->stride = c->len_pad + stagger;
+    c->n_rows = n_rows;
+    HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t nvec = (size_t)n_rows + kFixedSlots;
+    const size_t slab_doubles = nvec * c->stride + kMaxPartials + 64;
+    HIPCHK(c, hipMalloc(&c->slab, slab_doubles * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(c->slab, 0, slab_doubles * sizeof(double), c->stream));
+    c->krow.resize(n_rows);
+    c->kmap.resize(n_rows);
+    for (int r = 0; r < n_rows; ++r) {
+        c->krow[r] = c->slab + (size_t)r * c->stride;
+        c->kmap[r] = r;
+    }
+    c->kmap_last = c->kmap;
+    double *base = c->slab + (size_t)n_rows * c->stride;
+    c->y = base;
+    c->ynew = base + c->stride;
+    c->ystage = base + 2 * c->stride;
+    c->atolv = base + 3 * c->stride;
+    c->work = base + 4 * c->stride;
+    c->partials = base + 5 * c->stride;
+    c->d_result = c->partials + kMaxPartials;
+    HIPCHK(c, hipHostMalloc(&c->h_result, 64, hipHostMallocDefault));
+    // launch geometry: grid-stride kernels, a few resident blocks per CU
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    const unsigned cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const size_t n2 = c->len_pad / 2;
+    const size_t need = (n2 + kBlock - 1) / kBlock;
+    const unsigned per_cu = env_uint("ESQ_BLOCKS_PER_CU", 8);
+    size_t g = (size_t)cus * per_cu;
+    if (g > need) g = need;
+    if (g < 1) g = 1;
+    c->grid_stream = (unsigned)g;
+    c->grid_reduce = (unsigned)(g > (size_t)kMaxPartials ? kMaxPartials : g);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int esq_destroy(esq_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &ev : c->prof_live) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
+    for (auto &e : c->prof_pool) (void)hipEventDestroy(e);
+    if (c->slab) (void)hipFree(c->slab);
+    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+const char *esq_last_error(const esq_ctx *c) { return c ? c->err : "null context"; }
+
+int esq_synchronize(esq_ctx *c) {
+    if (!c) return ESQ_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+size_t esq_vector_len(const esq_ctx *c) { return c ? c->len : 0; }
+
+int esq_upload(esq_ctx *c, int slot, int row, const double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    double *d = slot_ptr(c, slot, row);
+    if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
+    const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
+    HIPCHK(c, hipMemcpyAsync(d, host, cnt * sizeof(double), hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int esq_download(esq_ctx *c, int slot, int row, double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    double *d = slot_ptr(c, slot, row);
+    if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
+    const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
+    HIPCHK(c, hipMemcpyAsync(host, d, cnt * sizeof(double), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int esq_copy(esq_ctx *c, int dst_slot, int dst_row, int src_slot, int src_row) {
+    if (!c) return ESQ_EINVAL;
+    double *d = slot_ptr(c, dst_slot, dst_row), *s = slot_ptr(c, src_slot, src_row);
+    if (!d || !s) return fail(c, ESQ_EINVAL, "bad slot/row");
+    HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),
+                             hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
+                       const double *C, const double *E, int fsal) {
+    if (!c || !A || !B || !C || !E || s < 1) return ESQ_EINVAL;
+    if (s + 1 > c->n_rows)
+        return fail(c, ESQ_EINVAL, "tableau needs %d rows, context has %d", s + 1,
+                    c->n_rows);
+    for (int i = 0; i < s; ++i) {
+        int nz = 0;
+        for (int j = 0; j < s; ++j) {
+            if (j >= i && A[i * s + j] != 0.0)
+                return fail(c, ESQ_EINVAL, "A must be strictly lower triangular");
+            nz += A[i * s + j] != 0.0;
+        }
+        if (nz > kMaxTerms)
+            return fail(c, ESQ_EINVAL, "row %d of A has %d > %d nonzeros", i, nz, kMaxTerms);
+    }
+    c->s = s;
+    c->fsal = fsal ? 1 : 0;
+    c->A.assign(A, A + (size_t)s * s);
+    c->B.assign(B, B + s);
+    c->C.assign(C, C + s);
+    c->E.assign(E, E + s + 1);
+    c->have_tab = true;
+    return 0;
+}
+
+int esq_set_tol(esq_ctx *c, double rtol, const double *atol, size_t n_atol) {
+    if (!c || !atol) return ESQ_EINVAL;
+    c->rtol = rtol;
+    if (n_atol == 1) {
+        c->atol_s = atol[0];
+        c->atol_is_vec = false;
+        return 0;
+    }
+    if (n_atol != c->n) return fail(c, ESQ_EINVAL, "atol has %zu entries, n = %zu", n_atol, c->n);
+    c->atol_is_vec = true;
+    HIPCHK(c, hipMemcpyAsync(c->atolv, atol, c->n * sizeof(double),
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
+    if (!c) return ESQ_EINVAL;
+    c->rhs = fn;
+    c->rhs_user = user;
+    return 0;
+}
+
+int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
+    if (!c) return ESQ_EINVAL;
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    if (i < 1 || i >= c->s) return fail(c, ESQ_EINVAL, "stage %d out of range", i);
+    Terms tm;
+    const int nt = build_row_terms(c, &c->A[(size_t)i * c->s], i, tm, c->kmap);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    Prof p(c, ESQ_PROF_STAGE, 8.0 * (nt + 2) * (double)c->len);
+    return launch_lincomb(c, c->ystage, c->y, tm, nt, h);
+}
+
+int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row) {
+    if (!c) return ESQ_EINVAL;
+    double *dst = slot_ptr(c, ESQ_SLOT_K, dst_row);
+    double *src = slot_ptr(c, src_slot, src_row);
+    if (!dst || !src) return fail(c, ESQ_EINVAL, "bad row/slot");
+    return call_rhs(c, t, src, dst);
+}
+
+int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
+    if (!c) return ESQ_EINVAL;
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    if (i_from < 1 || i_to > c->s || i_from > i_to)
+        return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
+    for (int i = i_from; i < i_to; ++i) {
+        int r = esq_rk_stage_accumulate(c, i, h);
+        if (r) return r;
+        r = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
+        if (r) return r;
+    }
+    return 0;
+}
+
+int esq_rk_solution(esq_ctx *c, double h) {
+    if (!c) return ESQ_EINVAL;
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    Terms tm;
+    const int nt = build_row_terms(c, c->B.data(), c->s, tm, c->kmap);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
+    return launch_lincomb(c, c->ynew, c->y, tm, nt, h);
+}
+
+int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    Terms tm;
+    const int nt = build_row_terms(c, c->E.data(), c->s + c->fsal, tm, c->kmap);
+    if (nt < 1) return fail(c, ESQ_EINVAL, "error weights are all zero");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
+        DISPATCH_1_20(launch_errnorm_n, nt, c, tm, h)
+        HIPCHK(c, hipGetLastError());
+    }
+    return finish_reduction(c, sumsq_out);
+}
+
+int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    if (c->fsal) {
+        int r = esq_rk_solution(c, h);
+        if (r) return r;
+        r = call_rhs(c, t + h, c->ynew, c->krow[c->kmap[c->s]]);
+        if (r) return r;
+        return esq_rk_error_norm(c, h, sumsq_out);
+    }
+    Terms2 tm;
+    const int nt = build_row_terms2(c, c->B.data(), c->s, c->E.data(), c->s, tm, c->kmap);
+    if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
+        DISPATCH_1_20(launch_solerr_n, nt, c, tm, h)
+        HIPCHK(c, hipGetLastError());
+    }
+    return finish_reduction(c, sumsq_out);
+}
+
+int esq_rk_pre_error(esq_ctx *c, double h, const double *e_pre,
+                     const double *b_scale_pre, int rows, double *sumsq_out) {
+    if (!c || !e_pre || !b_scale_pre || !sumsq_out) return ESQ_EINVAL;
+    if (rows < 1 || rows > c->n_rows) return fail(c, ESQ_EINVAL, "bad rows %d", rows);
+    Terms2 tm;
+    const int nt = build_row_terms2(c, b_scale_pre, rows, e_pre, rows, tm, c->kmap);
+    if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 1) * (double)c->len);
+        DISPATCH_1_20(launch_preerr_n, nt, c, tm, h)
+        HIPCHK(c, hipGetLastError());
+    }
+    return finish_reduction(c, sumsq_out);
+}
+
+int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval) {
+    if (!c) return ESQ_EINVAL;
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    if (!c->fsal && with_end_eval) {
+        int r = call_rhs(c, t_new, c->ynew, c->krow[c->kmap[c->s]]);
+        if (r) return r;
+    }
+    c->kmap_last = c->kmap;
+    std::swap(c->kmap[0], c->kmap[c->s]);
+    std::swap(c->y, c->ynew);
+    return 0;
+}
+
+int esq_rk_error_vector(esq_ctx *c, double h, int last_step) {
+    if (!c) return ESQ_EINVAL;
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    Terms tm;
+    const int nt = build_row_terms(c, c->E.data(), c->s + c->fsal, tm,
+                                   last_step ? c->kmap_last : c->kmap);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    return launch_lincomb(c, c->work, nullptr, tm, nt, h);
+}
+
+int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
+    HIPCHK(c, hipMemcpyAsync(host, c->krow[c->kmap_last[row]],
+                             c->len * sizeof(double), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int esq_rk_dense_coefficients(esq_ctx *c, const double *P, int rows, int p,
+                              double *Q_host) {
+    if (!c || !P || !Q_host || rows < 1 || rows > c->n_rows || p < 1)
+        return ESQ_EINVAL;
+    // column by column through the WORK vector: Q_host is (p, len) row-major,
+    // i.e. the TRANSPOSE of the reference's Q (common.py:363)
+    std::vector<double> col(rows);
+    for (int k = 0; k < p; ++k) {
+        for (int r = 0; r < rows; ++r) col[r] = P[(size_t)r * p + k];
+        Terms tm;
+        const int nt = build_row_terms(c, col.data(), rows, tm, c->kmap_last);
+        if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+        int r = launch_lincomb(c, c->work, nullptr, tm, nt, 1.0);
+        if (r) return r;
+        HIPCHK(c, hipMemcpyAsync(Q_host + (size_t)k * c->len, c->work,
+                                 c->len * sizeof(double), hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int esq_rk_dense_stage(esq_ctx *c, int row, const double *a, int count, double h) {
+    if (!c || !a) return ESQ_EINVAL;
+    if (row < 1 || row >= c->n_rows || count < 0 || count > row)
+        return fail(c, ESQ_EINVAL, "bad row/count %d/%d", row, count);
+    Terms tm;
+    const int nt = build_row_terms(c, a, count, tm, c->kmap_last);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    // after esq_rk_accept the pre-step state is in the YNEW slot
+    return launch_lincomb(c, c->ystage, c->ynew, tm, nt, h);
+}
+int esq_rk_dense_eval(esq_ctx *c, int row, double t) {
+    if (!c) return ESQ_EINVAL;
+    if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
+    return call_rhs(c, t, c->ystage, c->krow[c->kmap_last[row]]);
+}
+int esq_rk_upload_last_K(esq_ctx *c, int row, const double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
+    HIPCHK(c, hipMemcpyAsync(c->krow[c->kmap_last[row]], host,
+                             c->len * sizeof(double), hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- RKC ----------------------------------------------------------------------
+#define ROW(c, r) (((r) >= 0 && (r) < (c)->n_rows) ? (c)->krow[r] : nullptr)
+
+int esq_rkc_first_stage(esq_ctx *c, int dst, int yn, int fn, double hmus) {
+    if (!c) return ESQ_EINVAL;
+    double *d = ROW(c, dst), *a = ROW(c, yn), *f = ROW(c, fn);
+    if (!d || !a || !f) return fail(c, ESQ_EINVAL, "bad row");
+    Prof p(c, ESQ_PROF_RKC, 24.0 * (double)c->len);
+    hipLaunchKernelGGL(k_rkc_first, dim3(c->grid_stream), dim3(kBlock), 0,
+                       c->stream, d, a, f, hmus, c->len_pad / 2);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int esq_rkc_stage(esq_ctx *c, int dst, int fy, int yjm1, int yjm2, int yn, int fn,
+                  double mu, double nu, double hmus, double ajm1) {
+    if (!c) return ESQ_EINVAL;
+    double *d = ROW(c, dst), *f = ROW(c, fy), *a = ROW(c, yjm1), *b = ROW(c, yjm2),
+           *y0 = ROW(c, yn), *g = ROW(c, fn);
+    if (!d || !f || !a || !b || !y0 || !g) return fail(c, ESQ_EINVAL, "bad row");
+    const double omn = (1.0 - mu) - nu;   // (1.0 - mu - nu), left to right
+    Prof p(c, ESQ_PROF_RKC, 48.0 * (double)c->len);
+    hipLaunchKernelGGL(k_rkc_stage, dim3(c->grid_stream), dim3(kBlock), 0,
+                       c->stream, d, f, a, b, y0, g, mu, nu, omn, hmus, ajm1,
+                       c->len_pad / 2);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int esq_rkc_eval_rhs(esq_ctx *c, int dst, double t, int src) {
+    if (!c) return ESQ_EINVAL;
+    double *d = ROW(c, dst), *s = ROW(c, src);
+    if (!d || !s) return fail(c, ESQ_EINVAL, "bad row");
+    return call_rhs(c, t, s, d);
+}
+int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
+                   double hmus1, int m, const double *scalars, int *y_row_out) {
+    if (!c || !y_row_out || m < 1 || (m > 1 && !scalars)) return ESQ_EINVAL;
+    // rotation instead of the reference's two full copies per stage:
+    //   jm1 = first-stage result, jm2 = yn; every stage writes into a free row
+    int r = esq_rkc_first_stage(c, w0, yn, fn, hmus1);
+    if (r) return r;
+    int jm1 = w0, jm2 = yn, free_a = w1, free_b = w2;
+    int ycur = w0;
+    for (int j = 2; j <= m; ++j) {
+        const double *sc = scalars + 5 * (size_t)(j - 2);
+        // fy = rhs(t_stage, yjm1) into free_a, combination overwrites free_a
+        r = esq_rkc_eval_rhs(c, free_a, sc[4], jm1);
+        if (r) return r;
+        r = esq_rkc_stage(c, free_a, free_a, jm1, jm2, yn, fn, sc[0], sc[1],
+                          sc[2], sc[3]);
+        if (r) return r;
+        ycur = free_a;
+        // shift: jm2 <- jm1, jm1 <- new; the old jm2 row becomes free
+        const int old_jm2 = jm2;
+        jm2 = jm1;
+        jm1 = ycur;
+        if (old_jm2 == yn) {      // yn is never recycled
+            free_a = free_b;
+        } else {
+            free_a = old_jm2;
+        }
+    }
+    *y_row_out = ycur;
+    return 0;
+}
+int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
+                       double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    double *a = ROW(c, y), *b = ROW(c, yn), *f = ROW(c, fn), *g = ROW(c, fy);
+    if (!a || !b || !f || !g) return fail(c, ESQ_EINVAL, "bad row");
+    if (c->cplx) return fail(c, ESQ_EINVAL, "RKC is real-only (sommeijer.py:98)");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, 32.0 * (double)c->len);
+        hipLaunchKernelGGL(k_rkc_error, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, a, b, f, g, h,
+                           c->atol_is_vec ? c->atolv : nullptr, c->atol_s, c->rtol,
+                           c->len_pad / 2, c->n, c->partials);
+        HIPCHK(c, hipGetLastError());
+    }
+    return finish_reduction(c, sumsq_out);
+}
+int esq_vec_sumsq(esq_ctx *c, int x, int y, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    double *a = ROW(c, x), *b = y >= 0 ? ROW(c, y) : nullptr;
+    if (!a || (y >= 0 && !b)) return fail(c, ESQ_EINVAL, "bad row");
+    hipLaunchKernelGGL(k_sumsq, dim3(c->grid_reduce), dim3(kBlock), 0, c->stream,
+                       a, b, c->len_pad / 2, c->partials);
+    HIPCHK(c, hipGetLastError());
+    return finish_reduction(c, sumsq_out);
+}
+int esq_vec_axpbmc(esq_ctx *c, int dst, int a, double alpha, int b, int cc) {
+    if (!c) return ESQ_EINVAL;
+    double *d = ROW(c, dst), *pa = a >= 0 ? ROW(c, a) : nullptr, *pb = ROW(c, b),
+           *pc = cc >= 0 ? ROW(c, cc) : nullptr;
+    if (!d || !pb || (a >= 0 && !pa) || (cc >= 0 && !pc))
+        return fail(c, ESQ_EINVAL, "bad row");
+    hipLaunchKernelGGL(k_axpbmc, dim3(c->grid_stream), dim3(kBlock), 0, c->stream,
+                       d, pa, alpha, pb, pc, c->len_pad / 2);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int esq_vec_wdiff_sumsq(esq_ctx *c, int a, int b, int w, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    double *pa = ROW(c, a), *pb = ROW(c, b), *pw = ROW(c, w);
+    if (!pa || !pb || !pw) return fail(c, ESQ_EINVAL, "bad row");
+    hipLaunchKernelGGL(k_wdiff_sumsq, dim3(c->grid_reduce), dim3(kBlock), 0,
+                       c->stream, pa, pb, pw, c->atol_is_vec ? c->atolv : nullptr,
+                       c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
+    HIPCHK(c, hipGetLastError());
+    return finish_reduction(c, sumsq_out);
+}
+
+// ---- lock-step ------------------------------------------------------------------
+int esq_set_comm(esq_ctx *c, void *nccl_comm) {
+    if (!c) return ESQ_EINVAL;
+    if (nccl_comm && rccl_load() != 0) return fail(c, ESQ_ESTATE, "cannot load librccl");
+    c->comm = nccl_comm;
+    return 0;
+}
+int esq_comm_unique_id(void *id128_out) {
+    if (!id128_out) return ESQ_EINVAL;
+    if (rccl_load() != 0) return ESQ_ESTATE;
+    int r = g_rccl.GetUniqueId(id128_out);
+    return r ? 1000 + r : 0;
+}
+int esq_comm_init_rank(void **comm_out, int nranks, const void *id128, int rank,
+                       int device) {
+    if (!comm_out || !id128) return ESQ_EINVAL;
+    if (rccl_load() != 0) return ESQ_ESTATE;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return (int)e;
+    UniqueId id;
+    memcpy(id.bytes, id128, sizeof(id.bytes));
+    int r = ((init_rank_fn)g_rccl.CommInitRank)(comm_out, nranks, id, rank);
+    return r ? 1000 + r : 0;
+}
+int esq_comm_destroy(void *comm) {
+    if (!comm) return 0;
+    if (rccl_load() != 0) return ESQ_ESTATE;
+    int r = g_rccl.CommDestroy(comm);
+    return r ? 1000 + r : 0;
+}
+
+// ---- measurement ----------------------------------------------------------------
+int esq_profile_enable(esq_ctx *c, int on) {
+    if (!c) return ESQ_EINVAL;
+    if (!on) prof_drain(c);
+    c->prof_on = on != 0;
+    return 0;
+}
+int esq_profile_read(esq_ctx *c, int klass, double *total_ms, long *launches,
+                     double *bytes) {
+    if (!c || klass < 0 || klass >= ESQ_PROF_NCLASS) return ESQ_EINVAL;
+    prof_drain(c);
+    if (total_ms) *total_ms = c->prof_ms[klass];
+    if (launches) *launches = c->prof_cnt[klass];
+    if (bytes) *bytes = c->prof_bytes[klass];
+    return 0;
+}
+int esq_profile_reset(esq_ctx *c) {
+    if (!c) return ESQ_EINVAL;
+    prof_drain(c);
+    for (int k = 0; k < ESQ_PROF_NCLASS; ++k) {
+        c->prof_ms[k] = 0; c->prof_cnt[k] = 0; c->prof_bytes[k] = 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

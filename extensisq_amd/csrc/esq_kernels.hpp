@@ -1,0 +1,372 @@
+// esq_kernels.hpp -- gfx950 (CDNA4, wave64) device kernels of the explicit
+// Runge-Kutta hot path.  Everything here is HBM-bandwidth-bound streaming
+// arithmetic in fp64: 16-byte (double2) coalesced accesses, coefficients and row
+// pointers in kernel arguments (scalar registers), no re-reads.
+//
+// Reference expressions replaced (extensisq v0.6.0):
+//   k_lincomb         y + h*(K[:i].T @ A[i,:i])            common.py:355-356, 343
+//   k_solution_error  y_new, scale, h*(K.T@E)/scale, norm  common.py:341-351, 57-66
+//   k_error_norm      same, second pass of FSAL pairs      common.py:335-339
+//   k_pre_error       BS5 early estimate                   bogacki.py:340-346
+//   k_rkc_*           three-term Chebyshev recursion       sommeijer.py:289, 312-313, 218-220
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace esq {
+
+constexpr int kMaxTerms = 20;     // >= longest coefficient row (Pr9: 16)
+constexpr int kBlock = 256;       // 4 waves of 64 lanes
+constexpr int kMaxPartials = 8192;
+
+// One linear combination: up to kMaxTerms (pointer, coefficient) pairs, passed
+// BY VALUE so that hipcc keeps them in SGPRs (s_load from the kernarg segment):
+// the "A-row broadcast" costs no vector memory traffic at all.
+struct Terms {
+    const double *p[kMaxTerms];
+    double c[kMaxTerms];
+};
+// two coefficient sets over one row list (solution weights b, error weights e)
+struct Terms2 {
+    const double *p[kMaxTerms];
+    double b[kMaxTerms];
+    double e[kMaxTerms];
+};
+
+__device__ __forceinline__ double2 ld2(const double *p, size_t i) {
+    return reinterpret_cast<const double2 *>(p)[i];
+}
+__device__ __forceinline__ void st2(double *p, size_t i, double2 v) {
+    reinterpret_cast<double2 *>(p)[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// out = base + h * sum_j c_j * v_j        (base may be nullptr -> 0)
+// Evaluation order follows the reference: the weighted sum first (ascending j,
+// fused multiply-add chain like a BLAS gemv kernel), then *h, then +base, the
+// last two rounded separately as NumPy does.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(kBlock) void k_lincomb(
+    double *__restrict__ out, const double *__restrict__ base, Terms tm,
+    double h, size_t n2) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 v[NT > 0 ? NT : 1];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j] = ld2(tm.p[j], i);
+        double2 yb = make_double2(0.0, 0.0);
+        if (base) yb = ld2(base, i);
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc.x = fma(tm.c[j], v[j].x, acc.x);
+            acc.y = fma(tm.c[j], v[j].y, acc.y);
+        }
+        double2 r;
+        r.x = __dadd_rn(yb.x, __dmul_rn(h, acc.x));
+        r.y = __dadd_rn(yb.y, __dmul_rn(h, acc.y));
+        st2(out, i, r);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// block reduction: wave64 shuffle tree -> LDS across the 4 waves -> one
+// partial per block (fixed order => bitwise reproducible for a given grid).
+// NaN/Inf propagate through plain adds.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void block_partial(double v, double *partials) {
+    __shared__ double lds[kBlock / 64];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = lds[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) s += lds[w];
+        partials[blockIdx.x] = s;
+    }
+}
+
+// final deterministic sum of the per-block partials (one block)
+__global__ __launch_bounds__(1024) void k_final_sum(
+    const double *__restrict__ partials, int count, double *__restrict__ out) {
+    __shared__ double lds[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += 1024) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t += lds[w];
+        *out = t;
+    }
+}
+
+// np.maximum propagates NaN, fmax drops it: keep NumPy's semantics
+__device__ __forceinline__ double pmax(double a, double b) {
+    double m = fmax(a, b);
+    m = (a != a) ? a : m;
+    return (b != b) ? b : m;
+}
+// weights: scale = atol + rtol * max(|a|, |b|)         common.py:57-61
+// CPLX: one double2 is one complex element, |.| = hypot (NumPy's complex abs)
+template <bool CPLX>
+__device__ __forceinline__ double ratio_sq(double2 err, double2 ya, double2 yb,
+                                           const double *atol_vec,
+                                           double atol_s, double rtol, size_t i,
+                                           size_t n_valid) {
+    if (CPLX) {
+        if (i >= n_valid) return 0.0;
+        const double at = atol_vec ? atol_vec[i] : atol_s;
+        const double sc = at + rtol * pmax(hypot(ya.x, ya.y), hypot(yb.x, yb.y));
+        const double rx = err.x / sc, ry = err.y / sc;
+        return rx * rx + ry * ry;
+    } else {
+        const size_t e0 = 2 * i;
+        double s = 0.0;
+        if (e0 < n_valid) {
+            const double at = atol_vec ? atol_vec[e0] : atol_s;
+            const double sc = at + rtol * pmax(fabs(ya.x), fabs(yb.x));
+            const double r = err.x / sc;
+            s = r * r;
+        }
+        if (e0 + 1 < n_valid) {
+            const double at = atol_vec ? atol_vec[e0 + 1] : atol_s;
+            const double sc = at + rtol * pmax(fabs(ya.y), fabs(yb.y));
+            const double r = err.y / sc;
+            s += r * r;
+        }
+        return s;
+    }
+}
+// ---------------------------------------------------------------------------
+// Non-FSAL fused pass: y_new = y + h*sum b_j K_j ; err = h*sum e_j K_j ;
+// partial sum of |err/scale|^2.  Each K row is read ONCE for both sums.
+// ---------------------------------------------------------------------------
+template <int NT, bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_solution_error(
+    double *__restrict__ ynew, const double *__restrict__ y, Terms2 tm,
+    double h, const double *__restrict__ atol_vec, double atol_s, double rtol,
+    size_t n2, size_t n_valid, double *__restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 v[NT > 0 ? NT : 1];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j] = ld2(tm.p[j], i);
+        const double2 yy = ld2(y, i);
+        // rows are the union of the two supports; a zero weight contributes
+        // fma(0, v, s) == s (and 0*Inf = NaN, exactly like NumPy's gemv)
+        double2 sb = make_double2(0.0, 0.0), se = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            sb.x = fma(tm.b[j], v[j].x, sb.x);
+            sb.y = fma(tm.b[j], v[j].y, sb.y);
+            se.x = fma(tm.e[j], v[j].x, se.x);
+            se.y = fma(tm.e[j], v[j].y, se.y);
+        }
+        double2 yn, er;
+        yn.x = __dadd_rn(yy.x, __dmul_rn(h, sb.x));
+        yn.y = __dadd_rn(yy.y, __dmul_rn(h, sb.y));
+        er.x = __dmul_rn(h, se.x);
+        er.y = __dmul_rn(h, se.y);
+        st2(ynew, i, yn);
+        local += ratio_sq<CPLX>(er, yy, yn, atol_vec, atol_s, rtol, i, n_valid);
+    }
+    block_partial(local, partials);
+}
+
+// FSAL second pass (and the public _estimate_error_norm): err from K rows,
+// scale from y and y_new already in memory.
+template <int NT, bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_error_norm(
+    const double *__restrict__ y, const double *__restrict__ ynew, Terms tm,
+    double h, const double *__restrict__ atol_vec, double atol_s, double rtol,
+    size_t n2, size_t n_valid, double *__restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 v[NT > 0 ? NT : 1];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j] = ld2(tm.p[j], i);
+        const double2 ya = ld2(y, i), yb = ld2(ynew, i);
+        double2 se = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            se.x = fma(tm.c[j], v[j].x, se.x);
+            se.y = fma(tm.c[j], v[j].y, se.y);
+        }
+        double2 er;
+        er.x = __dmul_rn(h, se.x);
+        er.y = __dmul_rn(h, se.y);
+        local += ratio_sq<CPLX>(er, ya, yb, atol_vec, atol_s, rtol, i, n_valid);
+    }
+    block_partial(local, partials);
+}
+
+// BS5 pre-error: y_pre stays in registers.
+template <int NT, bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_pre_error(
+    const double *__restrict__ y, Terms2 tm, double h,
+    const double *__restrict__ atol_vec, double atol_s, double rtol, size_t n2,
+    size_t n_valid, double *__restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 v[NT > 0 ? NT : 1];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j] = ld2(tm.p[j], i);
+        const double2 yy = ld2(y, i);
+        double2 sb = make_double2(0.0, 0.0), se = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            sb.x = fma(tm.b[j], v[j].x, sb.x);
+            sb.y = fma(tm.b[j], v[j].y, sb.y);
+            se.x = fma(tm.e[j], v[j].x, se.x);
+            se.y = fma(tm.e[j], v[j].y, se.y);
+        }
+        double2 yp, er;
+        yp.x = __dadd_rn(yy.x, __dmul_rn(h, sb.x));
+        yp.y = __dadd_rn(yy.y, __dmul_rn(h, sb.y));
+        er.x = __dmul_rn(h, se.x);
+        er.y = __dmul_rn(h, se.y);
+        local += ratio_sq<CPLX>(er, yy, yp, atol_vec, atol_s, rtol, i, n_valid);
+    }
+    block_partial(local, partials);
+}
+
+// ---------------------------------------------------------------------------
+// Runge-Kutta-Chebyshev
+// ---------------------------------------------------------------------------
+// dst = yn + hmus*fn                                  sommeijer.py:289
+__global__ __launch_bounds__(kBlock) void k_rkc_first(
+    double *__restrict__ dst, const double *__restrict__ yn,
+    const double *__restrict__ fn, double hmus, size_t n2) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        const double2 a = ld2(yn, i), f = ld2(fn, i);
+        double2 r;
+        r.x = __dadd_rn(a.x, __dmul_rn(hmus, f.x));
+        r.y = __dadd_rn(a.y, __dmul_rn(hmus, f.y));
+        st2(dst, i, r);
+    }
+}
+// dst = mu*yjm1 + nu*yjm2 + (1-mu-nu)*yn + hmus*(fy - ajm1*fn)   :312-313
+// (left-to-right like the NumPy expression; every product rounded)
+// dst may alias fy (the combination overwrites the derivative it consumed)
+__global__ __launch_bounds__(kBlock) void k_rkc_stage(
+    double *dst, const double *fy,
+    const double *__restrict__ yjm1, const double *__restrict__ yjm2,
+    const double *__restrict__ yn, const double *__restrict__ fn, double mu,
+    double nu, double omn, double hmus, double ajm1, size_t n2) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        const double2 a = ld2(yjm1, i), b = ld2(yjm2, i), c = ld2(yn, i);
+        const double2 f = ld2(fy, i), g = ld2(fn, i);
+        double2 r;
+        r.x = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(mu, a.x), __dmul_rn(nu, b.x)),
+                                  __dmul_rn(omn, c.x)),
+                        __dmul_rn(hmus, __dsub_rn(f.x, __dmul_rn(ajm1, g.x))));
+        r.y = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(mu, a.y), __dmul_rn(nu, b.y)),
+                                  __dmul_rn(omn, c.y)),
+                        __dmul_rn(hmus, __dsub_rn(f.y, __dmul_rn(ajm1, g.y))));
+        st2(dst, i, r);
+    }
+}
+// est = 0.8*(yn - y) + 0.4*h*(fn + fy); wt = atol + rtol*max(|y|,|yn|) :218-220
+__global__ __launch_bounds__(kBlock) void k_rkc_error(
+    const double *__restrict__ y, const double *__restrict__ yn,
+    const double *__restrict__ fn, const double *__restrict__ fy, double h,
+    const double *__restrict__ atol_vec, double atol_s, double rtol, size_t n2,
+    size_t n_valid, double *__restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    double local = 0.0;
+    const double h04 = 0.4 * h;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        const double2 a = ld2(y, i), b = ld2(yn, i), f = ld2(fn, i), g = ld2(fy, i);
+        double2 er;
+        er.x = __dadd_rn(__dmul_rn(0.8, __dsub_rn(b.x, a.x)),
+                         __dmul_rn(h04, __dadd_rn(f.x, g.x)));
+        er.y = __dadd_rn(__dmul_rn(0.8, __dsub_rn(b.y, a.y)),
+                         __dmul_rn(h04, __dadd_rn(f.y, g.y)));
+        local += ratio_sq<false>(er, a, b, atol_vec, atol_s, rtol, i, n_valid);
+    }
+    block_partial(local, partials);
+}
+// sum (x - y)^2  (y may be nullptr)
+__global__ __launch_bounds__(kBlock) void k_sumsq(
+    const double *__restrict__ x, const double *__restrict__ y, size_t n2,
+    double *__restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 a = ld2(x, i);
+        if (y) {
+            const double2 b = ld2(y, i);
+            a.x -= b.x;
+            a.y -= b.y;
+        }
+        local += a.x * a.x + a.y * a.y;
+    }
+    block_partial(local, partials);
+}
+// dst = a + alpha*(b - c)   (a, c optional)
+__global__ __launch_bounds__(kBlock) void k_axpbmc(
+    double *__restrict__ dst, const double *__restrict__ a, double alpha,
+    const double *__restrict__ b, const double *__restrict__ c, size_t n2) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 d = ld2(b, i);
+        if (c) {
+            const double2 cc = ld2(c, i);
+            d.x = __dsub_rn(d.x, cc.x);
+            d.y = __dsub_rn(d.y, cc.y);
+        }
+        d.x = __dmul_rn(d.x, alpha);
+        d.y = __dmul_rn(d.y, alpha);
+        if (a) {
+            const double2 aa = ld2(a, i);
+            d.x = __dadd_rn(aa.x, d.x);
+            d.y = __dadd_rn(aa.y, d.y);
+        }
+        st2(dst, i, d);
+    }
+}
+// sum |(a - b) / (atol + rtol*|w|)|^2                  sommeijer.py:154-155
+__global__ __launch_bounds__(kBlock) void k_wdiff_sumsq(
+    const double *__restrict__ a, const double *__restrict__ b,
+    const double *__restrict__ w, const double *__restrict__ atol_vec,
+    double atol_s, double rtol, size_t n2, size_t n_valid,
+    double *__restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        const double2 aa = ld2(a, i), bb = ld2(b, i), ww = ld2(w, i);
+        double2 er;
+        er.x = __dsub_rn(aa.x, bb.x);
+        er.y = __dsub_rn(aa.y, bb.y);
+        local += ratio_sq<false>(er, ww, ww, atol_vec, atol_s, rtol, i, n_valid);
+    }
+    block_partial(local, partials);
+}
+
+}  // namespace esq

@@ -1,0 +1,321 @@
+"""Device-side objects: the per-solver HBM context and device RHS plugins.
+
+A `DeviceRHS` stands where the Python callable `fun(t, y)` stands in the
+reference (extensisq/common.py:356): it is still callable on host ndarrays (so
+scipy's own plumbing keeps working), but it also carries a C function pointer
+(`esq_rhs_fn`, include/extensisq_amd.h) that enqueues the evaluation on the
+solver's HIP stream, so the state never leaves HBM during a step.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (SLOT_ATOL, SLOT_K, SLOT_WORK, SLOT_Y, SLOT_YNEW,  # noqa: F401
+                   SLOT_YSTAGE, DeviceError, as_ptr, check)
+
+
+class DeviceContext:
+    """Thin owner of one `esq_ctx` (one device, one stream, one HBM slab)."""
+
+    def __init__(self, n, n_rows, is_complex=False, device=0):
+        self.lib = _lib.load()
+        self.n = int(n)
+        self.n_rows = int(n_rows)
+        self.is_complex = bool(is_complex)
+        self.dtype = np.complex128 if is_complex else np.float64
+        self.device = int(device)
+        handle = C.c_void_p()
+        code = self.lib.esq_create(C.byref(handle), self.device, self.n,
+                                   self.n_rows, int(self.is_complex))
+        self.handle = handle
+        if code != 0:
+            msg = self.lib.esq_last_error(handle) if handle else b""
+            if handle:
+                self.lib.esq_destroy(handle)
+            self.handle = None
+            raise DeviceError(
+                f"esq_create(device={device}, n={n}) failed with code {code}: "
+                f"{msg.decode(errors='replace') if msg else ''} -- an MI355X "
+                "and the built HIP library are required; there is no CPU path")
+        self._rhs_keepalive = None
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.esq_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, code, what):
+        check(code, self.handle, what)
+
+    # -- data
+    def upload(self, slot, row, arr):
+        dt = np.float64 if slot == SLOT_ATOL else self.dtype
+        a = np.ascontiguousarray(arr, dtype=dt)
+        if a.shape != (self.n,):
+            raise ValueError(f"expected shape ({self.n},), got {a.shape}")
+        self._chk(self.lib.esq_upload(self.handle, slot, row, as_ptr(a)),
+                  "esq_upload")
+
+    def download(self, slot, row=0):
+        dt = np.float64 if slot == SLOT_ATOL else self.dtype
+        out = np.empty(self.n, dtype=dt)
+        self._chk(self.lib.esq_download(self.handle, slot, row, as_ptr(out)),
+                  "esq_download")
+        return out
+
+    def download_last_K(self, row):
+        out = np.empty(self.n, dtype=self.dtype)
+        self._chk(self.lib.esq_rk_download_last_K(self.handle, row, as_ptr(out)),
+                  "esq_rk_download_last_K")
+        return out
+
+    def copy(self, dst_slot, dst_row, src_slot, src_row):
+        self._chk(self.lib.esq_copy(self.handle, dst_slot, dst_row, src_slot,
+                                    src_row), "esq_copy")
+
+    def synchronize(self):
+        self._chk(self.lib.esq_synchronize(self.handle), "esq_synchronize")
+
+    # -- method description
+    def set_tableau(self, A, B, Cc, E, fsal):
+        s = len(B)
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        Cc = np.ascontiguousarray(Cc, dtype=np.float64)
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        if A.shape != (s, s) or Cc.shape != (s,) or E.shape != (s + 1,):
+            raise ValueError("inconsistent tableau shapes")
+        self._chk(self.lib.esq_rk_set_tableau(self.handle, s, as_ptr(A),
+                                              as_ptr(B), as_ptr(Cc), as_ptr(E),
+                                              int(bool(fsal))),
+                  "esq_rk_set_tableau")
+
+    def set_tol(self, rtol, atol):
+        at = np.atleast_1d(np.ascontiguousarray(atol, dtype=np.float64))
+        self._chk(self.lib.esq_set_tol(self.handle, float(rtol), as_ptr(at),
+                                       at.size), "esq_set_tol")
+
+    def set_rhs(self, rhs):
+        """rhs: a bound DeviceRHS (or None to clear)"""
+        if rhs is None:
+            self._chk(self.lib.esq_set_rhs(self.handle, None, None), "esq_set_rhs")
+            self._rhs_keepalive = None
+            return
+        fn, user = rhs._bind(self)
+        self._rhs_keepalive = (rhs, fn)
+        self._chk(self.lib.esq_set_rhs(self.handle, C.cast(fn, C.c_void_p), user),
+                  "esq_set_rhs")
+
+    # -- scalar-returning launches
+    def _scalar(self, fn, what, *args):
+        out = C.c_double()
+        self._chk(fn(self.handle, *args, C.byref(out)), what)
+        return out.value
+
+    def rk_error_norm_sumsq(self, h):
+        return self._scalar(self.lib.esq_rk_error_norm, "esq_rk_error_norm", h)
+
+    def rk_solution_error_sumsq(self, t, h):
+        return self._scalar(self.lib.esq_rk_solution_error,
+                            "esq_rk_solution_error", t, h)
+
+    def rk_pre_error_sumsq(self, h, e_pre, b_scale_pre):
+        e = np.ascontiguousarray(e_pre, dtype=np.float64)
+        b = np.ascontiguousarray(b_scale_pre, dtype=np.float64)
+        return self._scalar(self.lib.esq_rk_pre_error, "esq_rk_pre_error", h,
+                            as_ptr(e), as_ptr(b), len(e))
+
+    # -- profiling (bench.py)
+    def profile_enable(self, on=True):
+        self._chk(self.lib.esq_profile_enable(self.handle, int(on)),
+                  "esq_profile_enable")
+
+    def profile_reset(self):
+        self._chk(self.lib.esq_profile_reset(self.handle), "esq_profile_reset")
+
+    def profile_read(self, klass):
+        ms, cnt, by = C.c_double(), C.c_long(), C.c_double()
+        self._chk(self.lib.esq_profile_read(self.handle, klass, C.byref(ms),
+                                            C.byref(cnt), C.byref(by)),
+                  "esq_profile_read")
+        return ms.value, cnt.value, by.value
+
+
+# ----------------------------------------------------------------------------
+# device RHS plugins
+# ----------------------------------------------------------------------------
+class DeviceRHS:
+    """Base class of right-hand sides that run on the GPU.
+
+    Subclasses implement `_create(lib, device) -> (fn_ptr, user_ptr)` and give
+    `n` (number of doubles of the state).  Instances are callable on host
+    arrays: `rhs(t, y)` uploads, evaluates on the device and downloads -- used
+    only off the hot path (first-step estimate, user curiosity)."""
+
+    n = None
+    is_complex = False
+
+    def __init__(self):
+        self._bound = {}       # device -> (fn, user)
+        self._host_ctx = None
+
+    def _create(self, lib, device):
+        raise NotImplementedError
+
+    def _bind(self, ctx):
+        if ctx.n != self.n:
+            raise ValueError(f"RHS is for n={self.n}, solver state has n={ctx.n}")
+        key = ctx.device
+        if key not in self._bound:
+            self._bound[key] = self._create(ctx.lib, ctx.device)
+        return self._bound[key]
+
+    def __call__(self, t, y):
+        y = np.asarray(y)
+        if y.ndim != 1:
+            raise ValueError("device RHS plugins take one state vector")
+        if self._host_ctx is None:
+            self._host_ctx = DeviceContext(self.n, 2, self.is_complex)
+            self._host_ctx.set_rhs(self)
+        ctx = self._host_ctx
+        ctx.upload(SLOT_Y, 0, y)
+        ctx._chk(ctx.lib.esq_rk_eval_rhs(ctx.handle, 0, float(t), SLOT_Y, 0),
+                 "esq_rk_eval_rhs")
+        return ctx.download(SLOT_K, 0)
+
+    def close(self):
+        lib = _lib.load()
+        if self._host_ctx is not None:
+            self._host_ctx.close()
+            self._host_ctx = None
+        for fn, user in self._bound.values():
+            if user:
+                lib.esq_rhs_free(user)
+        self._bound = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Builtin(DeviceRHS):
+    _symbol = None
+
+    def _make_user(self, lib, device):
+        raise NotImplementedError
+
+    def _create(self, lib, device):
+        user = self._make_user(lib, device)
+        fn = getattr(lib, self._symbol)
+        return fn, user
+
+
+class DiagonalLinear(_Builtin):
+    """f = lam * y + amp * sin(t)   (lam: vector of n reals)"""
+    _symbol = "esq_rhs_diag"
+
+    def __init__(self, lam, forcing_amp=0.0):
+        super().__init__()
+        self.lam = np.ascontiguousarray(lam, dtype=np.float64)
+        self.amp = float(forcing_amp)
+        self.n = self.lam.size
+
+    def _make_user(self, lib, device):
+        user = C.c_void_p()
+        check(lib.esq_rhs_diag_create(C.byref(user), device, as_ptr(self.lam),
+                                      self.n, self.amp), None,
+              "esq_rhs_diag_create")
+        return user
+
+
+class Heat2D(_Builtin):
+    """5-point heat equation on an N x N interior grid, Dirichlet 0
+    (BASELINE.json configs[1], configs[4]); twin of oracle/problems.py."""
+    _symbol = "esq_rhs_heat2d"
+
+    def __init__(self, N):
+        super().__init__()
+        self.N = int(N)
+        self.n = self.N * self.N
+
+    def _make_user(self, lib, device):
+        user = C.c_void_p()
+        check(lib.esq_rhs_heat2d_create(C.byref(user), self.N), None,
+              "esq_rhs_heat2d_create")
+        return user
+
+    def spectral_radius(self):
+        return 8.0 * (self.N + 1) ** 2
+
+
+class Brusselator2D(_Builtin):
+    """2-D Brusselator reaction-diffusion, periodic, y = [u.ravel(), v.ravel()]
+    (BASELINE.json configs[2], the north-star workload)."""
+    _symbol = "esq_rhs_bruss2d"
+
+    def __init__(self, N, alpha=0.1, a=1.0, b=3.4):
+        super().__init__()
+        self.N = int(N)
+        self.alpha, self.a, self.b = float(alpha), float(a), float(b)
+        self.n = 2 * self.N * self.N
+
+    def _make_user(self, lib, device):
+        user = C.c_void_p()
+        check(lib.esq_rhs_bruss2d_create(C.byref(user), self.N, self.alpha,
+                                         self.a, self.b), None,
+              "esq_rhs_bruss2d_create")
+        return user
+
+    def spectral_radius(self):
+        return 8.0 * self.alpha * self.N * self.N
+
+
+class Diffusion3D(_Builtin):
+    """7-point diffusion on an N^3 interior grid, Dirichlet 0
+    (BASELINE.json configs[3])."""
+    _symbol = "esq_rhs_diff3d"
+
+    def __init__(self, N):
+        super().__init__()
+        self.N = int(N)
+        self.n = self.N ** 3
+
+    def _make_user(self, lib, device):
+        user = C.c_void_p()
+        check(lib.esq_rhs_diff3d_create(C.byref(user), self.N), None,
+              "esq_rhs_diff3d_create")
+        return user
+
+    def spectral_radius(self):
+        return 12.0 * (self.N + 1) ** 2
+
+
+class CFunctionRHS(DeviceRHS):
+    """A user-compiled plugin: `fn_ptr` is the address of an `esq_rhs_fn`
+    (see include/extensisq_amd.h), `user_ptr` its opaque argument."""
+
+    def __init__(self, fn_ptr, user_ptr, n, is_complex=False):
+        super().__init__()
+        self._fn = _lib.RHS_FN(fn_ptr) if isinstance(fn_ptr, int) else fn_ptr
+        self._user = C.c_void_p(user_ptr) if isinstance(user_ptr, int) else user_ptr
+        self.n = int(n)
+        self.is_complex = bool(is_complex)
+
+    def _create(self, lib, device):
+        return self._fn, None if self._user is None else self._user
+
+    def close(self):
+        if self._host_ctx is not None:
+            self._host_ctx.close()
+            self._host_ctx = None
+        self._bound = {}

@@ -1,0 +1,374 @@
+"""SSV2stab: the Runge-Kutta-Chebyshev method of Sommeijer, Shampine & Verwer
+(J. Comput. Appl. Math. 88 (1998) 315-326, code rkc.f) with the state resident
+in MI355X HBM.  Reference counterpart: extensisq/sommeijer.py:17-406.
+
+Per step the device runs m (2 ... ~1000) internal stages
+    y_j = mu*y_{j-1} + nu*y_{j-2} + (1-mu-nu)*y_n + h*mus*(f(y_{j-1}) - a*f_n)
+as one fused 5-read/1-write kernel each (`esq_rkc_stage`); the two full vector
+copies the reference makes per stage (sommeijer.py:318-319) are replaced by
+rotating three work rows.  The Chebyshev scalar recurrences, the choice of m,
+the H211-type controller and the power-iteration control flow are host scalar
+code below; norms come back as one double per call.
+"""
+import ctypes as C
+from math import cosh, log, sinh, sqrt
+from warnings import warn
+
+import numpy as np
+from scipy.integrate._ivp.base import OdeSolver
+from scipy.integrate._ivp.common import (validate_first_step,
+                                         validate_max_step, warn_extraneous)
+
+from ._lib import SLOT_K, as_ptr
+from .common import NFS, CubicDenseOutput, validate_tol
+from .device import DeviceContext, DeviceRHS
+
+nrejct = NFS                  # rejected steps (shared counter)
+nfesig = np.array(0)          # RHS evaluations spent on spectral-radius estimates
+maxm = np.array(0)            # largest stage count used
+
+
+def chebyshev_scalars(m, t, h):
+    """Coefficients of the m-stage second-order Chebyshev recursion
+    (ref sommeijer.py:278-314).  Returns (h*mus_1, table) where table is an
+    (m-1, 5) array of (mu, nu, h*mus, ajm1, t + h*theta_{j-1}) for j = 2..m."""
+    w0 = 1.0 + 2.0 / (13.0 * m ** 2)
+    sq = w0 ** 2 - 1.0
+    rt = sqrt(sq)
+    arg = m * log(w0 + rt)
+    w1 = sinh(arg) * sq / (cosh(arg) * m * rt - w0 * sinh(arg))
+    b_prev = b_prev2 = 1.0 / (2.0 * w0) ** 2
+    mus1 = w1 * b_prev
+    th_prev2, th_prev = 0.0, mus1
+    z_prev, z_prev2 = w0, 1.0
+    dz_prev, dz_prev2 = 1.0, 0.0
+    d2z_prev, d2z_prev2 = 0.0, 0.0
+    table = np.empty((max(m - 1, 0), 5))
+    for j in range(2, m + 1):
+        z = 2.0 * w0 * z_prev - z_prev2
+        dz = 2.0 * w0 * dz_prev - dz_prev2 + 2.0 * z_prev
+        d2z = 2.0 * w0 * d2z_prev - d2z_prev2 + 4.0 * dz_prev
+        b = d2z / dz ** 2
+        a_prev = 1.0 - z_prev * b_prev
+        mu = 2.0 * w0 * b / b_prev
+        nu = -b / b_prev2
+        mus = mu * w1 / w0
+        table[j - 2] = (mu, nu, h * mus, a_prev, t + h * th_prev)
+        th = mu * th_prev + nu * th_prev2 + mus * (1.0 - a_prev)
+        th_prev2, th_prev = th_prev, th
+        b_prev2, b_prev = b_prev, b
+        z_prev2, z_prev = z_prev, z
+        dz_prev2, dz_prev = dz_prev, dz
+        d2z_prev2, d2z_prev = d2z_prev, d2z
+    return h * mus1, table
+
+
+class SSV2stab(OdeSolver):
+    """Stabilized second-order RKC solver (device-resident).  Same constructor
+    as the reference (sommeijer.py:93-95) plus `device` and `lockstep`."""
+
+    # physical row roles inside the context (rotated on the host)
+    _N_ROWS = 8
+
+    def __init__(self, fun, t0, y0, t_bound, max_step=np.inf, rtol=1e-3,
+                 atol=1e-6, vectorized=False, first_step=None,
+                 const_jac=False, rho_jac=None, device=0, lockstep=None,
+                 **extraneous):
+        warn_extraneous(extraneous)
+        self._dev = None
+        self._y_host = None
+        self._device_rhs = fun if isinstance(fun, DeviceRHS) else None
+        super().__init__(fun, t0, y0, t_bound, vectorized,
+                         support_complex=False)
+        y_host = self._y_host
+        self.absh = (None if first_step is None
+                     else validate_first_step(first_step, t0, t_bound))
+        self.hold = None
+        if not isinstance(const_jac, bool):
+            raise TypeError('`const_jac` should be True or False')
+        if rho_jac is not None:
+            if not callable(rho_jac):
+                raise TypeError('`rho_jac` should be None or a function: '
+                                '`sprad = rho_jac(t, y)`')
+            probe = rho_jac(self.t, y_host)
+            if not isinstance(probe, float):
+                raise TypeError('`rho_jac` should return a float')
+            if probe <= 0:
+                raise ValueError('`rho_jac` should return a positive float')
+        self.const_jac = const_jac
+        self.rho_jac = rho_jac
+        self.max_step = validate_max_step(max_step)
+        self.rtol, self.atol = validate_tol(rtol, atol, y_host)
+        fi = np.finfo(y_host.dtype)
+        self.uround = np.nextafter(fi.epsneg, 1)
+        self.sqrtu = sqrt(self.uround)
+        self.sqrtmin = sqrt(fi.tiny)
+        nrejct[()] = 0
+        nfesig[()] = 0
+        maxm[()] = 0
+        self.nstsig = 0
+        self.mlim = 0
+        self.mmax = max(int(round(sqrt(self.rtol / (10.0 * self.uround)))), 2)
+        self.newspc = True
+        self.jacatt = False
+
+        # ---- device state: 8 rows, roles rotated by index
+        self._dev = DeviceContext(self.n, self._N_ROWS, False, device)
+        self._lib = self._dev.lib
+        self._ctx = self._dev.handle
+        self._dev.set_tol(self.rtol, self.atol)
+        self._r = dict(yn=0, fn=1, w=[2, 3, 4], yold=5, fold=6, V=7)
+        self._have_V = False
+        self._n_norm = self.n
+        if lockstep is not None:
+            self._dev._chk(self._lib.esq_set_comm(self._ctx, lockstep.comm),
+                           "esq_set_comm")
+            self._n_norm = lockstep.n_total
+        self._dev.upload(SLOT_K, self._r["yn"], y_host)
+        if self._device_rhs is not None:
+            self._dev.set_rhs(self._device_rhs)
+            self._eval_rhs(self._r["fn"], self.t, self._r["yn"])
+        else:
+            self._dev.upload(SLOT_K, self._r["fn"], self.fun(self.t, y_host))
+
+        max_step = min(self.max_step, abs(self.t_bound - self.t))
+        self.max_step = min(max_step, sqrt(fi.max))
+        hmin = abs(self.t)
+        if self.t_bound != np.inf:
+            hmin = max(hmin, abs(self.max_step))
+        self.hmin = max(self.sqrtmin, 10.0 * self.uround * hmin)
+
+    # --------------------------------------------------------------- helpers
+    def _chk(self, code, what):
+        self._dev._chk(code, what)
+
+    @property
+    def y(self):
+        if self._y_host is None:
+            self._y_host = self._dev.download(SLOT_K, self._r["yn"])
+        return self._y_host
+
+    @y.setter
+    def y(self, value):
+        self._y_host = value
+        if self._dev is not None and value is not None:
+            self._dev.upload(SLOT_K, self._r["yn"], value)
+
+    def _eval_rhs(self, dst, t, src, count=True):
+        """row[dst] = fun(t, row[src]); `count=False` mirrors `fun_single`
+        (no nfev increment, ref sommeijer.py:369-372)"""
+        if self._device_rhs is not None:
+            self._chk(self._lib.esq_rkc_eval_rhs(self._ctx, dst, float(t), src),
+                      "esq_rkc_eval_rhs")
+            if count:
+                self.nfev += 1
+        else:
+            arg = self._dev.download(SLOT_K, src)
+            val = self.fun(t, arg) if count else self.fun_single(t, arg)
+            self._dev.upload(SLOT_K, dst, val)
+
+    def _sumsq(self, x, y=-1):
+        out = C.c_double()
+        self._chk(self._lib.esq_vec_sumsq(self._ctx, x, y, C.byref(out)),
+                  "esq_vec_sumsq")
+        return out.value
+
+    def _axpbmc(self, dst, a, alpha, b, c=-1):
+        self._chk(self._lib.esq_vec_axpbmc(self._ctx, dst, a, float(alpha), b, c),
+                  "esq_vec_axpbmc")
+
+    def _rms(self, sumsq):
+        return (sumsq / self._n_norm) ** 0.5 if self._n_norm else np.nan
+
+    # ------------------------------------------------------------ first step
+    def _init_step_size(self, t):
+        """ref sommeijer.py:147-160"""
+        r = self._r
+        absh = self.max_step
+        if self.sprad * absh > 1.0:
+            absh = 1.0 / self.sprad
+        absh = max(absh, self.hmin)
+        w1, w2 = r["w"][0], r["w"][1]
+        self._chk(self._lib.esq_rkc_first_stage(self._ctx, w1, r["yn"], r["fn"],
+                                                absh), "esq_rkc_first_stage")
+        self._eval_rhs(w2, t + absh, w1)
+        out = C.c_double()
+        self._chk(self._lib.esq_vec_wdiff_sumsq(self._ctx, w2, r["fn"], r["yn"],
+                                                C.byref(out)),
+                  "esq_vec_wdiff_sumsq")
+        est = absh * self._rms(out.value)
+        if 0.1 * absh < self.max_step * sqrt(est):
+            return max(0.1 * absh / sqrt(est), self.hmin)
+        return self.max_step
+
+    # ------------------------------------------------------------- the stages
+    def _stages(self, t, h, m):
+        """all m stages on the device; returns the row holding y_{n+1}
+        (ref sommeijer.py:273-329)"""
+        r = self._r
+        hmus1, table = chebyshev_scalars(m, t, h)
+        w = r["w"]
+        if self._device_rhs is not None:
+            yrow = C.c_int()
+            tab = np.ascontiguousarray(table)
+            self._chk(self._lib.esq_rkc_stages(
+                self._ctx, r["yn"], r["fn"], w[0], w[1], w[2], hmus1, m,
+                as_ptr(tab), C.byref(yrow)), "esq_rkc_stages")
+            self.nfev += m - 1
+            return yrow.value
+        # host-RHS mode: same rotation, RHS through Python
+        self._chk(self._lib.esq_rkc_first_stage(self._ctx, w[0], r["yn"],
+                                                r["fn"], hmus1),
+                  "esq_rkc_first_stage")
+        jm1, jm2, free, spare = w[0], r["yn"], w[1], w[2]
+        ycur = w[0]
+        for mu, nu, hmus, ajm1, t_stage in table:
+            self._eval_rhs(free, t_stage, jm1)
+            self._chk(self._lib.esq_rkc_stage(self._ctx, free, free, jm1, jm2,
+                                              r["yn"], r["fn"], mu, nu, hmus,
+                                              ajm1), "esq_rkc_stage")
+            ycur = free
+            released = jm2
+            jm2, jm1 = jm1, ycur
+            free = spare if released == r["yn"] else released
+        return ycur
+
+    # ------------------------------------------------------ spectral radius
+    def _rho(self, t):
+        """nonlinear power iteration for the spectral radius
+        (ref sommeijer.py:331-398); returns None on non-convergence"""
+        r = self._r
+        yn, fn, V = r["yn"], r["fn"], r["V"]
+        v, fv = r["w"][0], r["w"][1]
+        small = 1.0 / self.max_step
+        if not self._have_V:
+            self._dev.copy(SLOT_K, V, SLOT_K, fn)
+            self._have_V = True
+        ynrm = sqrt(self._sumsq(yn))
+        vnrm = sqrt(self._sumsq(V))
+        if ynrm != 0.0 and vnrm != 0.0:
+            dynrm = ynrm * self.sqrtu
+            self._axpbmc(v, yn, dynrm / vnrm, V)
+        elif ynrm != 0.0:
+            dynrm = ynrm * self.sqrtu
+            self._axpbmc(v, -1, 1.0 + self.sqrtu, V)
+        elif vnrm != 0.0:
+            dynrm = self.uround
+            self._axpbmc(v, -1, dynrm / vnrm, V)
+        else:
+            dynrm = self.uround
+            self._dev.upload(SLOT_K, v, np.full(self.n, dynrm))
+        sigma = 0.0
+        for it in range(50):
+            self._eval_rhs(fv, t, v, count=False)
+            nfesig[()] += 1
+            dfnrm = sqrt(self._sumsq(fv, fn))
+            sigma_last = sigma
+            sigma = dfnrm / dynrm
+            sprad = 1.2 * sigma
+            if it and abs(sigma - sigma_last) <= max(sigma, small) * 0.01:
+                self._axpbmc(V, -1, 1.0, v, yn)
+                return sprad
+            if dfnrm != 0.0:
+                self._axpbmc(v, yn, dynrm / dfnrm, fv, fn)
+            else:
+                vec = self._dev.download(SLOT_K, v)
+                idx = it % self.n
+                vec[idx] = -vec[idx]
+                self._dev.upload(SLOT_K, v, vec)
+        return None
+
+    # ------------------------------------------------------------------ step
+    def _step_impl(self):
+        """ref sommeijer.py:162-271 (subroutine RKCLOW of rkc.f)"""
+        t = self.t
+        absh = self.absh
+        r = self._r
+        while True:
+            if self.newspc:
+                if self.rho_jac is not None:
+                    self.sprad = self.rho_jac(t, self.y)
+                else:
+                    self.sprad = self._rho(t)
+                    if self.sprad is None:
+                        return False, ("The method to estimate the spectral "
+                                       "radius of the Jacobian did not converge")
+                self.jacatt = True
+            if absh is None:
+                absh = self._init_step_size(t)
+            if 1.1 * absh >= abs(self.t_bound - t):
+                absh = abs(self.t_bound - t)
+            m = 1 + int(sqrt(1.54 * absh * self.sprad + 1.0))
+            if m > self.mmax:
+                m = self.mmax
+                absh = (m ** 2 - 1) / (1.54 * self.sprad)
+                self.mlim += 1
+                if self.mlim == 15:
+                    warn('Your problem is too stiff for this method.')
+            else:
+                self.mlim = 0
+            maxm[()] = max(m, maxm[()])
+            h = self.direction * absh
+            hmin = max(self.sqrtmin,
+                       13.3 * self.uround * (abs(t) + absh) * (m ** 2 - 1))
+            yrow = self._stages(t, h, m)
+            fyrow = next(w for w in r["w"] if w != yrow)
+            self._eval_rhs(fyrow, t + h, yrow)
+            out = C.c_double()
+            self._chk(self._lib.esq_rkc_error_norm(
+                self._ctx, yrow, r["yn"], r["fn"], fyrow, h, C.byref(out)),
+                "esq_rkc_error_norm")
+            err = self._rms(out.value)
+            if err < 1.0:
+                break
+            if np.isnan(err) or np.isinf(err):
+                return False, "Overflow or underflow encountered."
+            nrejct[()] += 1
+            absh = 0.8 * absh / err ** (1 / 3)
+            if absh < hmin:
+                return False, self.TOO_SMALL_STEP
+            self.newspc = not self.jacatt
+            self.absh = absh
+
+        # accepted: rotate the roles instead of copying W (ref :245-251)
+        t += h
+        self.jacatt = self.const_jac
+        self.nstsig = (self.nstsig + 1) % 25
+        self.newspc = False
+        if self.rho_jac is not None or self.nstsig == 0:
+            self.newspc = not self.jacatt
+        spare = [w for w in r["w"] if w not in (yrow, fyrow)]
+        r["w"] = spare + [r["yold"], r["fold"]]
+        r["yold"], r["fold"] = r["yn"], r["fn"]
+        r["yn"], r["fn"] = yrow, fyrow
+        self._y_host = None
+
+        fac = 10.0
+        if self.hold is None:
+            temp2 = err ** (1 / 3)
+            if 0.8 < fac * temp2:
+                fac = 0.8 / temp2
+        else:
+            temp1 = 0.8 * absh * self.errold ** (1 / 3)
+            temp2 = abs(self.hold) * err ** (2 / 3)
+            if temp1 < fac * temp2:
+                fac = temp1 / temp2
+        absh = max(0.1, fac) * absh
+        self.absh = max(hmin, min(self.max_step, absh))
+        self.errold = err
+        self.hold = h
+        self.t = t
+        return True, None
+
+    def _dense_output_impl(self):
+        """cubic Hermite through (y_old, f_old), (y, f)  (ref :400-406)"""
+        r = self._r
+        dl = self._dev.download
+        return CubicDenseOutput(self.t_old, self.t, dl(SLOT_K, r["yold"]),
+                                dl(SLOT_K, r["yn"]), dl(SLOT_K, r["fold"]),
+                                dl(SLOT_K, r["fn"]))
+
+    def __del__(self):
+        dev = getattr(self, "_dev", None)
+        if dev is not None:
+            dev.close()

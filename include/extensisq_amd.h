@@ -1,0 +1,226 @@
+/*
+ * extensisq_amd.h -- C ABI of libextensisq_amd.so (gfx950 / MI355X)
+ *
+ * Drop-in boundary for ONE hot path of the reference package extensisq v0.6.0
+ * (pure Python/NumPy): the adaptive explicit Runge-Kutta step
+ *     RungeKutta._step_impl            extensisq/common.py:222-308
+ *     BS5._step_impl                   extensisq/bogacki.py:238-338
+ *     SSV2stab._step_impl / _stages    extensisq/sommeijer.py:162-329
+ * The reference has no FFI of its own (it is NumPy all the way down); every
+ * entry point below replaces the NumPy expression(s) cited next to it.  The
+ * step-size controller, the accept/reject decision and all scalar recurrences
+ * stay on the host (Python, extensisq_amd/common.py); one double -- the sum of
+ * squares of the weighted error -- crosses back per step attempt.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a positive hipError_t / ncclResult_t
+ *     (+1000) on a runtime failure, a negative ESQ_E* code on misuse;
+ *     esq_last_error(ctx) gives the text.
+ *   - all vectors are fp64 ("double"); a complex state of n elements is n
+ *     interleaved (re, im) pairs and is created with is_complex = 1.
+ *   - host pointers are borrowed for the duration of the call only.
+ *   - a context is bound to one device and one HIP stream; calls on one context
+ *     must come from one host thread at a time (the library holds no global
+ *     state, so one thread per context is fine).
+ *   - functions that return a host scalar synchronise the context's stream;
+ *     all others only enqueue work.
+ */
+#ifndef EXTENSISQ_AMD_H
+#define EXTENSISQ_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESQ_ABI_VERSION 1
+
+/* error codes (negative = misuse) */
+#define ESQ_EINVAL   (-1)   /* bad argument (row/slot out of range, NULL, ...) */
+#define ESQ_ESTATE   (-2)   /* call out of order (no tableau / no RHS set)     */
+#define ESQ_ENOMEM   (-3)   /* host allocation failed                          */
+#define ESQ_ERHS     (-4)   /* the RHS plugin returned non-zero                */
+
+/* vector slots of a context (row is ignored unless slot == ESQ_SLOT_K) */
+#define ESQ_SLOT_K       0  /* stage derivatives K[row], row < n_rows          */
+#define ESQ_SLOT_Y       1  /* current state y                                 */
+#define ESQ_SLOT_YNEW    2  /* tentative state y_new (== y_old after accept)   */
+#define ESQ_SLOT_YSTAGE  3  /* stage argument  y + h * sum_j a_ij K_j          */
+#define ESQ_SLOT_ATOL    4  /* per-component absolute tolerance (real, n)      */
+#define ESQ_SLOT_WORK    5  /* scratch (error vector, dense output, ...)       */
+
+typedef struct esq_ctx esq_ctx;
+
+/*
+ * Device RHS plugin: enqueue f_dev = fun(t, y_dev) on `hip_stream` (a
+ * hipStream_t) and return 0.  n counts doubles (2n' for a complex state).
+ * Replaces the Python callable `fun(t, y)` of scipy's OdeSolver contract
+ * (scipy/integrate/_ivp/base.py:139-166) for states that live in HBM.
+ */
+typedef int (*esq_rhs_fn)(void *user, double t, const double *y_dev,
+                          double *f_dev, size_t n, void *hip_stream);
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int  esq_abi_version(void);
+/* n: state dimension (complex elements if is_complex); n_rows: rows of K
+ * (n_stages + 1, plus extra rows for BS5's interpolants / RKC work vectors).
+ * Replaces `self.K = np.empty((n_stages + 1, n))`  common.py:216 and the
+ * per-step temporaries of common.py:343-356. */
+int  esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex);
+int  esq_destroy(esq_ctx *ctx);
+const char *esq_last_error(const esq_ctx *ctx);
+int  esq_synchronize(esq_ctx *ctx);
+/* number of doubles one vector holds on the device (n or 2n) */
+size_t esq_vector_len(const esq_ctx *ctx);
+
+/* ---- data movement ------------------------------------------------------ */
+/* `K[i] = f` (common.py:240), `y0` upload, and the lazy host mirror of
+ * solver.y / solver.K.  Synchronous.  K rows are addressed LOGICALLY (row 0 is
+ * always the first stage of the step in flight; esq_rk_accept rotates). */
+int  esq_upload(esq_ctx *ctx, int slot, int row, const double *host);
+int  esq_download(esq_ctx *ctx, int slot, int row, double *host);
+/* device-to-device copy between two (slot,row) vectors, asynchronous */
+int  esq_copy(esq_ctx *ctx, int dst_slot, int dst_row, int src_slot, int src_row);
+
+/* ---- method description ------------------------------------------------- */
+/* Butcher tableau: A is s*s row-major (strictly lower triangular), B[s], C[s],
+ * E[s+1]; fsal != 0 iff E[s] != 0 (common.py:217).  Zero coefficients are
+ * skipped by the kernels (only 0*Inf NaN propagation differs from NumPy).
+ * Mirrors the class attributes A, B, C, E of common.py:97-107. */
+int  esq_rk_set_tableau(esq_ctx *ctx, int s, const double *A, const double *B,
+                        const double *C, const double *E, int fsal);
+/* rtol scalar, atol scalar (n_atol == 1) or per-component (n_atol == n);
+ * values as returned by validate_tol  common.py:30-54. */
+int  esq_set_tol(esq_ctx *ctx, double rtol, const double *atol, size_t n_atol);
+int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
+
+/* ---- explicit RK launches ----------------------------------------------- */
+/* YSTAGE = Y + h * sum_j A[i][j] * K[j]           common.py:355 (`dy`, `y+dy`) */
+int  esq_rk_stage_accumulate(esq_ctx *ctx, int i, double h);
+/* K[dst_row] = rhs(t, <src vector>)                common.py:356, 348, 291    */
+int  esq_rk_eval_rhs(esq_ctx *ctx, int dst_row, double t, int src_slot,
+                     int src_row);
+/* for i in [i_from, i_to): stage_accumulate(i, h); K[i] = rhs(t + C[i]*h, YSTAGE)
+ *                                                  common.py:241-242, 353-356 */
+int  esq_rk_stages(esq_ctx *ctx, int i_from, int i_to, double t, double h);
+/* YNEW = Y + h * sum_j B[j] K[j]                   common.py:343              */
+int  esq_rk_solution(esq_ctx *ctx, double h);
+/* sum over elements of |h * sum_j E[j] K[j] / scale|^2 with
+ * scale = atol + rtol * max(|Y|, |YNEW|)           common.py:335-339, 57-66
+ * (host finishes with sqrt(sumsq / n)).  Synchronises. */
+int  esq_rk_error_norm(esq_ctx *ctx, double h, double *sumsq_out);
+/* Whole `_comp_sol_err` (common.py:341-351) with a device RHS: solution, the
+ * FSAL evaluation K[s] = rhs(t + h, YNEW) if the tableau is FSAL, error norm.
+ * Non-FSAL tableaux use ONE fused pass (solution + scale + error).
+ * Synchronises. */
+int  esq_rk_solution_error(esq_ctx *ctx, double t, double h, double *sumsq_out);
+/* BS5's early estimate (bogacki.py:340-346) over K[0..rows): YSTAGE-free,
+ * y_pre = Y + h*sum b_scale_pre[j] K[j] is formed in registers only.
+ * Synchronises. */
+int  esq_rk_pre_error(esq_ctx *ctx, double h, const double *e_pre,
+                      const double *b_scale_pre, int rows, double *sumsq_out);
+/* Accept the attempt (common.py:289-303): non-FSAL tableaux with a device RHS
+ * get K[s] = rhs(t_new, YNEW); then Y <-> YNEW are swapped and K[s] becomes the
+ * new K[0] by pointer rotation (no copies).  with_end_eval = 0 skips the RHS
+ * launch (host-RHS mode uploads K[s] itself before calling this). */
+int  esq_rk_accept(esq_ctx *ctx, double t_new, int with_end_eval);
+/* WORK = h * sum_j E[j] K[j]  (the vector `_estimate_error` returns,
+ * common.py:333-336); K rows of the step just accepted if last_step != 0. */
+int  esq_rk_error_vector(esq_ctx *ctx, double h, int last_step);
+/* logical->physical row of K for the step just accepted (for solver.K) */
+int  esq_rk_download_last_K(esq_ctx *ctx, int row, double *host);
+
+/* ---- dense output (common.py:358-368, 766-790) --------------------------- */
+/* Q[:, c] = sum_r K_last[r] * P[r][c] for c < p, evaluated on the device and
+ * written to host as an (n, p) row-major matrix.  P is (n_rows_used, p). */
+int  esq_rk_dense_coefficients(esq_ctx *ctx, const double *P, int rows, int p,
+                               double *Q_host);
+
+/* Extra stages of BS5's 'low'/'best' interpolants (bogacki.py:356-368), on the
+ * rows of the step just accepted:
+ *   YSTAGE = y_old + h * sum_{j<count} a[j] * K_last[j]   (y_old: pre-step state)
+ *   K_last[row] = rhs(t, YSTAGE)          -- or uploaded by the host */
+int  esq_rk_dense_stage(esq_ctx *ctx, int row, const double *a, int count,
+                        double h);
+int  esq_rk_dense_eval(esq_ctx *ctx, int row, double t);
+int  esq_rk_upload_last_K(esq_ctx *ctx, int row, const double *host);
+
+/* ---- Runge-Kutta-Chebyshev (SSV2stab) launches -------------------------- */
+/* Rows are PHYSICAL K rows chosen by the host (it rotates them instead of the
+ * two full copies of sommeijer.py:318-319).
+ * dst = yn + hmus * fn                              sommeijer.py:289          */
+int  esq_rkc_first_stage(esq_ctx *ctx, int dst, int yn, int fn, double hmus);
+/* dst = mu*yjm1 + nu*yjm2 + (1-mu-nu)*yn + hmus*(fy - ajm1*fn)
+ *                                                   sommeijer.py:312-313      */
+int  esq_rkc_stage(esq_ctx *ctx, int dst, int fy, int yjm1, int yjm2, int yn,
+                   int fn, double mu, double nu, double hmus, double ajm1);
+/* all m stages of one step incl. the RHS launches (sommeijer.py:273-329);
+ * scalars[5*(j-2)..] = (mu, nu, hmus, ajm1, t_stage) for j = 2..m.  The result
+ * is left in physical row *y_row_out. rows: yn, fn, and three work rows. */
+int  esq_rkc_stages(esq_ctx *ctx, int yn, int fn, int w0, int w1, int w2,
+                    double hmus1, int m, const double *scalars, int *y_row_out);
+/* sum |(0.8*(yn - y) + 0.4*h*(fn + fy)) / (atol + rtol*max(|y|,|yn|))|^2
+ *                                                   sommeijer.py:218-220      */
+int  esq_rkc_error_norm(esq_ctx *ctx, int y, int yn, int fn, int fy, double h,
+                        double *sumsq_out);
+/* generic K[dst] = rhs(t, K[src]) on physical rows   sommeijer.py:214, 311    */
+int  esq_rkc_eval_rhs(esq_ctx *ctx, int dst, double t, int src);
+/* sum x^2 and sum (x - y)^2 (np.linalg.norm pieces of sommeijer.py:350-374;
+ * y < 0 means "no subtraction") */
+int  esq_vec_sumsq(esq_ctx *ctx, int x, int y, double *sumsq_out);
+/* dst = a + alpha * (b - c)   (sommeijer.py:354, 389, 383; c < 0: no c;
+ * a < 0: no a) */
+int  esq_vec_axpbmc(esq_ctx *ctx, int dst, int a, double alpha, int b, int c);
+/* sum |(a - b) / (atol + rtol*|w|)|^2               sommeijer.py:154-155      */
+int  esq_vec_wdiff_sumsq(esq_ctx *ctx, int a, int b, int w, double *sumsq_out);
+
+/* ---- multi-GPU lock-step (BASELINE.json configs[4]; not in the reference) - */
+/* comm is an ncclComm_t created by the caller (one rank per GPU); every
+ * *_sumsq_out / error-norm entry point then all-reduces (sum) its double over
+ * the communicator before returning, so all ranks take identical decisions.
+ * n_total is informational (host divides by it). */
+int  esq_set_comm(esq_ctx *ctx, void *nccl_comm);
+/* helpers so the host never needs another RCCL binding */
+int  esq_comm_unique_id(void *id128_out);              /* 128-byte ncclUniqueId */
+int  esq_comm_init_rank(void **comm_out, int nranks, const void *id128, int rank,
+                        int device);
+int  esq_comm_destroy(void *comm);
+
+/* ---- built-in device RHS plugins (synthetic workloads of BASELINE.json) --- */
+/* each *_create returns an opaque `user` pointer to pass with the matching
+ * esq_rhs_* function to esq_set_rhs; free with esq_rhs_free. */
+int  esq_rhs_diag_create(void **user_out, int device, const double *lam_host,
+                         size_t n, double forcing_amp);  /* f = lam*y + amp*sin(t) */
+int  esq_rhs_heat2d_create(void **user_out, int N);       /* n = N*N            */
+int  esq_rhs_bruss2d_create(void **user_out, int N, double alpha, double a,
+                            double b);                    /* n = 2*N*N          */
+int  esq_rhs_diff3d_create(void **user_out, int N);       /* n = N*N*N          */
+int  esq_rhs_free(void *user);
+int  esq_rhs_diag(void *user, double t, const double *y, double *f, size_t n,
+                  void *stream);
+int  esq_rhs_heat2d(void *user, double t, const double *y, double *f, size_t n,
+                    void *stream);
+int  esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
+                     void *stream);
+int  esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
+                    void *stream);
+
+/* ---- measurement (bench.py `roofline`) ------------------------------------ */
+/* When enabled, every launch of the kernel classes below is bracketed by HIP
+ * events on the context's stream; esq_profile_read synchronises and returns
+ * the summed device time and launch count since the last reset. */
+#define ESQ_PROF_STAGE     0   /* stage-accumulate kernels                     */
+#define ESQ_PROF_RHS       1   /* RHS plugin launches                          */
+#define ESQ_PROF_SOLERR    2   /* solution / error-norm kernels (+final sum)   */
+#define ESQ_PROF_RKC       3   /* RKC stage kernels                            */
+#define ESQ_PROF_NCLASS    4
+int  esq_profile_enable(esq_ctx *ctx, int on);
+int  esq_profile_read(esq_ctx *ctx, int klass, double *total_ms, long *launches,
+                      double *bytes);
+int  esq_profile_reset(esq_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXTENSISQ_AMD_H */

@@ -1,0 +1,69 @@
+"""The C-ABI library loads and exports every symbol include/extensisq_amd.h
+declares (no compute calls: there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
+HEADER = os.path.join(ROOT, "include", "extensisq_amd.h")
+LIB = os.path.join(ROOT, "extensisq_amd", "libextensisq_amd.so")
+
+
+def header_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(esq_[A-Za-z0-9_]+)\s*\(", text))
+                  - {"esq_rhs_fn"})
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(LIB)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = header_symbols()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_the_header():
+    from extensisq_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+    bound = _lib.load()
+    assert bound.esq_abi_version() == 1
+
+
+def test_misuse_is_reported_not_crashing(lib):
+    lib.esq_last_error.restype = ctypes.c_char_p
+    assert lib.esq_create(None, 0, 8, 2, 0) == -1          # ESQ_EINVAL
+    assert lib.esq_rhs_heat2d_create(None, 4) == -1
+    assert lib.esq_last_error(None) == b"null context"
+
+
+def test_no_gpu_means_loud_failure():
+    """the product has no CPU fallback: constructing a solver without a GPU
+    raises (skipped on the GPU box, where construction succeeds)"""
+    import numpy as np
+    import extensisq_amd as esq
+    try:
+        s = esq.Pr8(lambda t, y: -y, 0.0, np.ones(4), 1.0)
+    except esq.DeviceError as exc:
+        assert "no CPU path" in str(exc) or "failed" in str(exc)
+    else:
+        assert s._dev.handle       # a real device context exists
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "extensisq_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src

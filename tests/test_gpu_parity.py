@@ -1,0 +1,400 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP path, called
+through the C ABI, against (a) the golden vectors recorded from the real
+reference and (b) the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64; SURVEY.md §7 "parity definition"): from identical (t, y, f, h)
+K and y_new agree to 1e-13 relative (max-norm, scaled by max|K|), error_norm
+and the next step size to 1e-10 relative; trajectories: identical accepted /
+rejected step counts and nfev, t_k to 1e-9 relative.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_equal
+from scipy.integrate import solve_ivp
+
+import extensisq_amd as esq
+from oracle import problems as pb
+from oracle import rk_oracle
+from tools_cases import bruss1d, single_step_cases
+
+pytestmark = pytest.mark.gpu
+
+ERK = ["BS5", "Ts5", "Pr7", "Pr8", "Pr9"]
+DEV = {n: getattr(esq, n) for n in ERK}
+
+
+@pytest.fixture(scope="module")
+def single(golden_dir):
+    return np.load(os.path.join(golden_dir, "erk_single_step.npz"))
+
+
+@pytest.fixture(scope="module")
+def traces(golden_dir):
+    with open(os.path.join(golden_dir, "erk_traces.json")) as fh:
+        return json.load(fh)
+
+
+def test_library_is_the_hip_build():
+    from extensisq_amd import _lib
+    lib = _lib.load()
+    assert lib.esq_abi_version() == 1
+    assert os.path.basename(_lib.LIB_PATH) == "libextensisq_amd.so"
+
+
+# ------------------------------------------------ golden single-step vectors
+@pytest.mark.parametrize("name", ERK)
+@pytest.mark.parametrize("pname", list(single_step_cases()))
+@pytest.mark.parametrize("direction", ["fwd", "bwd"])
+def test_single_step_golden(single, name, pname, direction):
+    """host-RHS mode (Python callable): all RK arithmetic on the GPU"""
+    fun, t0, y0, h = single_step_cases()[pname]
+    sign = 1 if direction == "fwd" else -1
+    key = f"{name}/{pname}/{direction}"
+    s = DEV[name](fun, t0, y0, t0 + sign * 10.0, first_step=abs(h), rtol=1e-6,
+                  atol=1e-9, nfev_stiff_detect=0)
+    assert s.step() is None
+    K = single[key + "/K"]
+    assert_allclose(s.K, K, rtol=0, atol=1e-13 * np.abs(K).max())
+    assert_allclose(s.y, single[key + "/y_new"], rtol=1e-13, atol=1e-300)
+    assert s.t == float(single[key + "/t_new"])
+    assert_allclose(s.error_norm_old, float(single[key + "/error_norm"]),
+                    rtol=1e-10)
+    assert_allclose(s.h_abs, float(single[key + "/h_abs_next"]), rtol=1e-10)
+    assert s.nfev == int(single[key + "/nfev"])
+    assert int(esq.NFS[()]) == int(single[key + "/nfs"])
+
+
+# -------------------------------------------- device RHS vs the CPU oracle
+def _pair(name, dev_rhs, cpu_rhs, t0, y0, tb, **kw):
+    d = DEV[name](dev_rhs, t0, y0, tb, **kw)
+    o = rk_oracle.METHODS[name](cpu_rhs, t0, y0, tb, **kw)
+    return d, o
+
+
+@pytest.mark.parametrize("name", ERK)
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 511, 513, 4099, 70001])
+def test_device_rhs_step_sizes(name, n):
+    """ragged sizes around the padding / block boundaries, device RHS"""
+    rng = np.random.default_rng(n)
+    lam = -rng.random(n) * 2.0
+    y0 = rng.standard_normal(n)
+    kw = dict(first_step=0.05, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+    d, o = _pair(name, esq.DiagonalLinear(lam, 1.0),
+                 lambda t, y: lam * y + np.sin(t), 0.3, y0, 5.0, **kw)
+    for _ in range(3):
+        assert d.step() is None and o.step() is None
+        assert d.t == o.t
+        scale = np.abs(o.K).max()
+        assert_allclose(d.K, o.K, rtol=0, atol=2e-13 * scale)
+        assert_allclose(d.y, o.y, rtol=2e-13, atol=1e-300)
+        assert_allclose(d.error_norm_old, o.error_norm_old, rtol=1e-9)
+        assert_allclose(d.h_abs, o.h_abs, rtol=1e-9)
+    assert d.nfev == o.nfev
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_atol_vector_and_rejections(name):
+    """per-component atol + a first step so large that steps are rejected"""
+    n = 1000
+    rng = np.random.default_rng(5)
+    lam = -rng.random(n) * 30.0
+    y0 = rng.standard_normal(n)
+    atol = 10.0 ** rng.uniform(-10, -6, n)
+    kw = dict(first_step=1.0, rtol=1e-7, atol=atol, nfev_stiff_detect=0)
+    d, o = _pair(name, esq.DiagonalLinear(lam), lambda t, y: lam * y, 0.0, y0,
+                 3.0, **kw)
+    nfs = []
+    for _ in range(4):
+        assert d.step() is None
+        nfs.append(int(esq.NFS[()]))
+    for k in range(4):
+        assert o.step() is None
+    assert nfs[-1] == int(rk_oracle.NFS[()]) and nfs[-1] > 0
+    assert d.nfev == o.nfev
+    assert_allclose(d.t, o.t, rtol=1e-9)
+    assert_allclose(d.y, o.y, rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,rhs,cpu,y0f,N", [
+    ("Ts5", esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 37),
+    ("Pr8", esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 50),
+    ("Pr9", esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 64),
+    ("BS5", esq.Diffusion3D, pb.diff3d_rhs, pb.diff3d_y0, 13),
+    ("Pr7", esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 31),
+])
+def test_pde_workloads(name, rhs, cpu, y0f, N):
+    """the BASELINE.json workloads at small N, 5 steps, device RHS"""
+    dev_rhs = rhs(N)
+    y0 = y0f(N)
+    h = 0.5 / dev_rhs.spectral_radius()
+    kw = dict(first_step=h, max_step=h, rtol=1e-6, atol=1e-9,
+              nfev_stiff_detect=0)
+    d, o = _pair(name, dev_rhs, cpu(N), 0.0, y0, 1.0, **kw)
+    for _ in range(5):
+        assert d.step() is None and o.step() is None
+        assert d.t == o.t
+        assert_allclose(d.K, o.K, rtol=0, atol=2e-13 * np.abs(o.K).max())
+        assert_allclose(d.y, o.y, rtol=2e-13, atol=1e-300)
+        assert_allclose(d.error_norm_old, o.error_norm_old, rtol=1e-8)
+    assert d.nfev == o.nfev
+
+
+@pytest.mark.parametrize("rhs,cpu,y0f,N", [
+    (esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 37),
+    (esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 300),
+    (esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 50),
+    (esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 301),
+    (esq.Diffusion3D, pb.diff3d_rhs, pb.diff3d_y0, 13),
+    (esq.Diffusion3D, pb.diff3d_rhs, pb.diff3d_y0, 40),
+])
+def test_builtin_rhs_bitwise(rhs, cpu, y0f, N):
+    """built-in device RHS == NumPy twin, bit for bit (same operation order,
+    library built with -ffp-contract=off)"""
+    r = rhs(N)
+    y = y0f(N) + 0.01 * np.random.default_rng(N).standard_normal(r.n)
+    assert_equal(r(0.0, y), cpu(N)(0.0, y))
+
+
+# ----------------------------------------------------------- trajectories
+CASES = {
+    "readme": (lambda t, y: -0.5 * y, [0, 10], [2, 4, 8], {}),
+    "duffing": (pb.duffing_rhs, [0.0, 20.0], [0.0, 0.0], {}),
+    "duffing_tight": (pb.duffing_rhs, [0.0, 20.0], [0.0, 0.0],
+                      dict(rtol=1e-9, atol=1e-12)),
+    "rational_fwd": (pb.rational_rhs, [5, 9], [1 / 3, 2 / 9],
+                     dict(rtol=1e-3, atol=1e-6)),
+    "rational_bwd": (pb.rational_rhs, [5, 1], [1 / 3, 2 / 9],
+                     dict(rtol=1e-3, atol=1e-6)),
+    "complex": (lambda t, y: -y, [0, 1], [0.5 + 1j],
+                dict(rtol=1e-3, atol=1e-6)),
+    "bruss1d": (bruss1d()[0], [0, 0.5], bruss1d()[1],
+                dict(rtol=1e-6, atol=1e-9)),
+}
+
+
+@pytest.mark.parametrize("name", ERK)
+@pytest.mark.parametrize("case", list(CASES))
+def test_trajectory_golden(traces, name, case):
+    """solve_ivp(method=<device class>) reproduces the reference's run"""
+    fun, t_span, y0, kw = CASES[case]
+    res = solve_ivp(fun, t_span, y0, method=DEV[name], **kw)
+    gold = traces[name][case]
+    assert res.status == gold["status"]
+    assert res.nfev == gold["nfev"]
+    assert int(esq.NFS[()]) == gold["nfs"]
+    assert_allclose(res.t, gold["t"], rtol=1e-9)
+    y_end = np.array(gold["y_end_re"]) + 1j * np.array(gold["y_end_im"])
+    tol = kw.get("rtol", 1e-3)
+    assert_allclose(res.y[:, -1],
+                    y_end if np.iscomplexobj(res.y) else y_end.real,
+                    rtol=1e-6 * tol / 1e-3, atol=1e-12)
+
+
+def test_published_known_answers():
+    """README.md:29-30 example; docs/Demo_BS5.ipynb:137,175 nfev"""
+    res = solve_ivp(lambda t, y: -0.5 * y, [0, 10], [2, 4, 8], method=esq.BS5)
+    assert res.nfev == 40 and int(esq.NFS[()]) == 0
+    assert_allclose(res.t, [0, 0.38027594845942564, 3.5949909992307925,
+                            6.671517050825296, 8.335758525412647, 10.0],
+                    rtol=1e-12)
+    assert_allclose(res.y[:, -1], [0.013389145036386444, 0.026778290072772888,
+                                   0.053556580145545776], rtol=1e-11)
+    assert solve_ivp(pb.duffing_rhs, [0, 20], [0, 0], method=esq.BS5).nfev == 212
+    assert solve_ivp(pb.duffing_rhs, [0, 20], [0, 0], method=esq.Ts5).nfev == 341
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_dense_output_golden(traces, name):
+    g = traces[name]["rational_dense"]
+    res = solve_ivp(pb.rational_rhs, [5, 9], [1 / 3, 2 / 9], method=DEV[name],
+                    dense_output=True)
+    assert_allclose(res.sol(np.array(g["tc"])), g["yc"], rtol=1e-10)
+    pmax = np.abs(DEV[name].P).max()
+    assert_allclose(res.sol(res.t), res.y, rtol=pmax * 1e-15, atol=pmax * 1e-15)
+
+
+@pytest.mark.parametrize("interp", ["free", "low", "best"])
+def test_bs5_interpolants_golden(traces, interp):
+    g = traces["BS5"]["dense_" + interp]
+    res = solve_ivp(pb.rational_rhs, [5, 9], [1 / 3, 2 / 9], method=esq.BS5,
+                    dense_output=True, interpolant=interp)
+    assert res.nfev == g["nfev"]
+    assert_allclose(res.sol(np.array(g["tc"])), g["yc"], rtol=1e-10)
+
+
+# --------------------------------------- reference test-suite re-expressions
+@pytest.mark.parametrize("name", ERK)
+def test_error_estimation(name):
+    """tests/test_rk.py:75-89"""
+    step = 0.2
+    s = DEV[name](lambda t, y: y, 0, [1], 1, first_step=step)
+    s.step()
+    est = s._estimate_error(s.K, step)
+    assert np.abs(s.y - np.exp([step])) < np.abs(est)
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_error_estimation_complex(name):
+    """tests/test_rk.py:92-98"""
+    h = 0.2
+    s = DEV[name](lambda t, y: 1j * y, 0, [1j], 1, first_step=h)
+    s.step()
+    assert np.isrealobj(s._estimate_error_norm(s.K, h, scale=[1]))
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_integration_rational(name):
+    """tests/test_ivp.py:150-213 (both directions, vectorized or not)"""
+    rtol, atol, y0 = 1e-3, 1e-6, [1 / 3, 2 / 9]
+
+    def err(y, y_true):
+        scale = np.abs(np.atleast_2d(y_true)).max(axis=1)[:, None]
+        e = (y - y_true) / (atol + rtol * scale)
+        return np.linalg.norm(e, axis=0) / np.sqrt(e.shape[0])
+
+    def fun_vec(t, y):
+        return np.vstack((y[1] / t,
+                          y[1] * (y[0] + 2 * y[1] - 1) / (t * (y[0] - 1))))
+    for vectorized in (False, True):
+        for t_span in ([5, 9], [5, 1]):
+            res = solve_ivp(fun_vec if vectorized else pb.rational_rhs, t_span,
+                            y0, rtol=rtol, atol=atol, method=DEV[name],
+                            dense_output=True, vectorized=vectorized)
+            assert res.t[0] == t_span[0] and res.success and res.status == 0
+            assert res.nfev < 44 and res.njev == 0 and res.nlu == 0
+            assert np.all(err(res.y, pb.rational_sol(res.t)) < 5)
+            tc = np.linspace(*t_span)
+            assert np.all(err(res.sol(tc), pb.rational_sol(tc)) < 5)
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_integration_complex(name):
+    """tests/test_ivp.py:216-259"""
+    res = solve_ivp(lambda t, y: -y, [0, 1], [0.5 + 1j], method=DEV[name],
+                    dense_output=True, rtol=1e-3, atol=1e-6)
+    assert res.success and res.status == 0
+    assert res.nfev < (40 if name in ("Pr8", "Pr9") else 28)
+    y_true = ((0.5 + 1j) * np.exp(-res.t)).reshape(1, -1)
+    scale = np.abs(y_true).max()
+    assert np.all(np.abs(res.y - y_true) / (1e-6 + 1e-3 * scale) < 5)
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_step_limits_and_failures(name):
+    """tests/test_ivp.py:582-665: max_step, first_step, ctor errors, TOO_SMALL"""
+    y0 = [1 / 3, 2 / 9]
+    cls = DEV[name]
+    for t_span in ([5, 9], [5, 1]):
+        res = solve_ivp(pb.rational_rhs, t_span, y0, max_step=0.5, method=cls,
+                        rtol=1e-3, atol=1e-6, first_step=0.1)
+        assert res.t[-1] == t_span[-1] and res.success
+        assert np.all(np.abs(np.diff(res.t)) <= 0.5 + 1e-15)
+        assert_allclose(0.1, np.abs(res.t[1] - 5))
+        with pytest.raises(ValueError):
+            cls(pb.rational_rhs, t_span[0], y0, t_span[1], max_step=-1)
+        with pytest.raises(ValueError):
+            cls(pb.rational_rhs, t_span[0], y0, t_span[1], first_step=-1)
+        with pytest.raises(ValueError):
+            cls(pb.rational_rhs, t_span[0], y0, t_span[1], first_step=5)
+        s = cls(pb.rational_rhs, t_span[0], y0, t_span[1], rtol=1e-3, atol=1e-6,
+                max_step=1e-20)
+        message = s.step()
+        assert s.status == 'failed' and "step size is less" in message
+        with pytest.raises(RuntimeError):
+            s.step()
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_classes_contract(name):
+    """tests/test_ivp.py:838-868 attribute contract; :785-825 corner cases"""
+    y0 = [1 / 3, 2 / 9]
+    s = DEV[name](pb.rational_rhs, 5, y0, np.inf)
+    assert s.n == 2 and s.status == 'running' and s.t_bound == np.inf
+    assert s.direction == 1 and s.t == 5 and s.step_size is None
+    assert_equal(s.y, y0)
+    assert s.nfev > 0 and s.njev >= 0 and s.nlu == 0
+    with pytest.raises(RuntimeError):
+        s.dense_output()
+    assert s.step() is None and s.status == 'running' and s.t > 5
+    assert not np.all(np.equal(s.y, y0)) and s.step_size > 0
+    assert_allclose(s.dense_output()(5), y0, rtol=1e-15, atol=0)
+    # t0 == tf
+    sol = solve_ivp(lambda t, y: -y, [4, 4], [2, 3], method=DEV[name],
+                    dense_output=True)
+    assert_equal(sol.sol(4), [2, 3])
+    # empty state
+    sol = solve_ivp(lambda t, y: np.zeros((0,)), [0, 10], np.zeros((0,)),
+                    method=DEV[name], dense_output=True)
+    assert_equal(sol.sol(10), np.zeros((0,)))
+    # zero RHS keeps y (tiny_err -> max_factor branch), test_ivp.py:1100-1105
+    res = solve_ivp(lambda t, y: np.zeros_like(y), [0, 10], np.ones(3),
+                    method=DEV[name])
+    assert res.success
+    assert_allclose(res.y, 1.0, rtol=1e-15)
+
+
+def test_nan_propagates_to_failure():
+    """a NaN anywhere in the state must fail the step, not be dropped by a
+    max-style reduction"""
+    n = 5000
+    lam = -np.ones(n)
+    y0 = np.ones(n)
+    y0[1234] = np.nan
+    s = esq.Pr8(esq.DiagonalLinear(lam), 0.0, y0, 1.0, first_step=0.1)
+    message = s.step()
+    assert s.status == 'failed' and "Overflow" in message
+
+
+def test_user_defined_tableau():
+    """docs/Demo_own_RK.ipynb contract: a tableau given as class attributes"""
+    class Heun(esq.RungeKutta):
+        n_stages, order, order_secondary = 2, 2, 1
+        A = np.array([[0, 0], [1, 0]])
+        B = np.array([0.5, 0.5])
+        C = np.array([0, 1])
+        E = np.array([0.5, -0.5, 0])
+    res = solve_ivp(lambda t, y: -y, [0, 1], [1.0], method=Heun, rtol=1e-4,
+                    atol=1e-7)
+    assert res.success
+    assert_allclose(res.y[0, -1], np.exp(-1), rtol=1e-3)
+
+
+# ------------------------------------------------ full-size properties
+def test_full_size_pr8_step_matches_oracle():
+    """BASELINE.json configs[2] size: one Pr8 step, n = 9 999 392, against the
+    oracle's step (a few seconds of NumPy)"""
+    N = 2236
+    y0 = pb.bruss2d_y0(N)
+    h = 1.0 / pb.bruss2d_rho(N)
+    kw = dict(first_step=h, max_step=h, rtol=1e-6, atol=1e-9,
+              nfev_stiff_detect=0)
+    d, o = _pair("Pr8", esq.Brusselator2D(N), pb.bruss2d_rhs(N), 0.0, y0, 1.0,
+                 **kw)
+    assert d.step() is None and o.step() is None
+    assert_allclose(d.y, o.y, rtol=2e-13, atol=1e-300)
+    assert_allclose(d.error_norm_old, o.error_norm_old, rtol=1e-8)
+    assert d.nfev == o.nfev == 14
+
+
+def test_full_size_linearity_and_exactness():
+    """size-independent properties at n = 1e7: for f = lam*y the Pr8 step is
+    linear in y0 (step(a*y0) == a*step(y0) with atol scaled alike) and the
+    result matches exp(lam*t) to the tolerance"""
+    n = 10_000_000
+    rng = np.random.default_rng(11)
+    lam = -rng.random(n)
+    y0 = rng.standard_normal(n)
+    rhs = esq.DiagonalLinear(lam)
+    outs = []
+    for a in (1.0, 4.0):
+        s = esq.Pr8(rhs, 0.0, a * y0, 0.5, first_step=0.1, rtol=1e-8,
+                    atol=a * 1e-10, nfev_stiff_detect=0)
+        while s.status == 'running':
+            s.step()
+        outs.append((s.y, s.nfev, s.t))
+    assert outs[0][1] == outs[1][1]
+    assert_equal(4.0 * outs[0][0], outs[1][0])        # exact: power of two
+    assert_allclose(outs[0][0], y0 * np.exp(lam * 0.5), rtol=1e-7, atol=1e-9)

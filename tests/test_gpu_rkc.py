@@ -1,0 +1,109 @@
+"""GPU parity tests of the device-resident SSV2stab (RKC) against golden
+vectors from the real reference and against the CPU oracle.  The reference's
+own tests/ hold no SSV2stab test; the pins are the stage vectors and the
+published integer table of docs/Demo_SSV2stab.ipynb:350-356."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+from scipy.integrate import solve_ivp
+
+import extensisq_amd as esq
+from extensisq_amd import sommeijer as dev_rkc
+from extensisq_amd._lib import SLOT_K
+from oracle import problems as pb
+from oracle import rkc_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m", [2, 3, 10, 100, 132])
+@pytest.mark.parametrize("mode", ["host_rhs", "device_rhs"])
+def test_stages_golden(golden_dir, m, mode):
+    g = np.load(os.path.join(golden_dir, "rkc_stages.npz"))
+    lam, yn = g[f"m{m}/lam"], g[f"m{m}/yn"]
+    h = float(g[f"m{m}/h"])
+    cpu = lambda t, y: lam * y + np.sin(t)  # noqa: E731
+    fun = cpu if mode == "host_rhs" else esq.DiagonalLinear(lam, 1.0)
+    s = esq.SSV2stab(fun, 0.0, yn, 1.0, first_step=1e-3,
+                     rho_jac=lambda t, y: 50.0)
+    yrow = s._stages(0.0, h, m)
+    y = s._dev.download(SLOT_K, yrow)
+    gold = g[f"m{m}/y"]
+    assert_allclose(y, gold, rtol=1e-13, atol=1e-13 * np.abs(gold).max())
+
+
+@pytest.mark.parametrize("tol,expect", [
+    (1e-1, (6, 1, 402, 132)),      # docs/Demo_SSV2stab.ipynb:350-356
+    (1e-2, (15, 4, 729, 85)),
+    (1e-3, (27, 2, 786, 40)),
+])
+def test_published_table(golden_dir, tol, expect):
+    """3-D tanh heat problem (n = 59 319), host-RHS mode"""
+    with open(os.path.join(golden_dir, "rkc_traces.json")) as fh:
+        gold = json.load(fh)[f"tanh3d_tol{tol:.0e}"]
+    fun, y0, rho = pb.tanh3d_problem(39)
+    res = solve_ivp(fun, (0, 0.7), y0, method=esq.SSV2stab, rtol=tol,
+                    atol=tol, const_jac=True, rho_jac=rho)
+    nfs = int(dev_rkc.nrejct[()])
+    got = (int(res.t.size - 1 + nfs), nfs, int(res.nfev), int(dev_rkc.maxm[()]))
+    assert got == expect
+    assert_allclose(res.t, gold["t"], rtol=1e-9)
+    assert_allclose(res.y[::5000, -1], gold["y_probe"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("mode", ["host_rhs", "device_rhs"])
+def test_power_iteration_golden(golden_dir, mode):
+    """rho_jac=None: the nonlinear power iteration runs on the device"""
+    with open(os.path.join(golden_dir, "rkc_traces.json")) as fh:
+        gold = json.load(fh)["heat2d_rho_power"]
+    N = 24
+    fun = pb.heat2d_rhs(N) if mode == "host_rhs" else esq.Heat2D(N)
+    res = solve_ivp(fun, (0, 0.01), pb.heat2d_y0(N, seed=1234),
+                    method=esq.SSV2stab, rtol=1e-4, atol=1e-6)
+    nfs = int(dev_rkc.nrejct[()])
+    assert (int(res.t.size - 1 + nfs), nfs, int(dev_rkc.maxm[()]),
+            int(dev_rkc.nfesig[()])) == (gold["steps"], gold["nfs"],
+                                         gold["maxm"], gold["nfesig"])
+    if mode == "host_rhs":
+        assert int(res.nfev) == gold["nfev"]
+    assert_allclose(res.t, gold["t"], rtol=1e-9)
+    assert_allclose(res.y[:, -1], gold["y_end"], rtol=1e-8, atol=1e-12)
+
+
+def test_diffusion3d_vs_oracle():
+    """BASELINE.json configs[3] at small N with the device RHS, m ~ 30"""
+    N = 21
+    rhs = esq.Diffusion3D(N)
+    rho = rhs.spectral_radius()
+    h0 = 600.0 / rho
+    kw = dict(rtol=1e-3, atol=1e-3, const_jac=True, first_step=h0,
+              rho_jac=lambda t, y: rho)
+    d = esq.SSV2stab(rhs, 0.0, pb.diff3d_y0(N), 0.1, **kw)
+    o = rkc_oracle.SSV2stab(pb.diff3d_rhs(N), 0.0, pb.diff3d_y0(N), 0.1, **kw)
+    for _ in range(4):
+        assert d.step() is None and o.step() is None
+        assert_allclose(d.t, o.t, rtol=1e-12)
+        assert_allclose(d.y, o.y, rtol=1e-11, atol=1e-14)
+        assert_allclose(d.errold, o.errold, rtol=1e-6)
+    assert d.nfev == o.nfev
+
+
+def test_dense_output_and_ctor_errors():
+    N = 16
+    res = solve_ivp(esq.Heat2D(N), (0, 0.005), pb.heat2d_y0(N), rtol=1e-4,
+                    atol=1e-6, method=esq.SSV2stab, dense_output=True)
+    ref = solve_ivp(pb.heat2d_rhs(N), (0, 0.005), pb.heat2d_y0(N), rtol=1e-4,
+                    atol=1e-6, method=rkc_oracle.SSV2stab, dense_output=True)
+    tc = np.linspace(0, 0.005, 7)
+    assert_allclose(res.sol(tc), ref.sol(tc), rtol=1e-7, atol=1e-10)
+    with pytest.raises(TypeError):
+        esq.SSV2stab(pb.heat2d_rhs(N), 0, pb.heat2d_y0(N), 1, const_jac=1)
+    with pytest.raises(TypeError):
+        esq.SSV2stab(pb.heat2d_rhs(N), 0, pb.heat2d_y0(N), 1, rho_jac=3.0)
+    with pytest.raises(ValueError):
+        esq.SSV2stab(pb.heat2d_rhs(N), 0, pb.heat2d_y0(N), 1,
+                     rho_jac=lambda t, y: -1.0)
