@@ -7,6 +7,7 @@
 // pointer swaps on the host; kernels receive row pointers and coefficients by
 // value in their kernel arguments.
 #include <dlfcn.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -65,7 +66,7 @@ struct esq_ctx {
     // lock-step
     void *comm = nullptr;
     // profiling
-    bool prof_on = false;
+    unsigned prof_mask = 0;           // bit k: time launches of class k
     std::vector<ProfEvent> prof_live;
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[ESQ_PROF_NCLASS] = {0};
@@ -108,11 +109,17 @@ double *slot_ptr(esq_ctx *c, int slot, int row, bool logical = true) {
 }
 
 // ---- profiling -------------------------------------------------------------
+// Own kernels are launched with hipExtLaunchKernelGGL(start, stop): the events
+// take the begin/end timestamps of THAT dispatch packet, no extra barrier
+// packets enter the queue (a hipEventRecord pair around each launch cost ~10 %
+// of a Pr8 step).  Opaque RHS plugins are bracketed with hipEventRecord.
 struct Prof {
     esq_ctx *c;
-    bool on;
+    bool on, recorded;
     ProfEvent ev;
-    Prof(esq_ctx *ctx, int klass, double bytes) : c(ctx), on(ctx->prof_on) {
+    Prof(esq_ctx *ctx, int klass, double bytes, bool record_now = false)
+        : c(ctx), on((ctx->prof_mask >> klass) & 1u), recorded(record_now) {
+        ev.start = ev.stop = nullptr;
         if (!on) return;
         auto take = [&]() {
             hipEvent_t e;
@@ -128,11 +135,13 @@ struct Prof {
         ev.stop = take();
         ev.klass = klass;
         ev.bytes = bytes;
-        (void)hipEventRecord(ev.start, c->stream);
+        if (recorded) (void)hipEventRecord(ev.start, c->stream);
     }
+    hipEvent_t start() const { return on && !recorded ? ev.start : nullptr; }
+    hipEvent_t stop() const { return on && !recorded ? ev.stop : nullptr; }
     ~Prof() {
         if (!on) return;
-        (void)hipEventRecord(ev.stop, c->stream);
+        if (recorded) (void)hipEventRecord(ev.stop, c->stream);
         c->prof_live.push_back(ev);
     }
 };
@@ -156,13 +165,15 @@ void prof_drain(esq_ctx *c) {
 // ---- launch helpers ----------------------------------------------------------
 template <int NT>
 void launch_lincomb_n(esq_ctx *c, double *out, const double *base,
-                      const Terms &tm, double h) {
-    hipLaunchKernelGGL(k_lincomb<NT>, dim3(c->grid_stream), dim3(kBlock), 0,
-                       c->stream, out, base, tm, h, c->len_pad / 2);
+                      const Terms &tm, double h, const Prof *p) {
+    hipExtLaunchKernelGGL(k_lincomb<NT>, dim3(c->grid_stream), dim3(kBlock), 0,
+                          c->stream, p ? p->start() : nullptr,
+                          p ? p->stop() : nullptr, 0, out, base, tm, h,
+                          c->len_pad / 2);
 }
 int launch_lincomb(esq_ctx *c, double *out, const double *base, const Terms &tm,
-                   int nt, double h) {
-#define CASE(N) case N: launch_lincomb_n<N>(c, out, base, tm, h); break;
+                   int nt, double h, const Prof *p = nullptr) {
+#define CASE(N) case N: launch_lincomb_n<N>(c, out, base, tm, h, p); break;
     switch (nt) {
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
         CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
@@ -175,39 +186,33 @@ int launch_lincomb(esq_ctx *c, double *out, const double *base, const Terms &tm,
 }
 
 template <int NT>
-void launch_solerr_n(esq_ctx *c, const Terms2 &tm, double h) {
+void launch_solerr_n(esq_ctx *c, const Terms2 &tm, double h, const Prof &p) {
     const double *av = c->atol_is_vec ? c->atolv : nullptr;
     if (c->cplx)
-        hipLaunchKernelGGL((k_solution_error<NT, true>), dim3(c->grid_reduce),
-                           dim3(kBlock), 0, c->stream, c->ynew, c->y, tm, h, av,
+        hipExtLaunchKernelGGL((k_solution_error<NT, true>), dim3(c->grid_reduce), dim3(kBlock), 0, c->stream, p.start(), p.stop(), 0, c->ynew, c->y, tm, h, av,
                            c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
     else
-        hipLaunchKernelGGL((k_solution_error<NT, false>), dim3(c->grid_reduce),
-                           dim3(kBlock), 0, c->stream, c->ynew, c->y, tm, h, av,
+        hipExtLaunchKernelGGL((k_solution_error<NT, false>), dim3(c->grid_reduce), dim3(kBlock), 0, c->stream, p.start(), p.stop(), 0, c->ynew, c->y, tm, h, av,
                            c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
 }
 template <int NT>
-void launch_errnorm_n(esq_ctx *c, const Terms &tm, double h) {
+void launch_errnorm_n(esq_ctx *c, const Terms &tm, double h, const Prof &p) {
     const double *av = c->atol_is_vec ? c->atolv : nullptr;
     if (c->cplx)
-        hipLaunchKernelGGL((k_error_norm<NT, true>), dim3(c->grid_reduce),
-                           dim3(kBlock), 0, c->stream, c->y, c->ynew, tm, h, av,
+        hipExtLaunchKernelGGL((k_error_norm<NT, true>), dim3(c->grid_reduce), dim3(kBlock), 0, c->stream, p.start(), p.stop(), 0, c->y, c->ynew, tm, h, av,
                            c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
     else
-        hipLaunchKernelGGL((k_error_norm<NT, false>), dim3(c->grid_reduce),
-                           dim3(kBlock), 0, c->stream, c->y, c->ynew, tm, h, av,
+        hipExtLaunchKernelGGL((k_error_norm<NT, false>), dim3(c->grid_reduce), dim3(kBlock), 0, c->stream, p.start(), p.stop(), 0, c->y, c->ynew, tm, h, av,
                            c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
 }
 template <int NT>
-void launch_preerr_n(esq_ctx *c, const Terms2 &tm, double h) {
+void launch_preerr_n(esq_ctx *c, const Terms2 &tm, double h, const Prof &p) {
     const double *av = c->atol_is_vec ? c->atolv : nullptr;
     if (c->cplx)
-        hipLaunchKernelGGL((k_pre_error<NT, true>), dim3(c->grid_reduce),
-                           dim3(kBlock), 0, c->stream, c->y, tm, h, av, c->atol_s,
+        hipExtLaunchKernelGGL((k_pre_error<NT, true>), dim3(c->grid_reduce), dim3(kBlock), 0, c->stream, p.start(), p.stop(), 0, c->y, tm, h, av, c->atol_s,
                            c->rtol, c->len_pad / 2, c->n, c->partials);
     else
-        hipLaunchKernelGGL((k_pre_error<NT, false>), dim3(c->grid_reduce),
-                           dim3(kBlock), 0, c->stream, c->y, tm, h, av, c->atol_s,
+        hipExtLaunchKernelGGL((k_pre_error<NT, false>), dim3(c->grid_reduce), dim3(kBlock), 0, c->stream, p.start(), p.stop(), 0, c->y, tm, h, av, c->atol_s,
                            c->rtol, c->len_pad / 2, c->n, c->partials);
 }
 #define DISPATCH_1_20(FN, nt, ...)                                              \
@@ -280,7 +285,7 @@ int finish_reduction(esq_ctx *c, double *out) {
 
 int call_rhs(esq_ctx *c, double t, const double *src, double *dst) {
     if (!c->rhs) return fail(c, ESQ_ESTATE, "no device RHS set (esq_set_rhs)");
-    Prof p(c, ESQ_PROF_RHS, 16.0 * (double)c->len);
+    Prof p(c, ESQ_PROF_RHS, 16.0 * (double)c->len, /*record_now=*/true);
     int r = c->rhs(c->rhs_user, t, src, dst, c->len, (void *)c->stream);
     if (r != 0) return fail(c, ESQ_ERHS, "RHS plugin returned %d", r);
     return 0;
@@ -491,7 +496,7 @@ int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
     const int nt = build_row_terms(c, &c->A[(size_t)i * c->s], i, tm, c->kmap);
     if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
     Prof p(c, ESQ_PROF_STAGE, 8.0 * (nt + 2) * (double)c->len);
-    return launch_lincomb(c, c->ystage, c->y, tm, nt, h);
+    return launch_lincomb(c, c->ystage, c->y, tm, nt, h, &p);
 }
 
 int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row) {
@@ -523,7 +528,7 @@ int esq_rk_solution(esq_ctx *c, double h) {
     const int nt = build_row_terms(c, c->B.data(), c->s, tm, c->kmap);
     if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
     Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
-    return launch_lincomb(c, c->ynew, c->y, tm, nt, h);
+    return launch_lincomb(c, c->ynew, c->y, tm, nt, h, &p);
 }
 
 int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
@@ -534,7 +539,7 @@ int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
     if (nt < 1) return fail(c, ESQ_EINVAL, "error weights are all zero");
     {
         Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
-        DISPATCH_1_20(launch_errnorm_n, nt, c, tm, h)
+        DISPATCH_1_20(launch_errnorm_n, nt, c, tm, h, p)
         HIPCHK(c, hipGetLastError());
     }
     return finish_reduction(c, sumsq_out);
@@ -555,7 +560,7 @@ int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
     if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
     {
         Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
-        DISPATCH_1_20(launch_solerr_n, nt, c, tm, h)
+        DISPATCH_1_20(launch_solerr_n, nt, c, tm, h, p)
         HIPCHK(c, hipGetLastError());
     }
     return finish_reduction(c, sumsq_out);
@@ -570,7 +575,7 @@ int esq_rk_pre_error(esq_ctx *c, double h, const double *e_pre,
     if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
     {
         Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 1) * (double)c->len);
-        DISPATCH_1_20(launch_preerr_n, nt, c, tm, h)
+        DISPATCH_1_20(launch_preerr_n, nt, c, tm, h, p)
         HIPCHK(c, hipGetLastError());
     }
     return finish_reduction(c, sumsq_out);
@@ -664,8 +669,9 @@ int esq_rkc_first_stage(esq_ctx *c, int dst, int yn, int fn, double hmus) {
     double *d = ROW(c, dst), *a = ROW(c, yn), *f = ROW(c, fn);
     if (!d || !a || !f) return fail(c, ESQ_EINVAL, "bad row");
     Prof p(c, ESQ_PROF_RKC, 24.0 * (double)c->len);
-    hipLaunchKernelGGL(k_rkc_first, dim3(c->grid_stream), dim3(kBlock), 0,
-                       c->stream, d, a, f, hmus, c->len_pad / 2);
+    hipExtLaunchKernelGGL(k_rkc_first, dim3(c->grid_stream), dim3(kBlock), 0,
+                          c->stream, p.start(), p.stop(), 0, d, a, f, hmus,
+                          c->len_pad / 2);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -677,9 +683,9 @@ int esq_rkc_stage(esq_ctx *c, int dst, int fy, int yjm1, int yjm2, int yn, int f
     if (!d || !f || !a || !b || !y0 || !g) return fail(c, ESQ_EINVAL, "bad row");
     const double omn = (1.0 - mu) - nu;   // (1.0 - mu - nu), left to right
     Prof p(c, ESQ_PROF_RKC, 48.0 * (double)c->len);
-    hipLaunchKernelGGL(k_rkc_stage, dim3(c->grid_stream), dim3(kBlock), 0,
-                       c->stream, d, f, a, b, y0, g, mu, nu, omn, hmus, ajm1,
-                       c->len_pad / 2);
+    hipExtLaunchKernelGGL(k_rkc_stage, dim3(c->grid_stream), dim3(kBlock), 0,
+                          c->stream, p.start(), p.stop(), 0, d, f, a, b, y0, g,
+                          mu, nu, omn, hmus, ajm1, c->len_pad / 2);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -728,8 +734,8 @@ int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
     if (c->cplx) return fail(c, ESQ_EINVAL, "RKC is real-only (sommeijer.py:98)");
     {
         Prof p(c, ESQ_PROF_SOLERR, 32.0 * (double)c->len);
-        hipLaunchKernelGGL(k_rkc_error, dim3(c->grid_reduce), dim3(kBlock), 0,
-                           c->stream, a, b, f, g, h,
+        hipExtLaunchKernelGGL(k_rkc_error, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, p.start(), p.stop(), 0, a, b, f, g, h,
                            c->atol_is_vec ? c->atolv : nullptr, c->atol_s, c->rtol,
                            c->len_pad / 2, c->n, c->partials);
         HIPCHK(c, hipGetLastError());
@@ -799,10 +805,10 @@ int esq_comm_destroy(void *comm) {
 }
 
 // ---- measurement ----------------------------------------------------------------
-int esq_profile_enable(esq_ctx *c, int on) {
+int esq_profile_enable(esq_ctx *c, int class_mask) {
     if (!c) return ESQ_EINVAL;
-    if (!on) prof_drain(c);
-    c->prof_on = on != 0;
+    if (!class_mask) prof_drain(c);
+    c->prof_mask = (unsigned)class_mask;
     return 0;
 }
 int esq_profile_read(esq_ctx *c, int klass, double *total_ms, long *launches,

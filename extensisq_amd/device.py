@@ -134,8 +134,12 @@ class DeviceContext:
                             as_ptr(e), as_ptr(b), len(e))
 
     # -- profiling (bench.py)
-    def profile_enable(self, on=True):
-        self._chk(self.lib.esq_profile_enable(self.handle, int(on)),
+    def profile_enable(self, classes=(0, 1, 2, 3)):
+        """classes: iterable of PROF_* ids to time, or a false value to stop"""
+        mask = 0
+        for k in (classes or ()):
+            mask |= 1 << int(k)
+        self._chk(self.lib.esq_profile_enable(self.handle, mask),
                   "esq_profile_enable")
 
     def profile_reset(self):

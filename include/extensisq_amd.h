@@ -207,15 +207,17 @@ int  esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
                     void *stream);
 
 /* ---- measurement (bench.py `roofline`) ------------------------------------ */
-/* When enabled, every launch of the kernel classes below is bracketed by HIP
- * events on the context's stream; esq_profile_read synchronises and returns
- * the summed device time and launch count since the last reset. */
+/* class_mask bit k = 1: every launch of kernel class k carries a start/stop HIP
+ * event pair on the context's stream (the library's own kernels take them as
+ * dispatch timestamps via hipExtLaunchKernelGGL, RHS plugins are bracketed with
+ * hipEventRecord); esq_profile_read synchronises and returns the summed device
+ * time, launch count and algorithmic bytes since the last reset. */
 #define ESQ_PROF_STAGE     0   /* stage-accumulate kernels                     */
 #define ESQ_PROF_RHS       1   /* RHS plugin launches                          */
 #define ESQ_PROF_SOLERR    2   /* solution / error-norm kernels (+final sum)   */
 #define ESQ_PROF_RKC       3   /* RKC stage kernels                            */
 #define ESQ_PROF_NCLASS    4
-int  esq_profile_enable(esq_ctx *ctx, int on);
+int  esq_profile_enable(esq_ctx *ctx, int class_mask);
 int  esq_profile_read(esq_ctx *ctx, int klass, double *total_ms, long *launches,
                       double *bytes);
 int  esq_profile_reset(esq_ctx *ctx);

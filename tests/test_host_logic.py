@@ -1,0 +1,161 @@
+"""CPU tests of the product's HOST logic (no GPU, no compute calls): the
+step-size controller, the look-ahead rule, tolerance validation, the starting
+step, the Chebyshev scalar recurrences -- each against the oracle, which is
+itself pinned to the reference's golden vectors (tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from extensisq_amd import common as dev_common
+from extensisq_amd import sommeijer as dev_rkc
+from extensisq_amd.bogacki import BS5
+from extensisq_amd.prince import Pr7, Pr8, Pr9
+from extensisq_amd.tsitouras import Ts5
+from oracle import problems as pb
+from oracle import rk_oracle, rkc_oracle
+
+PAIRS = [(BS5, rk_oracle.BS5), (Ts5, rk_oracle.Ts5), (Pr7, rk_oracle.Pr7),
+         (Pr8, rk_oracle.Pr8), (Pr9, rk_oracle.Pr9)]
+
+
+def bare(cls, sc_params=None):
+    """a product solver object WITHOUT device state: only the scalar fields
+    the controller reads"""
+    s = object.__new__(cls)
+    s._dev = None
+    s._y_host = np.zeros(3)
+    s.error_exponent = -1 / (min(cls.order_secondary, cls.order) + 1)
+    s.h_min_a, s.h_min_b = s._init_min_step_parameters()
+    s.tiny_err = s.h_min_b
+    s._init_sc_control(sc_params)
+    return s
+
+
+@pytest.mark.parametrize("dev_cls,ref_cls", PAIRS)
+@pytest.mark.parametrize("sc", [None, "G", "S", "standard", (0.5, -0.1, 0.1, 0.8)])
+def test_controller_matches_oracle(dev_cls, ref_cls, sc):
+    ref = ref_cls(lambda t, y: -y, 0.0, np.ones(3), 10.0, sc_params=sc,
+                  first_step=0.1)
+    dev = bare(dev_cls, sc)
+    for name in ("minbeta1", "minbeta2", "minalpha", "safety", "safety_sc",
+                 "h_min_a", "h_min_b", "tiny_err", "error_exponent"):
+        assert getattr(dev, name) == getattr(ref, name), name
+    rng = np.random.default_rng(0)
+    dev.h_previous = ref.h_previous = 0.07
+    dev.error_norm_old = ref.error_norm_old = 0.3
+    for k in range(200):
+        err = float(10 ** rng.uniform(-170, 0)) if k % 7 else 1e-200
+        h = float(rng.uniform(0.01, 0.2))
+        rejected = bool(rng.integers(2))
+        f_dev = dev._accept_factor(err, h, rejected)
+        f_ref = ref._growth_after_accept(err, h, rejected)
+        assert f_dev == f_ref
+        assert dev.standard_sc == ref.standard_sc
+        assert dev.max_factor == ref.max_factor
+        big = float(10 ** rng.uniform(0, 6))
+        assert dev._reject_factor(big) == max(
+            ref.min_factor, ref.safety * big ** ref.error_exponent)
+        dev.error_norm_old = ref.error_norm_old = err
+        dev.h_previous = ref.h_previous = h
+
+
+@pytest.mark.parametrize("dev_cls,ref_cls", PAIRS[:2])
+def test_step_limits_match_oracle(dev_cls, ref_cls):
+    rng = np.random.default_rng(1)
+    for direction, t_bound in ((1, 3.0), (-1, -3.0)):
+        ref = ref_cls(lambda t, y: -y, 0.0, np.ones(3), t_bound, first_step=0.1,
+                      max_step=0.8)
+        dev = bare(dev_cls)
+        dev.max_step, dev.t_bound = ref.max_step, ref.t_bound
+        for _ in range(300):
+            t = direction * float(rng.uniform(0, 3.0))
+            dev.h_abs = ref.h_abs = float(10 ** rng.uniform(-20, 1))
+            dev.standard_sc = ref.standard_sc = bool(rng.integers(2))
+            assert dev._reassess_stepsize(t) == ref._limit_step(t)
+            assert dev.standard_sc == ref.standard_sc
+
+
+def test_validate_tol_matches_oracle():
+    y = np.ones(4)
+    for rtol, atol in ((1e-3, 1e-6), (1e-20, 0.0), (0.5, np.array([1e-3, 0, 1e-9, 1])),
+                       (1e-10, 1e-300)):
+        a = dev_common.validate_tol(rtol, atol, y)
+        b = rk_oracle.check_tolerances(rtol, atol, y)
+        assert a[0] == b[0]
+        assert_allclose(a[1], b[1], rtol=0)
+    for bad in ((-1.0, 1e-6), (1e-3, -1.0), (1, 1e-6), (1e-3, np.ones(3))):
+        with pytest.raises(ValueError):
+            dev_common.validate_tol(bad[0], bad[1], y)
+
+
+@pytest.mark.parametrize("case", ["decay", "duffing", "heat", "zero", "complex",
+                                  "backward"])
+def test_h_start_matches_oracle(case):
+    if case == "decay":
+        fun, a, b, y = (lambda t, y: -0.5 * y), 0.0, 10.0, np.array([2., 4., 8.])
+    elif case == "duffing":
+        fun, a, b, y = pb.duffing_rhs, 0.0, 20.0, np.array([0.0, 0.0])
+    elif case == "heat":
+        fun, a, b, y = pb.heat2d_rhs(12), 0.0, 1.0, pb.heat2d_y0(12)
+    elif case == "zero":
+        fun, a, b, y = (lambda t, y: np.zeros_like(y)), 0.0, 10.0, np.ones(3)
+    elif case == "complex":
+        fun, a, b, y = (lambda t, y: -y), 0.0, 1.0, np.array([0.5 + 1j])
+    else:
+        fun, a, b, y = pb.rational_rhs, 5.0, 1.0, np.array([1 / 3, 2 / 9])
+    f0 = np.asarray(fun(a, y))
+    for order in (4, 5, 7):
+        for atol in (1e-6, np.full(y.size, 1e-8)):
+            got = dev_common.h_start(fun, a, b, y, f0, order, 1e-3, atol)
+            want = rk_oracle.first_step_size(fun, a, b, y, f0, order, 1e-3, atol)
+            assert got == want
+    assert dev_common.h_start(fun, a, b, y[:0], f0[:0], 4, 1e-3, 1e-6) == np.inf
+
+
+def test_h_start_golden(golden_dir):
+    """first step of the 8-shard lock-step reference run (tools/gen_golden.py)"""
+    import os
+    g = np.load(os.path.join(golden_dir, "lockstep.npz"))
+    N = int(g["N"])
+    n = N * N
+    f1 = pb.heat2d_rhs(N)
+    y0 = np.concatenate([pb.heat2d_y0(N, seed=int(s)) for s in g["seeds"]])
+
+    def fun(t, y):
+        return np.concatenate([f1(t, y[k * n:(k + 1) * n]) for k in range(8)])
+    rtol, atol = dev_common.validate_tol(1e-6, 1e-9, y0)
+    h = dev_common.h_start(fun, 0.0, float(g["t_end"]), y0, fun(0.0, y0),
+                           Pr9.order_secondary, rtol, atol)
+    assert_allclose(abs(h), float(g["h0"]), rtol=1e-12)
+
+
+@pytest.mark.parametrize("m", [2, 3, 7, 50, 132, 600])
+def test_chebyshev_scalars_match_oracle(m):
+    t, h = 0.3, 0.0123
+    hmus1, table = dev_rkc.chebyshev_scalars(m, t, h)
+    mus1, rows = rkc_oracle.chebyshev_stage_scalars(m)
+    assert hmus1 == h * mus1
+    assert table.shape == (m - 1, 5)
+    for got, (mu, nu, mus, ajm1, thjm1) in zip(table, rows):
+        assert tuple(got) == (mu, nu, h * mus, ajm1, t + h * thjm1)
+
+
+def test_dense_output_classes_match_oracle():
+    rng = np.random.default_rng(3)
+    Q = rng.standard_normal((5, 4))
+    y_old = rng.standard_normal(5)
+    a = dev_common.HornerDenseOutput(1.0, 1.5, y_old, Q.copy())
+    b = rk_oracle.HornerInterpolant(1.0, 1.5, y_old, Q.copy())
+    tt = np.linspace(1.0, 1.5, 9)
+    assert_allclose(a(tt), b(tt), rtol=1e-15)
+    assert_allclose(a(1.25), b(1.25), rtol=1e-15)
+    y, f_old, f = rng.standard_normal((3, 5))
+    c = dev_common.CubicDenseOutput(1.0, 1.5, y_old, y, f_old, f)
+    d = rk_oracle.HermiteInterpolant(1.0, 1.5, y_old, y, f_old, f)
+    assert_allclose(c(tt), d(tt), rtol=1e-14)
+
+
+def test_rms_from_sumsq_lockstep_bookkeeping():
+    s = bare(Pr9)
+    s._n_norm = 8 * 100
+    assert s._rms_from_sumsq(800.0 * 4.0) == 2.0
