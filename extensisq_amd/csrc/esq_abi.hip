@@ -63,6 +63,7 @@ struct esq_ctx {
     // launch geometry
     unsigned grid_stream = 0;         // grid for streaming kernels
     unsigned grid_reduce = 0;
+    int stage_policy = 0;             // cache policy of k_lincomb (tuning knob)
     // lock-step
     void *comm = nullptr;
     // profiling
@@ -163,13 +164,25 @@ void prof_drain(esq_ctx *c) {
 }
 
 // ---- launch helpers ----------------------------------------------------------
+template <int NT, int LDP, int STP>
+void launch_lincomb_p(esq_ctx *c, double *out, const double *base,
+                      const Terms &tm, double h, const Prof *p) {
+    hipExtLaunchKernelGGL((k_lincomb<NT, LDP, STP>), dim3(c->grid_stream),
+                          dim3(kBlock), 0, c->stream, p ? p->start() : nullptr,
+                          p ? p->stop() : nullptr, 0, out, base, tm, h,
+                          c->len_pad / 2);
+}
 template <int NT>
 void launch_lincomb_n(esq_ctx *c, double *out, const double *base,
                       const Terms &tm, double h, const Prof *p) {
-    hipExtLaunchKernelGGL(k_lincomb<NT>, dim3(c->grid_stream), dim3(kBlock), 0,
-                          c->stream, p ? p->start() : nullptr,
-                          p ? p->stop() : nullptr, 0, out, base, tm, h,
-                          c->len_pad / 2);
+    switch (c->stage_policy) {      // ESQ_STAGE_POLICY = <load><store>
+        case 1:  launch_lincomb_p<NT, 0, 1>(c, out, base, tm, h, p); break;
+        case 10: launch_lincomb_p<NT, 1, 0>(c, out, base, tm, h, p); break;
+        case 11: launch_lincomb_p<NT, 1, 1>(c, out, base, tm, h, p); break;
+        case 20: launch_lincomb_p<NT, 2, 0>(c, out, base, tm, h, p); break;
+        case 21: launch_lincomb_p<NT, 2, 1>(c, out, base, tm, h, p); break;
+        default: launch_lincomb_p<NT, 0, 0>(c, out, base, tm, h, p); break;
+    }
 }
 int launch_lincomb(esq_ctx *c, double *out, const double *base, const Terms &tm,
                    int nt, double h, const Prof *p = nullptr) {
@@ -379,6 +392,7 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     const size_t n2 = c->len_pad / 2;
     const size_t need = (n2 + kBlock - 1) / kBlock;
     const unsigned per_cu = env_uint("ESQ_BLOCKS_PER_CU", 8);
+    c->stage_policy = (int)env_uint("ESQ_STAGE_POLICY", 0);
     size_t g = (size_t)cus * per_cu;
     if (g > need) g = need;
     if (g < 1) g = 1;

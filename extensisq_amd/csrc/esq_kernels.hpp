@@ -39,6 +39,18 @@ __device__ __forceinline__ double2 ld2(const double *p, size_t i) {
 __device__ __forceinline__ void st2(double *p, size_t i, double2 v) {
     reinterpret_cast<double2 *>(p)[i] = v;
 }
+// non-temporal (streaming, "nt") 16-byte accesses
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2_nt(const double *p, size_t i) {
+    const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p) + i);
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void st2_nt(double *p, size_t i, double2 v) {
+    v2d w;
+    w.x = v.x;
+    w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(p) + i);
+}
 
 // ---------------------------------------------------------------------------
 // out = base + h * sum_j c_j * v_j        (base may be nullptr -> 0)
@@ -46,7 +58,9 @@ __device__ __forceinline__ void st2(double *p, size_t i, double2 v) {
 // fused multiply-add chain like a BLAS gemv kernel), then *h, then +base, the
 // last two rounded separately as NumPy does.
 // ---------------------------------------------------------------------------
-template <int NT>
+// LDP: 0 plain loads, 1 nt loads of the K rows, 2 nt loads of everything
+// STP: 0 plain store, 1 nt store
+template <int NT, int LDP = 0, int STP = 0>
 __global__ __launch_bounds__(kBlock) void k_lincomb(
     double *__restrict__ out, const double *__restrict__ base, Terms tm,
     double h, size_t n2) {
@@ -55,9 +69,10 @@ __global__ __launch_bounds__(kBlock) void k_lincomb(
          i += stride) {
         double2 v[NT > 0 ? NT : 1];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) v[j] = ld2(tm.p[j], i);
+        for (int j = 0; j < NT; ++j)
+            v[j] = LDP >= 1 ? ld2_nt(tm.p[j], i) : ld2(tm.p[j], i);
         double2 yb = make_double2(0.0, 0.0);
-        if (base) yb = ld2(base, i);
+        if (base) yb = LDP >= 2 ? ld2_nt(base, i) : ld2(base, i);
         double2 acc = make_double2(0.0, 0.0);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -67,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void k_lincomb(
         double2 r;
         r.x = __dadd_rn(yb.x, __dmul_rn(h, acc.x));
         r.y = __dadd_rn(yb.y, __dmul_rn(h, acc.y));
-        st2(out, i, r);
+        if (STP) st2_nt(out, i, r); else st2(out, i, r);
     }
 }
 

@@ -94,9 +94,14 @@ def test_device_rhs_step_sizes(name, n):
     # relative: pin the device to the oracle's step to keep comparing tightly.
     for _ in range(2):
         d.h_abs, d.error_norm_old = o.h_abs, o.error_norm_old
+        nfs0 = int(rk_oracle.NFS[()])
         assert d.step() is None and o.step() is None
-        assert d.t == o.t
-        assert_allclose(d.y, o.y, rtol=1e-12, atol=1e-14)
+        if int(rk_oracle.NFS[()]) == nfs0:      # no retry inside the step
+            assert d.t == o.t
+            assert_allclose(d.y, o.y, rtol=1e-12, atol=1e-14)
+        else:                                   # retried with h from err_norm
+            assert_allclose(d.t, o.t, rtol=1e-9)
+            assert_allclose(d.y, o.y, rtol=1e-8, atol=1e-11)
         assert_allclose(d.error_norm_old, o.error_norm_old, rtol=1e-4)
     assert d.nfev == o.nfev
 
