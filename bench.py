@@ -64,6 +64,24 @@ def cpu_baseline(N, h, steps):
                       f"{dt / steps:.2f} s/step"}
 
 
+def pmc_traffic(N):
+    """HBM bytes per stage-accumulate launch from the committed rocprofv3 PMC
+    passes of this same command (profiles/rNN_pmc_traffic.json, written by
+    tools/profile_bench.sh + tools/summarize_profiles.py); None if absent or
+    for another problem size"""
+    if N != 2236:
+        return None, None
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        names = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json"))
+        with open(os.path.join(pdir, names[-1])) as fh:
+            data = json.load(fh)
+        return (data["stage_accumulate"]["hbm_bytes_per_launch"],
+                f"profiles/{names[-1]}")
+    except Exception:
+        return None, None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -149,6 +167,7 @@ def main():
         rh_ms, rh_cnt, rh_bytes = prof[PROF_RHS]
         se_ms, se_cnt, se_bytes = prof[PROF_SOLERR]
         achieved = st_bytes / (st_ms * 1e-3) / 1e9 if st_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(N)
         out = {
             "metric": "accepted RK steps/s x state-dim (fp64), Pr8 n=1e7",
             "value": world * n * args.steps / elapsed,
@@ -172,7 +191,7 @@ def main():
                 "bound": "hbm", "kernel": "k_lincomb (fused stage-accumulate)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "launches": st_cnt,
                 "avg_launch_us": 1e3 * st_ms / st_cnt if st_cnt else None,
                 "algorithmic_bytes_per_launch": st_bytes / st_cnt if st_cnt else None,

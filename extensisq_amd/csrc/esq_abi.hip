@@ -204,6 +204,9 @@ void launch_solerr_n(esq_ctx *c, const Terms2 &tm, double h, const Prof &p) {
     if (c->cplx)
         hipExtLaunchKernelGGL((k_solution_error<NT, true>), dim3(c->grid_reduce), dim3(kBlock), 0, c->stream, p.start(), p.stop(), 0, c->ynew, c->y, tm, h, av,
                            c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
+    else if (c->stage_policy >= 10)
+        hipExtLaunchKernelGGL((k_solution_error<NT, false, true>), dim3(c->grid_reduce), dim3(kBlock), 0, c->stream, p.start(), p.stop(), 0, c->ynew, c->y, tm, h, av,
+                           c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
     else
         hipExtLaunchKernelGGL((k_solution_error<NT, false>), dim3(c->grid_reduce), dim3(kBlock), 0, c->stream, p.start(), p.stop(), 0, c->ynew, c->y, tm, h, av,
                            c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
@@ -337,8 +340,9 @@ int build_row_terms2(esq_ctx *c, const double *b, int nb, const double *e, int n
 unsigned env_uint(const char *name, unsigned dflt) {
     const char *s = getenv(name);
     if (!s || !*s) return dflt;
-    long v = strtol(s, nullptr, 10);
-    return v > 0 ? (unsigned)v : dflt;
+    char *end = nullptr;
+    long v = strtol(s, &end, 10);
+    return (end != s && v >= 0) ? (unsigned)v : dflt;
 }
 
 }  // namespace
@@ -391,8 +395,8 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     const unsigned cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t n2 = c->len_pad / 2;
     const size_t need = (n2 + kBlock - 1) / kBlock;
-    const unsigned per_cu = env_uint("ESQ_BLOCKS_PER_CU", 8);
-    c->stage_policy = (int)env_uint("ESQ_STAGE_POLICY", 0);
+    const unsigned per_cu = env_uint("ESQ_BLOCKS_PER_CU", 2);
+    c->stage_policy = (int)env_uint("ESQ_STAGE_POLICY", 10);
     size_t g = (size_t)cus * per_cu;
     if (g > need) g = need;
     if (g < 1) g = 1;

@@ -168,7 +168,7 @@ __device__ __forceinline__ double ratio_sq(double2 err, double2 ya, double2 yb,
 // Non-FSAL fused pass: y_new = y + h*sum b_j K_j ; err = h*sum e_j K_j ;
 // partial sum of |err/scale|^2.  Each K row is read ONCE for both sums.
 // ---------------------------------------------------------------------------
-template <int NT, bool CPLX>
+template <int NT, bool CPLX, bool NTL = false>
 __global__ __launch_bounds__(kBlock) void k_solution_error(
     double *__restrict__ ynew, const double *__restrict__ y, Terms2 tm,
     double h, const double *__restrict__ atol_vec, double atol_s, double rtol,
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(kBlock) void k_solution_error(
          i += stride) {
         double2 v[NT > 0 ? NT : 1];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) v[j] = ld2(tm.p[j], i);
+        for (int j = 0; j < NT; ++j)
+            v[j] = NTL ? ld2_nt(tm.p[j], i) : ld2(tm.p[j], i);
         const double2 yy = ld2(y, i);
         // rows are the union of the two supports; a zero weight contributes
         // fma(0, v, s) == s (and 0*Inf = NaN, exactly like NumPy's gemv)

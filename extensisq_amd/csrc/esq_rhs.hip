@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void k_heat2d(const double *__restrict__ u,
 
 // 2-D Brusselator, periodic.  y = [u.ravel(), v.ravel()]
 //   du = (A + u*u*v - (B+1)*u) + d*lap(u);  dv = (B*u - u*u*v) + d*lap(v)
+template <bool NTS>
 __global__ __launch_bounds__(kBlock) void k_bruss2d(
     const double *__restrict__ y, double *__restrict__ f, int N, double d,
     double A, double B, unsigned nblocks, unsigned bpr) {
@@ -90,8 +91,147 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d(
     const double lapu = ((u[kup] + u[kdn]) + (u[klf] + u[krt])) - 4.0 * uc;
     const double lapv = ((v[kup] + v[kdn]) + (v[klf] + v[krt])) - 4.0 * vc;
     const double uuv = uc * uc * vc;
-    f[k] = ((A + uuv) - (B + 1.0) * uc) + d * lapu;
-    f[NN + k] = (B * uc - uuv) + d * lapv;
+    const double fu = ((A + uuv) - (B + 1.0) * uc) + d * lapu;
+    const double fv = (B * uc - uuv) + d * lapv;
+    if (NTS) {
+        __builtin_nontemporal_store(fu, f + k);
+        __builtin_nontemporal_store(fv, f + NN + k);
+    } else {
+        f[k] = fu;
+        f[NN + k] = fv;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Vectorised 5-point sweeps (even N): one thread owns a column PAIR (16-byte
+// accesses) and marches down R rows with a rolling (up, centre, down) register
+// window, so every row is loaded once per row group instead of three times;
+// the left/right neighbours come from the adjacent lanes (wave64 shuffles),
+// only the lanes at a wave or row edge touch memory for them.  Arithmetic
+// order is identical to the scalar kernels (and to oracle/problems.py).
+// ---------------------------------------------------------------------------
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <bool PERIODIC>
+struct RowWin {
+    const double *__restrict__ f;   // field base
+    int N;
+    unsigned pair, npairs;          // this thread's column pair
+    bool live;                      // pair < npairs
+    __device__ __forceinline__ double2 row(int i) const {
+        // row i of the field at this thread's pair; rows outside are the
+        // periodic image or zero (Dirichlet)
+        if (PERIODIC) {
+            i = i < 0 ? i + N : (i >= N ? i - N : i);
+        } else if (i < 0 || i >= N) {
+            return make_double2(0.0, 0.0);
+        }
+        if (!live) return make_double2(0.0, 0.0);
+        return *reinterpret_cast<const double2 *>(f + (size_t)i * N + 2 * (size_t)pair);
+    }
+    // left neighbour of .x and right neighbour of .y in row i (centre c given)
+    __device__ __forceinline__ void sides(int i, double2 c, double &lf,
+                                          double &rt) const {
+        const int lane = threadIdx.x & 63;
+        lf = __shfl_up(c.y, 1, 64);
+        rt = __shfl_down(c.x, 1, 64);
+        if (!live) return;
+        const double *r = f + (size_t)i * N;
+        if (lane == 0 || pair == 0) {
+            if (pair > 0) lf = r[2 * (size_t)pair - 1];
+            else lf = PERIODIC ? r[N - 1] : 0.0;
+        }
+        if (lane == 63 || pair + 1 >= npairs) {
+            if (pair + 1 < npairs) rt = r[2 * (size_t)pair + 2];
+            else rt = PERIODIC ? r[0] : 0.0;
+        }
+    }
+};
+
+template <int R, bool NTS>
+__global__ __launch_bounds__(kBlock) void k_bruss2d_v2(
+    const double *__restrict__ y, double *__restrict__ f, int N, double d,
+    double A, double B, unsigned nblocks, unsigned bpr) {
+    // tiles are WAVE-granular (64 column pairs x R rows): `bpr` counts the
+    // 64-pair segments per row, so a ragged row end idles < 64 lanes
+    const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int i0 = (int)(tile / bpr) * R;
+    const size_t NN = (size_t)N * N;
+    RowWin<true> U, V;
+    U.f = y; V.f = y + NN;
+    U.N = V.N = N;
+    U.npairs = V.npairs = (unsigned)N / 2;
+    U.pair = V.pair = (tile % bpr) * 64 + (threadIdx.x & 63);
+    U.live = V.live = U.pair < U.npairs;
+    if (i0 >= N) return;
+    double2 uu = U.row(i0 - 1), uc = U.row(i0);
+    double2 vu = V.row(i0 - 1), vc = V.row(i0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = i0 + r;
+        if (i >= N) break;                       // uniform across the wave
+        const double2 ud = U.row(i + 1), vd = V.row(i + 1);
+        double ul, ur, vl, vr;
+        U.sides(i, uc, ul, ur);
+        V.sides(i, vc, vl, vr);
+        // .x : neighbours (left = ul, right = uc.y); .y : (left = uc.x, right = ur)
+        double2 lapu, lapv, fu, fv;
+        lapu.x = ((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x;
+        lapu.y = ((uu.y + ud.y) + (uc.x + ur)) - 4.0 * uc.y;
+        lapv.x = ((vu.x + vd.x) + (vl + vc.y)) - 4.0 * vc.x;
+        lapv.y = ((vu.y + vd.y) + (vc.x + vr)) - 4.0 * vc.y;
+        const double uuvx = uc.x * uc.x * vc.x, uuvy = uc.y * uc.y * vc.y;
+        fu.x = ((A + uuvx) - (B + 1.0) * uc.x) + d * lapu.x;
+        fu.y = ((A + uuvy) - (B + 1.0) * uc.y) + d * lapu.y;
+        fv.x = (B * uc.x - uuvx) + d * lapv.x;
+        fv.y = (B * uc.y - uuvy) + d * lapv.y;
+        if (U.live) {
+            const size_t k = (size_t)i * N + 2 * (size_t)U.pair;
+            if (NTS) {
+                v2d a, b;
+                a.x = fu.x; a.y = fu.y; b.x = fv.x; b.y = fv.y;
+                __builtin_nontemporal_store(a, reinterpret_cast<v2d *>(f + k));
+                __builtin_nontemporal_store(b, reinterpret_cast<v2d *>(f + NN + k));
+            } else {
+                *reinterpret_cast<double2 *>(f + k) = fu;
+                *reinterpret_cast<double2 *>(f + NN + k) = fv;
+            }
+        }
+        uu = uc; uc = ud;
+        vu = vc; vc = vd;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_heat2d_v2(
+    const double *__restrict__ u, double *__restrict__ f, int N, double c,
+    unsigned nblocks, unsigned bpr) {
+    const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int i0 = (int)(tile / bpr) * R;
+    RowWin<false> U;
+    U.f = u;
+    U.N = N;
+    U.npairs = (unsigned)N / 2;
+    U.pair = (tile % bpr) * 64 + (threadIdx.x & 63);
+    U.live = U.pair < U.npairs;
+    if (i0 >= N) return;
+    double2 uu = U.row(i0 - 1), uc = U.row(i0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = i0 + r;
+        if (i >= N) break;
+        const double2 ud = U.row(i + 1);
+        double ul, ur;
+        U.sides(i, uc, ul, ur);
+        double2 out;
+        out.x = c * (((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x);
+        out.y = c * (((uu.y + ud.y) + (uc.x + ur)) - 4.0 * uc.y);
+        if (U.live)
+            *reinterpret_cast<double2 *>(f + (size_t)i * N + 2 * (size_t)U.pair) = out;
+        uu = uc;
+        uc = ud;
+    }
 }
 
 // 3-D diffusion, Dirichlet 0, 7-point
@@ -114,6 +254,13 @@ __global__ __launch_bounds__(kBlock) void k_diff3d(const double *__restrict__ u,
     const double c0 = l > 0 ? u[k - 1] : 0.0;
     const double c1 = l + 1 < (unsigned)N ? u[k + 1] : 0.0;
     f[k] = c * ((((a0 + a1) + (b0 + b1)) + (c0 + c1)) - 6.0 * uc);
+}
+
+// ESQ_RHS_VARIANT: 1 = scalar kernels, 2/3/4/8 = rows per thread of the
+// vectorised sweeps (default 2)
+int rhs_variant() {
+    static const int v = getenv("ESQ_RHS_VARIANT") ? atoi(getenv("ESQ_RHS_VARIANT")) : 2;
+    return v;
 }
 
 int make(void **out, Rhs proto) {
@@ -190,10 +337,20 @@ int esq_rhs_heat2d(void *user, double t, const double *y, double *f, size_t n,
     (void)t;
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != HEAT2D || n != r->n) return ESQ_EINVAL;
+    const double c = (double)(r->N + 1) * (double)(r->N + 1);
+    if (r->N % 2 == 0 && r->N >= 4 && rhs_variant() != 1) {
+        constexpr int R = 2;
+        const unsigned wpr = (r->N / 2 + 63) / 64;              // wave tiles per row
+        const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
+        const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
+        const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+        hipLaunchKernelGGL(k_heat2d_v2<R>, dim3(grid), dim3(kBlock), 0,
+                           (hipStream_t)stream, y, f, r->N, c, grid, wpr);
+        return (int)hipGetLastError();
+    }
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;
     unsigned nblocks = bpr * (unsigned)r->N;
     const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
-    const double c = (double)(r->N + 1) * (double)(r->N + 1);
     hipLaunchKernelGGL(k_heat2d, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
                        y, f, r->N, c, grid, bpr);
     return (int)hipGetLastError();
@@ -203,12 +360,34 @@ int esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
     (void)t;
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != BRUSS2D || n != r->n) return ESQ_EINVAL;
+    const double d = r->alpha * ((double)r->N * (double)r->N);
+    if (r->N % 2 == 0 && r->N >= 4 && rhs_variant() != 1) {
+        const unsigned wpr = (r->N / 2 + 63) / 64;              // wave tiles per row
+        const int v = rhs_variant();
+        const int R = (v == 8 || v == 4 || v == 3) ? v : 2;
+        const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
+        const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
+        const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+#define LAUNCH_BR(RR)                                                           \
+    hipLaunchKernelGGL((k_bruss2d_v2<RR, false>), dim3(grid), dim3(kBlock), 0,  \
+                       (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, wpr)
+        if (R == 8) LAUNCH_BR(8);
+        else if (R == 4) LAUNCH_BR(4);
+        else if (R == 3) LAUNCH_BR(3);
+        else LAUNCH_BR(2);
+#undef LAUNCH_BR
+        return (int)hipGetLastError();
+    }
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;
     unsigned nblocks = bpr * (unsigned)r->N;
     const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
-    const double d = r->alpha * ((double)r->N * (double)r->N);
-    hipLaunchKernelGGL(k_bruss2d, dim3(grid), dim3(kBlock), 0,
-                       (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, bpr);
+    static const bool nts = getenv("ESQ_RHS_STORE_NT") && atoi(getenv("ESQ_RHS_STORE_NT"));
+    if (nts)
+        hipLaunchKernelGGL(k_bruss2d<true>, dim3(grid), dim3(kBlock), 0,
+                           (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, bpr);
+    else
+        hipLaunchKernelGGL(k_bruss2d<false>, dim3(grid), dim3(kBlock), 0,
+                           (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, bpr);
     return (int)hipGetLastError();
 }
 int esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,

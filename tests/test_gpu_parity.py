@@ -158,10 +158,19 @@ def test_pde_workloads(name, rhs, cpu, y0f, N):
 
 
 @pytest.mark.parametrize("rhs,cpu,y0f,N", [
+    (esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 2),
+    (esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 4),
     (esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 37),
     (esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 300),
+    (esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 514),
+    (esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 1030),
+    (esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 3),
+    (esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 4),
+    (esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 6),
     (esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 50),
     (esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 301),
+    (esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 514),
+    (esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 1030),
     (esq.Diffusion3D, pb.diff3d_rhs, pb.diff3d_y0, 13),
     (esq.Diffusion3D, pb.diff3d_rhs, pb.diff3d_y0, 40),
 ])
