@@ -73,6 +73,7 @@ SIGNATURES = {
     "esq_rhs_bruss2d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
     "esq_rhs_diff3d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
     "esq_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "esq_profile_sampling": (C.c_int, [_vp, C.c_int]),
     "esq_profile_read": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_long), _dp]),
     "esq_profile_reset": (C.c_int, [_vp]),
 }

@@ -7,6 +7,7 @@
 // pointer swaps on the host; kernels receive row pointers and coefficients by
 // value in their kernel arguments.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
@@ -68,6 +69,8 @@ struct esq_ctx {
     void *comm = nullptr;
     // profiling
     unsigned prof_mask = 0;           // bit k: time launches of class k
+    unsigned prof_every = 1;          // time every prof_every-th launch of a class
+    unsigned long prof_seen[ESQ_PROF_NCLASS] = {0};
     std::vector<ProfEvent> prof_live;
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[ESQ_PROF_NCLASS] = {0};
@@ -121,6 +124,7 @@ struct Prof {
     Prof(esq_ctx *ctx, int klass, double bytes, bool record_now = false)
         : c(ctx), on((ctx->prof_mask >> klass) & 1u), recorded(record_now) {
         ev.start = ev.stop = nullptr;
+        if (on) on = (ctx->prof_seen[klass]++ % ctx->prof_every) == 0;
         if (!on) return;
         auto take = [&]() {
             hipEvent_t e;
@@ -277,6 +281,20 @@ int rccl_load() {
     g_rccl.lib = lib;
     return 0;
 }
+// RCCL prints a version banner on stdout; callers (bench.py) own stdout, so the
+// banner is sent to stderr instead
+struct StdoutToStderr {
+    int saved;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved >= 0) { dup2(saved, 1); close(saved); }
+    }
+};
 constexpr int kNcclFloat64 = 8;   // ncclDouble
 constexpr int kNcclSum = 0;       // ncclSum
 
@@ -800,6 +818,7 @@ int esq_set_comm(esq_ctx *c, void *nccl_comm) {
 }
 int esq_comm_unique_id(void *id128_out) {
     if (!id128_out) return ESQ_EINVAL;
+    StdoutToStderr guard;
     if (rccl_load() != 0) return ESQ_ESTATE;
     int r = g_rccl.GetUniqueId(id128_out);
     return r ? 1000 + r : 0;
@@ -807,6 +826,7 @@ int esq_comm_unique_id(void *id128_out) {
 int esq_comm_init_rank(void **comm_out, int nranks, const void *id128, int rank,
                        int device) {
     if (!comm_out || !id128) return ESQ_EINVAL;
+    StdoutToStderr guard;
     if (rccl_load() != 0) return ESQ_ESTATE;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return (int)e;
@@ -817,6 +837,7 @@ int esq_comm_init_rank(void **comm_out, int nranks, const void *id128, int rank,
 }
 int esq_comm_destroy(void *comm) {
     if (!comm) return 0;
+    StdoutToStderr guard;
     if (rccl_load() != 0) return ESQ_ESTATE;
     int r = g_rccl.CommDestroy(comm);
     return r ? 1000 + r : 0;
@@ -827,6 +848,11 @@ int esq_profile_enable(esq_ctx *c, int class_mask) {
     if (!c) return ESQ_EINVAL;
     if (!class_mask) prof_drain(c);
     c->prof_mask = (unsigned)class_mask;
+    return 0;
+}
+int esq_profile_sampling(esq_ctx *c, int every) {
+    if (!c || every < 1) return ESQ_EINVAL;
+    c->prof_every = (unsigned)every;
     return 0;
 }
 int esq_profile_read(esq_ctx *c, int klass, double *total_ms, long *launches,
@@ -843,6 +869,7 @@ int esq_profile_reset(esq_ctx *c) {
     prof_drain(c);
     for (int k = 0; k < ESQ_PROF_NCLASS; ++k) {
         c->prof_ms[k] = 0; c->prof_cnt[k] = 0; c->prof_bytes[k] = 0;
+        c->prof_seen[k] = 0;
     }
     return 0;
 }

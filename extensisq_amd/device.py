@@ -134,8 +134,11 @@ class DeviceContext:
                             as_ptr(e), as_ptr(b), len(e))
 
     # -- profiling (bench.py)
-    def profile_enable(self, classes=(0, 1, 2, 3)):
-        """classes: iterable of PROF_* ids to time, or a false value to stop"""
+    def profile_enable(self, classes=(0, 1, 2, 3), every=1):
+        """classes: iterable of PROF_* ids to time, or a false value to stop;
+        every: time only every `every`-th launch of a class"""
+        self._chk(self.lib.esq_profile_sampling(self.handle, int(every)),
+                  "esq_profile_sampling")
         mask = 0
         for k in (classes or ()):
             mask |= 1 << int(k)

@@ -88,12 +88,20 @@ def _rccl_unique_id():
     return buf.raw
 
 
-def init_lockstep(rank, world_size, device, n_local, addr=None, port=None):
+def init_lockstep(rank, world_size, device, n_local, addr=None, port=None,
+                  exchange=None):
     """Create the RCCL communicator of this rank and return a `LockstepGroup`
-    to pass as `lockstep=` to a solver constructor."""
+    to pass as `lockstep=` to a solver constructor.
+
+    `exchange(make_id, n_local) -> (id_bytes, n_total)` may replace the built-in
+    TCP rendezvous (bench.py passes one that rides on its torch.distributed
+    gloo group, so no second port is needed)."""
     lib = _lib.load()
-    ident, n_total = rendezvous(rank, world_size, n_local, _rccl_unique_id,
-                                addr, port)
+    if exchange is not None:
+        ident, n_total = exchange(_rccl_unique_id, n_local)
+    else:
+        ident, n_total = rendezvous(rank, world_size, n_local, _rccl_unique_id,
+                                    addr, port)
     comm = C.c_void_p()
     buf = C.create_string_buffer(ident, _ID_BYTES)
     _lib.check(lib.esq_comm_init_rank(C.byref(comm), world_size, buf, rank,

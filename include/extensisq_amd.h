@@ -218,6 +218,9 @@ int  esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
 #define ESQ_PROF_RKC       3   /* RKC stage kernels                            */
 #define ESQ_PROF_NCLASS    4
 int  esq_profile_enable(esq_ctx *ctx, int class_mask);
+/* time only every `every`-th launch of an enabled class (an event-carrying
+ * dispatch costs ~6 us of queue time; a prime stride samples all stages evenly) */
+int  esq_profile_sampling(esq_ctx *ctx, int every);
 int  esq_profile_read(esq_ctx *ctx, int klass, double *total_ms, long *launches,
                       double *bytes);
 int  esq_profile_reset(esq_ctx *ctx);

@@ -427,3 +427,46 @@ def test_full_size_linearity_and_exactness():
     assert outs[0][1] == outs[1][1]
     assert_equal(4.0 * outs[0][0], outs[1][0])        # exact: power of two
     assert_allclose(outs[0][0], y0 * np.exp(lam * 0.5), rtol=1e-7, atol=1e-9)
+
+
+# ------------------------------------------------------------ lock-step / RCCL
+def test_rccl_single_rank_lockstep():
+    """the RCCL leg of the lock-step mode on one GPU: a 1-rank communicator is
+    created through the C ABI (dlopen librccl, ncclCommInitRank) and every
+    error evaluation goes through ncclAllReduce on the solver's stream; the
+    run must equal the communicator-free run bit for bit"""
+    from extensisq_amd import lockstep
+    N = 64
+    y0 = pb.heat2d_y0(N)
+    group = lockstep.init_lockstep(0, 1, 0, y0.size)
+    assert group.n_total == y0.size
+    kw = dict(rtol=1e-6, atol=1e-9, nfev_stiff_detect=0, first_step=1e-6)
+    a = esq.Pr9(esq.Heat2D(N), 0.0, y0, 1e-3, lockstep=group, **kw)
+    b = esq.Pr9(esq.Heat2D(N), 0.0, y0, 1e-3, **kw)
+    for _ in range(6):
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t and a.error_norm_old == b.error_norm_old
+    assert_equal(a.y, b.y)
+    r = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 1e-3, rtol=1e-4, atol=1e-6,
+                     lockstep=group)
+    s = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 1e-3, rtol=1e-4, atol=1e-6)
+    for _ in range(3):
+        assert r.step() is None and s.step() is None
+        assert r.t == s.t
+    assert_equal(r.y, s.y)
+    del a, r
+    lockstep.destroy_lockstep(group)
+
+
+def test_lockstep_total_size_changes_the_norm():
+    """n_total of the batch enters the RMS norm (two ranks' worth of elements
+    halves the mean square when the other shard contributes nothing)"""
+    n = 1000
+    lam = -np.ones(n)
+    y0 = np.ones(n)
+    a = esq.Pr8(esq.DiagonalLinear(lam), 0.0, y0, 1.0, first_step=0.3)
+    a.step()
+    b = esq.Pr8(esq.DiagonalLinear(lam), 0.0, y0, 1.0, first_step=0.3,
+                lockstep=esq.LockstepGroup(None, 2 * n))
+    b.step()
+    assert_allclose(b.error_norm_old, a.error_norm_old / np.sqrt(2), rtol=1e-12)
