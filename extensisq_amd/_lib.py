@@ -45,7 +45,11 @@ SIGNATURES = {
     "esq_rk_accept": (C.c_int, [_vp, C.c_double, C.c_int]),
     "esq_rk_error_vector": (C.c_int, [_vp, C.c_double, C.c_int]),
     "esq_rk_download_last_K": (C.c_int, [_vp, C.c_int, _vp]),
-    "esq_rk_dense_coefficients": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp]),
+    "esq_dense_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int,
+                                   _vpp]),
+    "esq_dense_eval": (C.c_int, [_vp, C.c_double, _vp]),
+    "esq_dense_download": (C.c_int, [_vp, _vp]),
+    "esq_dense_destroy": (C.c_int, [_vp]),
     "esq_rk_dense_stage": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double]),
     "esq_rk_dense_eval": (C.c_int, [_vp, C.c_int, C.c_double]),
     "esq_rk_upload_last_K": (C.c_int, [_vp, C.c_int, _vp]),

@@ -11,7 +11,7 @@ import numpy as np
 
 from ._lib import SLOT_K, SLOT_WORK, SLOT_YNEW, SLOT_YSTAGE, as_ptr  # noqa: F401
 from ._tableau import install
-from .common import NFS, HornerDenseOutput, RungeKutta
+from .common import NFS, RungeKutta
 
 
 class BS5(RungeKutta):
@@ -96,12 +96,10 @@ class BS5(RungeKutta):
         h = self.h_previous
         s = self.n_stages
         if self.interpolant == 'free':
-            return HornerDenseOutput(self.t_old, self.t, self.y_old,
-                                     self._dense_coefficients(self.P))
+            return self._horner_interpolant(self.P, self.t_old, self.t)
         if self.interpolant == 'low':
             self._extra_stage(s + 1, self.A_extra[0], self.C_extra[0], h)
-            return HornerDenseOutput(self.t_old, self.t, self.y_old,
-                                     self._dense_coefficients(self.Plow))
+            return self._horner_interpolant(self.Plow, self.t_old, self.t)
         for k, (a, c) in enumerate(zip(self.A_extra, self.C_extra)):
             self._extra_stage(s + 1 + k, a, c, h)
         # RKSUITE's 'best' interpolant looks back from the END of the step
@@ -111,8 +109,7 @@ class BS5(RungeKutta):
         P = self.Pbest.copy()
         P[:, 0] = 0.0
         P[7, 0] = 1.0
-        Q = self._dense_coefficients(P)
-        return HornerDenseOutput(self.t, self.t + h, self.y, Q)
+        return self._horner_interpolant(P, self.t, self.t + h, from_end=True)
 
 
 install(BS5, "BS5")

@@ -166,12 +166,13 @@ def h_start(df, a, b, y, yprime, morder, rtol, atol):
 
 class HornerDenseOutput(DenseOutput):
     """Polynomial interpolant y_old + sum_c Q[:, c] x^(c+1), evaluated with
-    Horner's rule (ref common.py:766-790)."""
+    Horner's rule on the host (ref common.py:766-790).  `scaled=True`: Q
+    already carries the factor h (it was formed on the device)."""
 
-    def __init__(self, t_old, t, y_old, Q):
+    def __init__(self, t_old, t, y_old, Q, scaled=False):
         super().__init__(t_old, t)
         self.h = t - t_old
-        self.Q = Q * self.h
+        self.Q = Q if scaled else Q * self.h
         self.y_old = y_old
 
     def _call_impl(self, t):
@@ -183,6 +184,38 @@ class HornerDenseOutput(DenseOutput):
             acc *= x
         acc += self.y_old[:, np.newaxis]
         return acc if t.shape else acc[:, 0]
+
+
+class DeviceHornerDenseOutput(DenseOutput):
+    """The same interpolant with Qh = h * K.T @ P and the base state kept in
+    HBM (`esq_dense_*`): building it is one fused pass over the K rows, every
+    evaluation is one Horner kernel plus an n-vector download.  It owns its
+    device memory, so it survives the step and the solver."""
+
+    def __init__(self, t_old, t, lib, handle, n, dtype):
+        super().__init__(t_old, t)
+        self.h = t - t_old
+        self._lib, self._handle = lib, handle
+        self._n, self._dtype = n, dtype
+
+    def _eval(self, x):
+        out = np.empty(self._n, dtype=self._dtype)
+        code = self._lib.esq_dense_eval(self._handle, float(x), as_ptr(out))
+        if code != 0:
+            from ._lib import DeviceError
+            raise DeviceError(f"esq_dense_eval failed with code {code}")
+        return out
+
+    def _call_impl(self, t):
+        x = (t - self.t_old) / self.h
+        if not t.shape:
+            return self._eval(x)
+        return np.stack([self._eval(xi) for xi in x], axis=1)
+
+    def __del__(self):
+        handle, self._handle = getattr(self, "_handle", None), None
+        if handle:
+            self._lib.esq_dense_destroy(handle)
 
 
 class CubicDenseOutput(DenseOutput):
@@ -563,21 +596,35 @@ class RungeKutta(OdeSolver):
         return norm(self._estimate_error(K, h) / scale)
 
     # ---------------------------------------------------------- dense output
-    def _dense_coefficients(self, P, rows=None):
-        """Q = K.T @ P evaluated on the device (ref common.py:363); returns the
-        (n, p) matrix as a transposed view of the (p, n) download"""
+    # below this size a host interpolant (one download of Qh) answers the many
+    # tiny evaluations of event root-finding faster than kernel launches do
+    _DEVICE_DENSE_MIN_N = 4096
+
+    def _horner_interpolant(self, P, t_a, t_b, from_end=False):
+        """interpolant over [t_a, t_b] from Q = K_last.T @ P (ref common.py:
+        361-364), built on the device in one pass; `from_end`: anchored at the
+        current state (BS5 'best'), else at the pre-step state"""
+        import ctypes
         P = np.ascontiguousarray(P, dtype=np.float64)
-        rows = P.shape[0] if rows is None else rows
-        Qt = np.empty((P.shape[1], self.n), dtype=self._dev.dtype)
-        self._chk(self._lib.esq_rk_dense_coefficients(
-            self._ctx, as_ptr(P), rows, P.shape[1], as_ptr(Qt)),
-            "esq_rk_dense_coefficients")
-        return Qt.T
+        handle = ctypes.c_void_p()
+        self._chk(self._lib.esq_dense_create(
+            self._ctx, as_ptr(P), P.shape[0], P.shape[1], float(t_b - t_a),
+            int(from_end), ctypes.byref(handle)), "esq_dense_create")
+        if self.n >= self._DEVICE_DENSE_MIN_N:
+            return DeviceHornerDenseOutput(t_a, t_b, self._lib, handle, self.n,
+                                           self._dev.dtype)
+        try:
+            Qh = np.empty((P.shape[1], self.n), dtype=self._dev.dtype)
+            self._chk(self._lib.esq_dense_download(handle, as_ptr(Qh)),
+                      "esq_dense_download")
+        finally:
+            self._lib.esq_dense_destroy(handle)
+        base = self.y if from_end else self.y_old
+        return HornerDenseOutput(t_a, t_b, base, Qh.T, scaled=True)
 
     def _dense_output_impl(self):
         if isinstance(self.P, np.ndarray):
-            return HornerDenseOutput(self.t_old, self.t, self.y_old,
-                                     self._dense_coefficients(self.P))
+            return self._horner_interpolant(self.P, self.t_old, self.t)
         return CubicDenseOutput(self.t_old, self.t, self.y_old, self.y,
                                 self.f_old, self.f)
 

@@ -650,28 +650,6 @@ int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
     return 0;
 }
 
-int esq_rk_dense_coefficients(esq_ctx *c, const double *P, int rows, int p,
-                              double *Q_host) {
-    if (!c || !P || !Q_host || rows < 1 || rows > c->n_rows || p < 1)
-        return ESQ_EINVAL;
-    // column by column through the WORK vector: Q_host is (p, len) row-major,
-    // i.e. the TRANSPOSE of the reference's Q (common.py:363)
-    std::vector<double> col(rows);
-    for (int k = 0; k < p; ++k) {
-        for (int r = 0; r < rows; ++r) col[r] = P[(size_t)r * p + k];
-        Terms tm;
-        const int nt = build_row_terms(c, col.data(), rows, tm, c->kmap_last);
-        if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
-        int r = launch_lincomb(c, c->work, nullptr, tm, nt, 1.0);
-        if (r) return r;
-        HIPCHK(c, hipMemcpyAsync(Q_host + (size_t)k * c->len, c->work,
-                                 c->len * sizeof(double), hipMemcpyDeviceToHost,
-                                 c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    return 0;
-}
-
 int esq_rk_dense_stage(esq_ctx *c, int row, const double *a, int count, double h) {
     if (!c || !a) return ESQ_EINVAL;
     if (row < 1 || row >= c->n_rows || count < 0 || count > row)
@@ -694,6 +672,117 @@ int esq_rk_upload_last_K(esq_ctx *c, int row, const double *host) {
                              c->len * sizeof(double), hipMemcpyHostToDevice,
                              c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- device-resident interpolant ------------------------------------------------
+}  // extern "C"
+struct esq_dense {
+    int device = 0;
+    size_t len = 0, len_pad = 0;
+    int np = 0;
+    unsigned grid = 0;
+    double *mem = nullptr;      // (np + 2) vectors: Qh columns, base, scratch
+    hipStream_t stream = nullptr;
+};
+template <int NT>
+void launch_dense_n(esq_ctx *c, const DenseArgs &a, int np, double scale) {
+    hipLaunchKernelGGL(k_dense_q<NT>, dim3(c->grid_stream), dim3(kBlock), 0,
+                       c->stream, a, np, scale, c->len_pad / 2);
+}
+extern "C" {
+int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
+                     int from_end, esq_dense **out) {
+    if (!c || !P || !out) return ESQ_EINVAL;
+    if (rows < 1 || rows > c->n_rows || p < 1 || p > kMaxCols)
+        return fail(c, ESQ_EINVAL, "bad interpolant shape (%d, %d)", rows, p);
+    esq_dense *d = new (std::nothrow) esq_dense();
+    if (!d) return ESQ_ENOMEM;
+    d->device = c->device;
+    d->len = c->len;
+    d->len_pad = c->len_pad;
+    d->np = p;
+    d->grid = c->grid_stream;
+    hipError_t e = hipMalloc(&d->mem, (size_t)(p + 2) * d->len_pad * sizeof(double));
+    if (e != hipSuccess) {
+        delete d;
+        return fail(c, (int)e, "hipMalloc for the interpolant failed: %s",
+                    hipGetErrorString(e));
+    }
+    e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipFree(d->mem); delete d; return fail(c, (int)e, "stream"); }
+    DenseArgs a;
+    int nt = 0;
+    for (int j = 0; j < rows; ++j) {
+        bool any = false;
+        for (int k = 0; k < p; ++k) any = any || P[(size_t)j * p + k] != 0.0;
+        if (!any) continue;
+        if (nt >= kMaxTerms) { esq_dense_destroy(d); return fail(c, ESQ_EINVAL, "too many rows"); }
+        a.p[nt] = c->krow[c->kmap_last[j]];
+        for (int k = 0; k < kMaxCols; ++k) a.w[nt][k] = k < p ? P[(size_t)j * p + k] : 0.0;
+        ++nt;
+    }
+    for (int j = nt; j < kMaxTerms; ++j) {
+        a.p[j] = nullptr;
+        for (int k = 0; k < kMaxCols; ++k) a.w[j][k] = 0.0;
+    }
+    for (int k = 0; k < kMaxCols; ++k) a.q[k] = k < p ? d->mem + (size_t)k * d->len_pad : nullptr;
+    if (nt < 1) { esq_dense_destroy(d); return fail(c, ESQ_EINVAL, "P is all zero"); }
+    switch (nt) {
+#define CASE(N) case N: launch_dense_n<N>(c, a, p, h); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+        CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17)
+        CASE(18) CASE(19) CASE(20)
+#undef CASE
+    }
+    // base state: after esq_rk_accept, Y is the new state, YNEW the pre-step one
+    const double *base = from_end ? c->y : c->ynew;
+    e = hipMemcpyAsync(d->mem + (size_t)p * d->len_pad, base,
+                       d->len_pad * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        esq_dense_destroy(d);
+        return fail(c, (int)e, "interpolant build failed: %s", hipGetErrorString(e));
+    }
+    *out = d;
+    return 0;
+}
+int esq_dense_eval(esq_dense *d, double x, double *host_out) {
+    if (!d || !host_out) return ESQ_EINVAL;
+    hipError_t e = hipSetDevice(d->device);
+    if (e != hipSuccess) return (int)e;
+    HornerArgs a;
+    for (int k = 0; k < kMaxCols; ++k)
+        a.q[k] = k < d->np ? d->mem + (size_t)k * d->len_pad : nullptr;
+    double *base = d->mem + (size_t)d->np * d->len_pad;
+    double *scratch = d->mem + (size_t)(d->np + 1) * d->len_pad;
+    hipLaunchKernelGGL(k_horner, dim3(d->grid), dim3(kBlock), 0, d->stream,
+                       scratch, base, a, d->np, x, d->len_pad / 2);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(host_out, scratch, d->len * sizeof(double),
+                       hipMemcpyDeviceToHost, d->stream);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamSynchronize(d->stream);
+}
+int esq_dense_download(esq_dense *d, double *Qh_host) {
+    if (!d || !Qh_host) return ESQ_EINVAL;
+    hipError_t e = hipSetDevice(d->device);
+    if (e != hipSuccess) return (int)e;
+    for (int k = 0; k < d->np; ++k) {
+        e = hipMemcpyAsync(Qh_host + (size_t)k * d->len, d->mem + (size_t)k * d->len_pad,
+                           d->len * sizeof(double), hipMemcpyDeviceToHost, d->stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return (int)hipStreamSynchronize(d->stream);
+}
+int esq_dense_destroy(esq_dense *d) {
+    if (!d) return 0;
+    (void)hipSetDevice(d->device);
+    if (d->stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
+    if (d->mem) (void)hipFree(d->mem);
+    delete d;
     return 0;
 }
 

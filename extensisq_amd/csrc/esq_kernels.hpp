@@ -87,6 +87,74 @@ __global__ __launch_bounds__(kBlock) void k_lincomb(
 }
 
 // ---------------------------------------------------------------------------
+// Dense-output coefficients in ONE pass over K:  Q_c = scale * sum_j P[j][c] K_j
+// for c < np (ref common.py:363 `Q = K.T @ P`, :772 `Q * h`).  Every K row is
+// read once; the (row, column) weights sit in the kernel arguments.
+// ---------------------------------------------------------------------------
+constexpr int kMaxCols = 8;
+struct DenseArgs {
+    const double *p[kMaxTerms];        // K rows with a non-zero P row
+    double w[kMaxTerms][kMaxCols];     // P[j][c]
+    double *q[kMaxCols];               // output columns
+};
+template <int NT>
+__global__ __launch_bounds__(kBlock) void k_dense_q(DenseArgs a, int np,
+                                                    double scale, size_t n2) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 v[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j] = ld2_nt(a.p[j], i);
+#pragma unroll
+        for (int c = 0; c < kMaxCols; ++c) {
+            if (c < np) {                      // uniform
+                double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc.x = fma(a.w[j][c], v[j].x, acc.x);
+                    acc.y = fma(a.w[j][c], v[j].y, acc.y);
+                }
+                acc.x = __dmul_rn(acc.x, scale);
+                acc.y = __dmul_rn(acc.y, scale);
+                st2(a.q[c], i, acc);
+            }
+        }
+    }
+}
+// Horner evaluation  out = y0 + x*(q0 + x*(q1 + ... x*q_{np-1}))   (common.py:775-785)
+struct HornerArgs {
+    const double *q[kMaxCols];
+};
+__global__ __launch_bounds__(kBlock) void k_horner(double *__restrict__ out,
+                                                   const double *__restrict__ y0,
+                                                   HornerArgs a, int np, double x,
+                                                   size_t n2) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int c = kMaxCols - 1; c >= 0; --c) {
+            if (c < np) {
+                const double2 q = ld2(a.q[c], i);
+                if (c == np - 1) {
+                    acc.x = __dmul_rn(q.x, x);
+                    acc.y = __dmul_rn(q.y, x);
+                } else {
+                    acc.x = __dmul_rn(__dadd_rn(acc.x, q.x), x);
+                    acc.y = __dmul_rn(__dadd_rn(acc.y, q.y), x);
+                }
+            }
+        }
+        const double2 b = ld2(y0, i);
+        acc.x = __dadd_rn(acc.x, b.x);
+        acc.y = __dadd_rn(acc.y, b.y);
+        st2(out, i, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // block reduction: wave64 shuffle tree -> LDS across the 4 waves -> one
 // partial per block (fixed order => bitwise reproducible for a given grid).
 // NaN/Inf propagate through plain adds.

@@ -132,10 +132,19 @@ int  esq_rk_error_vector(esq_ctx *ctx, double h, int last_step);
 int  esq_rk_download_last_K(esq_ctx *ctx, int row, double *host);
 
 /* ---- dense output (common.py:358-368, 766-790) --------------------------- */
-/* Q[:, c] = sum_r K_last[r] * P[r][c] for c < p, evaluated on the device and
- * written to host as an (n, p) row-major matrix.  P is (n_rows_used, p). */
-int  esq_rk_dense_coefficients(esq_ctx *ctx, const double *P, int rows, int p,
-                               double *Q_host);
+/* Device-resident interpolant (ref HornerDenseOutput, common.py:766-790): an
+ * object of its own (it outlives the step and even the solver context) holding
+ * Qh = h * K_last.T @ P (one fused pass over K) and the base state on the
+ * device.  from_end != 0: the polynomial is anchored at the END of the step
+ * (BS5 'best', bogacki.py:390-393): base = Y, else base = the pre-step state. */
+typedef struct esq_dense esq_dense;
+int  esq_dense_create(esq_ctx *ctx, const double *P, int rows, int p, double h,
+                      int from_end, esq_dense **out);
+/* host_out[n] = base + sum_c Qh[:,c] x^(c+1)  (Horner on the device, x scaled) */
+int  esq_dense_eval(esq_dense *d, double x, double *host_out);
+/* Qh as a (p, n) row-major host matrix (transpose of the reference's Q*h) */
+int  esq_dense_download(esq_dense *d, double *Qh_host);
+int  esq_dense_destroy(esq_dense *d);
 
 /* Extra stages of BS5's 'low'/'best' interpolants (bogacki.py:356-368), on the
  * rows of the step just accepted:

@@ -470,3 +470,46 @@ def test_lockstep_total_size_changes_the_norm():
                 lockstep=esq.LockstepGroup(None, 2 * n))
     b.step()
     assert_allclose(b.error_norm_old, a.error_norm_old / np.sqrt(2), rtol=1e-12)
+
+
+# ------------------------------------------------ device-resident interpolant
+@pytest.mark.parametrize("name", ERK)
+def test_device_dense_output_large_n(name):
+    """n >= 4096: Qh = h*K.T@P is formed in one fused pass and stays in HBM,
+    evaluations are Horner kernels; compare with the
+    oracle's host interpolant of the same step"""
+    n = 5000
+    rng = np.random.default_rng(17)
+    lam = -rng.random(n) * 2.0
+    y0 = rng.standard_normal(n)
+    kw = dict(first_step=0.05, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+    d, o = _pair(name, esq.DiagonalLinear(lam, 1.0),
+                 lambda t, y: lam * y + np.sin(t), 0.3, y0, 5.0, **kw)
+    assert d.step() is None and o.step() is None
+    sd, so = d.dense_output(), o.dense_output()
+    from extensisq_amd.common import DeviceHornerDenseOutput
+    if name != "BS5":       # BS5's default 'low' interpolant is Horner too
+        assert isinstance(sd, DeviceHornerDenseOutput)
+    tc = np.linspace(o.t_old, o.t, 5)
+    assert_allclose(sd(tc), so(tc), rtol=1e-11, atol=1e-13)
+    assert_allclose(sd(tc[2]), so(tc[2]), rtol=1e-11, atol=1e-13)
+    assert sd(tc).shape == (n, 5)
+    del d                   # the interpolant owns its memory
+    assert_allclose(sd(o.t), o.y, rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("interp", ["free", "low", "best"])
+def test_bs5_interpolants_device_resident(interp):
+    n = 6000
+    rng = np.random.default_rng(3)
+    lam = -rng.random(n)
+    y0 = rng.standard_normal(n)
+    kw = dict(first_step=0.1, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0,
+              interpolant=interp)
+    d = esq.BS5(esq.DiagonalLinear(lam), 0.0, y0, 5.0, **kw)
+    o = rk_oracle.BS5(lambda t, y: lam * y, 0.0, y0, 5.0, **kw)
+    assert d.step() is None and o.step() is None
+    sd, so = d.dense_output(), o.dense_output()
+    tc = np.linspace(o.t_old, o.t, 4)
+    assert_allclose(sd(tc), so(tc), rtol=1e-11, atol=1e-13)
+    assert d.nfev == o.nfev
