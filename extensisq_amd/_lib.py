@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libextensisq_amd.so")
 
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
 PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC = range(4)
+VEC_NONE, VEC_Y, VEC_YNEW, VEC_YSTAGE, VEC_WORK = -1, -2, -3, -4, -5
 
 RHS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                      C.c_size_t, C.c_void_p)
@@ -62,6 +63,13 @@ SIGNATURES = {
     "esq_vec_sumsq": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "esq_vec_axpbmc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]),
     "esq_vec_wdiff_sumsq": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+    "esq_vec_fill": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "esq_vec_copy": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "esq_vec_eval_rhs": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
+    "esq_vec_upload": (C.c_int, [_vp, C.c_int, _vp]),
+    "esq_vec_download": (C.c_int, [_vp, C.c_int, _vp]),
+    "esq_hs_log_etol": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "esq_hs_select": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double]),
     "esq_set_comm": (C.c_int, [_vp, _vp]),
     "esq_comm_unique_id": (C.c_int, [_vp]),
     "esq_comm_init_rank": (C.c_int, [_vpp, C.c_int, _vp, C.c_int, C.c_int]),

@@ -22,7 +22,8 @@ from scipy.integrate._ivp.base import DenseOutput, OdeSolver
 from scipy.integrate._ivp.common import (validate_first_step,
                                          validate_max_step, warn_extraneous)
 
-from ._lib import (SLOT_K, SLOT_WORK, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, as_ptr)
+from ._lib import (SLOT_K, SLOT_WORK, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, VEC_NONE,
+                   VEC_Y, as_ptr)
 from .device import DeviceContext, DeviceRHS
 
 # failed-step counter shared with the RKC module (reference: common.py:14)
@@ -302,8 +303,10 @@ class RungeKutta(OdeSolver):
         is_cplx = np.iscomplexobj(y_host)
         if self._device_rhs is not None and is_cplx != self._device_rhs.is_complex:
             raise TypeError('dtypes of solution and derivative do not match')
-        self._dev = DeviceContext(self.n, self.n_stages + 1 + self._extra_rows,
-                                  is_cplx, device)
+        # at least 5 K rows: rows 1..4 are the work vectors of the device
+        # starting-step estimate (they are free until the first step)
+        self._dev = DeviceContext(
+            self.n, max(self.n_stages + 1 + self._extra_rows, 5), is_cplx, device)
         self._lib = self._dev.lib
         self._ctx = self._dev.handle
         self._dev.set_tableau(self.A, self.B, self.C, self.E, self.FSAL)
@@ -334,8 +337,7 @@ class RungeKutta(OdeSolver):
         if first_step is None:
             b = self.t + self.direction * min(abs(self.t_bound - self.t),
                                               self.max_step)
-            self.h_abs = abs(h_start(self.fun, self.t, b, y_host, self.f,
-                                     self.order_secondary, self.rtol, self.atol))
+            self.h_abs = abs(self._device_h_start(b))
         else:
             self.h_abs = validate_first_step(first_step, t0, t_bound)
         self.h_previous = None
@@ -344,6 +346,128 @@ class RungeKutta(OdeSolver):
 
     def _chk(self, code, what):
         self._dev._chk(code, what)
+
+    # ------------------------------------------------------ starting step
+    def _device_h_start(self, b):
+        """Watts' starting step (ref `h_start`, common.py:519-763) with every
+        vector in HBM: the perturbation vectors live in K rows 1..4, norms come
+        back as one double each, the scalar decisions below are the host part.
+        `h_start` above is the same procedure on host arrays (used by the CPU
+        tests to pin this one)."""
+        import ctypes
+        if self.n == 0:
+            return np.inf
+        lib, ctx = self._lib, self._ctx
+        Y, F0, SF, YP, PV, SPY = VEC_Y, 0, 1, 2, 3, 4
+        neq = self._n_norm
+        dtype = self._dev.dtype
+
+        def sumsq(x, y=VEC_NONE):
+            out = ctypes.c_double()
+            self._chk(lib.esq_vec_sumsq(ctx, x, y, ctypes.byref(out)),
+                      "esq_vec_sumsq")
+            return out.value
+
+        def rms(x, y=VEC_NONE):
+            return (sumsq(x, y) / neq) ** 0.5
+
+        def axpbmc(dst, a, alpha, bb, c=VEC_NONE):
+            self._chk(lib.esq_vec_axpbmc(ctx, dst, a, float(alpha), bb, c),
+                      "esq_vec_axpbmc")
+
+        def rhs(dst, t, src):
+            if self._device_rhs is not None:
+                self._chk(lib.esq_vec_eval_rhs(ctx, dst, float(t), src),
+                          "esq_vec_eval_rhs")
+                self.nfev += 1
+                return
+            arg = np.empty(self.n, dtype=dtype)
+            self._chk(lib.esq_vec_download(ctx, src, as_ptr(arg)),
+                      "esq_vec_download")
+            val = np.ascontiguousarray(self.fun(t, arg), dtype=dtype)
+            self._chk(lib.esq_vec_upload(ctx, dst, as_ptr(val)),
+                      "esq_vec_upload")
+
+        fi = np.finfo(np.float64)
+        big = sqrt(fi.max)
+        small = np.nextafter(fi.epsneg, 1.0)
+        relper = small ** 0.375
+        a = self.t
+        dx = b - a
+        absdx = abs(dx)
+
+        # (1) t-derivative bound and |f| bound
+        da = copysign(max(min(relper * abs(a), absdx), 100. * small * abs(a)), dx)
+        if da == 0.0:
+            da = relper * dx
+        rhs(SF, a + da, Y)
+        delf = rms(SF, F0)
+        dfdxb = delf / abs(da) if delf < big * abs(da) else big
+        fbnd = rms(SF)
+
+        # (2) Lipschitz estimate
+        dely = relper * rms(Y)
+        if dely == 0.0:
+            dely = relper
+        dely = copysign(dely, dx)
+        delf = rms(F0)
+        fbnd = max(fbnd, delf)
+        if delf:
+            self._chk(lib.esq_vec_copy(ctx, SPY, F0), "esq_vec_copy")
+            self._chk(lib.esq_vec_copy(ctx, YP, F0), "esq_vec_copy")
+        else:
+            self._chk(lib.esq_vec_fill(ctx, SPY, 0.0), "esq_vec_fill")
+            self._chk(lib.esq_vec_fill(ctx, YP, 1.0), "esq_vec_fill")
+            delf = rms(YP)
+        dfdub = 0.0
+        n_iter = min(neq + 1, 3)
+        for k in range(1, n_iter + 1):
+            axpbmc(PV, Y, dely / delf, YP)
+            if k == 2:
+                rhs(YP, a + da, PV)
+                axpbmc(PV, VEC_NONE, 1.0, YP, SF)
+            else:
+                rhs(YP, a, PV)
+                axpbmc(PV, VEC_NONE, 1.0, YP, F0)
+            fbnd = max(fbnd, rms(YP))
+            delf = rms(PV)
+            if delf >= big * abs(dely):
+                dfdub = big
+                break
+            dfdub = max(dfdub, delf / abs(dely))
+            if k == n_iter:
+                break
+            if delf == 0.0:
+                delf = 1.0
+            src, fill = (Y, dely / relper) if k == 2 else (PV, delf)
+            self._chk(lib.esq_hs_select(ctx, YP, SPY, src, float(fill)),
+                      "esq_hs_select")
+            delf = rms(YP)
+
+        # (3) step from the bounds and the tolerances
+        ydpb = dfdxb + dfdub * fbnd
+        tolsum, tolmin = ctypes.c_double(), ctypes.c_double()
+        self._chk(lib.esq_hs_log_etol(ctx, Y, ctypes.byref(tolsum),
+                                      ctypes.byref(tolmin)), "esq_hs_log_etol")
+        tolp = 10.0 ** (0.5 * (tolsum.value / neq + min(tolmin.value, big))
+                        / (self.order_secondary + 1))
+        h = absdx
+        if ydpb == 0.0 and fbnd == 0.0:
+            if tolp < 1.0:
+                h = absdx * tolp
+        elif ydpb == 0.0:
+            if tolp < fbnd * absdx:
+                h = tolp / fbnd
+        else:
+            srydpb = sqrt(0.5 * ydpb)
+            if tolp < srydpb * absdx:
+                h = tolp / srydpb
+        if dfdub:
+            h = min(h, 1.0 / dfdub)
+        h = max(h, 100.0 * small * abs(a))
+        if h == 0.0:
+            h = small * abs(b)
+        return copysign(h, dx)
 
     # ------------------------------------------------- lazy host mirrors
     @property

@@ -51,6 +51,7 @@ struct esq_ctx {
     double *y = nullptr, *ynew = nullptr, *ystage = nullptr, *atolv = nullptr,
            *work = nullptr;
     double *partials = nullptr;       // kMaxPartials doubles
+    double *partials2 = nullptr;      // second set (min reductions)
     double *d_result = nullptr;       // 1 double (device)
     double *h_result = nullptr;       // 1 double (pinned host)
     // method
@@ -297,15 +298,23 @@ struct StdoutToStderr {
 };
 constexpr int kNcclFloat64 = 8;   // ncclDouble
 constexpr int kNcclSum = 0;       // ncclSum
+constexpr int kNcclMin = 3;       // ncclMin
 
 // partials -> one double on the host (all-reduced over the communicator if set)
-int finish_reduction(esq_ctx *c, double *out) {
-    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(1024), 0, c->stream,
-                       c->partials, (int)c->grid_reduce, c->d_result);
+int finish_reduction(esq_ctx *c, double *out, bool take_min = false,
+                     const double *partials = nullptr) {
+    if (!partials) partials = c->partials;
+    if (take_min)
+        hipLaunchKernelGGL(k_final_min, dim3(1), dim3(1024), 0, c->stream,
+                           partials, (int)c->grid_reduce, c->d_result);
+    else
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(1024), 0, c->stream,
+                           partials, (int)c->grid_reduce, c->d_result);
     HIPCHK(c, hipGetLastError());
     if (c->comm) {
         int r = g_rccl.AllReduce(c->d_result, c->d_result, 1, kNcclFloat64,
-                                 kNcclSum, c->comm, c->stream);
+                                 take_min ? kNcclMin : kNcclSum, c->comm,
+                                 c->stream);
         if (r != 0)
             return fail(c, 1000 + r, "ncclAllReduce failed: %s",
                         g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
@@ -388,7 +397,7 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t nvec = (size_t)n_rows + kFixedSlots;
-    const size_t slab_doubles = nvec * c->stride + kMaxPartials + 64;
+    const size_t slab_doubles = nvec * c->stride + 2 * kMaxPartials + 64;
     HIPCHK(c, hipMalloc(&c->slab, slab_doubles * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(c->slab, 0, slab_doubles * sizeof(double), c->stream));
     c->krow.resize(n_rows);
@@ -405,7 +414,8 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     c->atolv = base + 3 * c->stride;
     c->work = base + 4 * c->stride;
     c->partials = base + 5 * c->stride;
-    c->d_result = c->partials + kMaxPartials;
+    c->partials2 = c->partials + kMaxPartials;
+    c->d_result = c->partials2 + kMaxPartials;
     HIPCHK(c, hipHostMalloc(&c->h_result, 64, hipHostMallocDefault));
     // launch geometry: grid-stride kernels, a few resident blocks per CU
     hipDeviceProp_t prop;
@@ -787,7 +797,19 @@ int esq_dense_destroy(esq_dense *d) {
 }
 
 // ---- RKC ----------------------------------------------------------------------
-#define ROW(c, r) (((r) >= 0 && (r) < (c)->n_rows) ? (c)->krow[r] : nullptr)
+// vector ids of the esq_rkc_* / esq_vec_* family: r >= 0 is a PHYSICAL K row,
+// ESQ_VEC_Y ... ESQ_VEC_WORK name the fixed slots
+static double *vec_ptr(esq_ctx *c, int r) {
+    if (r >= 0) return r < c->n_rows ? c->krow[r] : nullptr;
+    switch (r) {
+        case ESQ_VEC_Y: return c->y;
+        case ESQ_VEC_YNEW: return c->ynew;
+        case ESQ_VEC_YSTAGE: return c->ystage;
+        case ESQ_VEC_WORK: return c->work;
+        default: return nullptr;
+    }
+}
+#define ROW(c, r) vec_ptr((c), (r))
 
 int esq_rkc_first_stage(esq_ctx *c, int dst, int yn, int fn, double hmus) {
     if (!c) return ESQ_EINVAL;
@@ -869,8 +891,8 @@ int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
 }
 int esq_vec_sumsq(esq_ctx *c, int x, int y, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
-    double *a = ROW(c, x), *b = y >= 0 ? ROW(c, y) : nullptr;
-    if (!a || (y >= 0 && !b)) return fail(c, ESQ_EINVAL, "bad row");
+    double *a = ROW(c, x), *b = y != ESQ_VEC_NONE ? ROW(c, y) : nullptr;
+    if (!a || (y != ESQ_VEC_NONE && !b)) return fail(c, ESQ_EINVAL, "bad row");
     hipLaunchKernelGGL(k_sumsq, dim3(c->grid_reduce), dim3(kBlock), 0, c->stream,
                        a, b, c->len_pad / 2, c->partials);
     HIPCHK(c, hipGetLastError());
@@ -878,9 +900,9 @@ int esq_vec_sumsq(esq_ctx *c, int x, int y, double *sumsq_out) {
 }
 int esq_vec_axpbmc(esq_ctx *c, int dst, int a, double alpha, int b, int cc) {
     if (!c) return ESQ_EINVAL;
-    double *d = ROW(c, dst), *pa = a >= 0 ? ROW(c, a) : nullptr, *pb = ROW(c, b),
-           *pc = cc >= 0 ? ROW(c, cc) : nullptr;
-    if (!d || !pb || (a >= 0 && !pa) || (cc >= 0 && !pc))
+    double *d = ROW(c, dst), *pa = a != ESQ_VEC_NONE ? ROW(c, a) : nullptr,
+           *pb = ROW(c, b), *pc = cc != ESQ_VEC_NONE ? ROW(c, cc) : nullptr;
+    if (!d || !pb || (a != ESQ_VEC_NONE && !pa) || (cc != ESQ_VEC_NONE && !pc))
         return fail(c, ESQ_EINVAL, "bad row");
     hipLaunchKernelGGL(k_axpbmc, dim3(c->grid_stream), dim3(kBlock), 0, c->stream,
                        d, pa, alpha, pb, pc, c->len_pad / 2);
@@ -896,6 +918,83 @@ int esq_vec_wdiff_sumsq(esq_ctx *c, int a, int b, int w, double *sumsq_out) {
                        c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
     HIPCHK(c, hipGetLastError());
     return finish_reduction(c, sumsq_out);
+}
+
+int esq_vec_fill(esq_ctx *c, int dst, double value) {
+    if (!c) return ESQ_EINVAL;
+    double *d = ROW(c, dst);
+    if (!d) return fail(c, ESQ_EINVAL, "bad vector id %d", dst);
+    if (c->cplx)
+        hipLaunchKernelGGL(k_fill<true>, dim3(c->grid_stream), dim3(kBlock), 0,
+                           c->stream, d, value, c->len_pad / 2, c->n);
+    else
+        hipLaunchKernelGGL(k_fill<false>, dim3(c->grid_stream), dim3(kBlock), 0,
+                           c->stream, d, value, c->len_pad / 2, c->n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int esq_vec_copy(esq_ctx *c, int dst, int src) {
+    if (!c) return ESQ_EINVAL;
+    double *d = ROW(c, dst), *s = ROW(c, src);
+    if (!d || !s) return fail(c, ESQ_EINVAL, "bad vector id");
+    HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),
+                             hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+int esq_vec_eval_rhs(esq_ctx *c, int dst, double t, int src) {
+    if (!c) return ESQ_EINVAL;
+    double *d = ROW(c, dst), *s = ROW(c, src);
+    if (!d || !s) return fail(c, ESQ_EINVAL, "bad vector id");
+    return call_rhs(c, t, s, d);
+}
+int esq_vec_upload(esq_ctx *c, int dst, const double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    double *d = ROW(c, dst);
+    if (!d) return fail(c, ESQ_EINVAL, "bad vector id %d", dst);
+    HIPCHK(c, hipMemcpyAsync(d, host, c->len * sizeof(double),
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int esq_vec_download(esq_ctx *c, int src, double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    double *s = ROW(c, src);
+    if (!s) return fail(c, ESQ_EINVAL, "bad vector id %d", src);
+    HIPCHK(c, hipMemcpyAsync(host, s, c->len * sizeof(double),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int esq_hs_log_etol(esq_ctx *c, int y, double *sum_out, double *min_out) {
+    if (!c || !sum_out || !min_out) return ESQ_EINVAL;
+    double *py = ROW(c, y);
+    if (!py) return fail(c, ESQ_EINVAL, "bad vector id %d", y);
+    const double *av = c->atol_is_vec ? c->atolv : nullptr;
+    if (c->cplx)
+        hipLaunchKernelGGL(k_log_etol<true>, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, py, av, c->atol_s, c->rtol, c->len_pad / 2,
+                           c->n, c->partials, c->partials2);
+    else
+        hipLaunchKernelGGL(k_log_etol<false>, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, py, av, c->atol_s, c->rtol, c->len_pad / 2,
+                           c->n, c->partials, c->partials2);
+    HIPCHK(c, hipGetLastError());
+    int r = finish_reduction(c, sum_out);
+    if (r) return r;
+    return finish_reduction(c, min_out, /*take_min=*/true, c->partials2);
+}
+int esq_hs_select(esq_ctx *c, int yp, int spy, int src, double fill) {
+    if (!c) return ESQ_EINVAL;
+    double *a = ROW(c, yp), *b = ROW(c, spy), *s = ROW(c, src);
+    if (!a || !b || !s) return fail(c, ESQ_EINVAL, "bad vector id");
+    if (c->cplx)
+        hipLaunchKernelGGL(k_hs_select<true>, dim3(c->grid_stream), dim3(kBlock), 0,
+                           c->stream, a, b, s, fill, c->len_pad / 2, c->n);
+    else
+        hipLaunchKernelGGL(k_hs_select<false>, dim3(c->grid_stream), dim3(kBlock), 0,
+                           c->stream, a, b, s, fill, c->len_pad / 2, c->n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
 }
 
 // ---- lock-step ------------------------------------------------------------------

@@ -453,4 +453,130 @@ __global__ __launch_bounds__(kBlock) void k_wdiff_sumsq(
     block_partial(local, partials);
 }
 
+// ---------------------------------------------------------------------------
+// Starting-step helpers (Watts' dhstrt as restated in common.py:519-763)
+// ---------------------------------------------------------------------------
+// partial sums of log10(atol + rtol*|y|) and partial minima of the same
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_log_etol(
+    const double *__restrict__ y, const double *__restrict__ atol_vec,
+    double atol_s, double rtol, size_t n2, size_t n_valid,
+    double *__restrict__ part_sum, double *__restrict__ part_min) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    double s = 0.0, m = INFINITY;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        const double2 v = ld2(y, i);
+        if (CPLX) {
+            if (i < n_valid) {
+                const double at = atol_vec ? atol_vec[i] : atol_s;
+                const double e = log10(at + rtol * hypot(v.x, v.y));
+                s += e;
+                m = fmin(m, e);
+            }
+        } else {
+            if (2 * i < n_valid) {
+                const double at = atol_vec ? atol_vec[2 * i] : atol_s;
+                const double e = log10(at + rtol * fabs(v.x));
+                s += e;
+                m = fmin(m, e);
+            }
+            if (2 * i + 1 < n_valid) {
+                const double at = atol_vec ? atol_vec[2 * i + 1] : atol_s;
+                const double e = log10(at + rtol * fabs(v.y));
+                s += e;
+                m = fmin(m, e);
+            }
+        }
+    }
+    // sum -> part_sum, min -> part_min (same tree, two operators)
+    __shared__ double lmin[kBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) lmin[threadIdx.x >> 6] = m;
+    block_partial(s, part_sum);          // contains the __syncthreads()
+    if (threadIdx.x == 0) {
+        double t = lmin[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) t = fmin(t, lmin[w]);
+        part_min[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_final_min(
+    const double *__restrict__ partials, int count, double *__restrict__ out) {
+    __shared__ double lds[16];
+    double m = INFINITY;
+    for (int i = threadIdx.x; i < count; i += 1024) m = fmin(m, partials[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t = fmin(t, lds[w]);
+        *out = t;
+    }
+}
+// next perturbation direction (common.py:700-714):
+//   dy  = where(src, src, fill);  spy = where(spy, spy, yp)
+//   yp  = where(spy, copysign(dy, spy), dy)      (per real/imag component;
+//   the `where` conditions test the whole complex number)
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_hs_select(
+    double *__restrict__ yp, double *__restrict__ spy,
+    const double *__restrict__ src, double fill, size_t n2, size_t n_valid) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 d = ld2(src, i), s = ld2(spy, i);
+        const double2 y = ld2(yp, i);
+        // the zero padding behind the n valid elements must stay zero (it is
+        // summed by the norm kernels)
+        const size_t first = CPLX ? i : 2 * i;
+        if (first >= n_valid) continue;
+        const bool second_valid = CPLX || first + 1 < n_valid;
+        if (CPLX) {
+            if (d.x == 0.0 && d.y == 0.0) { d.x = fill; d.y = 0.0; }
+            if (s.x == 0.0 && s.y == 0.0) s = y;
+            double2 r = d;
+            if (s.x != 0.0 || s.y != 0.0) {
+                r.x = copysign(d.x, s.x);
+                r.y = copysign(d.y, s.y);
+            }
+            st2(spy, i, s);
+            st2(yp, i, r);
+        } else {
+            if (d.x == 0.0) d.x = fill;
+            if (d.y == 0.0) d.y = fill;
+            if (s.x == 0.0) s.x = y.x;
+            if (s.y == 0.0) s.y = y.y;
+            double2 r;
+            r.x = s.x != 0.0 ? copysign(d.x, s.x) : d.x;
+            r.y = s.y != 0.0 ? copysign(d.y, s.y) : d.y;
+            if (!second_valid) { r.y = 0.0; s.y = 0.0; }
+            st2(spy, i, s);
+            st2(yp, i, r);
+        }
+    }
+}
+// dst[0..len) = value (re) / 0 (im) -- padding stays zero
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_fill(double *__restrict__ dst,
+                                                 double value, size_t n2,
+                                                 size_t n_valid) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 v = make_double2(0.0, 0.0);
+        if (CPLX) {
+            if (i < n_valid) v.x = value;
+        } else {
+            if (2 * i < n_valid) v.x = value;
+            if (2 * i + 1 < n_valid) v.y = value;
+        }
+        st2(dst, i, v);
+    }
+}
+
 }  // namespace esq

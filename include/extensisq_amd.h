@@ -155,8 +155,16 @@ int  esq_rk_dense_stage(esq_ctx *ctx, int row, const double *a, int count,
 int  esq_rk_dense_eval(esq_ctx *ctx, int row, double t);
 int  esq_rk_upload_last_K(esq_ctx *ctx, int row, const double *host);
 
+/* vector ids of the esq_rkc_* / esq_vec_* / esq_hs_* family: id >= 0 is a
+ * PHYSICAL K row (no rotation map), the negative ids name the fixed slots */
+#define ESQ_VEC_NONE    (-1)
+#define ESQ_VEC_Y       (-2)
+#define ESQ_VEC_YNEW    (-3)
+#define ESQ_VEC_YSTAGE  (-4)
+#define ESQ_VEC_WORK    (-5)
+
 /* ---- Runge-Kutta-Chebyshev (SSV2stab) launches -------------------------- */
-/* Rows are PHYSICAL K rows chosen by the host (it rotates them instead of the
+/* Rows are vector ids chosen by the host (it rotates them instead of the
  * two full copies of sommeijer.py:318-319).
  * dst = yn + hmus * fn                              sommeijer.py:289          */
 int  esq_rkc_first_stage(esq_ctx *ctx, int dst, int yn, int fn, double hmus);
@@ -176,13 +184,29 @@ int  esq_rkc_error_norm(esq_ctx *ctx, int y, int yn, int fn, int fy, double h,
 /* generic K[dst] = rhs(t, K[src]) on physical rows   sommeijer.py:214, 311    */
 int  esq_rkc_eval_rhs(esq_ctx *ctx, int dst, double t, int src);
 /* sum x^2 and sum (x - y)^2 (np.linalg.norm pieces of sommeijer.py:350-374;
- * y < 0 means "no subtraction") */
+ * y == ESQ_VEC_NONE means "no subtraction") */
 int  esq_vec_sumsq(esq_ctx *ctx, int x, int y, double *sumsq_out);
-/* dst = a + alpha * (b - c)   (sommeijer.py:354, 389, 383; c < 0: no c;
- * a < 0: no a) */
+/* dst = a + alpha * (b - c)   (sommeijer.py:354, 389, 383; a and/or c may be
+ * ESQ_VEC_NONE) */
 int  esq_vec_axpbmc(esq_ctx *ctx, int dst, int a, double alpha, int b, int c);
 /* sum |(a - b) / (atol + rtol*|w|)|^2               sommeijer.py:154-155      */
 int  esq_vec_wdiff_sumsq(esq_ctx *ctx, int a, int b, int w, double *sumsq_out);
+
+/* generic vector plumbing on vector ids (used by the starting-step estimate
+ * and the spectral-radius iteration) */
+int  esq_vec_fill(esq_ctx *ctx, int dst, double value);
+int  esq_vec_copy(esq_ctx *ctx, int dst, int src);
+int  esq_vec_eval_rhs(esq_ctx *ctx, int dst, double t, int src);  /* dst = rhs(t, src) */
+int  esq_vec_upload(esq_ctx *ctx, int dst, const double *host);
+int  esq_vec_download(esq_ctx *ctx, int src, double *host);
+
+/* ---- starting step size (Watts' dhstrt; ref h_start, common.py:519-763) --- */
+/* sum and min over components of log10(atol + rtol*|y|)      common.py:725-727 */
+int  esq_hs_log_etol(esq_ctx *ctx, int y, double *sum_out, double *min_out);
+/* next perturbation direction                                 common.py:700-714
+ *   dy = where(src, src, fill); spy = where(spy, spy, yp);
+ *   yp = where(spy, copysign(dy, spy), dy)   (componentwise for complex) */
+int  esq_hs_select(esq_ctx *ctx, int yp, int spy, int src, double fill);
 
 /* ---- multi-GPU lock-step (BASELINE.json configs[4]; not in the reference) - */
 /* comm is an ncclComm_t created by the caller (one rank per GPU); every

@@ -513,3 +513,52 @@ def test_bs5_interpolants_device_resident(interp):
     tc = np.linspace(o.t_old, o.t, 4)
     assert_allclose(sd(tc), so(tc), rtol=1e-11, atol=1e-13)
     assert d.nfev == o.nfev
+
+
+# ------------------------------------------------------- device starting step
+@pytest.mark.parametrize("case", ["decay", "duffing", "heat", "zero", "complex",
+                                  "backward", "scalar", "atol_vec", "big"])
+@pytest.mark.parametrize("mode", ["host_rhs", "device_rhs"])
+def test_device_h_start(case, mode):
+    """the device-resident starting-step estimate (perturbation vectors in K
+    rows, norms by reduction kernels) equals the host NumPy procedure, which
+    tests/test_host_logic.py pins to the oracle and the golden first step"""
+    from extensisq_amd.common import h_start, validate_tol
+    atol = 1e-6
+    dev_fun = None
+    if case == "decay":
+        fun, a, b, y = (lambda t, y: -0.5 * y), 0.0, 10.0, np.array([2., 4., 8.])
+    elif case == "duffing":
+        fun, a, b, y = pb.duffing_rhs, 0.0, 20.0, np.array([0.0, 0.0])
+    elif case == "heat":
+        fun, a, b, y = pb.heat2d_rhs(12), 0.0, 1.0, pb.heat2d_y0(12)
+        dev_fun = esq.Heat2D(12)
+    elif case == "zero":
+        fun, a, b, y = (lambda t, y: np.zeros_like(y)), 0.0, 10.0, np.ones(3)
+    elif case == "complex":
+        fun, a, b, y = (lambda t, y: -y), 0.0, 1.0, np.array([0.5 + 1j, -2j])
+    elif case == "backward":
+        fun, a, b, y = pb.rational_rhs, 5.0, 1.0, np.array([1 / 3, 2 / 9])
+    elif case == "scalar":
+        fun, a, b, y = (lambda t, y: np.cos(t) * y), 1.0, 3.0, np.array([0.7])
+    elif case == "atol_vec":
+        rng = np.random.default_rng(2)
+        lam = -rng.random(777) * 5
+        fun, a, b, y = (lambda t, y: lam * y + np.sin(t)), 0.5, 2.0, \
+            rng.standard_normal(777)
+        y[::7] = 0.0
+        atol = 10.0 ** rng.uniform(-9, -5, 777)
+        dev_fun = esq.DiagonalLinear(lam, 1.0)
+    else:
+        fun, a, b, y = pb.bruss2d_rhs(64), 0.0, 1.0, pb.bruss2d_y0(64)
+        dev_fun = esq.Brusselator2D(64)
+    if mode == "device_rhs" and dev_fun is None:
+        pytest.skip("no device twin for this RHS")
+    for cls in (esq.Ts5, esq.Pr8):
+        s = cls(dev_fun if mode == "device_rhs" else fun, a, y, b, rtol=1e-4,
+                atol=atol)
+        y_arr = np.asarray(y, dtype=complex if np.iscomplexobj(y) else float)
+        rtol_v, atol_v = validate_tol(1e-4, atol, y_arr)
+        want = abs(h_start(fun, a, b, y_arr, np.asarray(fun(a, y_arr)),
+                           cls.order_secondary, rtol_v, atol_v))
+        assert_allclose(s.h_abs, want, rtol=1e-11)
