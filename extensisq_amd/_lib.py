@@ -45,6 +45,7 @@ SIGNATURES = {
     "esq_rk_pre_error": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _dp]),
     "esq_rk_accept": (C.c_int, [_vp, C.c_double, C.c_int]),
     "esq_rk_error_vector": (C.c_int, [_vp, C.c_double, C.c_int]),
+    "esq_rk_row_id": (C.c_int, [_vp, C.c_int, C.c_int]),
     "esq_rk_download_last_K": (C.c_int, [_vp, C.c_int, _vp]),
     "esq_dense_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int,
                                    _vpp]),
@@ -63,7 +64,10 @@ SIGNATURES = {
     "esq_vec_sumsq": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "esq_vec_axpbmc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]),
     "esq_vec_wdiff_sumsq": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
-    "esq_vec_fill": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "esq_aux_rows": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "esq_vec_wdot": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_double, _dp]),
+    "esq_vec_fill": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double]),
     "esq_vec_copy": (C.c_int, [_vp, C.c_int, C.c_int]),
     "esq_vec_eval_rhs": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
     "esq_vec_upload": (C.c_int, [_vp, C.c_int, _vp]),

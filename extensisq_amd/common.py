@@ -416,8 +416,8 @@ class RungeKutta(OdeSolver):
             self._chk(lib.esq_vec_copy(ctx, SPY, F0), "esq_vec_copy")
             self._chk(lib.esq_vec_copy(ctx, YP, F0), "esq_vec_copy")
         else:
-            self._chk(lib.esq_vec_fill(ctx, SPY, 0.0), "esq_vec_fill")
-            self._chk(lib.esq_vec_fill(ctx, YP, 1.0), "esq_vec_fill")
+            self._chk(lib.esq_vec_fill(ctx, SPY, 0.0, 0.0), "esq_vec_fill")
+            self._chk(lib.esq_vec_fill(ctx, YP, 1.0, 0.0), "esq_vec_fill")
             delf = rms(YP)
         dfdub = 0.0
         n_iter = min(neq + 1, 3)
@@ -754,11 +754,10 @@ class RungeKutta(OdeSolver):
 
     # ---------------------------------------------------- stiffness detection
     def _diagnose_stiffness(self):
-        """Bookkeeping of RKSuite's stiffness check (ref common.py:370-410).
-        The diagnosis itself (`stiff_a`, a nonlinear power iteration run every
-        `nfev_stiff_detect` evaluations) is a SURVEY.md §8f "next" row and is
-        not implemented yet: when it would trigger, an INFO record is logged
-        instead of a warning."""
+        """RKSuite's stiffness check (ref common.py:370-516): test after every
+        `nfev_stiff_detect` evaluations' worth of steps or after >= 10 failed
+        steps within 40; the diagnosis itself runs on the device
+        (extensisq_amd/stiffness.py)."""
         if self.nfev_stiff_detect == 0:
             return
         self.okstp += 1
@@ -774,8 +773,8 @@ class RungeKutta(OdeSolver):
         many_steps = self.nfev_stiff_detect // self.n_stages
         toomch = self.okstp % many_steps == many_steps - 1
         if toomch or lotsfl:
-            logging.info('extensisq_amd: stiffness check point reached '
-                         '(diagnosis not implemented on the device path)')
+            from .stiffness import diagnose
+            diagnose(self, lotsfl)
 
     def __del__(self):
         dev = getattr(self, "_dev", None)

@@ -45,6 +45,7 @@ struct esq_ctx {
     bool cplx = false;
     hipStream_t stream = nullptr;
     double *slab = nullptr;
+    std::vector<double *> aux_slabs;   // lazily added work rows (esq_aux_rows)
     std::vector<double *> krow;       // physical K rows
     std::vector<int> kmap;            // logical -> physical (step in flight)
     std::vector<int> kmap_last;       // mapping of the step just accepted
@@ -441,6 +442,7 @@ int esq_destroy(esq_ctx *c) {
     for (auto &ev : c->prof_live) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
     for (auto &e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->slab) (void)hipFree(c->slab);
+    for (double *p : c->aux_slabs) (void)hipFree(p);
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -650,6 +652,10 @@ int esq_rk_error_vector(esq_ctx *c, double h, int last_step) {
     return launch_lincomb(c, c->work, nullptr, tm, nt, h);
 }
 
+int esq_rk_row_id(esq_ctx *c, int logical_row, int last_step) {
+    if (!c || logical_row < 0 || logical_row >= c->n_rows) return ESQ_EINVAL;
+    return last_step ? c->kmap_last[logical_row] : c->kmap[logical_row];
+}
 int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
@@ -920,16 +926,48 @@ int esq_vec_wdiff_sumsq(esq_ctx *c, int a, int b, int w, double *sumsq_out) {
     return finish_reduction(c, sumsq_out);
 }
 
-int esq_vec_fill(esq_ctx *c, int dst, double value) {
+int esq_aux_rows(esq_ctx *c, int count, int *first_id) {
+    if (!c || !first_id || count < 1 || count > 32) return ESQ_EINVAL;
+    double *mem = nullptr;
+    const size_t bytes = (size_t)count * c->stride * sizeof(double);
+    HIPCHK(c, hipMalloc(&mem, bytes));
+    HIPCHK(c, hipMemsetAsync(mem, 0, bytes, c->stream));
+    c->aux_slabs.push_back(mem);
+    *first_id = c->n_rows;
+    for (int r = 0; r < count; ++r) {
+        c->krow.push_back(mem + (size_t)r * c->stride);
+        c->kmap.push_back(c->n_rows + r);
+        c->kmap_last.push_back(c->n_rows + r);
+    }
+    c->n_rows += count;
+    return 0;
+}
+int esq_vec_wdot(esq_ctx *c, int a, int b, int y1, int y2, double floor_,
+                 double *out) {
+    if (!c || !out) return ESQ_EINVAL;
+    double *pa = ROW(c, a), *pb = ROW(c, b), *p1 = ROW(c, y1), *p2 = ROW(c, y2);
+    if (!pa || !pb || !p1 || !p2) return fail(c, ESQ_EINVAL, "bad vector id");
+    if (c->cplx)
+        hipLaunchKernelGGL(k_wdot<true>, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, pa, pb, p1, p2, floor_, c->len_pad / 2, c->n,
+                           c->partials);
+    else
+        hipLaunchKernelGGL(k_wdot<false>, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, pa, pb, p1, p2, floor_, c->len_pad / 2, c->n,
+                           c->partials);
+    HIPCHK(c, hipGetLastError());
+    return finish_reduction(c, out);
+}
+int esq_vec_fill(esq_ctx *c, int dst, double value, double value_im) {
     if (!c) return ESQ_EINVAL;
     double *d = ROW(c, dst);
     if (!d) return fail(c, ESQ_EINVAL, "bad vector id %d", dst);
     if (c->cplx)
         hipLaunchKernelGGL(k_fill<true>, dim3(c->grid_stream), dim3(kBlock), 0,
-                           c->stream, d, value, c->len_pad / 2, c->n);
+                           c->stream, d, value, value_im, c->len_pad / 2, c->n);
     else
         hipLaunchKernelGGL(k_fill<false>, dim3(c->grid_stream), dim3(kBlock), 0,
-                           c->stream, d, value, c->len_pad / 2, c->n);
+                           c->stream, d, value, value_im, c->len_pad / 2, c->n);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

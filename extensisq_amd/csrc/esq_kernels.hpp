@@ -560,17 +560,49 @@ __global__ __launch_bounds__(kBlock) void k_hs_select(
         }
     }
 }
+// weighted dot product of RKSuite's stiffness check (common.py:413-415, 968,
+// 1014):  sum a.b / wt^2,  wt = max(0.5*(|y1| + |y2|), floor).  A complex state
+// is treated as the real vector (re, im) with the weight of the complex
+// modulus on both parts (common.py:916-924).
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void k_wdot(
+    const double *__restrict__ a, const double *__restrict__ b,
+    const double *__restrict__ y1, const double *__restrict__ y2, double floor_,
+    size_t n2, size_t n_valid, double *__restrict__ partials) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        const double2 va = ld2(a, i), vb = ld2(b, i), p = ld2(y1, i), q = ld2(y2, i);
+        if (CPLX) {
+            if (i < n_valid) {
+                const double w = fmax(0.5 * (hypot(p.x, p.y) + hypot(q.x, q.y)), floor_);
+                local += (va.x / w) * (vb.x / w) + (va.y / w) * (vb.y / w);
+            }
+        } else {
+            if (2 * i < n_valid) {
+                const double w = fmax(0.5 * (fabs(p.x) + fabs(q.x)), floor_);
+                local += (va.x / w) * (vb.x / w);
+            }
+            if (2 * i + 1 < n_valid) {
+                const double w = fmax(0.5 * (fabs(p.y) + fabs(q.y)), floor_);
+                local += (va.y / w) * (vb.y / w);
+            }
+        }
+    }
+    block_partial(local, partials);
+}
 // dst[0..len) = value (re) / 0 (im) -- padding stays zero
 template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void k_fill(double *__restrict__ dst,
-                                                 double value, size_t n2,
-                                                 size_t n_valid) {
+                                                 double value, double value_im,
+                                                 size_t n2, size_t n_valid) {
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
          i += stride) {
         double2 v = make_double2(0.0, 0.0);
         if (CPLX) {
-            if (i < n_valid) v.x = value;
+            if (i < n_valid) { v.x = value; v.y = value_im; }
         } else {
             if (2 * i < n_valid) v.x = value;
             if (2 * i + 1 < n_valid) v.y = value;

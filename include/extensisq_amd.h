@@ -128,6 +128,9 @@ int  esq_rk_accept(esq_ctx *ctx, double t_new, int with_end_eval);
 /* WORK = h * sum_j E[j] K[j]  (the vector `_estimate_error` returns,
  * common.py:333-336); K rows of the step just accepted if last_step != 0. */
 int  esq_rk_error_vector(esq_ctx *ctx, double h, int last_step);
+/* vector id (physical row, >= 0) of logical K row `logical_row` of the step in
+ * flight, or of the step just accepted if last_step != 0; negative on misuse */
+int  esq_rk_row_id(esq_ctx *ctx, int logical_row, int last_step);
 /* logical->physical row of K for the step just accepted (for solver.K) */
 int  esq_rk_download_last_K(esq_ctx *ctx, int row, double *host);
 
@@ -194,11 +197,21 @@ int  esq_vec_wdiff_sumsq(esq_ctx *ctx, int a, int b, int w, double *sumsq_out);
 
 /* generic vector plumbing on vector ids (used by the starting-step estimate
  * and the spectral-radius iteration) */
-int  esq_vec_fill(esq_ctx *ctx, int dst, double value);
+/* value_im is the imaginary part for a complex context (ignored otherwise) */
+int  esq_vec_fill(esq_ctx *ctx, int dst, double value, double value_im);
 int  esq_vec_copy(esq_ctx *ctx, int dst, int src);
 int  esq_vec_eval_rhs(esq_ctx *ctx, int dst, double t, int src);  /* dst = rhs(t, src) */
 int  esq_vec_upload(esq_ctx *ctx, int dst, const double *host);
 int  esq_vec_download(esq_ctx *ctx, int src, double *host);
+
+/* add `count` zeroed work vectors to the context; their ids are
+ * *first_id ... *first_id + count - 1 (used by the stiffness diagnosis, which
+ * must not disturb the K rows of the step just taken) */
+int  esq_aux_rows(esq_ctx *ctx, int count, int *first_id);
+/* sum a.b / wt^2 with wt = max(0.5*(|y1| + |y2|), floor)   common.py:413-415,
+ * 968, 1014 (RKSuite's weighted inner product of the stiffness diagnosis) */
+int  esq_vec_wdot(esq_ctx *ctx, int a, int b, int y1, int y2, double floor_,
+                  double *out);
 
 /* ---- starting step size (Watts' dhstrt; ref h_start, common.py:519-763) --- */
 /* sum and min over components of log10(atol + rtol*|y|)      common.py:725-727 */

@@ -196,11 +196,54 @@ def gen_lockstep():
     print("lockstep: steps", len(ts), "nfev", s.nfev)
 
 
+def gen_stiffness():
+    """G6: the reference's stiffness diagnosis (stiff_a, common.py:824-1103) on
+    stiff / oscillatory / mild problems: every call's inputs and verdict, and
+    the warnings the run emitted."""
+    import warnings
+    import extensisq.common as rc
+    from stiffness_cases import stiffness_cases
+    out = {}
+    orig = rc.stiff_a
+    for cname, (fun, t_span, y0, kw) in stiffness_cases().items():
+        for name in ("BS5", "Ts5", "Pr8"):
+            calls = []
+
+            def spy(f, x, y, hnow, havg, xend, maxfcn, wt, fxy, v0, cost):
+                res = orig(f, x, y, hnow, havg, xend, maxfcn, wt, fxy, v0, cost)
+                stif, rootre, root = res
+                calls.append({"t": float(x), "hnow": float(hnow),
+                              "havg": float(havg),
+                              "stif": None if stif is None else bool(stif),
+                              "rootre": None if rootre is None else bool(rootre),
+                              "roots": None if root is None else
+                              [list(map(float, root[0])), list(map(float, root[1])),
+                               float(root[2])]})
+                return res
+            rc.stiff_a = spy
+            try:
+                with warnings.catch_warnings(record=True) as wlist:
+                    warnings.simplefilter("always")
+                    res = solve_ivp(fun, t_span, y0, method=getattr(ref, name), **kw)
+            finally:
+                rc.stiff_a = orig
+            out[f"{cname}/{name}"] = {
+                "calls": calls, "nfev": int(res.nfev), "nfs": int(ref.NFS[()]),
+                "steps": int(res.t.size - 1),
+                "warnings": sorted({str(w.message)[:60] for w in wlist}),
+            }
+    with open(os.path.join(GOLD, "stiffness.json"), "w") as fh:
+        json.dump(out, fh)
+    print("stiffness:", {k: (len(v["calls"]), v["warnings"][:1], v["nfev"])
+                         for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     gen_single_step()
     gen_traces()
     gen_rkc()
     gen_lockstep()
+    gen_stiffness()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
