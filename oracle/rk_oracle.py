@@ -541,7 +541,70 @@ class BS5(OracleERK):
         return HornerInterpolant(self.t, self.t + h, self.y, Q)
 
 
-for _cls in (Ts5, BS5, Pr7, Pr8, Pr9):
+class CK5(OracleERK):
+    """Cash-Karp 5(4), data only (cash.py:9-112)"""
+
+
+class Me4(OracleERK):
+    """Merson 4(3), data only (merson.py:5-122)"""
+
+
+class CFMR7osc(OracleERK):
+    """Calvo-Franco-Montijano-Randez 7(5) for oscillatory problems: an early
+    error test after 8 stages saves the last stage of a rejected step
+    (calvo.py:152-261)"""
+
+    def _pre_error_norm(self, y, h):                         # :255-261
+        y_pre = y + h * (self.K[:8].T @ self.A[8, :8])
+        scale = error_scale(self.atol, self.rtol, y, y_pre)
+        err = h * (self.K[:8, :].T @ self.E[:8])
+        return rms(err / scale)
+
+    def _step_impl(self):                                    # :152-253
+        t, y = self.t, self.y
+        h_abs, min_step = self._limit_step(t)
+        had_reject = False
+        while True:
+            if h_abs < min_step:
+                return False, self.TOO_SMALL_STEP
+            h = h_abs * self.direction
+            t_new = t + h
+            self.K[0] = self.f
+            for i in range(1, self.n_stages - 1):
+                self._stage(h, i)
+            pre = self._pre_error_norm(y, h)
+            if pre > 1:
+                self.trace.append((t_new, h, float(pre), False))
+                had_reject = True
+                h_abs *= max(self.min_factor,
+                             self.safety * pre ** self.error_exponent)
+                NFS[()] += 1
+                continue
+            self._stage(h, self.n_stages - 1)
+            y_new, error_norm = self._solution_and_error(y, h)
+            self.trace.append((t_new, h, float(error_norm), error_norm < 1))
+            if error_norm < 1:
+                h_abs *= self._growth_after_accept(error_norm, h, had_reject)
+                break
+            had_reject = True
+            h_abs *= max(self.min_factor,
+                         self.safety * error_norm ** self.error_exponent)
+            NFS[()] += 1
+            self.jflstp += 1
+            if np.isnan(error_norm) or np.isinf(error_norm):
+                return False, "Overflow or underflow encountered."
+        self.K[self.n_stages] = self.fun(t + h, y_new)
+        self.h_previous = h
+        self.y_old = y
+        self.h_abs = h_abs
+        self.f = self.K[self.n_stages].copy()
+        self.error_norm_old = error_norm
+        self.t = t_new
+        self.y = y_new
+        return True, None
+
+
+for _cls in (Ts5, BS5, Pr7, Pr8, Pr9, CK5, Me4, CFMR7osc):
     _cls._install(_cls.__name__)
 
-METHODS = {c.__name__: c for c in (BS5, Ts5, Pr7, Pr8, Pr9)}
+METHODS = {c.__name__: c for c in (BS5, Ts5, Pr7, Pr8, Pr9, CK5, Me4, CFMR7osc)}

@@ -19,11 +19,11 @@ import extensisq_amd as esq
 from oracle import problems as pb
 from oracle import rk_oracle
 from oracle.tolerances import check_step
-from tools_cases import bruss1d, single_step_cases
+from tools_cases import bruss1d, compare_trajectory, single_step_cases
 
 pytestmark = pytest.mark.gpu
 
-ERK = ["BS5", "Ts5", "Pr7", "Pr8", "Pr9"]
+ERK = ["BS5", "Ts5", "Pr7", "Pr8", "Pr9", "CK5", "Me4", "CFMR7osc"]
 DEV = {n: getattr(esq, n) for n in ERK}
 
 
@@ -57,11 +57,22 @@ def test_single_step_golden(single, name, pname, direction):
     s = DEV[name](fun, t0, y0, t0 + sign * 10.0, first_step=abs(h), rtol=1e-6,
                   atol=1e-9, nfev_stiff_detect=0)
     assert s.step() is None
-    assert s.t == float(single[key + "/t_new"])
-    check_step(s, single[key + "/K"], single[key + "/y_new"],
-               float(single[key + "/error_norm"]),
-               float(single[key + "/h_abs_next"]), np.asarray(y0, dtype=float),
-               float(single[key + "/h"]), 1e-6, 1e-9)
+    if int(single[key + "/nfs"]) == 0:
+        assert s.t == float(single[key + "/t_new"])
+        check_step(s, single[key + "/K"], single[key + "/y_new"],
+                   float(single[key + "/error_norm"]),
+                   float(single[key + "/h_abs_next"]),
+                   np.asarray(y0, dtype=float), float(single[key + "/h"]),
+                   1e-6, 1e-9)
+    else:
+        # the reference retried with a step derived from the (cancelling)
+        # error norm of the rejected attempt: h agrees to ~1e-9 only
+        K = single[key + "/K"]
+        assert_allclose(s.t, float(single[key + "/t_new"]), rtol=1e-10)
+        assert_allclose(s.K, K, rtol=0, atol=1e-8 * np.abs(K).max())
+        assert_allclose(s.y, single[key + "/y_new"], rtol=1e-8, atol=1e-12)
+        assert_allclose(s.error_norm_old, float(single[key + "/error_norm"]),
+                        rtol=1e-5)
     assert s.nfev == int(single[key + "/nfev"])
     assert int(esq.NFS[()]) == int(single[key + "/nfs"])
 
@@ -92,11 +103,13 @@ def test_device_rhs_step_sizes(name, n):
     # two more steps.  The controllers see error norms that differ in the last
     # digits (cancelling sum), so the proposed steps would drift apart by ~1e-8
     # relative: pin the device to the oracle's step to keep comparing tightly.
+    drifted = False
     for _ in range(2):
         d.h_abs, d.error_norm_old = o.h_abs, o.error_norm_old
         nfs0 = int(rk_oracle.NFS[()])
         assert d.step() is None and o.step() is None
-        if int(rk_oracle.NFS[()]) == nfs0:      # no retry inside the step
+        drifted = drifted or int(rk_oracle.NFS[()]) != nfs0
+        if not drifted:                         # no retry inside a step so far
             assert d.t == o.t
             assert_allclose(d.y, o.y, rtol=1e-12, atol=1e-14)
         else:                                   # retried with h from err_norm
@@ -205,21 +218,9 @@ def test_trajectory_golden(traces, name, case):
     """solve_ivp(method=<device class>) reproduces the reference's run"""
     fun, t_span, y0, kw = CASES[case]
     res = solve_ivp(fun, t_span, y0, method=DEV[name], **kw)
-    gold = traces[name][case]
-    assert res.status == gold["status"]
-    assert res.nfev == gold["nfev"]
-    assert int(esq.NFS[()]) == gold["nfs"]
-    # duffing_tight starts from y = 0 with rtol 1e-9: the first error estimates
-    # are pure rounding noise (|err| ~ 1e-22 from terms ~1e-3) in the reference
-    # too, so the step sequences agree in count but only to ~1e-3 in t_k; both
-    # are valid solutions at that tolerance (SURVEY.md §7 parity definition iii)
-    noisy = case == "duffing_tight"
-    assert_allclose(res.t, gold["t"], rtol=5e-3 if noisy else 1e-7)
-    y_end = np.array(gold["y_end_re"]) + 1j * np.array(gold["y_end_im"])
-    tol = kw.get("rtol", 1e-3)
-    assert_allclose(res.y[:, -1],
-                    y_end if np.iscomplexobj(res.y) else y_end.real,
-                    rtol=(1e3 if noisy else 1e-3) * tol, atol=1e-12)
+    compare_trajectory(res, int(esq.NFS[()]), traces[name][case],
+                       kw.get("rtol", 1e-3), t_rtol=1e-7,
+                       noisy=case == "duffing_tight")
 
 
 def test_published_known_answers():
@@ -255,9 +256,10 @@ def test_bs5_interpolants_golden(traces, interp):
 
 
 # --------------------------------------- reference test-suite re-expressions
-@pytest.mark.parametrize("name", ERK)
+@pytest.mark.parametrize("name", [n for n in ERK if n != "Me4"])
 def test_error_estimation(name):
-    """tests/test_rk.py:75-89"""
+    """tests/test_rk.py:75-89 (Me4 is excluded there too: its estimate is of
+    fifth order)"""
     step = 0.2
     s = DEV[name](lambda t, y: y, 0, [1], 1, first_step=step)
     s.step()

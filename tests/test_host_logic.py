@@ -14,8 +14,13 @@ from extensisq_amd.tsitouras import Ts5
 from oracle import problems as pb
 from oracle import rk_oracle, rkc_oracle
 
+from extensisq_amd.calvo import CFMR7osc
+from extensisq_amd.cash import CK5
+from extensisq_amd.merson import Me4
+
 PAIRS = [(BS5, rk_oracle.BS5), (Ts5, rk_oracle.Ts5), (Pr7, rk_oracle.Pr7),
-         (Pr8, rk_oracle.Pr8), (Pr9, rk_oracle.Pr9)]
+         (Pr8, rk_oracle.Pr8), (Pr9, rk_oracle.Pr9), (CK5, rk_oracle.CK5),
+         (Me4, rk_oracle.Me4), (CFMR7osc, rk_oracle.CFMR7osc)]
 
 
 def bare(cls, sc_params=None):

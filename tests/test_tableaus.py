@@ -9,10 +9,13 @@ from numpy.testing import assert_allclose, assert_array_equal
 from extensisq_amd.bogacki import BS5
 from extensisq_amd.prince import Pr7, Pr8, Pr9
 from extensisq_amd.tsitouras import Ts5
+from extensisq_amd.cash import CK5
+from extensisq_amd.merson import Me4
+from extensisq_amd.calvo import CFMR7osc
 from oracle import rk_oracle
 from rooted_trees import max_residual
 
-METHODS = [BS5, Ts5, Pr7, Pr8, Pr9]
+METHODS = [BS5, Ts5, Pr7, Pr8, Pr9, CK5, Me4, CFMR7osc]
 
 
 @pytest.mark.parametrize("cls", METHODS)

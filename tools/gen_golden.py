@@ -38,7 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from tools_cases import bruss1d, single_step_cases  # noqa: E402  (seeded inputs)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-ERK = ["BS5", "Ts5", "Pr7", "Pr8", "Pr9"]
+ERK = ["BS5", "Ts5", "Pr7", "Pr8", "Pr9", "CK5", "Me4", "CFMR7osc"]
 
 
 def gen_single_step():

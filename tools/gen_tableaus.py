@@ -66,6 +66,12 @@ def main():
         "Pr7": dump(ref.Pr7),
         "Pr8": dump(ref.Pr8),
         "Pr9": dump(ref.Pr9),
+        # free riders on the generic step: Cash-Karp
+        # 5(4), Merson 4(3), Calvo et al. 7(5) (cash.py:76-112, merson.py:82-122,
+        # calvo.py:89-150)
+        "CK5": dump(ref.CK5),
+        "Me4": dump(ref.Me4),
+        "CFMR7osc": dump(ref.CFMR7osc),
     }
     with open(OUT, "w") as fh:
         json.dump(out, fh, indent=0, separators=(",", ":"))
