@@ -63,6 +63,7 @@ struct esq_ctx {
     bool atol_is_vec = false;
     esq_rhs_fn rhs = nullptr;
     void *rhs_user = nullptr;
+    esq_rhs_stage_fn rhs_stage = nullptr;   // optional fused stage entry
     // launch geometry
     unsigned grid_stream = 0;         // grid for streaming kernels
     unsigned grid_reduce = 0;
@@ -143,6 +144,12 @@ struct Prof {
         ev.klass = klass;
         ev.bytes = bytes;
         if (recorded) (void)hipEventRecord(ev.start, c->stream);
+    }
+    void cancel() {            // the launch did not happen: return the events
+        if (!on) return;
+        c->prof_pool.push_back(ev.start);
+        c->prof_pool.push_back(ev.stop);
+        on = false;
     }
     hipEvent_t start() const { return on && !recorded ? ev.start : nullptr; }
     hipEvent_t stop() const { return on && !recorded ? ev.stop : nullptr; }
@@ -533,6 +540,12 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     if (!c) return ESQ_EINVAL;
     c->rhs = fn;
     c->rhs_user = user;
+    c->rhs_stage = nullptr;
+    return 0;
+}
+int esq_set_rhs_stage(esq_ctx *c, esq_rhs_stage_fn fn) {
+    if (!c) return ESQ_EINVAL;
+    c->rhs_stage = fn;
     return 0;
 }
 
@@ -561,6 +574,21 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     if (i_from < 1 || i_to > c->s || i_from > i_to)
         return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
     for (int i = i_from; i < i_to; ++i) {
+        if (c->rhs_stage) {
+            // one fused kernel: K[i] = rhs(t_i, Y + h*sum a_ij K_j), no YSTAGE
+            Terms tm;
+            const int nt = build_row_terms(c, &c->A[(size_t)i * c->s], i, tm, c->kmap);
+            if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+            Prof p(c, ESQ_PROF_STAGE, 8.0 * (nt + 2) * (double)c->len);
+            const int r = c->rhs_stage(c->rhs_user, t + c->C[i] * h, nt, tm.p, tm.c,
+                                       c->y, h, c->krow[c->kmap[i]], c->len,
+                                       (void *)c->stream, (void *)p.start(),
+                                       (void *)p.stop());
+            if (r == 0) continue;
+            if (r != ESQ_ENOTSUP)
+                return fail(c, ESQ_ERHS, "fused RHS stage returned %d", r);
+            p.cancel();
+        }
         int r = esq_rk_stage_accumulate(c, i, h);
         if (r) return r;
         r = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);

@@ -7,6 +7,7 @@ scipy's own plumbing keeps working), but it also carries a C function pointer
 solver's HIP stream, so the state never leaves HBM during a step.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -113,6 +114,16 @@ class DeviceContext:
         self._rhs_keepalive = (rhs, fn)
         self._chk(self.lib.esq_set_rhs(self.handle, C.cast(fn, C.c_void_p), user),
                   "esq_set_rhs")
+        # The fused stage+RHS entry (one kernel per stage, no stage-argument
+        # round trip) is bit-identical but measured SLOWER on MI355X than the
+        # two streaming kernels (147 vs 95 + 31 us per Pr8 stage at n = 1e7: its
+        # rolling-window form holds 180 VGPRs -> 2 waves/SIMD and one memory
+        # round trip per row), so it is opt-in: ESQ_FUSE_STAGE=1.
+        fused = rhs._fused_entry(self.lib)
+        if fused is not None and os.environ.get("ESQ_FUSE_STAGE", "0") == "1":
+            self._chk(self.lib.esq_set_rhs_stage(self.handle,
+                                                 C.cast(fused, C.c_void_p)),
+                      "esq_set_rhs_stage")
 
     # -- scalar-returning launches
     def _scalar(self, fn, what, *args):
@@ -177,6 +188,10 @@ class DeviceRHS:
     def _create(self, lib, device):
         raise NotImplementedError
 
+    def _fused_entry(self, lib):
+        """optional `esq_rhs_stage_fn` of this plugin (None: two-kernel path)"""
+        return None
+
     def _bind(self, ctx):
         if ctx.n != self.n:
             raise ValueError(f"RHS is for n={self.n}, solver state has n={ctx.n}")
@@ -217,6 +232,10 @@ class DeviceRHS:
 
 class _Builtin(DeviceRHS):
     _symbol = None
+    _symbol_fused = None
+
+    def _fused_entry(self, lib):
+        return getattr(lib, self._symbol_fused) if self._symbol_fused else None
 
     def _make_user(self, lib, device):
         raise NotImplementedError
@@ -269,6 +288,7 @@ class Brusselator2D(_Builtin):
     """2-D Brusselator reaction-diffusion, periodic, y = [u.ravel(), v.ravel()]
     (BASELINE.json configs[2], the north-star workload)."""
     _symbol = "esq_rhs_bruss2d"
+    _symbol_fused = "esq_rhs_bruss2d_stage"
 
     def __init__(self, N, alpha=0.1, a=1.0, b=3.4):
         super().__init__()

@@ -41,6 +41,7 @@ extern "C" {
 #define ESQ_ESTATE   (-2)   /* call out of order (no tableau / no RHS set)     */
 #define ESQ_ENOMEM   (-3)   /* host allocation failed                          */
 #define ESQ_ERHS     (-4)   /* the RHS plugin returned non-zero                */
+#define ESQ_ENOTSUP  (-5)   /* optional plugin entry cannot handle this case   */
 
 /* vector slots of a context (row is ignored unless slot == ESQ_SLOT_K) */
 #define ESQ_SLOT_K       0  /* stage derivatives K[row], row < n_rows          */
@@ -60,6 +61,21 @@ typedef struct esq_ctx esq_ctx;
  */
 typedef int (*esq_rhs_fn)(void *user, double t, const double *y_dev,
                           double *f_dev, size_t n, void *hip_stream);
+
+/*
+ * OPTIONAL fused entry of a plugin: enqueue
+ *     f_dev = fun(t, y_dev + h * sum_{j<nt} coef[j] * rows[j])
+ * without materialising the argument (rows/coef are host arrays of device
+ * pointers / weights, borrowed for the call).  It must round exactly like the
+ * two-step path (FMA chain over j, then *h, then +y).  start/stop are
+ * hipEvent_t or NULL (dispatch timestamps for esq_profile_*).  Return
+ * ESQ_ENOTSUP to make the caller fall back to stage_accumulate + esq_rhs_fn.
+ */
+typedef int (*esq_rhs_stage_fn)(void *user, double t, int nt,
+                                const double *const *rows, const double *coef,
+                                const double *y_dev, double h, double *f_dev,
+                                size_t n, void *hip_stream, void *start_event,
+                                void *stop_event);
 
 /* ---- lifecycle ---------------------------------------------------------- */
 int  esq_abi_version(void);
@@ -94,6 +110,9 @@ int  esq_rk_set_tableau(esq_ctx *ctx, int s, const double *A, const double *B,
  * values as returned by validate_tol  common.py:30-54. */
 int  esq_set_tol(esq_ctx *ctx, double rtol, const double *atol, size_t n_atol);
 int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
+/* register (or clear, fn = NULL) the optional fused entry of the current RHS;
+ * esq_rk_stages then issues ONE kernel per stage instead of two */
+int  esq_set_rhs_stage(esq_ctx *ctx, esq_rhs_stage_fn fn);
 
 /* ---- explicit RK launches ----------------------------------------------- */
 /* YSTAGE = Y + h * sum_j A[i][j] * K[j]           common.py:355 (`dy`, `y+dy`) */
@@ -251,6 +270,11 @@ int  esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
                      void *stream);
 int  esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
                     void *stream);
+/* fused stage entry (esq_rhs_stage_fn) of the Brusselator plugin */
+int  esq_rhs_bruss2d_stage(void *user, double t, int nt, const double *const *rows,
+                           const double *coef, const double *y, double h,
+                           double *f, size_t n, void *stream, void *start_event,
+                           void *stop_event);
 
 /* ---- measurement (bench.py `roofline`) ------------------------------------ */
 /* class_mask bit k = 1: every launch of kernel class k carries a start/stop HIP

@@ -564,3 +564,28 @@ def test_device_h_start(case, mode):
         want = abs(h_start(fun, a, b, y_arr, np.asarray(fun(a, y_arr)),
                            cls.order_secondary, rtol_v, atol_v))
         assert_allclose(s.h_abs, want, rtol=1e-11)
+
+
+# ------------------------------------------------------ fused stage + RHS path
+@pytest.mark.parametrize("name", ["Pr8", "Pr9", "Ts5", "BS5", "CFMR7osc"])
+@pytest.mark.parametrize("N", [4, 50, 130, 258])
+def test_fused_stage_is_bit_identical(monkeypatch, name, N):
+    """the Brusselator plugin's opt-in fused entry (ESQ_FUSE_STAGE=1: one kernel
+    per stage, stage argument never written) gives bit-identical K rows, states
+    and error norms to the default two-kernel path"""
+    y0 = pb.bruss2d_y0(N)
+    h = 0.4 / pb.bruss2d_rho(N)
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7,
+              nfev_stiff_detect=0)
+    monkeypatch.setenv("ESQ_FUSE_STAGE", "1")
+    fused = DEV[name](esq.Brusselator2D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_FUSE_STAGE", "0")
+    plain = DEV[name](esq.Brusselator2D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_FUSE_STAGE")
+    for _ in range(3):
+        assert fused.step() is None and plain.step() is None
+        assert fused.t == plain.t
+        assert fused.error_norm_old == plain.error_norm_old
+        assert_equal(fused.K, plain.K)
+        assert_equal(fused.y, plain.y)
+    assert fused.nfev == plain.nfev
