@@ -431,8 +431,13 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     const unsigned cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t n2 = c->len_pad / 2;
     const size_t need = (n2 + kBlock - 1) / kBlock;
-    const unsigned per_cu = env_uint("ESQ_BLOCKS_PER_CU", 2);
-    c->stage_policy = (int)env_uint("ESQ_STAGE_POLICY", 10);
+    // Cache policy (measured): a working set beyond the 256 MiB
+    // Infinity Cache streams its K rows with non-temporal loads so that y and
+    // the stage argument stay on-die (2 workgroups per CU); a working set that
+    // fits is left to the cache (plain loads, 8 workgroups per CU).
+    const bool fits_mall = slab_doubles * sizeof(double) <= (size_t)160 << 20;
+    const unsigned per_cu = env_uint("ESQ_BLOCKS_PER_CU", fits_mall ? 8 : 2);
+    c->stage_policy = (int)env_uint("ESQ_STAGE_POLICY", fits_mall ? 0 : 10);
     size_t g = (size_t)cus * per_cu;
     if (g > need) g = need;
     if (g < 1) g = 1;
