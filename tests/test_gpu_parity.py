@@ -589,3 +589,27 @@ def test_fused_stage_is_bit_identical(monkeypatch, name, N):
         assert_equal(fused.K, plain.K)
         assert_equal(fused.y, plain.y)
     assert fused.nfev == plain.nfev
+
+
+# ----------------------------------------- solve_ivp end to end, device RHS
+@pytest.mark.parametrize("name", ["Ts5", "BS5", "Pr8"])
+def test_solve_ivp_device_rhs_t_eval_and_events(name):
+    """plain `solve_ivp(DeviceRHS, ..., method=<class>, t_eval=..., events=...)`:
+    default first step (device h_start), lazy `solver.y` mirror, device-resident
+    interpolant (n = 6400 >= 4096) for t_eval and the event root-finder"""
+    N = 80
+    y0 = pb.heat2d_y0(N, seed=7)
+    t_eval = np.array([0.0, 2e-5, 7e-5, 1e-4])
+
+    def event(t, y):                       # the centre value decays through 0.9
+        return y[(N // 2) * N + N // 2] - 0.9
+    event.terminal = False
+    kw = dict(rtol=1e-5, atol=1e-8, t_eval=t_eval, events=event)
+    got = solve_ivp(esq.Heat2D(N), (0.0, 1e-4), y0, method=DEV[name], **kw)
+    ref = solve_ivp(pb.heat2d_rhs(N), (0.0, 1e-4), y0,
+                    method=rk_oracle.METHODS[name], **kw)
+    assert got.success and ref.success
+    assert got.nfev == ref.nfev and got.t.shape == ref.t.shape
+    assert_allclose(got.y, ref.y, rtol=1e-8, atol=1e-11)
+    assert len(got.t_events[0]) == len(ref.t_events[0])
+    assert_allclose(got.t_events[0], ref.t_events[0], rtol=1e-7)
