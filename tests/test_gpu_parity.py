@@ -613,3 +613,50 @@ def test_solve_ivp_device_rhs_t_eval_and_events(name):
     assert_allclose(got.y, ref.y, rtol=1e-8, atol=1e-11)
     assert len(got.t_events[0]) == len(ref.t_events[0])
     assert_allclose(got.t_events[0], ref.t_events[0], rtol=1e-7)
+
+
+# ---------------------------------------------------- user-compiled RHS plugin
+PLUGIN_SRC = r'''
+#include <hip/hip_runtime.h>
+// f_i = -k * y_i + cos(t)  -- a user plugin following include/extensisq_amd.h
+__global__ void k_user(const double* y, double* f, size_t n, double k, double c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = -k * y[i] + c;
+}
+extern "C" int user_rhs(void* user, double t, const double* y, double* f, size_t n,
+                        void* stream) {
+    const double k = *(const double*)user;
+    hipLaunchKernelGGL(k_user, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, y, f, n, k, cos(t));
+    return (int)hipGetLastError();
+}
+'''
+
+
+def test_user_plugin_compiled_with_hipcc(tmp_path):
+    """INTEGRATION.md §4: a user's own `esq_rhs_fn`, built with hipcc and passed
+    as a C function pointer through `CFunctionRHS`"""
+    import ctypes
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = tmp_path / "user_rhs.hip"
+    so = tmp_path / "libuser_rhs.so"
+    src.write_text(PLUGIN_SRC)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-fPIC", "-shared",
+                    "-ffp-contract=off", str(src), "-o", str(so)], check=True)
+    lib = ctypes.CDLL(str(so))
+    kval = ctypes.c_double(0.75)
+    n = 3001
+    rhs = esq.CFunctionRHS(ctypes.cast(lib.user_rhs, ctypes.c_void_p).value,
+                           ctypes.addressof(kval), n)
+    y0 = np.linspace(-1.0, 2.0, n)
+    cpu = lambda t, y: -0.75 * y + np.cos(t)  # noqa: E731
+    assert_allclose(rhs(0.3, y0), cpu(0.3, y0), rtol=1e-15)
+    got = solve_ivp(rhs, (0.0, 2.0), y0, method=esq.Pr7, rtol=1e-7, atol=1e-10)
+    ref = solve_ivp(cpu, (0.0, 2.0), y0, method=rk_oracle.Pr7, rtol=1e-7,
+                    atol=1e-10)
+    assert got.nfev == ref.nfev
+    # step sizes follow the (cancelling) error norms: ~1e-7 relative agreement
+    assert_allclose(got.t, ref.t, rtol=1e-6)
+    assert_allclose(got.y[:, -1], ref.y[:, -1], rtol=1e-7, atol=1e-11)
