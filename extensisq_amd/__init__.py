@@ -11,7 +11,7 @@ from .tsitouras import Ts5  # noqa: F401
 from .bogacki import BS5  # noqa: F401
 from .prince import Pr7, Pr8, Pr9  # noqa: F401
 from .sommeijer import SSV2stab  # noqa: F401
-from .cash import CK5  # noqa: F401
+from .cash import CK5, CKdisc  # noqa: F401
 from .merson import Me4  # noqa: F401
 from .calvo import CFMR7osc  # noqa: F401
 from .device import (Brusselator2D, CFunctionRHS, DeviceContext,  # noqa: F401
@@ -19,7 +19,7 @@ from .device import (Brusselator2D, CFunctionRHS, DeviceContext,  # noqa: F401
 from ._lib import DeviceError  # noqa: F401
 
 __version__ = "0.1.0"
-__all__ = ["BS5", "Ts5", "Pr7", "Pr8", "Pr9", "SSV2stab", "CK5", "Me4",
+__all__ = ["BS5", "Ts5", "Pr7", "Pr8", "Pr9", "SSV2stab", "CK5", "CKdisc", "Me4",
            "CFMR7osc", "RungeKutta",
            "NFS", "DeviceRHS", "Heat2D", "Brusselator2D", "Diffusion3D",
            "DiagonalLinear", "CFunctionRHS", "LockstepGroup", "DeviceError"]

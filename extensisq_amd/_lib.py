@@ -44,6 +44,8 @@ SIGNATURES = {
     "esq_rk_error_norm": (C.c_int, [_vp, C.c_double, _dp]),
     "esq_rk_solution_error": (C.c_int, [_vp, C.c_double, C.c_double, _dp]),
     "esq_rk_pre_error": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _dp]),
+    "esq_rk_custom_sol_err": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, C.c_int,
+                                        _dp]),
     "esq_rk_accept": (C.c_int, [_vp, C.c_double, C.c_int]),
     "esq_rk_error_vector": (C.c_int, [_vp, C.c_double, C.c_int]),
     "esq_rk_row_id": (C.c_int, [_vp, C.c_int, C.c_int]),

@@ -33,6 +33,8 @@ def tableau(name):
             out[key] = _matrix(val)
         elif isinstance(val, list):
             out[key] = np.array([float.fromhex(s) for s in val])
+        elif isinstance(val, str) and key not in ("sc_params",):
+            out[key] = float.fromhex(val)
         else:
             out[key] = val
     return out

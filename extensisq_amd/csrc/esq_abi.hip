@@ -662,6 +662,22 @@ int esq_rk_pre_error(esq_ctx *c, double h, const double *e_pre,
     return finish_reduction(c, sumsq_out);
 }
 
+int esq_rk_custom_sol_err(esq_ctx *c, double h, const double *b, const double *e,
+                          int rows, int store_ynew, double *sumsq_out) {
+    if (!store_ynew) return esq_rk_pre_error(c, h, e, b, rows, sumsq_out);
+    if (!c || !b || !e || !sumsq_out) return ESQ_EINVAL;
+    if (rows < 1 || rows > c->n_rows) return fail(c, ESQ_EINVAL, "bad rows %d", rows);
+    Terms2 tm;
+    const int nt = build_row_terms2(c, b, rows, e, rows, tm, c->kmap);
+    if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
+        DISPATCH_1_20(launch_solerr_n, nt, c, tm, h, p)
+        HIPCHK(c, hipGetLastError());
+    }
+    return finish_reduction(c, sumsq_out);
+}
+
 int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval) {
     if (!c) return ESQ_EINVAL;
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");

@@ -139,6 +139,14 @@ int  esq_rk_solution_error(esq_ctx *ctx, double t, double h, double *sumsq_out);
  * Synchronises. */
 int  esq_rk_pre_error(esq_ctx *ctx, double h, const double *e_pre,
                       const double *b_scale_pre, int rows, double *sumsq_out);
+/* Same pass with caller-supplied weights over K[0..rows): the embedded pairs of
+ * the variable-order CKdisc (`_comp_sol_err_tol`, cash.py:397-401):
+ *   sol = Y + h*sum b[j] K[j];  err = h*sum e[j] K[j];
+ *   sum |err / (atol + rtol*max(|Y|, |sol|))|^2
+ * store_ynew != 0 also writes sol into YNEW.  Synchronises. */
+int  esq_rk_custom_sol_err(esq_ctx *ctx, double h, const double *b,
+                           const double *e, int rows, int store_ynew,
+                           double *sumsq_out);
 /* Accept the attempt (common.py:289-303): non-FSAL tableaux with a device RHS
  * get K[s] = rhs(t_new, YNEW); then Y <-> YNEW are swapped and K[s] becomes the
  * new K[0] by pointer rotation (no copies).  with_end_eval = 0 skips the RHS

@@ -72,6 +72,8 @@ def load_tableau(name):
             tab[key] = _unhex_mat(val)
         elif isinstance(val, list):
             tab[key] = _unhex_vec(val)
+        elif isinstance(val, str) and key != "sc_params":
+            tab[key] = float.fromhex(val)
         else:
             tab[key] = val
     return tab
@@ -604,7 +606,118 @@ class CFMR7osc(OracleERK):
         return True, None
 
 
-for _cls in (Ts5, BS5, Pr7, Pr8, Pr9, CK5, Me4, CFMR7osc):
+class CKdisc(OracleERK):
+    """Cash-Karp variable order (5, 3, 2) for non-smooth problems
+    (cash.py:115-416)."""
+    SAFETY = 0.9                                             # cash.py:6
+
+    def __init__(self, fun, t0, y0, t_bound, **extraneous):  # :243-249
+        super().__init__(fun, t0, y0, t_bound, nfev_stiff_detect=0,
+                         **extraneous)
+        self.twiddle = [1.5, 1.1]
+        self.quit = [100., 100.]
+
+    def _pair(self, h, B, E, i=6):                           # :397-401
+        sol = h * (self.K[:i, :].T @ B[:i]) + self.y
+        err = h * (self.K[:i, :].T @ E[:i])
+        tol = error_scale(self.atol, self.rtol, self.y, sol)
+        return sol, err, tol
+
+    def _step_impl(self):                                    # :253-395
+        t = self.t
+        twiddle, quit = self.twiddle, self.quit
+        h_abs, min_step = self._limit_step(t)
+        order_accepted = 0
+        had_reject = False
+        while not order_accepted:
+            if h_abs < min_step:
+                return False, self.TOO_SMALL_STEP
+            h = h_abs * self.direction
+            self.K[0] = self.f
+            self._stage(h, 1)
+            _y, err, tol = self._pair(h, self.B_assess[0], self.E_assess[0], 2)
+            E1 = rms(err / tol) ** (1 / 2)
+            esttol = E1 / quit[0]
+            if E1 < twiddle[0] * quit[0]:
+                self._stage(h, 2)
+                self._stage(h, 3)
+                _y, err, tol = self._pair(h, self.B_assess[1],
+                                          self.E_assess[1], 4)
+                E2 = rms(err / tol) ** (1 / 3)
+                esttol = E2 / quit[1]
+                if E2 < twiddle[1] * quit[1]:
+                    self._stage(h, 4)
+                    self._stage(h, 5)
+                    y_new, err, tol = self._pair(h, self.B, self.E)
+                    E4 = rms(err / tol) ** (1 / 5)
+                    E4 = E4 or 1e-160
+                    esttol = E4
+                    if E4 < 1:
+                        order_accepted = 4
+                        factor = min(self.max_factor, self.SAFETY / E4)
+                        if had_reject:
+                            factor = min(1.0, factor)
+                        h_abs *= factor
+                        q = [E1 / E4, E2 / E4]
+                        for j in (0, 1):
+                            if q[j] > quit[j]:
+                                q[j] = min(q[j], 10 * quit[j])
+                            else:
+                                q[j] = max(q[j], 2 / 3 * quit[j])
+                            quit[j] = max(1., min(10000., q[j]))
+                        break
+                    if np.isnan(E4) or np.isinf(E4):
+                        return False, "Overflow or underflow encountered."
+                    e = [E1, E2]
+                    for i in (0, 1):
+                        EQ = e[i] / quit[i]
+                        if EQ < twiddle[i]:
+                            twiddle[i] = max(1.1, EQ)
+                    if E2 < 1:
+                        y_new, err, tol = self._pair(h, self.B_fallback[1],
+                                                     self.E_fallback[1], 4)
+                        if rms(err / tol) < 1:
+                            order_accepted = 2
+                            h_abs *= self.C_fallback[1]
+                            h = h_abs * self.direction
+                            break
+                if E1 < 1:
+                    y_new, err, tol = self._pair(h, self.B_fallback[0],
+                                                 self.E_fallback[0], 2)
+                    if rms(err / tol) < 1:
+                        order_accepted = 1
+                        h_abs *= self.C_fallback[0]
+                        h = h_abs * self.direction
+                        break
+                    had_reject = True
+                    h_abs *= self.C_fallback[0]
+                    NFS[()] += 1
+                    continue
+            had_reject = True
+            h_abs *= max(self.min_factor, self.SAFETY / esttol)
+            NFS[()] += 1
+        t_new = t + h
+        f_new = self.fun(t_new, y_new)
+        self.K[-1, :] = f_new
+        self.order_accepted = order_accepted
+        self.h_previous = h
+        self.y_old = self.y
+        self.h_abs = h_abs
+        self.f = f_new
+        self.t = t_new
+        self.y = y_new
+        return True, None
+
+    def _dense_output_impl(self):                            # :403-416
+        if self.order_accepted == 4:
+            return HornerInterpolant(self.t_old, self.t, self.y_old,
+                                     self.K.T @ self.P)
+        return HermiteInterpolant(self.t_old, self.t, self.y_old, self.y,
+                                  self.K[0, :], self.K[-1, :])
+
+
+for _cls in (Ts5, BS5, Pr7, Pr8, Pr9, CK5, Me4, CFMR7osc, CKdisc):
     _cls._install(_cls.__name__)
 
-METHODS = {c.__name__: c for c in (BS5, Ts5, Pr7, Pr8, Pr9, CK5, Me4, CFMR7osc)}
+METHODS = {c.__name__: c for c in (BS5, Ts5, Pr7, Pr8, Pr9, CK5, Me4, CFMR7osc,
+                                   CKdisc)}

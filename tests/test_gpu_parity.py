@@ -660,3 +660,36 @@ def test_user_plugin_compiled_with_hipcc(tmp_path):
     # step sizes follow the (cancelling) error norms: ~1e-7 relative agreement
     assert_allclose(got.t, ref.t, rtol=1e-6)
     assert_allclose(got.y[:, -1], ref.y[:, -1], rtol=1e-7, atol=1e-11)
+
+
+# -------------------------------------------------- CKdisc (variable order)
+@pytest.mark.parametrize("case", ["readme", "duffing", "rational_bwd", "complex",
+                                  "sawtooth", "kink", "bruss1d"])
+def test_ckdisc_golden(golden_dir, case):
+    """variable-order Cash-Karp on the device: every order assessment is one
+    fused `esq_rk_custom_sol_err` pass; trajectories, accepted orders and dense
+    output against the reference's run"""
+    from test_oracle_golden import _ckdisc_check
+    with open(os.path.join(golden_dir, "ckdisc_traces.json")) as fh:
+        gold = json.load(fh)
+    _ckdisc_check(esq.CKdisc, case, gold, esq.NFS, 1e-7)
+
+
+def test_ckdisc_device_rhs_matches_oracle():
+    n = 5000
+    rng = np.random.default_rng(8)
+    lam = -rng.random(n) * 3
+    y0 = rng.standard_normal(n)
+    kw = dict(rtol=1e-5, atol=1e-8)
+    d = esq.CKdisc(esq.DiagonalLinear(lam, 1.0), 0.0, y0, 2.0, **kw)
+    o = rk_oracle.CKdisc(lambda t, y: lam * y + np.sin(t), 0.0, y0, 2.0, **kw)
+    assert_allclose(d.h_abs, o.h_abs, rtol=1e-11)
+    for _ in range(6):
+        assert d.step() is None and o.step() is None
+        assert d.order_accepted == o.order_accepted
+        assert_allclose(d.t, o.t, rtol=1e-7)
+        assert_allclose(d.y, o.y, rtol=1e-7, atol=1e-10)
+    assert d.nfev == o.nfev
+    tc = np.linspace(o.t_old, o.t, 4)
+    assert_allclose(d.dense_output()(tc), o.dense_output()(tc), rtol=1e-7,
+                    atol=1e-10)

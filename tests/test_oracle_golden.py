@@ -193,3 +193,43 @@ def test_lockstep_reference(golden_dir):
     assert_allclose(errs, g["err"], rtol=1e-6)
     assert_allclose(s.y, g["y_end"], rtol=1e-9, atol=1e-12)
     assert s.nfev == int(g["nfev"])
+
+
+# ------------------------------------------------------------------ CKdisc --
+def _ckdisc_check(cls, case, gold, nfs_counter, t_rtol):
+    from tools_cases import ckdisc_cases
+    fun, t_span, y0, kw = ckdisc_cases()[case]
+    res = solve_ivp(fun, t_span, y0, method=cls, dense_output=True, **kw)
+    g = gold[case]
+    noisy = case == "sawtooth"      # 80 rejected steps around discontinuities
+    assert res.status == g["status"]
+    if noisy:
+        assert abs(res.nfev - g["nfev"]) <= 0.02 * g["nfev"]
+    else:
+        assert res.nfev == g["nfev"] and int(nfs_counter[()]) == g["nfs"]
+        assert_allclose(res.t, g["t"], rtol=t_rtol)
+    y_end = np.array(g["y_end_re"]) + 1j * np.array(g["y_end_im"])
+    tol = kw.get("rtol", 1e-3)
+    assert_allclose(res.y[:, -1], y_end if np.iscomplexobj(res.y) else y_end.real,
+                    rtol=(50 if noisy else 1e-3) * tol, atol=1e-9)
+    dense = np.array(g["dense"]["re"]) + 1j * np.array(g["dense"]["im"])
+    got = res.sol(np.array(g["dense"]["tc"]))
+    assert_allclose(got, dense if np.iscomplexobj(got) else dense.real,
+                    rtol=(50 if noisy else 1e-2) * tol, atol=1e-8)
+    s = cls(fun, t_span[0], y0, t_span[1], **kw)
+    orders = []
+    while s.status == "running":
+        s.step()
+        orders.append(int(s.order_accepted))
+    if noisy:
+        assert set(orders) == set(g["orders"])       # 5th order + both fall-backs
+    else:
+        assert orders == g["orders"]
+
+
+@pytest.mark.parametrize("case", ["readme", "duffing", "rational_bwd", "complex",
+                                  "sawtooth", "kink", "bruss1d"])
+def test_ckdisc_trajectory(golden_dir, case):
+    with open(os.path.join(golden_dir, "ckdisc_traces.json")) as fh:
+        gold = json.load(fh)
+    _ckdisc_check(rk_oracle.CKdisc, case, gold, rk_oracle.NFS, 1e-9)

@@ -55,3 +55,24 @@ def compare_trajectory(res, nfs, gold, rtol_used, t_rtol=1e-7, noisy=False):
     assert nfs == gold["nfs"]
     assert_allclose(res.t, gold["t"], rtol=t_rtol)
     assert_allclose(res.y[:, -1], y_end, rtol=1e-3 * rtol_used, atol=1e-12)
+
+
+def ckdisc_cases():
+    """problems for the variable-order CKdisc fixtures"""
+    def sawtooth(t, y):                 # discontinuous forcing (non-smooth)
+        return np.array([np.sign(np.sin(5.0 * t)) - y[0], y[0] - 0.5 * y[1]])
+
+    def kink(t, y):                     # derivative jump at y = 0.5
+        return np.array([-abs(y[0] - 0.5) - 0.1, y[0]])
+    fb, yb = bruss1d()
+    return {
+        "readme": (lambda t, y: -0.5 * y, [0, 10], [2, 4, 8], {}),
+        "duffing": (pb.duffing_rhs, [0.0, 20.0], [0.0, 0.0], {}),
+        "rational_bwd": (pb.rational_rhs, [5, 1], [1 / 3, 2 / 9],
+                         dict(rtol=1e-3, atol=1e-6)),
+        "complex": (lambda t, y: -y, [0, 1], [0.5 + 1j],
+                    dict(rtol=1e-3, atol=1e-6)),
+        "sawtooth": (sawtooth, [0.0, 4.0], [0.0, 1.0], dict(rtol=1e-5, atol=1e-8)),
+        "kink": (kink, [0.0, 3.0], [1.0, 0.0], dict(rtol=1e-6, atol=1e-9)),
+        "bruss1d": (fb, [0, 0.5], yb, dict(rtol=1e-6, atol=1e-9)),
+    }

@@ -117,6 +117,32 @@ def gen_traces():
           {k: v["duffing"]["nfev"] for k, v in out.items()})
 
 
+def gen_ckdisc():
+    """G7: CKdisc (variable order, no error_norm_old): trajectories only, incl.
+    a non-smooth RHS that exercises the order-3 and order-2 fall-backs"""
+    from tools_cases import ckdisc_cases
+    out = {}
+    for cname, (fun, t_span, y0, kw) in ckdisc_cases().items():
+        d = run_trace(ref.CKdisc, fun, t_span, y0, **kw)
+        r = solve_ivp(fun, t_span, y0, method=ref.CKdisc, dense_output=True, **kw)
+        tc = np.linspace(t_span[0], t_span[1], 9)
+        yc = r.sol(tc)
+        d["dense"] = {"tc": tc.tolist(), "re": np.real(yc).tolist(),
+                      "im": np.imag(yc).tolist()}
+        # which orders were accepted (5th-order step = 4, fall-backs = 2, 1)
+        s = ref.CKdisc(fun, t_span[0], y0, t_span[1], **kw)
+        orders = []
+        while s.status == "running":
+            s.step()
+            orders.append(int(s.order_accepted))
+        d["orders"] = orders
+        out[cname] = d
+    with open(os.path.join(GOLD, "ckdisc_traces.json"), "w") as fh:
+        json.dump(out, fh)
+    print("ckdisc:", {k: (v["nfev"], v["nfs"], sorted(set(v["orders"])))
+                      for k, v in out.items()})
+
+
 def gen_rkc():
     out = {}
     rng = np.random.default_rng(64)
@@ -245,5 +271,6 @@ if __name__ == "__main__":
     gen_rkc()
     gen_lockstep()
     gen_stiffness()
+    gen_ckdisc()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))

@@ -41,12 +41,13 @@ def dump(cls, extra=()):
         "n_stages": int(cls.n_stages),
         "order": int(cls.order),
         "order_secondary": int(cls.order_secondary),
-        "tanang": float(cls.tanang),
-        "stbrad": float(cls.stbrad),
         "sc_params": cls.sc_params,
         "A": sparse(cls.A), "B": vec(cls.B), "C": vec(cls.C), "E": vec(cls.E),
         "P": sparse(cls.P),
     }
+    if cls.tanang is not NotImplemented:
+        d["tanang"] = float(cls.tanang)
+        d["stbrad"] = float(cls.stbrad)
     for name in extra:
         val = getattr(cls, name)
         if np.ndim(val) == 2:
@@ -54,7 +55,7 @@ def dump(cls, extra=()):
         elif np.ndim(val) == 1:
             d[name] = vec(val)
         else:
-            d[name] = int(val)
+            d[name] = int(val) if float(val).is_integer() else float(val).hex()
     return d
 
 
@@ -72,6 +73,11 @@ def main():
         "CK5": dump(ref.CK5),
         "Me4": dump(ref.Me4),
         "CFMR7osc": dump(ref.CFMR7osc),
+        # variable-order Cash-Karp (5, 3, 2) for non-smooth problems
+        # (cash.py:186-236): embedded weights of all orders + fallback pairs
+        "CKdisc": dump(ref.CKdisc, ("B_all", "B_assess", "E_assess", "C_fallback",
+                                    "B_fallback", "E_fallback", "max_factor",
+                                    "min_factor")),
     }
     with open(OUT, "w") as fh:
         json.dump(out, fh, indent=0, separators=(",", ":"))
