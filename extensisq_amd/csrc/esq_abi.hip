@@ -372,6 +372,16 @@ int build_row_terms2(esq_ctx *c, const double *b, int nb, const double *e, int n
     return nt;
 }
 
+// One process per GPU is the intended use (a context never changes device), but
+// a process MAY hold contexts on several devices (threads driving one context
+// each): once that happens every entry point re-selects the context's device.
+bool g_multi_device = false;
+int g_first_device = -1;
+#define ENTER(c)                                                  \
+    do {                                                          \
+        if (g_multi_device) (void)hipSetDevice((c)->device);      \
+    } while (0)
+
 unsigned env_uint(const char *name, unsigned dflt) {
     const char *s = getenv(name);
     if (!s || !*s) return dflt;
@@ -392,6 +402,8 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     if (!c) return ESQ_ENOMEM;
     *out = c;   // returned even on failure so the caller can read the message
     c->device = device;
+    if (g_first_device < 0) g_first_device = device;
+    else if (device != g_first_device) g_multi_device = true;
     c->n = n;
     c->cplx = is_complex != 0;
     c->len = c->cplx ? 2 * n : n;
@@ -465,6 +477,7 @@ const char *esq_last_error(const esq_ctx *c) { return c ? c->err : "null context
 
 int esq_synchronize(esq_ctx *c) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -472,6 +485,7 @@ size_t esq_vector_len(const esq_ctx *c) { return c ? c->len : 0; }
 
 int esq_upload(esq_ctx *c, int slot, int row, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    ENTER(c);
     double *d = slot_ptr(c, slot, row);
     if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
     const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
@@ -482,6 +496,7 @@ int esq_upload(esq_ctx *c, int slot, int row, const double *host) {
 }
 int esq_download(esq_ctx *c, int slot, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    ENTER(c);
     double *d = slot_ptr(c, slot, row);
     if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
     const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
@@ -492,6 +507,7 @@ int esq_download(esq_ctx *c, int slot, int row, double *host) {
 }
 int esq_copy(esq_ctx *c, int dst_slot, int dst_row, int src_slot, int src_row) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *d = slot_ptr(c, dst_slot, dst_row), *s = slot_ptr(c, src_slot, src_row);
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad slot/row");
     HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),
@@ -502,6 +518,7 @@ int esq_copy(esq_ctx *c, int dst_slot, int dst_row, int src_slot, int src_row) {
 int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
                        const double *C, const double *E, int fsal) {
     if (!c || !A || !B || !C || !E || s < 1) return ESQ_EINVAL;
+    ENTER(c);
     if (s + 1 > c->n_rows)
         return fail(c, ESQ_EINVAL, "tableau needs %d rows, context has %d", s + 1,
                     c->n_rows);
@@ -527,6 +544,7 @@ int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
 
 int esq_set_tol(esq_ctx *c, double rtol, const double *atol, size_t n_atol) {
     if (!c || !atol) return ESQ_EINVAL;
+    ENTER(c);
     c->rtol = rtol;
     if (n_atol == 1) {
         c->atol_s = atol[0];
@@ -543,6 +561,7 @@ int esq_set_tol(esq_ctx *c, double rtol, const double *atol, size_t n_atol) {
 
 int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     c->rhs = fn;
     c->rhs_user = user;
     c->rhs_stage = nullptr;
@@ -550,12 +569,14 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
 }
 int esq_set_rhs_stage(esq_ctx *c, esq_rhs_stage_fn fn) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     c->rhs_stage = fn;
     return 0;
 }
 
 int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (i < 1 || i >= c->s) return fail(c, ESQ_EINVAL, "stage %d out of range", i);
     Terms tm;
@@ -567,6 +588,7 @@ int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
 
 int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *dst = slot_ptr(c, ESQ_SLOT_K, dst_row);
     double *src = slot_ptr(c, src_slot, src_row);
     if (!dst || !src) return fail(c, ESQ_EINVAL, "bad row/slot");
@@ -575,6 +597,7 @@ int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row
 
 int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (i_from < 1 || i_to > c->s || i_from > i_to)
         return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
@@ -604,6 +627,7 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
 
 int esq_rk_solution(esq_ctx *c, double h) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     Terms tm;
     const int nt = build_row_terms(c, c->B.data(), c->s, tm, c->kmap);
@@ -614,6 +638,7 @@ int esq_rk_solution(esq_ctx *c, double h) {
 
 int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     Terms tm;
     const int nt = build_row_terms(c, c->E.data(), c->s + c->fsal, tm, c->kmap);
@@ -628,6 +653,7 @@ int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
 
 int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (c->fsal) {
         int r = esq_rk_solution(c, h);
@@ -650,6 +676,7 @@ int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
 int esq_rk_pre_error(esq_ctx *c, double h, const double *e_pre,
                      const double *b_scale_pre, int rows, double *sumsq_out) {
     if (!c || !e_pre || !b_scale_pre || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
     if (rows < 1 || rows > c->n_rows) return fail(c, ESQ_EINVAL, "bad rows %d", rows);
     Terms2 tm;
     const int nt = build_row_terms2(c, b_scale_pre, rows, e_pre, rows, tm, c->kmap);
@@ -666,6 +693,7 @@ int esq_rk_custom_sol_err(esq_ctx *c, double h, const double *b, const double *e
                           int rows, int store_ynew, double *sumsq_out) {
     if (!store_ynew) return esq_rk_pre_error(c, h, e, b, rows, sumsq_out);
     if (!c || !b || !e || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
     if (rows < 1 || rows > c->n_rows) return fail(c, ESQ_EINVAL, "bad rows %d", rows);
     Terms2 tm;
     const int nt = build_row_terms2(c, b, rows, e, rows, tm, c->kmap);
@@ -680,6 +708,7 @@ int esq_rk_custom_sol_err(esq_ctx *c, double h, const double *b, const double *e
 
 int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (!c->fsal && with_end_eval) {
         int r = call_rhs(c, t_new, c->ynew, c->krow[c->kmap[c->s]]);
@@ -693,6 +722,7 @@ int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval) {
 
 int esq_rk_error_vector(esq_ctx *c, double h, int last_step) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     Terms tm;
     const int nt = build_row_terms(c, c->E.data(), c->s + c->fsal, tm,
@@ -703,10 +733,12 @@ int esq_rk_error_vector(esq_ctx *c, double h, int last_step) {
 
 int esq_rk_row_id(esq_ctx *c, int logical_row, int last_step) {
     if (!c || logical_row < 0 || logical_row >= c->n_rows) return ESQ_EINVAL;
+    ENTER(c);
     return last_step ? c->kmap_last[logical_row] : c->kmap[logical_row];
 }
 int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    ENTER(c);
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
     HIPCHK(c, hipMemcpyAsync(host, c->krow[c->kmap_last[row]],
                              c->len * sizeof(double), hipMemcpyDeviceToHost,
@@ -717,6 +749,7 @@ int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
 
 int esq_rk_dense_stage(esq_ctx *c, int row, const double *a, int count, double h) {
     if (!c || !a) return ESQ_EINVAL;
+    ENTER(c);
     if (row < 1 || row >= c->n_rows || count < 0 || count > row)
         return fail(c, ESQ_EINVAL, "bad row/count %d/%d", row, count);
     Terms tm;
@@ -727,11 +760,13 @@ int esq_rk_dense_stage(esq_ctx *c, int row, const double *a, int count, double h
 }
 int esq_rk_dense_eval(esq_ctx *c, int row, double t) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
     return call_rhs(c, t, c->ystage, c->krow[c->kmap_last[row]]);
 }
 int esq_rk_upload_last_K(esq_ctx *c, int row, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    ENTER(c);
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
     HIPCHK(c, hipMemcpyAsync(c->krow[c->kmap_last[row]], host,
                              c->len * sizeof(double), hipMemcpyHostToDevice,
@@ -759,6 +794,7 @@ extern "C" {
 int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
                      int from_end, esq_dense **out) {
     if (!c || !P || !out) return ESQ_EINVAL;
+    ENTER(c);
     if (rows < 1 || rows > c->n_rows || p < 1 || p > kMaxCols)
         return fail(c, ESQ_EINVAL, "bad interpolant shape (%d, %d)", rows, p);
     esq_dense *d = new (std::nothrow) esq_dense();
@@ -868,6 +904,7 @@ static double *vec_ptr(esq_ctx *c, int r) {
 
 int esq_rkc_first_stage(esq_ctx *c, int dst, int yn, int fn, double hmus) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *d = ROW(c, dst), *a = ROW(c, yn), *f = ROW(c, fn);
     if (!d || !a || !f) return fail(c, ESQ_EINVAL, "bad row");
     Prof p(c, ESQ_PROF_RKC, 24.0 * (double)c->len);
@@ -880,6 +917,7 @@ int esq_rkc_first_stage(esq_ctx *c, int dst, int yn, int fn, double hmus) {
 int esq_rkc_stage(esq_ctx *c, int dst, int fy, int yjm1, int yjm2, int yn, int fn,
                   double mu, double nu, double hmus, double ajm1) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *d = ROW(c, dst), *f = ROW(c, fy), *a = ROW(c, yjm1), *b = ROW(c, yjm2),
            *y0 = ROW(c, yn), *g = ROW(c, fn);
     if (!d || !f || !a || !b || !y0 || !g) return fail(c, ESQ_EINVAL, "bad row");
@@ -893,6 +931,7 @@ int esq_rkc_stage(esq_ctx *c, int dst, int fy, int yjm1, int yjm2, int yn, int f
 }
 int esq_rkc_eval_rhs(esq_ctx *c, int dst, double t, int src) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *d = ROW(c, dst), *s = ROW(c, src);
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad row");
     return call_rhs(c, t, s, d);
@@ -900,6 +939,7 @@ int esq_rkc_eval_rhs(esq_ctx *c, int dst, double t, int src) {
 int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
                    double hmus1, int m, const double *scalars, int *y_row_out) {
     if (!c || !y_row_out || m < 1 || (m > 1 && !scalars)) return ESQ_EINVAL;
+    ENTER(c);
     // rotation instead of the reference's two full copies per stage:
     //   jm1 = first-stage result, jm2 = yn; every stage writes into a free row
     int r = esq_rkc_first_stage(c, w0, yn, fn, hmus1);
@@ -931,6 +971,7 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
 int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
                        double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
     double *a = ROW(c, y), *b = ROW(c, yn), *f = ROW(c, fn), *g = ROW(c, fy);
     if (!a || !b || !f || !g) return fail(c, ESQ_EINVAL, "bad row");
     if (c->cplx) return fail(c, ESQ_EINVAL, "RKC is real-only (sommeijer.py:98)");
@@ -946,6 +987,7 @@ int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
 }
 int esq_vec_sumsq(esq_ctx *c, int x, int y, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
     double *a = ROW(c, x), *b = y != ESQ_VEC_NONE ? ROW(c, y) : nullptr;
     if (!a || (y != ESQ_VEC_NONE && !b)) return fail(c, ESQ_EINVAL, "bad row");
     hipLaunchKernelGGL(k_sumsq, dim3(c->grid_reduce), dim3(kBlock), 0, c->stream,
@@ -955,6 +997,7 @@ int esq_vec_sumsq(esq_ctx *c, int x, int y, double *sumsq_out) {
 }
 int esq_vec_axpbmc(esq_ctx *c, int dst, int a, double alpha, int b, int cc) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *d = ROW(c, dst), *pa = a != ESQ_VEC_NONE ? ROW(c, a) : nullptr,
            *pb = ROW(c, b), *pc = cc != ESQ_VEC_NONE ? ROW(c, cc) : nullptr;
     if (!d || !pb || (a != ESQ_VEC_NONE && !pa) || (cc != ESQ_VEC_NONE && !pc))
@@ -966,6 +1009,7 @@ int esq_vec_axpbmc(esq_ctx *c, int dst, int a, double alpha, int b, int cc) {
 }
 int esq_vec_wdiff_sumsq(esq_ctx *c, int a, int b, int w, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
     double *pa = ROW(c, a), *pb = ROW(c, b), *pw = ROW(c, w);
     if (!pa || !pb || !pw) return fail(c, ESQ_EINVAL, "bad row");
     hipLaunchKernelGGL(k_wdiff_sumsq, dim3(c->grid_reduce), dim3(kBlock), 0,
@@ -977,6 +1021,7 @@ int esq_vec_wdiff_sumsq(esq_ctx *c, int a, int b, int w, double *sumsq_out) {
 
 int esq_aux_rows(esq_ctx *c, int count, int *first_id) {
     if (!c || !first_id || count < 1 || count > 32) return ESQ_EINVAL;
+    ENTER(c);
     double *mem = nullptr;
     const size_t bytes = (size_t)count * c->stride * sizeof(double);
     HIPCHK(c, hipMalloc(&mem, bytes));
@@ -994,6 +1039,7 @@ int esq_aux_rows(esq_ctx *c, int count, int *first_id) {
 int esq_vec_wdot(esq_ctx *c, int a, int b, int y1, int y2, double floor_,
                  double *out) {
     if (!c || !out) return ESQ_EINVAL;
+    ENTER(c);
     double *pa = ROW(c, a), *pb = ROW(c, b), *p1 = ROW(c, y1), *p2 = ROW(c, y2);
     if (!pa || !pb || !p1 || !p2) return fail(c, ESQ_EINVAL, "bad vector id");
     if (c->cplx)
@@ -1009,6 +1055,7 @@ int esq_vec_wdot(esq_ctx *c, int a, int b, int y1, int y2, double floor_,
 }
 int esq_vec_fill(esq_ctx *c, int dst, double value, double value_im) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *d = ROW(c, dst);
     if (!d) return fail(c, ESQ_EINVAL, "bad vector id %d", dst);
     if (c->cplx)
@@ -1022,6 +1069,7 @@ int esq_vec_fill(esq_ctx *c, int dst, double value, double value_im) {
 }
 int esq_vec_copy(esq_ctx *c, int dst, int src) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *d = ROW(c, dst), *s = ROW(c, src);
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad vector id");
     HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),
@@ -1030,12 +1078,14 @@ int esq_vec_copy(esq_ctx *c, int dst, int src) {
 }
 int esq_vec_eval_rhs(esq_ctx *c, int dst, double t, int src) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *d = ROW(c, dst), *s = ROW(c, src);
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad vector id");
     return call_rhs(c, t, s, d);
 }
 int esq_vec_upload(esq_ctx *c, int dst, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    ENTER(c);
     double *d = ROW(c, dst);
     if (!d) return fail(c, ESQ_EINVAL, "bad vector id %d", dst);
     HIPCHK(c, hipMemcpyAsync(d, host, c->len * sizeof(double),
@@ -1045,6 +1095,7 @@ int esq_vec_upload(esq_ctx *c, int dst, const double *host) {
 }
 int esq_vec_download(esq_ctx *c, int src, double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    ENTER(c);
     double *s = ROW(c, src);
     if (!s) return fail(c, ESQ_EINVAL, "bad vector id %d", src);
     HIPCHK(c, hipMemcpyAsync(host, s, c->len * sizeof(double),
@@ -1054,6 +1105,7 @@ int esq_vec_download(esq_ctx *c, int src, double *host) {
 }
 int esq_hs_log_etol(esq_ctx *c, int y, double *sum_out, double *min_out) {
     if (!c || !sum_out || !min_out) return ESQ_EINVAL;
+    ENTER(c);
     double *py = ROW(c, y);
     if (!py) return fail(c, ESQ_EINVAL, "bad vector id %d", y);
     const double *av = c->atol_is_vec ? c->atolv : nullptr;
@@ -1072,6 +1124,7 @@ int esq_hs_log_etol(esq_ctx *c, int y, double *sum_out, double *min_out) {
 }
 int esq_hs_select(esq_ctx *c, int yp, int spy, int src, double fill) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     double *a = ROW(c, yp), *b = ROW(c, spy), *s = ROW(c, src);
     if (!a || !b || !s) return fail(c, ESQ_EINVAL, "bad vector id");
     if (c->cplx)
@@ -1087,6 +1140,7 @@ int esq_hs_select(esq_ctx *c, int yp, int spy, int src, double fill) {
 // ---- lock-step ------------------------------------------------------------------
 int esq_set_comm(esq_ctx *c, void *nccl_comm) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     if (nccl_comm && rccl_load() != 0) return fail(c, ESQ_ESTATE, "cannot load librccl");
     c->comm = nccl_comm;
     return 0;
@@ -1121,18 +1175,21 @@ int esq_comm_destroy(void *comm) {
 // ---- measurement ----------------------------------------------------------------
 int esq_profile_enable(esq_ctx *c, int class_mask) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     if (!class_mask) prof_drain(c);
     c->prof_mask = (unsigned)class_mask;
     return 0;
 }
 int esq_profile_sampling(esq_ctx *c, int every) {
     if (!c || every < 1) return ESQ_EINVAL;
+    ENTER(c);
     c->prof_every = (unsigned)every;
     return 0;
 }
 int esq_profile_read(esq_ctx *c, int klass, double *total_ms, long *launches,
                      double *bytes) {
     if (!c || klass < 0 || klass >= ESQ_PROF_NCLASS) return ESQ_EINVAL;
+    ENTER(c);
     prof_drain(c);
     if (total_ms) *total_ms = c->prof_ms[klass];
     if (launches) *launches = c->prof_cnt[klass];
@@ -1141,6 +1198,7 @@ int esq_profile_read(esq_ctx *c, int klass, double *total_ms, long *launches,
 }
 int esq_profile_reset(esq_ctx *c) {
     if (!c) return ESQ_EINVAL;
+    ENTER(c);
     prof_drain(c);
     for (int k = 0; k < ESQ_PROF_NCLASS; ++k) {
         c->prof_ms[k] = 0; c->prof_cnt[k] = 0; c->prof_bytes[k] = 0;
