@@ -693,3 +693,38 @@ def test_ckdisc_device_rhs_matches_oracle():
     tc = np.linspace(o.t_old, o.t, 4)
     assert_allclose(d.dense_output()(tc), o.dense_output()(tc), rtol=1e-7,
                     atol=1e-10)
+
+
+# --------------------------------- the other BASELINE.json configs, full size
+def test_full_size_ts5_heat_step_matches_oracle():
+    """configs[1]: Ts5, 2-D heat N = 1000 (n = 1e6), two steps vs the oracle"""
+    N = 1000
+    rhs = esq.Heat2D(N)
+    y0 = pb.heat2d_y0(N)
+    h = 1.0 / rhs.spectral_radius()
+    kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+    d, o = _pair("Ts5", rhs, pb.heat2d_rhs(N), 0.0, y0, 1.0, **kw)
+    y_old = o.y
+    assert d.step() is None and o.step() is None
+    check_step(d, o.K, o.y, o.error_norm_old, o.h_abs, y_old, o.h_previous,
+               1e-3, 1e-6, k_rtol=2e-13, lipschitz=rhs.spectral_radius())
+    assert int(esq.NFS[()]) == 0
+    assert d.step() is None and o.step() is None
+    assert d.t == o.t and d.nfev == o.nfev
+    assert_allclose(d.y, o.y, rtol=1e-12, atol=1e-14)
+
+
+def test_full_size_pr9_heat_step_matches_oracle():
+    """configs[4] shard: Pr9, 2-D heat N = 2236 (n = 4 999 696), one step"""
+    N = 2236
+    rhs = esq.Heat2D(N)
+    y0 = pb.heat2d_y0(N)
+    h = 1.0 / rhs.spectral_radius()
+    kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+    d, o = _pair("Pr9", rhs, pb.heat2d_rhs(N), 0.0, y0, 1.0, **kw)
+    y_old = o.y
+    assert d.step() is None and o.step() is None
+    check_step(d, o.K, o.y, o.error_norm_old, o.h_abs, y_old, o.h_previous,
+               1e-3, 1e-6, k_rtol=2e-13, lipschitz=rhs.spectral_radius())
+    assert int(esq.NFS[()]) == 0
+    assert d.nfev == o.nfev == 18

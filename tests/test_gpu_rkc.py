@@ -107,3 +107,28 @@ def test_dense_output_and_ctor_errors():
     with pytest.raises(ValueError):
         esq.SSV2stab(pb.heat2d_rhs(N), 0, pb.heat2d_y0(N), 1,
                      rho_jac=lambda t, y: -1.0)
+
+
+def test_full_size_rkc_diffusion_step_matches_oracle():
+    """configs[3]: SSV2stab, 3-D diffusion N = 159 (n = 4 019 679), m = 100
+    stages in the first step, against the oracle's step"""
+    N = 159
+    rhs = esq.Diffusion3D(N)
+    rho = rhs.spectral_radius()
+    h0 = ((100 - 1) ** 2 - 1 + 0.5 * (2 * 100 - 1)) / (1.54 * rho)
+    kw = dict(rtol=1e-3, atol=1e-3, const_jac=True, first_step=h0, max_step=h0,
+              rho_jac=lambda t, y: rho)
+    y0 = pb.diff3d_y0(N)
+    d = esq.SSV2stab(rhs, 0.0, y0, 1.0, **kw)
+    o = rkc_oracle.SSV2stab(pb.diff3d_rhs(N), 0.0, y0, 1.0, **kw)
+    assert d.step() is None and o.step() is None
+    assert int(dev_rkc.maxm[()]) == int(rkc_oracle.maxm[()]) == 100
+    # the m = 100 attempt is rejected in both and retried with a step derived
+    # from its error norm: t agrees to rounding, not bitwise
+    assert int(dev_rkc.nrejct[()]) == int(rkc_oracle.nrejct[()])
+    assert_allclose(d.t, o.t, rtol=1e-12)
+    assert d.nfev == o.nfev
+    # 100 stages of a recursion whose RHS has Lipschitz constant rho ~ 3e5:
+    # rounding differences are amplified along the stages
+    assert_allclose(d.y, o.y, rtol=1e-9, atol=1e-12)
+    assert_allclose(d.errold, o.errold, rtol=1e-5)
