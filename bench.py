@@ -55,6 +55,9 @@ def parse():
                          "~6 us of queue time)")
     ap.add_argument("--force-lockstep", action="store_true",
                     help="create the RCCL communicator even for one rank")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1 without the lock-step collective: fully "
+                         "independent solvers per GPU (upper bound, SURVEY.md §8e)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise only the multi-rank control plane (gloo "
                          "rendezvous, id exchange, barrier, max-over-ranks, JSON) "
@@ -234,7 +237,7 @@ def main():
     w = make_workload(args.config, args.grid, rank)
     n = w["y0"].size
     group = None
-    if world > 1 or args.force_lockstep:
+    if (world > 1 and not args.replicas) or args.force_lockstep:
         group = lockstep.init_lockstep(
             rank, world, local, n,
             exchange=gloo_exchange(dist, rank) if dist is not None else None)
@@ -321,7 +324,9 @@ def main():
                 "n_per_gpu": n, "global_state_dim": world * n,
                 "parallelism": (f"lockstep x{world}: independent IVP per GPU, "
                                 "1 fp64 RCCL all-reduce per step")
-                if group is not None else "single GPU",
+                if group is not None else
+                (f"replicas x{world}: independent solvers, no collective"
+                 if world > 1 else "single GPU"),
                 "rejected_steps_in_timed_region": rejected,
                 "rhs_evaluations_in_timed_region": nfev_timed,
                 "ms_per_step_without_events": 1e3 * elapsed_noprof / args.steps,
