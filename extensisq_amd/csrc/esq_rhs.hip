@@ -168,22 +168,29 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d_v2(
     U.pair = V.pair = (tile % bpr) * 64 + (threadIdx.x & 63);
     U.live = V.live = U.pair < U.npairs;
     if (i0 >= N) return;
-    double2 uu = U.row(i0 - 1), uc = U.row(i0);
-    double2 vu = V.row(i0 - 1), vc = V.row(i0);
+    // all R + 2 rows of the window are requested up front (independent loads:
+    // one memory round trip per tile instead of one per row)
+    double2 ur[R + 2], vr[R + 2];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+        ur[r] = U.row(i0 - 1 + r);
+        vr[r] = V.row(i0 - 1 + r);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = i0 + r;
         if (i >= N) break;                       // uniform across the wave
-        const double2 ud = U.row(i + 1), vd = V.row(i + 1);
-        double ul, ur, vl, vr;
-        U.sides(i, uc, ul, ur);
-        V.sides(i, vc, vl, vr);
-        // .x : neighbours (left = ul, right = uc.y); .y : (left = uc.x, right = ur)
+        const double2 uu = ur[r], uc = ur[r + 1], ud = ur[r + 2];
+        const double2 vu = vr[r], vc = vr[r + 1], vd = vr[r + 2];
+        double ul, urt, vl, vrt;
+        U.sides(i, uc, ul, urt);
+        V.sides(i, vc, vl, vrt);
+        // .x : neighbours (left = ul, right = uc.y); .y : (left = uc.x, right = urt)
         double2 lapu, lapv, fu, fv;
         lapu.x = ((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x;
-        lapu.y = ((uu.y + ud.y) + (uc.x + ur)) - 4.0 * uc.y;
+        lapu.y = ((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y;
         lapv.x = ((vu.x + vd.x) + (vl + vc.y)) - 4.0 * vc.x;
-        lapv.y = ((vu.y + vd.y) + (vc.x + vr)) - 4.0 * vc.y;
+        lapv.y = ((vu.y + vd.y) + (vc.x + vrt)) - 4.0 * vc.y;
         const double uuvx = uc.x * uc.x * vc.x, uuvy = uc.y * uc.y * vc.y;
         fu.x = ((A + uuvx) - (B + 1.0) * uc.x) + d * lapu.x;
         fu.y = ((A + uuvy) - (B + 1.0) * uc.y) + d * lapu.y;
@@ -201,8 +208,6 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d_v2(
                 *reinterpret_cast<double2 *>(f + NN + k) = fv;
             }
         }
-        uu = uc; uc = ud;
-        vu = vc; vc = vd;
     }
 }
 
@@ -219,21 +224,21 @@ __global__ __launch_bounds__(kBlock) void k_heat2d_v2(
     U.pair = (tile % bpr) * 64 + (threadIdx.x & 63);
     U.live = U.pair < U.npairs;
     if (i0 >= N) return;
-    double2 uu = U.row(i0 - 1), uc = U.row(i0);
+    double2 ur[R + 2];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) ur[r] = U.row(i0 - 1 + r);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = i0 + r;
         if (i >= N) break;
-        const double2 ud = U.row(i + 1);
-        double ul, ur;
-        U.sides(i, uc, ul, ur);
+        const double2 uu = ur[r], uc = ur[r + 1], ud = ur[r + 2];
+        double ul, urt;
+        U.sides(i, uc, ul, urt);
         double2 out;
         out.x = c * (((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x);
-        out.y = c * (((uu.y + ud.y) + (uc.x + ur)) - 4.0 * uc.y);
+        out.y = c * (((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y);
         if (U.live)
             *reinterpret_cast<double2 *>(f + (size_t)i * N + 2 * (size_t)U.pair) = out;
-        uu = uc;
-        uc = ud;
     }
 }
 
@@ -386,10 +391,10 @@ __global__ __launch_bounds__(kBlock) void k_diff3d(const double *__restrict__ u,
     f[k] = c * ((((a0 + a1) + (b0 + b1)) + (c0 + c1)) - 6.0 * uc);
 }
 
-// ESQ_RHS_VARIANT: 1 = scalar kernels, 2/3/4/8 = rows per thread of the
-// vectorised sweeps (default 2)
+// ESQ_RHS_VARIANT: 1 = scalar kernels, 2/3/4/8 = rows per wave tile of the
+// vectorised sweeps (default: one row -- measured fastest, most waves in flight)
 int rhs_variant() {
-    static const int v = getenv("ESQ_RHS_VARIANT") ? atoi(getenv("ESQ_RHS_VARIANT")) : 2;
+    static const int v = getenv("ESQ_RHS_VARIANT") ? atoi(getenv("ESQ_RHS_VARIANT")) : 0;
     return v;
 }
 
@@ -512,7 +517,7 @@ int esq_rhs_heat2d(void *user, double t, const double *y, double *f, size_t n,
     if (!r || r->kind != HEAT2D || n != r->n) return ESQ_EINVAL;
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
     if (r->N % 2 == 0 && r->N >= 4 && rhs_variant() != 1) {
-        constexpr int R = 2;
+        constexpr int R = 1;
         const unsigned wpr = (r->N / 2 + 63) / 64;              // wave tiles per row
         const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
         const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
@@ -537,14 +542,15 @@ int esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
     if (r->N % 2 == 0 && r->N >= 4 && rhs_variant() != 1) {
         const unsigned wpr = (r->N / 2 + 63) / 64;              // wave tiles per row
         const int v = rhs_variant();
-        const int R = (v == 8 || v == 4 || v == 3) ? v : 2;
+        const int R = (v == 8 || v == 4 || v == 3 || v == 2) ? v : 1;
         const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
         const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
         const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
 #define LAUNCH_BR(RR)                                                           \
     hipLaunchKernelGGL((k_bruss2d_v2<RR, false>), dim3(grid), dim3(kBlock), 0,  \
                        (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, wpr)
-        if (R == 8) LAUNCH_BR(8);
+        if (R == 1) LAUNCH_BR(1);
+        else if (R == 8) LAUNCH_BR(8);
         else if (R == 4) LAUNCH_BR(4);
         else if (R == 3) LAUNCH_BR(3);
         else LAUNCH_BR(2);
