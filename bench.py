@@ -274,6 +274,7 @@ def main():
     rejected = int(esq.NFS[()]) - nfs0
     nfev_timed = solver.nfev - nfev0
     prof = {klass: dev.profile_read(klass)}
+    moved_bytes = dev.profile_read_moved(klass)
     # ---- the same K steps again without any event: the cost of measuring
     barrier()
     t1 = time.perf_counter()
@@ -339,6 +340,10 @@ def main():
                 "launches_timed": cnt, "sampled_every": args.sample_every,
                 "avg_launch_us": 1e3 * ms / cnt if cnt else None,
                 "algorithmic_bytes_per_launch": nbytes / cnt if cnt else None,
+                # bytes the timed launches are designed to move: below the
+                # algorithmic count where blocked accumulation reads a K row
+                # once for several stages
+                "moved_gbs": moved_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None,
                 "other_kernels": {names[k]: klass_info(k) for k in others
                                   if prof[k][1]},
                 "whole_step_gbs": (w["bytes_per_elt_step"] * n * args.steps

@@ -38,6 +38,8 @@ SIGNATURES = {
     "esq_set_rhs": (C.c_int, [_vp, _vp, _vp]),
     "esq_set_rhs_stage": (C.c_int, [_vp, _vp]),
     "esq_rk_stage_accumulate": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "esq_rk_block_plan": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "esq_rk_eval_rhs": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int, C.c_int]),
     "esq_rk_stages": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double]),
     "esq_rk_solution": (C.c_int, [_vp, C.c_double]),
@@ -96,6 +98,7 @@ SIGNATURES = {
     "esq_profile_enable": (C.c_int, [_vp, C.c_int]),
     "esq_profile_sampling": (C.c_int, [_vp, C.c_int]),
     "esq_profile_read": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_long), _dp]),
+    "esq_profile_read_moved": (C.c_int, [_vp, C.c_int, _dp]),
     "esq_profile_reset": (C.c_int, [_vp]),
 }
 

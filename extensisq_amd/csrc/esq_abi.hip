@@ -30,7 +30,8 @@ constexpr int kFixedSlots = 5;        // Y, YNEW, YSTAGE, ATOL, WORK
 struct ProfEvent {
     hipEvent_t start, stop;
     int klass;
-    double bytes;
+    double bytes;      // algorithmic bytes (SURVEY.md §8d definition)
+    double moved;      // bytes the launch is designed to move
 };
 
 }  // namespace
@@ -64,9 +65,21 @@ struct esq_ctx {
     esq_rhs_fn rhs = nullptr;
     void *rhs_user = nullptr;
     esq_rhs_stage_fn rhs_stage = nullptr;   // optional fused stage entry
+    // blocked accumulation plan (esq_rk_set_tableau)
+    struct Block {
+        int J = 0, prev = 0;              // columns [prev, J) of A
+        std::vector<int> cols;            // non-zero columns of the block
+        std::vector<int> stages;          // later stages that use them
+        std::vector<int> out_vec;         // physical row of each stage's partial
+        std::vector<int> in_vec;          // previous-level partial (-1: none)
+    };
+    std::vector<Block> blocks;
+    std::vector<int> stage_init;          // per stage: row of its partial or -1
+    std::vector<int> stage_from;          // per stage: first column still to add
     // launch geometry
     unsigned grid_stream = 0;         // grid for streaming kernels
     unsigned grid_reduce = 0;
+    unsigned grid_block = 0;          // grid of the (write-heavy) block kernel
     int stage_policy = 0;             // cache policy of k_lincomb (tuning knob)
     // lock-step
     void *comm = nullptr;
@@ -79,6 +92,7 @@ struct esq_ctx {
     double prof_ms[ESQ_PROF_NCLASS] = {0};
     long prof_cnt[ESQ_PROF_NCLASS] = {0};
     double prof_bytes[ESQ_PROF_NCLASS] = {0};
+    double prof_moved[ESQ_PROF_NCLASS] = {0};
     char err[512] = {0};
 };
 
@@ -124,10 +138,19 @@ struct Prof {
     esq_ctx *c;
     bool on, recorded;
     ProfEvent ev;
-    Prof(esq_ctx *ctx, int klass, double bytes, bool record_now = false)
+    Prof(esq_ctx *ctx, int klass, double bytes, bool record_now = false,
+         double moved = -1.0)
         : c(ctx), on((ctx->prof_mask >> klass) & 1u), recorded(record_now) {
         ev.start = ev.stop = nullptr;
-        if (on) on = (ctx->prof_seen[klass]++ % ctx->prof_every) == 0;
+        if (on && ctx->prof_every > 1) {
+            // pseudo-random 1-in-`every` sampling: a fixed stride would alias
+            // with the number of launches per step (e.g. 14 for Pr8, stride 7)
+            unsigned x = (unsigned)(ctx->prof_seen[klass]++) * 2654435761u;
+            x ^= x >> 15;
+            x *= 2246822519u;
+            x ^= x >> 13;
+            on = (x % ctx->prof_every) == 0;
+        }
         if (!on) return;
         auto take = [&]() {
             hipEvent_t e;
@@ -143,6 +166,7 @@ struct Prof {
         ev.stop = take();
         ev.klass = klass;
         ev.bytes = bytes;
+        ev.moved = moved < 0.0 ? bytes : moved;
         if (recorded) (void)hipEventRecord(ev.start, c->stream);
     }
     void cancel() {            // the launch did not happen: return the events
@@ -169,6 +193,7 @@ void prof_drain(esq_ctx *c) {
             c->prof_ms[ev.klass] += ms;
             c->prof_cnt[ev.klass] += 1;
             c->prof_bytes[ev.klass] += ev.bytes;
+            c->prof_moved[ev.klass] += ev.moved;
         }
         c->prof_pool.push_back(ev.start);
         c->prof_pool.push_back(ev.stop);
@@ -179,27 +204,30 @@ void prof_drain(esq_ctx *c) {
 // ---- launch helpers ----------------------------------------------------------
 template <int NT, int LDP, int STP>
 void launch_lincomb_p(esq_ctx *c, double *out, const double *base,
-                      const Terms &tm, double h, const Prof *p) {
+                      const double *init, const Terms &tm, double h,
+                      const Prof *p) {
     hipExtLaunchKernelGGL((k_lincomb<NT, LDP, STP>), dim3(c->grid_stream),
                           dim3(kBlock), 0, c->stream, p ? p->start() : nullptr,
-                          p ? p->stop() : nullptr, 0, out, base, tm, h,
+                          p ? p->stop() : nullptr, 0, out, base, init, tm, h,
                           c->len_pad / 2);
 }
 template <int NT>
 void launch_lincomb_n(esq_ctx *c, double *out, const double *base,
-                      const Terms &tm, double h, const Prof *p) {
+                      const double *init, const Terms &tm, double h,
+                      const Prof *p) {
     switch (c->stage_policy) {      // ESQ_STAGE_POLICY = <load><store>
-        case 1:  launch_lincomb_p<NT, 0, 1>(c, out, base, tm, h, p); break;
-        case 10: launch_lincomb_p<NT, 1, 0>(c, out, base, tm, h, p); break;
-        case 11: launch_lincomb_p<NT, 1, 1>(c, out, base, tm, h, p); break;
-        case 20: launch_lincomb_p<NT, 2, 0>(c, out, base, tm, h, p); break;
-        case 21: launch_lincomb_p<NT, 2, 1>(c, out, base, tm, h, p); break;
-        default: launch_lincomb_p<NT, 0, 0>(c, out, base, tm, h, p); break;
+        case 1:  launch_lincomb_p<NT, 0, 1>(c, out, base, init, tm, h, p); break;
+        case 10: launch_lincomb_p<NT, 1, 0>(c, out, base, init, tm, h, p); break;
+        case 11: launch_lincomb_p<NT, 1, 1>(c, out, base, init, tm, h, p); break;
+        case 20: launch_lincomb_p<NT, 2, 0>(c, out, base, init, tm, h, p); break;
+        case 21: launch_lincomb_p<NT, 2, 1>(c, out, base, init, tm, h, p); break;
+        default: launch_lincomb_p<NT, 0, 0>(c, out, base, init, tm, h, p); break;
     }
 }
 int launch_lincomb(esq_ctx *c, double *out, const double *base, const Terms &tm,
-                   int nt, double h, const Prof *p = nullptr) {
-#define CASE(N) case N: launch_lincomb_n<N>(c, out, base, tm, h, p); break;
+                   int nt, double h, const Prof *p = nullptr,
+                   const double *init = nullptr) {
+#define CASE(N) case N: launch_lincomb_n<N>(c, out, base, init, tm, h, p); break;
     switch (nt) {
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
         CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
@@ -372,6 +400,50 @@ int build_row_terms2(esq_ctx *c, const double *b, int nb, const double *e, int n
     return nt;
 }
 
+// ---- blocked accumulation plan ------------------------------------------------
+// words per element and step moved by the stage kernels (+ block kernels) for a
+// set of column boundaries; returns -1 if a block needs too many outputs/rows
+int plan_words(const std::vector<double> &A, int s, const std::vector<int> &bounds,
+               std::vector<esq_ctx::Block> *out) {
+    auto nz = [&](int i, int j) { return A[(size_t)i * s + j] != 0.0; };
+    std::vector<char> has(s, 0);
+    int total = 0, prev = 0;
+    if (out) out->clear();
+    for (int J : bounds) {
+        esq_ctx::Block b;
+        b.J = J;
+        b.prev = prev;
+        std::vector<char> col(s, 0);
+        for (int i = J; i < s; ++i) {
+            bool any = false;
+            for (int j = prev; j < J; ++j)
+                if (nz(i, j)) { any = true; col[j] = 1; }
+            if (any) b.stages.push_back(i);
+        }
+        for (int j = prev; j < J; ++j)
+            if (col[j]) b.cols.push_back(j);
+        if ((int)b.stages.size() > kMaxOut || (int)b.cols.size() > kMaxTerms) return -1;
+        if (b.stages.empty()) return -1;
+        total += (int)b.cols.size();
+        for (int i : b.stages) {
+            total += 1 + (has[i] ? 1 : 0);
+            has[i] = 1;
+        }
+        if (out) out->push_back(b);
+        prev = J;
+    }
+    for (int i = 1; i < s; ++i) {
+        int last = 0;
+        for (int J : bounds)
+            if (J <= i) last = J;
+        int c = 2;
+        for (int j = last; j < i; ++j) c += nz(i, j);
+        if (last > 0 && has[i]) c += 1;
+        total += c;
+    }
+    return total;
+}
+
 // One process per GPU is the intended use (a context never changes device), but
 // a process MAY hold contexts on several devices (threads driving one context
 // each): once that happens every entry point re-selects the context's device.
@@ -391,6 +463,36 @@ unsigned env_uint(const char *name, unsigned dflt) {
 }
 
 }  // namespace
+
+template <int NT>
+void launch_block_n(esq_ctx *c, const BlockArgs &a, int no, const Prof &p) {
+    hipExtLaunchKernelGGL(k_block_acc<NT>, dim3(c->grid_block), dim3(kBlock), 0,
+                          c->stream, p.start(), p.stop(), 0, a, no,
+                          c->len_pad / 2);
+}
+// leading parts of the sums of all later stages, one pass over the block's rows
+static int run_block(esq_ctx *c, const esq_ctx::Block &b) {
+    BlockArgs a;
+    const int nt = (int)b.cols.size(), no = (int)b.stages.size();
+    for (int j = 0; j < kMaxTerms; ++j) {
+        a.p[j] = j < nt ? c->krow[c->kmap[b.cols[j]]] : nullptr;
+        for (int o = 0; o < kMaxOut; ++o)
+            a.w[j][o] = (j < nt && o < no)
+                            ? c->A[(size_t)b.stages[o] * c->s + b.cols[j]] : 0.0;
+    }
+    double reads = nt;
+    for (int o = 0; o < kMaxOut; ++o) {
+        a.out[o] = o < no ? c->krow[b.out_vec[o]] : nullptr;
+        a.init[o] = (o < no && b.in_vec[o] >= 0) ? c->krow[b.in_vec[o]] : nullptr;
+        if (a.init[o]) reads += 1;
+    }
+    // algorithmic bytes: none of its own (they are booked on the stages it
+    // serves); moved bytes: its real traffic
+    Prof p(c, ESQ_PROF_STAGE, 0.0, false, 8.0 * (reads + no) * (double)c->len);
+    DISPATCH_1_20(launch_block_n, nt, c, a, no, p)
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
 
 extern "C" {
 
@@ -455,6 +557,9 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     if (g < 1) g = 1;
     c->grid_stream = (unsigned)g;
     c->grid_reduce = (unsigned)(g > (size_t)kMaxPartials ? kMaxPartials : g);
+    size_t gb = (size_t)cus * env_uint("ESQ_BLOCK_BPC", 16);
+    if (gb > need) gb = need;
+    c->grid_block = (unsigned)(gb < 1 ? 1 : gb);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -539,6 +644,57 @@ int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
     c->C.assign(C, C + s);
     c->E.assign(E, E + s + 1);
     c->have_tab = true;
+    // ---- blocked accumulation plan (up to 3 column boundaries, exhaustive)
+    c->blocks.clear();
+    c->stage_init.assign(s, -1);
+    c->stage_from.assign(s, 0);
+    if (env_uint("ESQ_BLOCK_ACC", 1) != 0 && s >= 4) {
+        std::vector<int> best;
+        int best_words = plan_words(c->A, s, best, nullptr);
+        // fewest boundaries first: a plan with more boundaries must be strictly
+        // better (every boundary is one more launch)
+        for (int b1 = 2; b1 < s; ++b1) {
+            const int w = plan_words(c->A, s, {b1}, nullptr);
+            if (w >= 0 && w < best_words) { best_words = w; best = {b1}; }
+        }
+        for (int b1 = 2; b1 < s; ++b1)
+            for (int b2 = b1 + 1; b2 < s; ++b2) {
+                const int w = plan_words(c->A, s, {b1, b2}, nullptr);
+                if (w >= 0 && w < best_words) { best_words = w; best = {b1, b2}; }
+            }
+        for (int b1 = 2; b1 < s; ++b1)
+            for (int b2 = b1 + 1; b2 < s; ++b2)
+                for (int b3 = b2 + 1; b3 < s; ++b3) {
+                    const int w = plan_words(c->A, s, {b1, b2, b3}, nullptr);
+                    if (w >= 0 && w < best_words) { best_words = w; best = {b1, b2, b3}; }
+                }
+        if (!best.empty()) {
+            std::vector<esq_ctx::Block> blocks;
+            plan_words(c->A, s, best, &blocks);
+            int count = 0;
+            for (auto &bl : blocks) count += (int)bl.stages.size();
+            int first = 0;
+            int r = esq_aux_rows(c, count, &first);
+            if (r) return r;
+            std::vector<int> cur(s, -1);
+            for (auto &bl : blocks) {
+                for (int i : bl.stages) {
+                    bl.in_vec.push_back(cur[i]);
+                    bl.out_vec.push_back(first);
+                    cur[i] = first++;
+                }
+            }
+            c->blocks = blocks;
+            for (int i = 1; i < s; ++i) {
+                int last = 0;
+                for (int J : best)
+                    if (J <= i) last = J;
+                c->stage_from[i] = cur[i] >= 0 ? last : 0;
+                c->stage_init[i] = cur[i] >= 0 && last > 0 ? cur[i] : -1;
+                if (c->stage_init[i] < 0) c->stage_from[i] = 0;
+            }
+        }
+    }
     return 0;
 }
 
@@ -571,6 +727,11 @@ int esq_set_rhs_stage(esq_ctx *c, esq_rhs_stage_fn fn) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
     c->rhs_stage = fn;
+    if (fn) {       // the fused entry forms whole sums itself: no blocked plan
+        c->blocks.clear();
+        c->stage_init.assign(c->stage_init.size(), -1);
+        c->stage_from.assign(c->stage_from.size(), 0);
+    }
     return 0;
 }
 
@@ -579,11 +740,39 @@ int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (i < 1 || i >= c->s) return fail(c, ESQ_EINVAL, "stage %d out of range", i);
+    for (const auto &b : c->blocks)
+        if (b.J == i) {
+            const int r = run_block(c, b);
+            if (r) return r;
+        }
+    const int from = c->stage_from[i];
+    const double *init = c->stage_init[i] >= 0 ? c->krow[c->stage_init[i]] : nullptr;
     Terms tm;
-    const int nt = build_row_terms(c, &c->A[(size_t)i * c->s], i, tm, c->kmap);
+    // columns [from, i): the chain resumes from the stored partial sum
+    std::vector<double> row(c->A.begin() + (size_t)i * c->s,
+                            c->A.begin() + (size_t)i * c->s + i);
+    int nnz_all = 0;
+    for (int j = 0; j < i; ++j) {
+        nnz_all += row[j] != 0.0;
+        if (j < from) row[j] = 0.0;
+    }
+    const int nt = build_row_terms(c, row.data(), i, tm, c->kmap);
     if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
-    Prof p(c, ESQ_PROF_STAGE, 8.0 * (nt + 2) * (double)c->len);
-    return launch_lincomb(c, c->ystage, c->y, tm, nt, h, &p);
+    Prof p(c, ESQ_PROF_STAGE, 8.0 * (nnz_all + 2) * (double)c->len, false,
+           8.0 * (nt + 2 + (init ? 1 : 0)) * (double)c->len);
+    return launch_lincomb(c, c->ystage, c->y, tm, nt, h, &p, init);
+}
+
+int esq_rk_block_plan(esq_ctx *c, int *boundaries, int max_boundaries,
+                      int *words_plain, int *words_blocked) {
+    if (!c || !c->have_tab) return ESQ_EINVAL;
+    std::vector<int> b;
+    for (const auto &bl : c->blocks) b.push_back(bl.J);
+    if (words_plain) *words_plain = plan_words(c->A, c->s, {}, nullptr);
+    if (words_blocked) *words_blocked = plan_words(c->A, c->s, b, nullptr);
+    for (int k = 0; k < (int)b.size() && k < max_boundaries; ++k)
+        if (boundaries) boundaries[k] = b[k];
+    return (int)b.size();
 }
 
 int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row) {
@@ -1196,12 +1385,19 @@ int esq_profile_read(esq_ctx *c, int klass, double *total_ms, long *launches,
     if (bytes) *bytes = c->prof_bytes[klass];
     return 0;
 }
+int esq_profile_read_moved(esq_ctx *c, int klass, double *moved_bytes) {
+    if (!c || !moved_bytes || klass < 0 || klass >= ESQ_PROF_NCLASS) return ESQ_EINVAL;
+    prof_drain(c);
+    *moved_bytes = c->prof_moved[klass];
+    return 0;
+}
 int esq_profile_reset(esq_ctx *c) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
     prof_drain(c);
     for (int k = 0; k < ESQ_PROF_NCLASS; ++k) {
         c->prof_ms[k] = 0; c->prof_cnt[k] = 0; c->prof_bytes[k] = 0;
+        c->prof_moved[k] = 0;
         c->prof_seen[k] = 0;
     }
     return 0;

@@ -25,10 +25,13 @@ namespace esq {
 // ---------------------------------------------------------------------------
 // LDP: 0 plain loads, 1 nt loads of the K rows, 2 nt loads of everything
 // STP: 0 plain store, 1 nt store
+// `init` (optional): the value of the SAME FMA chain after its leading terms,
+// stored by k_block_acc -- resuming from it is bit-identical to running the
+// whole chain here.
 template <int NT, int LDP = 0, int STP = 0>
 __global__ __launch_bounds__(kBlock) void k_lincomb(
-    double *__restrict__ out, const double *__restrict__ base, Terms tm,
-    double h, size_t n2) {
+    double *__restrict__ out, const double *__restrict__ base,
+    const double *__restrict__ init, Terms tm, double h, size_t n2) {
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
          i += stride) {
@@ -39,6 +42,7 @@ __global__ __launch_bounds__(kBlock) void k_lincomb(
         double2 yb = make_double2(0.0, 0.0);
         if (base) yb = LDP >= 2 ? ld2_nt(base, i) : ld2(base, i);
         double2 acc = make_double2(0.0, 0.0);
+        if (init) acc = LDP >= 1 ? ld2_nt(init, i) : ld2(init, i);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             acc.x = fma(tm.c[j], v[j].x, acc.x);
@@ -48,6 +52,49 @@ __global__ __launch_bounds__(kBlock) void k_lincomb(
         r.x = __dadd_rn(yb.x, __dmul_rn(h, acc.x));
         r.y = __dadd_rn(yb.y, __dmul_rn(h, acc.y));
         if (STP) st2_nt(out, i, r); else st2(out, i, r);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Blocked accumulation.  Stage i needs sum_{j<i} a_ij K_j; the leading columns
+// j < J are needed by ALL later stages, so ONE pass over those K rows forms the
+// leading part of every later stage's sum at once (NO outputs) and each later
+// stage kernel resumes its chain from the stored value.  Each K row of the
+// block is then read once instead of once per later stage (Pr8, J = 7: 93 -> 75
+// words per element and step; Pr9, J = 8, 13: 154 -> 109).  The arithmetic is
+// the SAME ascending-j FMA chain, cut at J: results are bit-identical.
+// ---------------------------------------------------------------------------
+constexpr int kMaxOut = 12;
+struct BlockArgs {
+    const double *p[kMaxTerms];        // K rows of the block (non-zero columns)
+    double w[kMaxTerms][kMaxOut];      // a_ij for output stage o, 0 = skip
+    const double *init[kMaxOut];       // previous-level partial sum or nullptr
+    double *out[kMaxOut];
+};
+template <int NT>
+__global__ __launch_bounds__(kBlock) void k_block_acc(BlockArgs a, int no,
+                                                      size_t n2) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        double2 v[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j] = ld2_nt(a.p[j], i);
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+            if (o < no) {                              // uniform
+                double2 acc = make_double2(0.0, 0.0);
+                if (a.init[o]) acc = ld2_nt(a.init[o], i);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (a.w[j][o] != 0.0) {            // uniform (SGPR weights)
+                        acc.x = fma(a.w[j][o], v[j].x, acc.x);
+                        acc.y = fma(a.w[j][o], v[j].y, acc.y);
+                    }
+                }
+                st2(a.out[o], i, acc);   // plain or nt stores: no difference measured
+            }
+        }
     }
 }
 

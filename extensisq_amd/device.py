@@ -166,6 +166,13 @@ class DeviceContext:
                   "esq_profile_read")
         return ms.value, cnt.value, by.value
 
+    def profile_read_moved(self, klass):
+        mv = C.c_double()
+        self._chk(self.lib.esq_profile_read_moved(self.handle, klass,
+                                                  C.byref(mv)),
+                  "esq_profile_read_moved")
+        return mv.value
+
 
 # ----------------------------------------------------------------------------
 # device RHS plugins

@@ -115,8 +115,18 @@ int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
 int  esq_set_rhs_stage(esq_ctx *ctx, esq_rhs_stage_fn fn);
 
 /* ---- explicit RK launches ----------------------------------------------- */
-/* YSTAGE = Y + h * sum_j A[i][j] * K[j]           common.py:355 (`dy`, `y+dy`) */
+/* YSTAGE = Y + h * sum_j A[i][j] * K[j]           common.py:355 (`dy`, `y+dy`)
+ * Blocked accumulation (ESQ_BLOCK_ACC, default on): at column boundaries chosen
+ * from the tableau's sparsity, one extra pass forms the leading part of the sums
+ * of ALL later stages, which then resume the same FMA chain -- bit-identical
+ * results, each K row of a block read once instead of once per later stage.
+ * Stages must therefore be requested in ascending order within an attempt. */
 int  esq_rk_stage_accumulate(esq_ctx *ctx, int i, double h);
+/* the blocked-accumulation plan of the current tableau: returns the number of
+ * column boundaries (>= 0; negative on misuse), writes them and the 8-byte
+ * words per element and step moved by the stage kernels without / with it */
+int  esq_rk_block_plan(esq_ctx *ctx, int *boundaries, int max_boundaries,
+                       int *words_plain, int *words_blocked);
 /* K[dst_row] = rhs(t, <src vector>)                common.py:356, 348, 291    */
 int  esq_rk_eval_rhs(esq_ctx *ctx, int dst_row, double t, int src_slot,
                      int src_row);
@@ -301,6 +311,10 @@ int  esq_profile_enable(esq_ctx *ctx, int class_mask);
 int  esq_profile_sampling(esq_ctx *ctx, int every);
 int  esq_profile_read(esq_ctx *ctx, int klass, double *total_ms, long *launches,
                       double *bytes);
+/* bytes the timed launches of a class were DESIGNED to move (equals the
+ * algorithmic bytes except where blocked accumulation reads K rows once for
+ * several stages) */
+int  esq_profile_read_moved(esq_ctx *ctx, int klass, double *moved_bytes);
 int  esq_profile_reset(esq_ctx *ctx);
 
 #ifdef __cplusplus

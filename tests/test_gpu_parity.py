@@ -728,3 +728,50 @@ def test_full_size_pr9_heat_step_matches_oracle():
                1e-3, 1e-6, k_rtol=2e-13, lipschitz=rhs.spectral_radius())
     assert int(esq.NFS[()]) == 0
     assert d.nfev == o.nfev == 18
+
+
+# ------------------------------------------------------ blocked accumulation
+@pytest.mark.parametrize("name", ERK + ["CKdisc"])
+@pytest.mark.parametrize("mode", ["device_rhs", "host_rhs"])
+def test_blocked_accumulation_is_bit_identical(monkeypatch, name, mode):
+    """ESQ_BLOCK_ACC (default on): leading columns of A are accumulated once
+    for all later stages and each stage resumes the same FMA chain -- K rows,
+    states, error norms must equal the one-kernel-per-stage path bit for bit"""
+    n = 3001
+    rng = np.random.default_rng(21)
+    lam = -rng.random(n) * 2.0
+    y0 = rng.standard_normal(n)
+    cls = getattr(esq, name)
+
+    def make():
+        fun = (esq.DiagonalLinear(lam, 1.0) if mode == "device_rhs"
+               else (lambda t, y: lam * y + np.sin(t)))
+        return cls(fun, 0.2, y0, 5.0, first_step=0.05, rtol=1e-6, atol=1e-9)
+    blocked = make()
+    monkeypatch.setenv("ESQ_BLOCK_ACC", "0")
+    plain = make()
+    monkeypatch.delenv("ESQ_BLOCK_ACC")
+    for _ in range(4):
+        assert blocked.step() is None and plain.step() is None
+        assert blocked.t == plain.t and blocked.h_abs == plain.h_abs
+        assert_equal(blocked.K, plain.K)
+        assert_equal(blocked.y, plain.y)
+    assert blocked.nfev == plain.nfev
+    assert int(esq.NFS[()]) >= 0
+
+
+def test_blocked_accumulation_plans():
+    """the column boundaries the library derives from each tableau's sparsity
+    and the 8-byte words per element and step the stage kernels then move"""
+    import ctypes
+    expect = {"Ts5": ([], 25, 25), "BS5": ([4], 33, 31), "Pr7": ([6], 58, 51),
+              "Pr8": ([7], 93, 75), "Pr9": ([8, 13], 154, 109),
+              "CK5": ([], 25, 25), "Me4": ([], 16, 16), "CFMR7osc": ([5], 46, 42)}
+    for name, (bounds, plain, blocked) in expect.items():
+        s = getattr(esq, name)(lambda t, y: -y, 0.0, np.ones(7), 1.0,
+                               first_step=0.1)
+        b = (ctypes.c_int * 8)()
+        wp, wb = ctypes.c_int(), ctypes.c_int()
+        k = s._lib.esq_rk_block_plan(s._ctx, b, 8, ctypes.byref(wp),
+                                     ctypes.byref(wb))
+        assert (list(b[:k]), wp.value, wb.value) == (bounds, plain, blocked), name

@@ -59,7 +59,7 @@ def main():
             rec["avg_ns_kernel_trace"] = float(stats[k]["AverageNs"])
             rec["calls_kernel_trace"] = int(stats[k]["Calls"])
         out["kernels"][short(k)] = rec
-        if "k_lincomb" in k and k in stats:
+        if ("k_lincomb" in k or "k_block_acc" in k) and k in stats:
             st_bytes += (f_b + w_b) * int(stats[k]["Calls"])
             st_launch += int(stats[k]["Calls"])
             st_ns += float(stats[k]["TotalDurationNs"])
