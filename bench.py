@@ -336,6 +336,9 @@ def main():
                 "bound": "hbm", "kernel": w["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "note": "achieved = SURVEY.md algorithmic bytes / device time; "
+                        "blocked accumulation moves fewer bytes than that "
+                        "(moved_gbs), so frac may exceed what the fabric carries",
                 "traffic": traffic, "traffic_source": traffic_src,
                 "launches_timed": cnt, "sampled_every": args.sample_every,
                 "avg_launch_us": 1e3 * ms / cnt if cnt else None,
