@@ -65,6 +65,7 @@ struct esq_ctx {
     esq_rhs_fn rhs = nullptr;
     void *rhs_user = nullptr;
     esq_rhs_stage_fn rhs_stage = nullptr;   // optional fused stage entry
+    esq_rhs_chain_fn rhs_chain = nullptr;   // optional RHS + next-accumulate entry
     // blocked accumulation plan (esq_rk_set_tableau)
     struct Block {
         int J = 0, prev = 0;              // columns [prev, J) of A
@@ -721,6 +722,13 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     c->rhs = fn;
     c->rhs_user = user;
     c->rhs_stage = nullptr;
+    c->rhs_chain = nullptr;
+    return 0;
+}
+int esq_set_rhs_chain(esq_ctx *c, esq_rhs_chain_fn fn) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    c->rhs_chain = fn;
     return 0;
 }
 int esq_set_rhs_stage(esq_ctx *c, esq_rhs_stage_fn fn) {
@@ -790,6 +798,7 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (i_from < 1 || i_to > c->s || i_from > i_to)
         return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
+    bool ready = false;     // YSTAGE already holds the argument of stage i
     for (int i = i_from; i < i_to; ++i) {
         if (c->rhs_stage) {
             // one fused kernel: K[i] = rhs(t_i, Y + h*sum a_ij K_j), no YSTAGE
@@ -806,9 +815,52 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 return fail(c, ESQ_ERHS, "fused RHS stage returned %d", r);
             p.cancel();
         }
-        int r = esq_rk_stage_accumulate(c, i, h);
-        if (r) return r;
-        r = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
+        if (!ready) {
+            const int r = esq_rk_stage_accumulate(c, i, h);
+            if (r) return r;
+        }
+        ready = false;
+        // chained form: this stage's RHS also forms the NEXT stage's argument
+        // (not across a blocked-accumulation boundary: its block kernel needs
+        // K[i] in memory first)
+        bool boundary_next = false;
+        for (const auto &b : c->blocks) boundary_next |= (b.J == i + 1);
+        if (c->rhs_chain && i + 1 < i_to && !boundary_next) {
+            const int nx = i + 1;
+            const int from = c->stage_from[nx];
+            const double *init =
+                c->stage_init[nx] >= 0 ? c->krow[c->stage_init[nx]] : nullptr;
+            std::vector<double> row(c->A.begin() + (size_t)nx * c->s,
+                                    c->A.begin() + (size_t)nx * c->s + nx);
+            int nnz_all = 0;
+            for (int j = 0; j < nx; ++j) {
+                nnz_all += row[j] != 0.0;
+                if (j < from) row[j] = 0.0;
+            }
+            const double c_self = row[i];
+            row[i] = 0.0;                      // K[i] comes from registers
+            Terms tm;
+            const int nt = build_row_terms(c, row.data(), nx, tm, c->kmap);
+            if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+            // booked on the stage class: next stage's algorithmic bytes + the
+            // RHS's 16 B; moved: ys_in, rows, init, y in; K[i], ys_out out
+            Prof p(c, ESQ_PROF_STAGE, 8.0 * (nnz_all + 4) * (double)c->len, false,
+                   8.0 * (nt + 4 + (init ? 1 : 0)) * (double)c->len);
+            const int r = c->rhs_chain(c->rhs_user, t + c->C[i] * h, c->ystage,
+                                       c->krow[c->kmap[i]], nt, tm.p, tm.c, c_self,
+                                       init, c->y, h, c->work, c->len,
+                                       (void *)c->stream, (void *)p.start(),
+                                       (void *)p.stop());
+            if (r == 0) {
+                std::swap(c->ystage, c->work);   // double buffer
+                ready = true;
+                continue;
+            }
+            if (r != ESQ_ENOTSUP)
+                return fail(c, ESQ_ERHS, "chained RHS returned %d", r);
+            p.cancel();
+        }
+        const int r = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
         if (r) return r;
     }
     return 0;

@@ -369,6 +369,124 @@ void launch_bruss_fused(const esq::Terms &tm, const double *y, double h, double 
                           stream, e0, e1, 0, sa, f, r->N, d, r->a, r->b, grid, wpr);
 }
 
+// ---------------------------------------------------------------------------
+// CHAINED stage: K_i = f(t, ys_in) AND, from the value still in registers, the
+// argument of the NEXT stage
+//     ys_out = y + h * (init + sum_j c_j K_j + c_self * K_i)
+// in one sweep.  The next stage's accumulate is pointwise, so unlike the fused
+// form above nothing is recomputed on halos: this is the plain one-row stencil
+// kernel plus NT + 2 streaming loads and one more store per element.  The next
+// stage kernel (and its re-read of K_i) disappears.  Same ascending-j FMA chain
+// with K_i last (it has the largest column index), so results are bit-identical.
+// ---------------------------------------------------------------------------
+struct ChainArgs {
+    esq::Terms tm;                 // rows j < i of the next stage (non-zero a)
+    const double *init;            // its leading partial sum or nullptr
+    const double *y;
+    double *ys_out;
+    double c_self, h;
+};
+// operands of one chain element, requested BEFORE the stencil is evaluated so
+// that all loads of the thread are in flight together (they are independent of
+// the stencil, but the compiler may not move them above the stores to f)
+template <int NT>
+struct ChainIn {
+    double2 v[NT > 0 ? NT : 1], yb, acc0;
+    __device__ __forceinline__ void load(const ChainArgs &ca, size_t i2) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j] = esq::ld2_nt(ca.tm.p[j], i2);
+        yb = esq::ld2(ca.y, i2);
+        acc0 = ca.init ? esq::ld2_nt(ca.init, i2) : make_double2(0.0, 0.0);
+    }
+    __device__ __forceinline__ double2 finish(const ChainArgs &ca,
+                                              double2 fresh) const {
+        double2 acc = acc0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc.x = fma(ca.tm.c[j], v[j].x, acc.x);
+            acc.y = fma(ca.tm.c[j], v[j].y, acc.y);
+        }
+        if (ca.c_self != 0.0) {                       // uniform
+            acc.x = fma(ca.c_self, fresh.x, acc.x);
+            acc.y = fma(ca.c_self, fresh.y, acc.y);
+        }
+        return make_double2(__dadd_rn(yb.x, __dmul_rn(ca.h, acc.x)),
+                            __dadd_rn(yb.y, __dmul_rn(ca.h, acc.y)));
+    }
+};
+
+template <int NT>
+__global__ __launch_bounds__(kBlock) void k_bruss2d_chain(
+    const double *__restrict__ ys, double *__restrict__ f, ChainArgs ca, int N,
+    double d, double A, double B, unsigned nblocks, unsigned wpr) {
+    const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int i = (int)(tile / wpr);
+    if (i >= N) return;
+    const size_t NN = (size_t)N * N;
+    RowWin<true> U, V;
+    U.f = ys; V.f = ys + NN;
+    U.N = V.N = N;
+    U.npairs = V.npairs = (unsigned)N / 2;
+    U.pair = V.pair = (tile % wpr) * 64 + (threadIdx.x & 63);
+    U.live = V.live = U.pair < U.npairs;
+    const size_t k2 = ((size_t)i * N) / 2 + (U.live ? U.pair : 0);   // N even
+    const size_t v2 = NN / 2 + k2;
+    ChainIn<NT> cu, cv;
+    cu.load(ca, k2);
+    cv.load(ca, v2);
+    const double2 uu = U.row(i - 1), uc = U.row(i), ud = U.row(i + 1);
+    const double2 vu = V.row(i - 1), vc = V.row(i), vd = V.row(i + 1);
+    double ul, urt, vl, vrt;
+    U.sides(i, uc, ul, urt);
+    V.sides(i, vc, vl, vrt);
+    double2 fu, fv;
+    {
+        const double lapx = ((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x;
+        const double lapy = ((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y;
+        const double lvx = ((vu.x + vd.x) + (vl + vc.y)) - 4.0 * vc.x;
+        const double lvy = ((vu.y + vd.y) + (vc.x + vrt)) - 4.0 * vc.y;
+        const double uuvx = uc.x * uc.x * vc.x, uuvy = uc.y * uc.y * vc.y;
+        fu.x = ((A + uuvx) - (B + 1.0) * uc.x) + d * lapx;
+        fu.y = ((A + uuvy) - (B + 1.0) * uc.y) + d * lapy;
+        fv.x = (B * uc.x - uuvx) + d * lvx;
+        fv.y = (B * uc.y - uuvy) + d * lvy;
+    }
+    if (!U.live) return;
+    const double2 su = cu.finish(ca, fu), sv = cv.finish(ca, fv);
+    esq::st2(f, k2, fu);
+    esq::st2(f, v2, fv);
+    esq::st2(ca.ys_out, k2, su);
+    esq::st2(ca.ys_out, v2, sv);
+}
+
+template <int NT>
+__global__ __launch_bounds__(kBlock) void k_heat2d_chain(
+    const double *__restrict__ ys, double *__restrict__ f, ChainArgs ca, int N,
+    double c, unsigned nblocks, unsigned wpr) {
+    const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int i = (int)(tile / wpr);
+    if (i >= N) return;
+    RowWin<false> U;
+    U.f = ys;
+    U.N = N;
+    U.npairs = (unsigned)N / 2;
+    U.pair = (tile % wpr) * 64 + (threadIdx.x & 63);
+    U.live = U.pair < U.npairs;
+    const size_t k2 = ((size_t)i * N) / 2 + (U.live ? U.pair : 0);
+    ChainIn<NT> cu;
+    cu.load(ca, k2);
+    const double2 uu = U.row(i - 1), uc = U.row(i), ud = U.row(i + 1);
+    double ul, urt;
+    U.sides(i, uc, ul, urt);
+    double2 out;
+    out.x = c * (((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x);
+    out.y = c * (((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y);
+    if (!U.live) return;
+    const double2 su = cu.finish(ca, out);
+    esq::st2(f, k2, out);
+    esq::st2(ca.ys_out, k2, su);
+}
+
 // 3-D diffusion, Dirichlet 0, 7-point
 __global__ __launch_bounds__(kBlock) void k_diff3d(const double *__restrict__ u,
                                                    double *__restrict__ f, int N,
@@ -590,6 +708,84 @@ int esq_rhs_bruss2d_stage(void *user, double t, int nt,
         CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
 #undef CASE
     }
+    return (int)hipGetLastError();
+}
+
+static void fill_chain(ChainArgs &ca, int nt, const double *const *rows,
+                       const double *coef, double c_self, const double *init,
+                       const double *y, double h, double *ys_out) {
+    for (int j = 0; j < esq::kMaxTerms; ++j) {
+        ca.tm.p[j] = j < nt ? rows[j] : nullptr;
+        ca.tm.c[j] = j < nt ? coef[j] : 0.0;
+    }
+    ca.init = init;
+    ca.y = y;
+    ca.ys_out = ys_out;
+    ca.c_self = c_self;
+    ca.h = h;
+}
+#define CHAIN_CASES(LAUNCH)                                                     \
+    switch (nt) {                                                               \
+        case 0: LAUNCH(0); break;   case 1: LAUNCH(1); break;                   \
+        case 2: LAUNCH(2); break;   case 3: LAUNCH(3); break;                   \
+        case 4: LAUNCH(4); break;   case 5: LAUNCH(5); break;                   \
+        case 6: LAUNCH(6); break;   case 7: LAUNCH(7); break;                   \
+        case 8: LAUNCH(8); break;   case 9: LAUNCH(9); break;                   \
+        case 10: LAUNCH(10); break; case 11: LAUNCH(11); break;                 \
+        case 12: LAUNCH(12); break; case 13: LAUNCH(13); break;                 \
+        case 14: LAUNCH(14); break; case 15: LAUNCH(15); break;                 \
+        case 16: LAUNCH(16); break;                                             \
+        default: return ESQ_ENOTSUP;                                            \
+    }
+
+int esq_rhs_bruss2d_chain(void *user, double t, const double *ys_in, double *f,
+                          int nt, const double *const *rows, const double *coef,
+                          double c_self, const double *init, const double *y,
+                          double h, double *ys_out, size_t n, void *stream,
+                          void *start_event, void *stop_event) {
+    (void)t;
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != BRUSS2D || n != r->n) return ESQ_EINVAL;
+    if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
+    ChainArgs ca;
+    fill_chain(ca, nt, rows, coef, c_self, init, y, h, ys_out);
+    const unsigned wpr = (r->N / 2 + 63) / 64;
+    const unsigned tiles = wpr * (unsigned)r->N;
+    const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
+    const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+    const double d = r->alpha * ((double)r->N * (double)r->N);
+#define LAUNCH(K)                                                               \
+    hipExtLaunchKernelGGL((k_bruss2d_chain<K>), dim3(grid), dim3(kBlock), 0,    \
+                          (hipStream_t)stream, (hipEvent_t)start_event,         \
+                          (hipEvent_t)stop_event, 0, ys_in, f, ca, r->N, d,     \
+                          r->a, r->b, grid, wpr)
+    CHAIN_CASES(LAUNCH)
+#undef LAUNCH
+    return (int)hipGetLastError();
+}
+int esq_rhs_heat2d_chain(void *user, double t, const double *ys_in, double *f,
+                         int nt, const double *const *rows, const double *coef,
+                         double c_self, const double *init, const double *y,
+                         double h, double *ys_out, size_t n, void *stream,
+                         void *start_event, void *stop_event) {
+    (void)t;
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != HEAT2D || n != r->n) return ESQ_EINVAL;
+    if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
+    ChainArgs ca;
+    fill_chain(ca, nt, rows, coef, c_self, init, y, h, ys_out);
+    const unsigned wpr = (r->N / 2 + 63) / 64;
+    const unsigned tiles = wpr * (unsigned)r->N;
+    const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
+    const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+    const double c = (double)(r->N + 1) * (double)(r->N + 1);
+#define LAUNCH(K)                                                               \
+    hipExtLaunchKernelGGL((k_heat2d_chain<K>), dim3(grid), dim3(kBlock), 0,     \
+                          (hipStream_t)stream, (hipEvent_t)start_event,         \
+                          (hipEvent_t)stop_event, 0, ys_in, f, ca, r->N, c, grid, \
+                          wpr)
+    CHAIN_CASES(LAUNCH)
+#undef LAUNCH
     return (int)hipGetLastError();
 }
 int esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,

@@ -114,6 +114,18 @@ class DeviceContext:
         self._rhs_keepalive = (rhs, fn)
         self._chk(self.lib.esq_set_rhs(self.handle, C.cast(fn, C.c_void_p), user),
                   "esq_set_rhs")
+        # chained entry: RHS of stage i + accumulate of stage i+1 in one kernel.
+        # Bit-identical everywhere; measured faster for the one-field heat
+        # plugin (Pr9 1.10 -> 1.01 ms/step, Ts5 0.107 -> 0.101) and slower for
+        # the two-field Brusselator (1.41 -> 1.45), hence the per-plugin default;
+        # ESQ_CHAIN=1 / 0 forces it on / off.
+        chain = rhs._chain_entry(self.lib)
+        want = os.environ.get("ESQ_CHAIN", "")
+        use_chain = (want == "1") or (want != "0" and rhs._chain_default)
+        if chain is not None and use_chain:
+            self._chk(self.lib.esq_set_rhs_chain(self.handle,
+                                                 C.cast(chain, C.c_void_p)),
+                      "esq_set_rhs_chain")
         # The fused stage+RHS entry (one kernel per stage, no stage-argument
         # round trip) is bit-identical but measured SLOWER on MI355X than the
         # two streaming kernels (147 vs 95 + 31 us per Pr8 stage at n = 1e7: its
@@ -187,6 +199,7 @@ class DeviceRHS:
 
     n = None
     is_complex = False
+    _chain_default = False     # use the chained entry unless ESQ_CHAIN says otherwise
 
     def __init__(self):
         self._bound = {}       # device -> (fn, user)
@@ -197,6 +210,10 @@ class DeviceRHS:
 
     def _fused_entry(self, lib):
         """optional `esq_rhs_stage_fn` of this plugin (None: two-kernel path)"""
+        return None
+
+    def _chain_entry(self, lib):
+        """optional `esq_rhs_chain_fn` of this plugin"""
         return None
 
     def _bind(self, ctx):
@@ -240,9 +257,13 @@ class DeviceRHS:
 class _Builtin(DeviceRHS):
     _symbol = None
     _symbol_fused = None
+    _symbol_chain = None
 
     def _fused_entry(self, lib):
         return getattr(lib, self._symbol_fused) if self._symbol_fused else None
+
+    def _chain_entry(self, lib):
+        return getattr(lib, self._symbol_chain) if self._symbol_chain else None
 
     def _make_user(self, lib, device):
         raise NotImplementedError
@@ -275,6 +296,8 @@ class Heat2D(_Builtin):
     """5-point heat equation on an N x N interior grid, Dirichlet 0
     (BASELINE.json configs[1], configs[4]); twin of oracle/problems.py."""
     _symbol = "esq_rhs_heat2d"
+    _symbol_chain = "esq_rhs_heat2d_chain"
+    _chain_default = True
 
     def __init__(self, N):
         super().__init__()
@@ -296,6 +319,7 @@ class Brusselator2D(_Builtin):
     (BASELINE.json configs[2], the north-star workload)."""
     _symbol = "esq_rhs_bruss2d"
     _symbol_fused = "esq_rhs_bruss2d_stage"
+    _symbol_chain = "esq_rhs_bruss2d_chain"
 
     def __init__(self, N, alpha=0.1, a=1.0, b=3.4):
         super().__init__()

@@ -77,6 +77,23 @@ typedef int (*esq_rhs_stage_fn)(void *user, double t, int nt,
                                 size_t n, void *hip_stream, void *start_event,
                                 void *stop_event);
 
+/*
+ * OPTIONAL chained entry of a plugin: enqueue BOTH
+ *     f_dev  = fun(t, ys_in)
+ *     ys_out = y_dev + h * (init + sum_{j<nt} coef[j]*rows[j] + c_self*f_dev)
+ * i.e. this stage's derivative and, from the value still in registers, the NEXT
+ * stage's argument (its accumulate is pointwise, nothing is recomputed).  init
+ * may be NULL; the FMA chain runs over j ascending and adds c_self*f_dev last
+ * (skipped if c_self == 0), then *h, then +y: bit-identical to the separate
+ * kernels.  Return ESQ_ENOTSUP to fall back to esq_rhs_fn + stage_accumulate.
+ */
+typedef int (*esq_rhs_chain_fn)(void *user, double t, const double *ys_in,
+                                double *f_dev, int nt, const double *const *rows,
+                                const double *coef, double c_self,
+                                const double *init, const double *y_dev, double h,
+                                double *ys_out, size_t n, void *hip_stream,
+                                void *start_event, void *stop_event);
+
 /* ---- lifecycle ---------------------------------------------------------- */
 int  esq_abi_version(void);
 /* n: state dimension (complex elements if is_complex); n_rows: rows of K
@@ -113,6 +130,10 @@ int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
 /* register (or clear, fn = NULL) the optional fused entry of the current RHS;
  * esq_rk_stages then issues ONE kernel per stage instead of two */
 int  esq_set_rhs_stage(esq_ctx *ctx, esq_rhs_stage_fn fn);
+/* register (or clear) the optional chained entry: esq_rk_stages then issues ONE
+ * kernel per stage (RHS of stage i + accumulate of stage i+1) wherever stage
+ * i+1 lies in the requested range and is not a blocked-accumulation boundary */
+int  esq_set_rhs_chain(esq_ctx *ctx, esq_rhs_chain_fn fn);
 
 /* ---- explicit RK launches ----------------------------------------------- */
 /* YSTAGE = Y + h * sum_j A[i][j] * K[j]           common.py:355 (`dy`, `y+dy`)
@@ -288,6 +309,17 @@ int  esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
                      void *stream);
 int  esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
                     void *stream);
+/* chained entries (esq_rhs_chain_fn) of the 2-D plugins */
+int  esq_rhs_bruss2d_chain(void *user, double t, const double *ys_in, double *f,
+                           int nt, const double *const *rows, const double *coef,
+                           double c_self, const double *init, const double *y,
+                           double h, double *ys_out, size_t n, void *stream,
+                           void *start_event, void *stop_event);
+int  esq_rhs_heat2d_chain(void *user, double t, const double *ys_in, double *f,
+                          int nt, const double *const *rows, const double *coef,
+                          double c_self, const double *init, const double *y,
+                          double h, double *ys_out, size_t n, void *stream,
+                          void *start_event, void *stop_event);
 /* fused stage entry (esq_rhs_stage_fn) of the Brusselator plugin */
 int  esq_rhs_bruss2d_stage(void *user, double t, int nt, const double *const *rows,
                            const double *coef, const double *y, double h,

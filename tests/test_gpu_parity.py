@@ -775,3 +775,35 @@ def test_blocked_accumulation_plans():
         k = s._lib.esq_rk_block_plan(s._ctx, b, 8, ctypes.byref(wp),
                                      ctypes.byref(wb))
         assert (list(b[:k]), wp.value, wb.value) == (bounds, plain, blocked), name
+
+
+# ------------------------------------------------------------- chained stages
+@pytest.mark.parametrize("name", ERK + ["CKdisc"])
+@pytest.mark.parametrize("plugin,N", [("bruss", 4), ("bruss", 50), ("bruss", 258),
+                                      ("heat", 6), ("heat", 130)])
+def test_chained_stages_are_bit_identical(monkeypatch, name, plugin, N):
+    """ESQ_CHAIN (default on for the heat plugin): one kernel does the RHS of
+    stage i and the accumulate of stage i+1; K rows, states and error norms
+    must equal the separate-kernel path bit for bit (also combined with blocked
+    accumulation, whose boundaries are never chained across)"""
+    if plugin == "bruss":
+        mk, y0, rho = (lambda: esq.Brusselator2D(N)), pb.bruss2d_y0(N), pb.bruss2d_rho(N)
+    else:
+        mk, y0, rho = (lambda: esq.Heat2D(N)), pb.heat2d_y0(N), pb.heat2d_rho(N)
+    h = 0.4 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
+    cls = getattr(esq, name)
+    monkeypatch.setenv("ESQ_CHAIN", "1")
+    chained = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_CHAIN", "0")
+    plain = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_CHAIN")
+    for _ in range(3):
+        assert chained.step() is None and plain.step() is None
+        assert chained.t == plain.t and chained.h_abs == plain.h_abs
+        assert_equal(chained.K, plain.K)
+        assert_equal(chained.y, plain.y)
+    assert chained.nfev == plain.nfev
+    sd, sp = chained.dense_output(), plain.dense_output()
+    tc = np.linspace(plain.t_old, plain.t, 3)
+    assert_equal(sd(tc), sp(tc))
