@@ -38,6 +38,7 @@ SIGNATURES = {
     "esq_set_rhs": (C.c_int, [_vp, _vp, _vp]),
     "esq_set_rhs_stage": (C.c_int, [_vp, _vp]),
     "esq_set_rhs_chain": (C.c_int, [_vp, _vp]),
+    "esq_set_rhs_rkc": (C.c_int, [_vp, _vp]),
     "esq_rk_stage_accumulate": (C.c_int, [_vp, C.c_int, C.c_double]),
     "esq_rk_block_plan": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -94,6 +95,8 @@ SIGNATURES = {
     "esq_rhs_heat2d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
     "esq_rhs_bruss2d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
     "esq_rhs_diff3d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
+    "esq_rhs_heat2d_rkc": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp] + [C.c_double] * 5 + [_vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_diff3d_rkc": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp] + [C.c_double] * 5 + [_vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_bruss2d_chain": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp,
                                         C.c_double, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_heat2d_chain": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp,

@@ -66,6 +66,7 @@ struct esq_ctx {
     void *rhs_user = nullptr;
     esq_rhs_stage_fn rhs_stage = nullptr;   // optional fused stage entry
     esq_rhs_chain_fn rhs_chain = nullptr;   // optional RHS + next-accumulate entry
+    esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
     // blocked accumulation plan (esq_rk_set_tableau)
     struct Block {
         int J = 0, prev = 0;              // columns [prev, J) of A
@@ -723,6 +724,13 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     c->rhs_user = user;
     c->rhs_stage = nullptr;
     c->rhs_chain = nullptr;
+    c->rhs_rkc = nullptr;
+    return 0;
+}
+int esq_set_rhs_rkc(esq_ctx *c, esq_rhs_rkc_fn fn) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    c->rhs_rkc = fn;
     return 0;
 }
 int esq_set_rhs_chain(esq_ctx *c, esq_rhs_chain_fn fn) {
@@ -1189,12 +1197,31 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
     int ycur = w0;
     for (int j = 2; j <= m; ++j) {
         const double *sc = scalars + 5 * (size_t)(j - 2);
-        // fy = rhs(t_stage, yjm1) into free_a, combination overwrites free_a
-        r = esq_rkc_eval_rhs(c, free_a, sc[4], jm1);
-        if (r) return r;
-        r = esq_rkc_stage(c, free_a, free_a, jm1, jm2, yn, fn, sc[0], sc[1],
-                          sc[2], sc[3]);
-        if (r) return r;
+        bool done = false;
+        if (c->rhs_rkc) {
+            // ONE sweep: derivative of yjm1 and the recursion, no fy in memory
+            double *d = ROW(c, free_a), *a = ROW(c, jm1), *b = ROW(c, jm2),
+                   *y0 = ROW(c, yn), *g = ROW(c, fn);
+            if (!d || !a || !b || !y0 || !g) return fail(c, ESQ_EINVAL, "bad row");
+            const double omn = (1.0 - sc[0]) - sc[1];
+            Prof p(c, ESQ_PROF_RKC, 64.0 * (double)c->len, false,
+                   40.0 * (double)c->len);
+            r = c->rhs_rkc(c->rhs_user, sc[4], a, b, y0, g, sc[0], sc[1], omn,
+                           sc[2], sc[3], d, c->len, (void *)c->stream,
+                           (void *)p.start(), (void *)p.stop());
+            if (r == 0) done = true;
+            else if (r != ESQ_ENOTSUP)
+                return fail(c, ESQ_ERHS, "RKC plugin entry returned %d", r);
+            else p.cancel();
+        }
+        if (!done) {
+            // fy = rhs(t_stage, yjm1) into free_a, combination overwrites free_a
+            r = esq_rkc_eval_rhs(c, free_a, sc[4], jm1);
+            if (r) return r;
+            r = esq_rkc_stage(c, free_a, free_a, jm1, jm2, yn, fn, sc[0], sc[1],
+                              sc[2], sc[3]);
+            if (r) return r;
+        }
         ycur = free_a;
         // shift: jm2 <- jm1, jm1 <- new; the old jm2 row becomes free
         const int old_jm2 = jm2;

@@ -211,10 +211,27 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d_v2(
     }
 }
 
-template <int R>
+// Optional RKC epilogue: instead of storing f(y_{j-1}) the sweep finishes the
+// Chebyshev recursion of that stage,
+//   y_j = mu*y_{j-1} + nu*y_{j-2} + (1-mu-nu)*y_n + hmus*(f - ajm1*f_n)
+// (sommeijer.py:312-313, same operation order as k_rkc_stage), so the derivative
+// never goes to memory: 40 instead of 64 bytes per element and stage.
+struct RkcEpi {
+    const double *yjm2, *yn, *fn;
+    double *out;
+    double mu, nu, omn, hmus, ajm1;
+    __device__ __forceinline__ double apply(double yjm1, double b, double c0,
+                                            double g, double fy) const {
+        return __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(mu, yjm1), __dmul_rn(nu, b)),
+                                   __dmul_rn(omn, c0)),
+                         __dmul_rn(hmus, __dsub_rn(fy, __dmul_rn(ajm1, g))));
+    }
+};
+
+template <int R, bool RKC>
 __global__ __launch_bounds__(kBlock) void k_heat2d_v2(
     const double *__restrict__ u, double *__restrict__ f, int N, double c,
-    unsigned nblocks, unsigned bpr) {
+    unsigned nblocks, unsigned bpr, RkcEpi epi) {
     const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
     const int i0 = (int)(tile / bpr) * R;
     RowWin<false> U;
@@ -237,8 +254,20 @@ __global__ __launch_bounds__(kBlock) void k_heat2d_v2(
         double2 out;
         out.x = c * (((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x);
         out.y = c * (((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y);
-        if (U.live)
-            *reinterpret_cast<double2 *>(f + (size_t)i * N + 2 * (size_t)U.pair) = out;
+        if (U.live) {
+            const size_t k = (size_t)i * N + 2 * (size_t)U.pair;
+            if (RKC) {
+                const double2 b = *reinterpret_cast<const double2 *>(epi.yjm2 + k);
+                const double2 c0 = *reinterpret_cast<const double2 *>(epi.yn + k);
+                const double2 g = *reinterpret_cast<const double2 *>(epi.fn + k);
+                double2 yj;
+                yj.x = epi.apply(uc.x, b.x, c0.x, g.x, out.x);
+                yj.y = epi.apply(uc.y, b.y, c0.y, g.y, out.y);
+                *reinterpret_cast<double2 *>(epi.out + k) = yj;
+            } else {
+                *reinterpret_cast<double2 *>(f + k) = out;
+            }
+        }
     }
 }
 
@@ -522,10 +551,10 @@ int rhs_variant() {
 // (below, centre, above) window; the l-neighbours come from adjacent lanes,
 // the j-neighbours are two coalesced loads of the centre plane.  3 loads per
 // output instead of 7; arithmetic order identical to k_diff3d.
-template <int R>
+template <int R, bool RKC>
 __global__ __launch_bounds__(kBlock) void k_diff3d_v2(
     const double *__restrict__ u, double *__restrict__ f, int N, double c,
-    unsigned nblocks, unsigned bpp) {
+    unsigned nblocks, unsigned bpp, RkcEpi epi) {
     const unsigned lb = band_block(blockIdx.x, nblocks);
     const int i0 = (int)(lb / bpp) * R;
     const unsigned p = (lb % bpp) * kBlock + threadIdx.x;     // plane index
@@ -551,8 +580,13 @@ __global__ __launch_bounds__(kBlock) void k_diff3d_v2(
             else if (lane == 63 || p + 1 >= NN) c1 = pl[p + 1];
             const double b0 = j > 0 ? pl[p - N] : 0.0;
             const double b1 = j + 1 < (unsigned)N ? pl[p + N] : 0.0;
-            f[(size_t)i * NN + p] =
+            const double fy =
                 c * ((((below + above) + (b0 + b1)) + (c0 + c1)) - 6.0 * centre);
+            const size_t k = (size_t)i * NN + p;
+            if (RKC)
+                epi.out[k] = epi.apply(centre, epi.yjm2[k], epi.yn[k], epi.fn[k], fy);
+            else
+                f[k] = fy;
         }
         below = centre;
         centre = above;
@@ -640,8 +674,8 @@ int esq_rhs_heat2d(void *user, double t, const double *y, double *f, size_t n,
         const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
         const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
         const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
-        hipLaunchKernelGGL(k_heat2d_v2<R>, dim3(grid), dim3(kBlock), 0,
-                           (hipStream_t)stream, y, f, r->N, c, grid, wpr);
+        hipLaunchKernelGGL((k_heat2d_v2<R, false>), dim3(grid), dim3(kBlock), 0,
+                           (hipStream_t)stream, y, f, r->N, c, grid, wpr, RkcEpi{});
         return (int)hipGetLastError();
     }
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;
@@ -788,6 +822,57 @@ int esq_rhs_heat2d_chain(void *user, double t, const double *ys_in, double *f,
 #undef LAUNCH
     return (int)hipGetLastError();
 }
+
+static RkcEpi make_epi(const double *yjm2, const double *yn, const double *fn,
+                       double mu, double nu, double omn, double hmus, double ajm1,
+                       double *out) {
+    RkcEpi e;
+    e.yjm2 = yjm2; e.yn = yn; e.fn = fn; e.out = out;
+    e.mu = mu; e.nu = nu; e.omn = omn; e.hmus = hmus; e.ajm1 = ajm1;
+    return e;
+}
+int esq_rhs_heat2d_rkc(void *user, double t, const double *yjm1, const double *yjm2,
+                       const double *yn, const double *fn, double mu, double nu,
+                       double omn, double hmus, double ajm1, double *y_out,
+                       size_t n, void *stream, void *start_event, void *stop_event) {
+    (void)t;
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != HEAT2D || n != r->n) return ESQ_EINVAL;
+    if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
+    constexpr int R = 1;
+    const unsigned wpr = (r->N / 2 + 63) / 64;
+    const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
+    const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
+    const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+    const double c = (double)(r->N + 1) * (double)(r->N + 1);
+    hipExtLaunchKernelGGL((k_heat2d_v2<R, true>), dim3(grid), dim3(kBlock), 0,
+                          (hipStream_t)stream, (hipEvent_t)start_event,
+                          (hipEvent_t)stop_event, 0, yjm1, (double *)nullptr, r->N,
+                          c, grid, wpr,
+                          make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out));
+    return (int)hipGetLastError();
+}
+int esq_rhs_diff3d_rkc(void *user, double t, const double *yjm1, const double *yjm2,
+                       const double *yn, const double *fn, double mu, double nu,
+                       double omn, double hmus, double ajm1, double *y_out,
+                       size_t n, void *stream, void *start_event, void *stop_event) {
+    (void)t;
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != DIFF3D || n != r->n) return ESQ_EINVAL;
+    if (r->N < 2) return ESQ_ENOTSUP;
+    constexpr int R = 8;
+    const unsigned NN = (unsigned)r->N * (unsigned)r->N;
+    const unsigned bpp = (NN + kBlock - 1) / kBlock;
+    const unsigned nb = bpp * (unsigned)((r->N + R - 1) / R);
+    const unsigned grid = ((nb + kXcd - 1) / kXcd) * kXcd;
+    const double c = (double)(r->N + 1) * (double)(r->N + 1);
+    hipExtLaunchKernelGGL((k_diff3d_v2<R, true>), dim3(grid), dim3(kBlock), 0,
+                          (hipStream_t)stream, (hipEvent_t)start_event,
+                          (hipEvent_t)stop_event, 0, yjm1, (double *)nullptr, r->N,
+                          c, grid, bpp,
+                          make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out));
+    return (int)hipGetLastError();
+}
 int esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
                    void *stream) {
     (void)t;
@@ -800,8 +885,8 @@ int esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
         const unsigned bpp = (NN + kBlock - 1) / kBlock;        // blocks per plane
         const unsigned nb = bpp * (unsigned)((r->N + R - 1) / R);
         const unsigned grid = ((nb + kXcd - 1) / kXcd) * kXcd;
-        hipLaunchKernelGGL(k_diff3d_v2<R>, dim3(grid), dim3(kBlock), 0,
-                           (hipStream_t)stream, y, f, r->N, c, grid, bpp);
+        hipLaunchKernelGGL((k_diff3d_v2<R, false>), dim3(grid), dim3(kBlock), 0,
+                           (hipStream_t)stream, y, f, r->N, c, grid, bpp, RkcEpi{});
         return (int)hipGetLastError();
     }
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;

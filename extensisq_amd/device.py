@@ -126,6 +126,12 @@ class DeviceContext:
             self._chk(self.lib.esq_set_rhs_chain(self.handle,
                                                  C.cast(chain, C.c_void_p)),
                       "esq_set_rhs_chain")
+        # RKC entry: derivative + Chebyshev recursion in one sweep
+        rkc = rhs._rkc_entry(self.lib)
+        if rkc is not None and os.environ.get("ESQ_RKC_CHAIN", "1") != "0":
+            self._chk(self.lib.esq_set_rhs_rkc(self.handle,
+                                               C.cast(rkc, C.c_void_p)),
+                      "esq_set_rhs_rkc")
         # The fused stage+RHS entry (one kernel per stage, no stage-argument
         # round trip) is bit-identical but measured SLOWER on MI355X than the
         # two streaming kernels (147 vs 95 + 31 us per Pr8 stage at n = 1e7: its
@@ -216,6 +222,10 @@ class DeviceRHS:
         """optional `esq_rhs_chain_fn` of this plugin"""
         return None
 
+    def _rkc_entry(self, lib):
+        """optional `esq_rhs_rkc_fn` of this plugin"""
+        return None
+
     def _bind(self, ctx):
         if ctx.n != self.n:
             raise ValueError(f"RHS is for n={self.n}, solver state has n={ctx.n}")
@@ -258,6 +268,10 @@ class _Builtin(DeviceRHS):
     _symbol = None
     _symbol_fused = None
     _symbol_chain = None
+    _symbol_rkc = None
+
+    def _rkc_entry(self, lib):
+        return getattr(lib, self._symbol_rkc) if self._symbol_rkc else None
 
     def _fused_entry(self, lib):
         return getattr(lib, self._symbol_fused) if self._symbol_fused else None
@@ -297,6 +311,7 @@ class Heat2D(_Builtin):
     (BASELINE.json configs[1], configs[4]); twin of oracle/problems.py."""
     _symbol = "esq_rhs_heat2d"
     _symbol_chain = "esq_rhs_heat2d_chain"
+    _symbol_rkc = "esq_rhs_heat2d_rkc"
     _chain_default = True
 
     def __init__(self, N):
@@ -342,6 +357,7 @@ class Diffusion3D(_Builtin):
     """7-point diffusion on an N^3 interior grid, Dirichlet 0
     (BASELINE.json configs[3])."""
     _symbol = "esq_rhs_diff3d"
+    _symbol_rkc = "esq_rhs_diff3d_rkc"
 
     def __init__(self, N):
         super().__init__()

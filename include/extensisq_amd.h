@@ -94,6 +94,20 @@ typedef int (*esq_rhs_chain_fn)(void *user, double t, const double *ys_in,
                                 double *ys_out, size_t n, void *hip_stream,
                                 void *start_event, void *stop_event);
 
+/*
+ * OPTIONAL RKC entry of a plugin: enqueue ONE sweep that evaluates
+ * f = fun(t, yjm1) and finishes the Chebyshev stage without storing f,
+ *   y_out = mu*yjm1 + nu*yjm2 + omn*yn + hmus*(f - ajm1*fn)
+ * (sommeijer.py:311-313; every product and sum rounded, left to right).
+ * y_out must not alias yjm1.  Return ESQ_ENOTSUP to fall back.
+ */
+typedef int (*esq_rhs_rkc_fn)(void *user, double t, const double *yjm1,
+                              const double *yjm2, const double *yn,
+                              const double *fn, double mu, double nu, double omn,
+                              double hmus, double ajm1, double *y_out, size_t n,
+                              void *hip_stream, void *start_event,
+                              void *stop_event);
+
 /* ---- lifecycle ---------------------------------------------------------- */
 int  esq_abi_version(void);
 /* n: state dimension (complex elements if is_complex); n_rows: rows of K
@@ -134,6 +148,9 @@ int  esq_set_rhs_stage(esq_ctx *ctx, esq_rhs_stage_fn fn);
  * kernel per stage (RHS of stage i + accumulate of stage i+1) wherever stage
  * i+1 lies in the requested range and is not a blocked-accumulation boundary */
 int  esq_set_rhs_chain(esq_ctx *ctx, esq_rhs_chain_fn fn);
+/* register (or clear) the optional RKC entry: esq_rkc_stages then issues ONE
+ * kernel per Chebyshev stage (RHS + recursion) instead of two */
+int  esq_set_rhs_rkc(esq_ctx *ctx, esq_rhs_rkc_fn fn);
 
 /* ---- explicit RK launches ----------------------------------------------- */
 /* YSTAGE = Y + h * sum_j A[i][j] * K[j]           common.py:355 (`dy`, `y+dy`)
@@ -309,6 +326,17 @@ int  esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
                      void *stream);
 int  esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
                     void *stream);
+/* RKC entries (esq_rhs_rkc_fn) */
+int  esq_rhs_heat2d_rkc(void *user, double t, const double *yjm1,
+                        const double *yjm2, const double *yn, const double *fn,
+                        double mu, double nu, double omn, double hmus, double ajm1,
+                        double *y_out, size_t n, void *stream, void *start_event,
+                        void *stop_event);
+int  esq_rhs_diff3d_rkc(void *user, double t, const double *yjm1,
+                        const double *yjm2, const double *yn, const double *fn,
+                        double mu, double nu, double omn, double hmus, double ajm1,
+                        double *y_out, size_t n, void *stream, void *start_event,
+                        void *stop_event);
 /* chained entries (esq_rhs_chain_fn) of the 2-D plugins */
 int  esq_rhs_bruss2d_chain(void *user, double t, const double *ys_in, double *f,
                            int nt, const double *const *rows, const double *coef,

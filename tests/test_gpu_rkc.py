@@ -132,3 +132,27 @@ def test_full_size_rkc_diffusion_step_matches_oracle():
     # rounding differences are amplified along the stages
     assert_allclose(d.y, o.y, rtol=1e-9, atol=1e-12)
     assert_allclose(d.errold, o.errold, rtol=1e-5)
+
+
+@pytest.mark.parametrize("plugin,N", [("heat", 6), ("heat", 130), ("diff3d", 5),
+                                      ("diff3d", 24), ("diff3d", 41)])
+def test_rkc_chained_stage_is_bit_identical(monkeypatch, plugin, N):
+    """ESQ_RKC_CHAIN (default on): one sweep evaluates f(y_{j-1}) and finishes
+    the Chebyshev recursion without storing f -- must equal the two-kernel path
+    bit for bit"""
+    if plugin == "heat":
+        mk, y0 = (lambda: esq.Heat2D(N)), pb.heat2d_y0(N)
+    else:
+        mk, y0 = (lambda: esq.Diffusion3D(N)), pb.diff3d_y0(N)
+    rho = mk().spectral_radius()
+    kw = dict(rtol=1e-4, atol=1e-6, const_jac=True, rho_jac=lambda t, y: rho,
+              first_step=150.0 / rho)
+    a = esq.SSV2stab(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_RKC_CHAIN", "0")
+    b = esq.SSV2stab(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_RKC_CHAIN")
+    for _ in range(4):
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t and a.errold == b.errold
+        np.testing.assert_array_equal(a.y, b.y)
+    assert a.nfev == b.nfev and a.nfev > 20
