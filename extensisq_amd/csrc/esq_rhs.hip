@@ -482,8 +482,10 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d_chain(
     }
     if (!U.live) return;
     const double2 su = cu.finish(ca, fu), sv = cv.finish(ca, fv);
-    esq::st2(f, k2, fu);
-    esq::st2(f, v2, fv);
+    // K_i is not re-read by the next stage (it was consumed from registers):
+    // stream it out so that ys_in / ys_out / y keep the Infinity Cache
+    esq::st2_nt(f, k2, fu);
+    esq::st2_nt(f, v2, fv);
     esq::st2(ca.ys_out, k2, su);
     esq::st2(ca.ys_out, v2, sv);
 }
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(kBlock) void k_heat2d_chain(
     out.y = c * (((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y);
     if (!U.live) return;
     const double2 su = cu.finish(ca, out);
-    esq::st2(f, k2, out);
+    esq::st2_nt(f, k2, out);
     esq::st2(ca.ys_out, k2, su);
 }
 

@@ -115,10 +115,10 @@ class DeviceContext:
         self._chk(self.lib.esq_set_rhs(self.handle, C.cast(fn, C.c_void_p), user),
                   "esq_set_rhs")
         # chained entry: RHS of stage i + accumulate of stage i+1 in one kernel.
-        # Bit-identical everywhere; measured faster for the one-field heat
-        # plugin (Pr9 1.10 -> 1.01 ms/step, Ts5 0.107 -> 0.101) and slower for
-        # the two-field Brusselator (1.41 -> 1.45), hence the per-plugin default;
-        # ESQ_CHAIN=1 / 0 forces it on / off.
+        # Bit-identical; measured Pr8/Brusselator 1.40 -> 1.35 ms/step, Pr9/heat
+        # 1.10 -> 1.02, Ts5/heat 0.107 -> 0.097 (K_i must be streamed out with
+        # non-temporal stores, or the four live vectors of the sweep overflow
+        # the Infinity Cache at n = 1e7).  ESQ_CHAIN=1 / 0 forces it on / off.
         chain = rhs._chain_entry(self.lib)
         want = os.environ.get("ESQ_CHAIN", "")
         use_chain = (want == "1") or (want != "0" and rhs._chain_default)
@@ -335,6 +335,7 @@ class Brusselator2D(_Builtin):
     _symbol = "esq_rhs_bruss2d"
     _symbol_fused = "esq_rhs_bruss2d_stage"
     _symbol_chain = "esq_rhs_bruss2d_chain"
+    _chain_default = True
 
     def __init__(self, N, alpha=0.1, a=1.0, b=3.4):
         super().__init__()
