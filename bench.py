@@ -123,7 +123,8 @@ def make_workload(name, N, rank):
             cls=esq.Pr8, oracle="Pr8", rhs=rhs, y0=y0, kw=kw, N=N,
             cpu_problem=("bruss2d_rhs", "bruss2d_y0"),
             bytes_per_elt_step=1040.0, klass=PROF_STAGE,
-            kernel="k_lincomb (fused stage-accumulate)")
+            kernel="stage-accumulate class: k_lincomb / k_*_chain (RHS of the previous "
+                   "stage chained in) / k_block_acc")
     if name == "ts5":
         N = N or 1000
         rhs, y0, h = wl.ts5_heat(N, seed=1234 + rank)
@@ -135,7 +136,8 @@ def make_workload(name, N, rank):
             cls=esq.Ts5, oracle="Ts5", rhs=rhs, y0=y0, kw=kw, N=N,
             cpu_problem=("heat2d_rhs", "heat2d_y0"),
             bytes_per_elt_step=432.0, klass=PROF_STAGE,
-            kernel="k_lincomb (fused stage-accumulate)")
+            kernel="stage-accumulate class: k_lincomb / k_*_chain (RHS of the previous "
+                   "stage chained in) / k_block_acc")
     if name == "pr9":
         N = N or 2236
         rhs = esq.Heat2D(N)
@@ -149,7 +151,8 @@ def make_workload(name, N, rank):
             cls=esq.Pr9, oracle="Pr9", rhs=rhs, y0=y0, kw=kw, N=N,
             cpu_problem=("heat2d_rhs", "heat2d_y0"),
             bytes_per_elt_step=1624.0, klass=PROF_STAGE,
-            kernel="k_lincomb (fused stage-accumulate)")
+            kernel="stage-accumulate class: k_lincomb / k_*_chain (RHS of the previous "
+                   "stage chained in) / k_block_acc")
     N = N or 159
     rhs, y0, h, rho = wl.rkc_diffusion(N, m_target=100)
     kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-3, const_jac=True,

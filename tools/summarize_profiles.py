@@ -28,7 +28,7 @@ def mean_counter(path):
 
 
 def short(name):
-    m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", name)
+    m = re.search(r"(k_[a-z0-9_]+(<[^>(]*>)?)", name)
     return m.group(1) if m else name[:40]
 
 
@@ -59,7 +59,7 @@ def main():
             rec["avg_ns_kernel_trace"] = float(stats[k]["AverageNs"])
             rec["calls_kernel_trace"] = int(stats[k]["Calls"])
         out["kernels"][short(k)] = rec
-        if ("k_lincomb" in k or "k_block_acc" in k) and k in stats:
+        if ("k_lincomb" in k or "k_block_acc" in k or "_chain<" in k) and k in stats:
             st_bytes += (f_b + w_b) * int(stats[k]["Calls"])
             st_launch += int(stats[k]["Calls"])
             st_ns += float(stats[k]["TotalDurationNs"])
