@@ -36,7 +36,6 @@ SIGNATURES = {
     "esq_rk_set_tableau": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "esq_set_tol": (C.c_int, [_vp, C.c_double, _vp, C.c_size_t]),
     "esq_set_rhs": (C.c_int, [_vp, _vp, _vp]),
-    "esq_set_rhs_stage": (C.c_int, [_vp, _vp]),
     "esq_set_rhs_chain": (C.c_int, [_vp, _vp]),
     "esq_set_rhs_rkc": (C.c_int, [_vp, _vp]),
     "esq_rk_stage_accumulate": (C.c_int, [_vp, C.c_int, C.c_double]),
@@ -100,8 +99,6 @@ SIGNATURES = {
     "esq_rhs_bruss2d_chain": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp,
                                         C.c_double, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_heat2d_chain": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp,
-                                        C.c_double, _vp, C.c_size_t, _vp, _vp, _vp]),
-    "esq_rhs_bruss2d_stage": (C.c_int, [_vp, C.c_double, C.c_int, _vp, _vp, _vp,
                                         C.c_double, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_profile_enable": (C.c_int, [_vp, C.c_int]),
     "esq_profile_sampling": (C.c_int, [_vp, C.c_int]),

@@ -64,7 +64,6 @@ struct esq_ctx {
     bool atol_is_vec = false;
     esq_rhs_fn rhs = nullptr;
     void *rhs_user = nullptr;
-    esq_rhs_stage_fn rhs_stage = nullptr;   // optional fused stage entry
     esq_rhs_chain_fn rhs_chain = nullptr;   // optional RHS + next-accumulate entry
     esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
     // blocked accumulation plan (esq_rk_set_tableau)
@@ -722,7 +721,6 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     ENTER(c);
     c->rhs = fn;
     c->rhs_user = user;
-    c->rhs_stage = nullptr;
     c->rhs_chain = nullptr;
     c->rhs_rkc = nullptr;
     return 0;
@@ -737,17 +735,6 @@ int esq_set_rhs_chain(esq_ctx *c, esq_rhs_chain_fn fn) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
     c->rhs_chain = fn;
-    return 0;
-}
-int esq_set_rhs_stage(esq_ctx *c, esq_rhs_stage_fn fn) {
-    if (!c) return ESQ_EINVAL;
-    ENTER(c);
-    c->rhs_stage = fn;
-    if (fn) {       // the fused entry forms whole sums itself: no blocked plan
-        c->blocks.clear();
-        c->stage_init.assign(c->stage_init.size(), -1);
-        c->stage_from.assign(c->stage_from.size(), 0);
-    }
     return 0;
 }
 
@@ -808,21 +795,6 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
         return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
     bool ready = false;     // YSTAGE already holds the argument of stage i
     for (int i = i_from; i < i_to; ++i) {
-        if (c->rhs_stage) {
-            // one fused kernel: K[i] = rhs(t_i, Y + h*sum a_ij K_j), no YSTAGE
-            Terms tm;
-            const int nt = build_row_terms(c, &c->A[(size_t)i * c->s], i, tm, c->kmap);
-            if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
-            Prof p(c, ESQ_PROF_STAGE, 8.0 * (nt + 2) * (double)c->len);
-            const int r = c->rhs_stage(c->rhs_user, t + c->C[i] * h, nt, tm.p, tm.c,
-                                       c->y, h, c->krow[c->kmap[i]], c->len,
-                                       (void *)c->stream, (void *)p.start(),
-                                       (void *)p.stop());
-            if (r == 0) continue;
-            if (r != ESQ_ENOTSUP)
-                return fail(c, ESQ_ERHS, "fused RHS stage returned %d", r);
-            p.cancel();
-        }
         if (!ready) {
             const int r = esq_rk_stage_accumulate(c, i, h);
             if (r) return r;

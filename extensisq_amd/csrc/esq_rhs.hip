@@ -272,138 +272,10 @@ __global__ __launch_bounds__(kBlock) void k_heat2d_v2(
 }
 
 // ---------------------------------------------------------------------------
-// FUSED stage: K_i = f(t, y + h*sum_j c_j K_j) for the Brusselator WITHOUT
-// materialising the stage argument.  A thread owns a column pair and marches
-// down R rows; the stage argument of the (up, centre, down) window of both
-// fields is formed in registers from the K rows (non-temporal 16-byte loads, the
-// same FMA chain and roundings as k_lincomb, so the result is bit-identical to
-// the two-kernel path); left/right neighbours come from adjacent lanes, the two
-// edge lanes of a wave form theirs from scalar loads (L2 hits).  Per element it
-// reads NT rows + y and writes K_i: (NT + 2)*8 B -- the y_stage round trip
-// (16 B) of the two-kernel path is gone.
-// ---------------------------------------------------------------------------
-template <int NT>
-struct StageArg {
-    esq::Terms tm;
-    const double *__restrict__ y;
-    double h;
-    // stage argument of the double2 at index i2 (units of 16 B)
-    __device__ __forceinline__ double2 at2(size_t i2) const {
-        double2 v[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) v[j] = esq::ld2_nt(tm.p[j], i2);
-        const double2 yb = esq::ld2(y, i2);
-        double2 acc = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            acc.x = fma(tm.c[j], v[j].x, acc.x);
-            acc.y = fma(tm.c[j], v[j].y, acc.y);
-        }
-        return make_double2(__dadd_rn(yb.x, __dmul_rn(h, acc.x)),
-                            __dadd_rn(yb.y, __dmul_rn(h, acc.y)));
-    }
-    // stage argument of ONE element
-    __device__ __forceinline__ double at1(size_t i) const {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc = fma(tm.c[j], tm.p[j][i], acc);
-        return __dadd_rn(y[i], __dmul_rn(h, acc));
-    }
-};
-
-template <int NT, int R>
-__global__ __launch_bounds__(kBlock) void k_bruss2d_fused(
-    StageArg<NT> sa, double *__restrict__ f, int N, double d, double A, double B,
-    unsigned nblocks, unsigned wpr) {
-    const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
-    const int i0 = (int)(tile / wpr) * R;
-    if (i0 >= N) return;
-    const int lane = threadIdx.x & 63;
-    const unsigned npairs = (unsigned)N / 2;
-    const unsigned pair = (tile % wpr) * 64 + lane;
-    const bool live = pair < npairs;
-    const size_t NN = (size_t)N * N;
-    auto wrap = [N](int i) { return i < 0 ? i + N : (i >= N ? i - N : i); };
-    auto row2 = [&](int fld, int i) -> double2 {
-        if (!live) return make_double2(0.0, 0.0);
-        return sa.at2((fld * NN + (size_t)wrap(i) * N) / 2 + pair);
-    };
-    const bool need_l = live && (lane == 0 || pair == 0);
-    const bool need_r = live && (lane == 63 || pair + 1 >= npairs);
-    const unsigned col_l = pair == 0 ? N - 1 : 2 * pair - 1;
-    const unsigned col_r = pair + 1 >= npairs ? 0 : 2 * pair + 2;
-
-    // software pipeline: iteration r loads row i+1 (vector loads) AND the
-    // edge-lane neighbours of row i+1 (scalar loads) in one batch, so a row
-    // costs one memory round trip
-    auto edges = [&](int i, double &l_u, double &r_u, double &l_v, double &r_v) {
-        const size_t rb = (size_t)wrap(i) * N;
-        if (need_l) { l_u = sa.at1(rb + col_l); l_v = sa.at1(NN + rb + col_l); }
-        if (need_r) { r_u = sa.at1(rb + col_r); r_v = sa.at1(NN + rb + col_r); }
-    };
-    double2 uu = row2(0, i0 - 1), uc = row2(0, i0);
-    double2 vu = row2(1, i0 - 1), vc = row2(1, i0);
-    double eul = 0.0, eur = 0.0, evl = 0.0, evr = 0.0;      // edges of the centre row
-    edges(i0, eul, eur, evl, evr);
-#pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-        const int i = i0 + r;
-        if (i >= N) break;
-        const double2 ud = row2(0, i + 1), vd = row2(1, i + 1);
-        double nul = 0.0, nur = 0.0, nvl = 0.0, nvr = 0.0;  // edges of row i+1
-        if (r + 1 < R && i + 1 < N) edges(i + 1, nul, nur, nvl, nvr);
-        double ul = __shfl_up(uc.y, 1, 64), ur = __shfl_down(uc.x, 1, 64);
-        double vl = __shfl_up(vc.y, 1, 64), vr = __shfl_down(vc.x, 1, 64);
-        if (need_l) { ul = eul; vl = evl; }
-        if (need_r) { ur = eur; vr = evr; }
-        const size_t rb = (size_t)i * N;
-        double2 fu, fv;
-        {
-            const double lapx = ((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x;
-            const double lapy = ((uu.y + ud.y) + (uc.x + ur)) - 4.0 * uc.y;
-            const double lvx = ((vu.x + vd.x) + (vl + vc.y)) - 4.0 * vc.x;
-            const double lvy = ((vu.y + vd.y) + (vc.x + vr)) - 4.0 * vc.y;
-            const double uuvx = uc.x * uc.x * vc.x, uuvy = uc.y * uc.y * vc.y;
-            fu.x = ((A + uuvx) - (B + 1.0) * uc.x) + d * lapx;
-            fu.y = ((A + uuvy) - (B + 1.0) * uc.y) + d * lapy;
-            fv.x = (B * uc.x - uuvx) + d * lvx;
-            fv.y = (B * uc.y - uuvy) + d * lvy;
-        }
-        if (live) {
-            const size_t k = rb + 2 * (size_t)pair;
-            *reinterpret_cast<double2 *>(f + k) = fu;
-            *reinterpret_cast<double2 *>(f + NN + k) = fv;
-        }
-        uu = uc; uc = ud;
-        vu = vc; vc = vd;
-        eul = nul; eur = nur; evl = nvl; evr = nvr;
-    }
-}
-
-template <int NT>
-void launch_bruss_fused(const esq::Terms &tm, const double *y, double h, double *f,
-                        const Rhs *r, hipStream_t stream, hipEvent_t e0,
-                        hipEvent_t e1) {
-    constexpr int R = 16;
-    StageArg<NT> sa;
-    sa.tm = tm;
-    sa.y = y;
-    sa.h = h;
-    const unsigned wpr = (r->N / 2 + 63) / 64;
-    const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
-    const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
-    const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
-    const double d = r->alpha * ((double)r->N * (double)r->N);
-    hipExtLaunchKernelGGL((k_bruss2d_fused<NT, R>), dim3(grid), dim3(kBlock), 0,
-                          stream, e0, e1, 0, sa, f, r->N, d, r->a, r->b, grid, wpr);
-}
-
-// ---------------------------------------------------------------------------
 // CHAINED stage: K_i = f(t, ys_in) AND, from the value still in registers, the
 // argument of the NEXT stage
 //     ys_out = y + h * (init + sum_j c_j K_j + c_self * K_i)
-// in one sweep.  The next stage's accumulate is pointwise, so unlike the fused
-// form above nothing is recomputed on halos: this is the plain one-row stencil
+// in one sweep.  The next stage's accumulate is pointwise, so nothing is recomputed on halos: this is the plain one-row stencil
 // kernel plus NT + 2 streaming loads and one more store per element.  The next
 // stage kernel (and its re-read of K_i) disappears.  Same ascending-j FMA chain
 // with K_i last (it has the largest column index), so results are bit-identical.
@@ -723,30 +595,6 @@ int esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
                            (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, bpr);
     return (int)hipGetLastError();
 }
-int esq_rhs_bruss2d_stage(void *user, double t, int nt,
-                          const double *const *rows, const double *coef,
-                          const double *y, double h, double *f, size_t n,
-                          void *stream, void *start_event, void *stop_event) {
-    (void)t;
-    Rhs *r = (Rhs *)user;
-    if (!r || r->kind != BRUSS2D || n != r->n || !rows || !coef) return ESQ_EINVAL;
-    if (r->N % 2 != 0 || r->N < 4 || nt < 1 || nt > 16) return ESQ_ENOTSUP;
-    esq::Terms tm;
-    for (int j = 0; j < esq::kMaxTerms; ++j) {
-        tm.p[j] = j < nt ? rows[j] : nullptr;
-        tm.c[j] = j < nt ? coef[j] : 0.0;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
-    switch (nt) {
-#define CASE(K) case K: launch_bruss_fused<K>(tm, y, h, f, r, st, e0, e1); break;
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
-        CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
-#undef CASE
-    }
-    return (int)hipGetLastError();
-}
-
 static void fill_chain(ChainArgs &ca, int nt, const double *const *rows,
                        const double *coef, double c_self, const double *init,
                        const double *y, double h, double *ys_out) {

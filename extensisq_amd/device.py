@@ -132,16 +132,6 @@ class DeviceContext:
             self._chk(self.lib.esq_set_rhs_rkc(self.handle,
                                                C.cast(rkc, C.c_void_p)),
                       "esq_set_rhs_rkc")
-        # The fused stage+RHS entry (one kernel per stage, no stage-argument
-        # round trip) is bit-identical but measured SLOWER on MI355X than the
-        # two streaming kernels (147 vs 95 + 31 us per Pr8 stage at n = 1e7: its
-        # rolling-window form holds 180 VGPRs -> 2 waves/SIMD and one memory
-        # round trip per row), so it is opt-in: ESQ_FUSE_STAGE=1.
-        fused = rhs._fused_entry(self.lib)
-        if fused is not None and os.environ.get("ESQ_FUSE_STAGE", "0") == "1":
-            self._chk(self.lib.esq_set_rhs_stage(self.handle,
-                                                 C.cast(fused, C.c_void_p)),
-                      "esq_set_rhs_stage")
 
     # -- scalar-returning launches
     def _scalar(self, fn, what, *args):
@@ -214,10 +204,6 @@ class DeviceRHS:
     def _create(self, lib, device):
         raise NotImplementedError
 
-    def _fused_entry(self, lib):
-        """optional `esq_rhs_stage_fn` of this plugin (None: two-kernel path)"""
-        return None
-
     def _chain_entry(self, lib):
         """optional `esq_rhs_chain_fn` of this plugin"""
         return None
@@ -266,15 +252,12 @@ class DeviceRHS:
 
 class _Builtin(DeviceRHS):
     _symbol = None
-    _symbol_fused = None
     _symbol_chain = None
     _symbol_rkc = None
 
     def _rkc_entry(self, lib):
         return getattr(lib, self._symbol_rkc) if self._symbol_rkc else None
 
-    def _fused_entry(self, lib):
-        return getattr(lib, self._symbol_fused) if self._symbol_fused else None
 
     def _chain_entry(self, lib):
         return getattr(lib, self._symbol_chain) if self._symbol_chain else None
@@ -333,7 +316,6 @@ class Brusselator2D(_Builtin):
     """2-D Brusselator reaction-diffusion, periodic, y = [u.ravel(), v.ravel()]
     (BASELINE.json configs[2], the north-star workload)."""
     _symbol = "esq_rhs_bruss2d"
-    _symbol_fused = "esq_rhs_bruss2d_stage"
     _symbol_chain = "esq_rhs_bruss2d_chain"
     _chain_default = True
 

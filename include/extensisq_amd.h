@@ -63,21 +63,6 @@ typedef int (*esq_rhs_fn)(void *user, double t, const double *y_dev,
                           double *f_dev, size_t n, void *hip_stream);
 
 /*
- * OPTIONAL fused entry of a plugin: enqueue
- *     f_dev = fun(t, y_dev + h * sum_{j<nt} coef[j] * rows[j])
- * without materialising the argument (rows/coef are host arrays of device
- * pointers / weights, borrowed for the call).  It must round exactly like the
- * two-step path (FMA chain over j, then *h, then +y).  start/stop are
- * hipEvent_t or NULL (dispatch timestamps for esq_profile_*).  Return
- * ESQ_ENOTSUP to make the caller fall back to stage_accumulate + esq_rhs_fn.
- */
-typedef int (*esq_rhs_stage_fn)(void *user, double t, int nt,
-                                const double *const *rows, const double *coef,
-                                const double *y_dev, double h, double *f_dev,
-                                size_t n, void *hip_stream, void *start_event,
-                                void *stop_event);
-
-/*
  * OPTIONAL chained entry of a plugin: enqueue BOTH
  *     f_dev  = fun(t, ys_in)
  *     ys_out = y_dev + h * (init + sum_{j<nt} coef[j]*rows[j] + c_self*f_dev)
@@ -85,7 +70,9 @@ typedef int (*esq_rhs_stage_fn)(void *user, double t, int nt,
  * stage's argument (its accumulate is pointwise, nothing is recomputed).  init
  * may be NULL; the FMA chain runs over j ascending and adds c_self*f_dev last
  * (skipped if c_self == 0), then *h, then +y: bit-identical to the separate
- * kernels.  Return ESQ_ENOTSUP to fall back to esq_rhs_fn + stage_accumulate.
+ * kernels.  start/stop are hipEvent_t or NULL (dispatch timestamps for
+ * esq_profile_*).  Return ESQ_ENOTSUP to fall back to esq_rhs_fn +
+ * stage_accumulate.
  */
 typedef int (*esq_rhs_chain_fn)(void *user, double t, const double *ys_in,
                                 double *f_dev, int nt, const double *const *rows,
@@ -141,9 +128,6 @@ int  esq_rk_set_tableau(esq_ctx *ctx, int s, const double *A, const double *B,
  * values as returned by validate_tol  common.py:30-54. */
 int  esq_set_tol(esq_ctx *ctx, double rtol, const double *atol, size_t n_atol);
 int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
-/* register (or clear, fn = NULL) the optional fused entry of the current RHS;
- * esq_rk_stages then issues ONE kernel per stage instead of two */
-int  esq_set_rhs_stage(esq_ctx *ctx, esq_rhs_stage_fn fn);
 /* register (or clear) the optional chained entry: esq_rk_stages then issues ONE
  * kernel per stage (RHS of stage i + accumulate of stage i+1) wherever stage
  * i+1 lies in the requested range and is not a blocked-accumulation boundary */
@@ -348,11 +332,6 @@ int  esq_rhs_heat2d_chain(void *user, double t, const double *ys_in, double *f,
                           double c_self, const double *init, const double *y,
                           double h, double *ys_out, size_t n, void *stream,
                           void *start_event, void *stop_event);
-/* fused stage entry (esq_rhs_stage_fn) of the Brusselator plugin */
-int  esq_rhs_bruss2d_stage(void *user, double t, int nt, const double *const *rows,
-                           const double *coef, const double *y, double h,
-                           double *f, size_t n, void *stream, void *start_event,
-                           void *stop_event);
 
 /* ---- measurement (bench.py `roofline`) ------------------------------------ */
 /* class_mask bit k = 1: every launch of kernel class k carries a start/stop HIP
