@@ -472,7 +472,10 @@ void launch_block_n(esq_ctx *c, const BlockArgs &a, int no, const Prof &p) {
                           c->len_pad / 2);
 }
 // leading parts of the sums of all later stages, one pass over the block's rows
-static int run_block(esq_ctx *c, const esq_ctx::Block &b) {
+// returns 0 on success; *made_ystage = true if the block also wrote the
+// boundary stage's argument into YSTAGE
+static int run_block(esq_ctx *c, const esq_ctx::Block &b, double h,
+                     bool *made_ystage) {
     BlockArgs a;
     const int nt = (int)b.cols.size(), no = (int)b.stages.size();
     for (int j = 0; j < kMaxTerms; ++j) {
@@ -487,9 +490,26 @@ static int run_block(esq_ctx *c, const esq_ctx::Block &b) {
         a.init[o] = (o < no && b.in_vec[o] >= 0) ? c->krow[b.in_vec[o]] : nullptr;
         if (a.init[o]) reads += 1;
     }
-    // algorithmic bytes: none of its own (they are booked on the stages it
-    // serves); moved bytes: its real traffic
-    Prof p(c, ESQ_PROF_STAGE, 0.0, false, 8.0 * (reads + no) * (double)c->len);
+    // the boundary stage J itself (always output 0 when it uses the block) has
+    // no later column to add: write its argument y + h*sum straight to YSTAGE
+    a.y = nullptr;
+    a.h = h;
+    double alg = 0.0;
+    *made_ystage = false;
+    static const bool fold = env_uint("ESQ_BLOCK_FOLD", 1) != 0;
+    if (fold && no > 0 && b.stages[0] == b.J && c->stage_init[b.J] == b.out_vec[0] &&
+        c->stage_from[b.J] == b.J) {
+        a.y = c->y;
+        a.out[0] = c->ystage;
+        reads += 1;
+        int nnz_all = 0;
+        for (int j = 0; j < b.J; ++j) nnz_all += c->A[(size_t)b.J * c->s + j] != 0.0;
+        alg = 8.0 * (nnz_all + 2) * (double)c->len;   // that stage's booking
+        *made_ystage = true;
+    }
+    // algorithmic bytes: only the folded-in stage (the other partial sums are
+    // booked on the stages they serve); moved bytes: its real traffic
+    Prof p(c, ESQ_PROF_STAGE, alg, false, 8.0 * (reads + no) * (double)c->len);
     DISPATCH_1_20(launch_block_n, nt, c, a, no, p)
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -745,8 +765,10 @@ int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
     if (i < 1 || i >= c->s) return fail(c, ESQ_EINVAL, "stage %d out of range", i);
     for (const auto &b : c->blocks)
         if (b.J == i) {
-            const int r = run_block(c, b);
+            bool made = false;
+            const int r = run_block(c, b, h, &made);
             if (r) return r;
+            if (made) return 0;        // YSTAGE already holds this stage's argument
         }
     const int from = c->stage_from[i];
     const double *init = c->stage_init[i] >= 0 ? c->krow[c->stage_init[i]] : nullptr;

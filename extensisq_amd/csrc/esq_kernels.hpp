@@ -70,6 +70,11 @@ struct BlockArgs {
     double w[kMaxTerms][kMaxOut];      // a_ij for output stage o, 0 = skip
     const double *init[kMaxOut];       // previous-level partial sum or nullptr
     double *out[kMaxOut];
+    // output 0 belongs to the boundary stage itself, whose sum is complete here:
+    // if y != nullptr its ARGUMENT y + h*sum is written to out[0] instead of the
+    // sum (same rounding as k_lincomb), and that stage needs no kernel of its own
+    const double *y;
+    double h;
 };
 template <int NT>
 __global__ __launch_bounds__(kBlock) void k_block_acc(BlockArgs a, int no,
@@ -92,7 +97,14 @@ __global__ __launch_bounds__(kBlock) void k_block_acc(BlockArgs a, int no,
                         acc.y = fma(a.w[j][o], v[j].y, acc.y);
                     }
                 }
-                st2(a.out[o], i, acc);   // plain or nt stores: no difference measured
+                if (o == 0 && a.y) {
+                    const double2 yb = ld2(a.y, i);
+                    acc.x = __dadd_rn(yb.x, __dmul_rn(a.h, acc.x));
+                    acc.y = __dadd_rn(yb.y, __dmul_rn(a.h, acc.y));
+                    st2(a.out[o], i, acc);      // stage argument: read next, keep cached
+                } else {
+                    st2_nt(a.out[o], i, acc);   // partial sums: stream past the cache
+                }
             }
         }
     }
