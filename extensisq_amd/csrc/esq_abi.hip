@@ -66,6 +66,7 @@ struct esq_ctx {
     void *rhs_user = nullptr;
     esq_rhs_chain_fn rhs_chain = nullptr;   // optional RHS + next-accumulate entry
     esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
+    bool ynew_ready = false;                // YNEW already formed by the last stage's chained sweep
     // blocked accumulation plan (esq_rk_set_tableau)
     struct Block {
         int J = 0, prev = 0;              // columns [prev, J) of A
@@ -816,6 +817,7 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     if (i_from < 1 || i_to > c->s || i_from > i_to)
         return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
     bool ready = false;     // YSTAGE already holds the argument of stage i
+    c->ynew_ready = false;
     for (int i = i_from; i < i_to; ++i) {
         if (!ready) {
             const int r = esq_rk_stage_accumulate(c, i, h);
@@ -862,6 +864,32 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 return fail(c, ESQ_ERHS, "chained RHS returned %d", r);
             p.cancel();
         }
+        // FSAL pairs: the LAST stage's sweep also forms y_new = y + h*sum b_j K_j
+        // (K_{s-1} from registers); esq_rk_solution_error then skips that kernel
+        if (c->rhs_chain && c->fsal && i == c->s - 1 && i_to == c->s) {
+            std::vector<double> row(c->B.begin(), c->B.begin() + c->s);
+            int nnz_all = 0;
+            for (int j = 0; j < c->s; ++j) nnz_all += row[j] != 0.0;
+            const double c_self = row[i];
+            row[i] = 0.0;
+            Terms tm;
+            const int nt = build_row_terms(c, row.data(), c->s, tm, c->kmap);
+            if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+            Prof p(c, ESQ_PROF_STAGE, 8.0 * (nnz_all + 4) * (double)c->len, false,
+                   8.0 * (nt + 4) * (double)c->len);
+            const int r = c->rhs_chain(c->rhs_user, t + c->C[i] * h, c->ystage,
+                                       c->krow[c->kmap[i]], nt, tm.p, tm.c, c_self,
+                                       nullptr, c->y, h, c->ynew, c->len,
+                                       (void *)c->stream, (void *)p.start(),
+                                       (void *)p.stop());
+            if (r == 0) {
+                c->ynew_ready = true;
+                continue;
+            }
+            if (r != ESQ_ENOTSUP)
+                return fail(c, ESQ_ERHS, "chained RHS returned %d", r);
+            p.cancel();
+        }
         const int r = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
         if (r) return r;
     }
@@ -899,7 +927,9 @@ int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (c->fsal) {
-        int r = esq_rk_solution(c, h);
+        int r = 0;
+        if (!c->ynew_ready) r = esq_rk_solution(c, h);
+        c->ynew_ready = false;
         if (r) return r;
         r = call_rhs(c, t + h, c->ynew, c->krow[c->kmap[c->s]]);
         if (r) return r;
