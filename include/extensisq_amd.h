@@ -153,7 +153,11 @@ int  esq_rk_block_plan(esq_ctx *ctx, int *boundaries, int max_boundaries,
 int  esq_rk_eval_rhs(esq_ctx *ctx, int dst_row, double t, int src_slot,
                      int src_row);
 /* for i in [i_from, i_to): stage_accumulate(i, h); K[i] = rhs(t + C[i]*h, YSTAGE)
- *                                                  common.py:241-242, 353-356 */
+ *                                                  common.py:241-242, 353-356
+ * With a chained plugin entry (esq_set_rhs_chain) the RHS sweep of stage i also
+ * forms stage i+1's argument (and, for FSAL tableaux when i_to == s, the last
+ * sweep forms YNEW, which esq_rk_solution_error then does not recompute).  The
+ * results are bit-identical to the one-kernel-per-operation sequence. */
 int  esq_rk_stages(esq_ctx *ctx, int i_from, int i_to, double t, double h);
 /* YNEW = Y + h * sum_j B[j] K[j]                   common.py:343              */
 int  esq_rk_solution(esq_ctx *ctx, double h);
