@@ -48,10 +48,10 @@ def parse():
                     help="pr8 = the BASELINE.json metric config (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--sample-every", type=int, default=7,
+    ap.add_argument("--sample-every", type=int, default=13,
                     help="attach HIP events to every k-th launch of the dominant "
-                         "kernel class in the timed region (prime: cycles evenly "
-                         "through the stages; an event-carrying dispatch costs "
+                         "kernel class in the timed region (pseudo-random 1-in-k "
+                         "sampling; an event-carrying dispatch costs "
                          "~6 us of queue time)")
     ap.add_argument("--force-lockstep", action="store_true",
                     help="create the RCCL communicator even for one rank")
