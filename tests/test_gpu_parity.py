@@ -643,3 +643,25 @@ def test_chained_stages_are_bit_identical(monkeypatch, name, plugin, N):
     sd, sp = chained.dense_output(), plain.dense_output()
     tc = np.linspace(plain.t_old, plain.t, 3)
     assert_equal(sd(tc), sp(tc))
+
+
+@pytest.mark.parametrize("N", [2, 3, 5, 7])
+def test_plugin_fallback_paths_small_and_odd_grids(N):
+    """grids the vectorised / chained plugin entries decline (odd N, N < 4):
+    the library must fall back to the plain kernels and still match the oracle"""
+    y0 = pb.heat2d_y0(N)
+    kw = dict(rtol=1e-5, atol=1e-8)
+    for name in ("Ts5", "Pr7"):
+        d, o = _pair(name, esq.Heat2D(N), pb.heat2d_rhs(N), 0.0, y0, 0.05, **kw)
+        while o.status == "running":
+            assert d.step() is None and o.step() is None
+        assert d.status == "finished" and d.nfev == o.nfev
+        assert_allclose(d.t, o.t, rtol=1e-12)
+        assert_allclose(d.y, o.y, rtol=1e-8, atol=1e-12)
+    from oracle import rkc_oracle
+    d = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 0.05, **kw)
+    o = rkc_oracle.SSV2stab(pb.heat2d_rhs(N), 0.0, y0, 0.05, **kw)
+    while o.status == "running":
+        assert d.step() is None and o.step() is None
+    assert d.status == "finished"
+    assert_allclose(d.y, o.y, rtol=1e-7, atol=1e-11)
