@@ -456,6 +456,22 @@ int g_first_device = -1;
         if (g_multi_device) (void)hipSetDevice((c)->device);      \
     } while (0)
 
+// Device-to-host copy into a caller's (pageable) buffer.  Large copies pin the
+// destination for the duration of the call: measured for 80 MB into a fresh
+// NumPy array 4.3 ms (register 2.8 + copy 1.5 at 54 GB/s) against 6.5-7 ms for
+// the staged pageable copy.
+int d2h(esq_ctx *c, void *host, const void *dev, size_t bytes) {
+    bool pinned = false;
+    if (bytes >= ((size_t)8 << 20))
+        pinned = hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess;
+    hipError_t e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (pinned) (void)hipHostUnregister(host);
+    if (e != hipSuccess)
+        return fail(c, (int)e, "device-to-host copy failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 unsigned env_uint(const char *name, unsigned dflt) {
     const char *s = getenv(name);
     if (!s || !*s) return dflt;
@@ -627,10 +643,7 @@ int esq_download(esq_ctx *c, int slot, int row, double *host) {
     double *d = slot_ptr(c, slot, row);
     if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
     const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
-    HIPCHK(c, hipMemcpyAsync(host, d, cnt * sizeof(double), hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return d2h(c, host, d, cnt * sizeof(double));
 }
 int esq_copy(esq_ctx *c, int dst_slot, int dst_row, int src_slot, int src_row) {
     if (!c) return ESQ_EINVAL;
@@ -1013,11 +1026,7 @@ int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
     ENTER(c);
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
-    HIPCHK(c, hipMemcpyAsync(host, c->krow[c->kmap_last[row]],
-                             c->len * sizeof(double), hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return d2h(c, host, c->krow[c->kmap_last[row]], c->len * sizeof(double));
 }
 
 int esq_rk_dense_stage(esq_ctx *c, int row, const double *a, int count, double h) {
@@ -1390,10 +1399,7 @@ int esq_vec_download(esq_ctx *c, int src, double *host) {
     ENTER(c);
     double *s = ROW(c, src);
     if (!s) return fail(c, ESQ_EINVAL, "bad vector id %d", src);
-    HIPCHK(c, hipMemcpyAsync(host, s, c->len * sizeof(double),
-                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return d2h(c, host, s, c->len * sizeof(double));
 }
 int esq_hs_log_etol(esq_ctx *c, int y, double *sum_out, double *min_out) {
     if (!c || !sum_out || !min_out) return ESQ_EINVAL;
