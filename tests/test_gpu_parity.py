@@ -596,10 +596,11 @@ def test_blocked_accumulation_is_bit_identical(monkeypatch, name, mode):
     assert int(esq.NFS[()]) >= 0
 
 
-def test_blocked_accumulation_plans():
+def test_blocked_accumulation_plans(monkeypatch):
     """the column boundaries the library derives from each tableau's sparsity
     and the 8-byte words per element and step the stage kernels then move"""
     import ctypes
+    monkeypatch.delenv("ESQ_BLOCK_ACC", raising=False)
     expect = {"Ts5": ([], 25, 25), "BS5": ([4], 33, 31), "Pr7": ([6], 58, 51),
               "Pr8": ([7], 93, 75), "Pr9": ([8, 13], 154, 109),
               "CK5": ([], 25, 25), "Me4": ([], 16, 16), "CFMR7osc": ([5], 46, 42)}
