@@ -1,0 +1,75 @@
+"""CPU-side guard of the GPU parity matrix: the `-m gpu` tests named below must
+exist (be collected).  A commit that deletes or renames one of them fails HERE,
+in the CPU suite, instead of silently shrinking the matrix the GPU box runs
+(round-1 lesson: six parity tests vanished with an unrelated cleanup)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
+
+# test function -> minimum number of collected parametrisations
+REQUIRED = {
+    # golden vectors of the real reference
+    "test_gpu_parity.py::test_single_step_golden": 80,
+    "test_gpu_parity.py::test_trajectory_golden": 56,
+    "test_gpu_parity.py::test_published_known_answers": 1,
+    "test_gpu_parity.py::test_dense_output_golden": 8,
+    "test_gpu_parity.py::test_bs5_interpolants_golden": 3,
+    "test_gpu_parity.py::test_ckdisc_golden": 7,
+    # device RHS vs the oracle
+    "test_gpu_parity.py::test_device_rhs_step_sizes": 80,
+    "test_gpu_parity.py::test_atol_vector_and_rejections": 8,
+    "test_gpu_parity.py::test_pde_workloads": 17,
+    "test_gpu_parity.py::test_builtin_rhs_bitwise": 15,
+    "test_gpu_parity.py::test_ckdisc_device_rhs_matches_oracle": 1,
+    "test_gpu_parity.py::test_plugin_fallback_paths_small_and_odd_grids": 4,
+    # BASELINE.json configs at full size
+    "test_gpu_parity.py::test_full_size_pr8_step_matches_oracle": 1,
+    "test_gpu_parity.py::test_full_size_ts5_heat_step_matches_oracle": 1,
+    "test_gpu_parity.py::test_full_size_pr9_heat_step_matches_oracle": 1,
+    "test_gpu_parity.py::test_full_size_linearity_and_exactness": 1,
+    "test_gpu_rkc.py::test_full_size_rkc_diffusion_step_matches_oracle": 1,
+    # the scipy surface and the boundary
+    "test_gpu_parity.py::test_solve_ivp_device_rhs_t_eval_and_events": 3,
+    "test_gpu_parity.py::test_user_plugin_compiled_with_hipcc": 1,
+    "test_gpu_parity.py::test_user_defined_tableau": 1,
+    "test_gpu_parity.py::test_step_limits_and_failures": 8,
+    "test_gpu_parity.py::test_classes_contract": 8,
+    "test_gpu_parity.py::test_nan_propagates_to_failure": 1,
+    "test_gpu_scipy_surface.py::test_events": 1,
+    "test_gpu_scipy_surface.py::test_t_eval": 1,
+    # bit-identical restructurings, each with its on/off switch
+    "test_gpu_parity.py::test_blocked_accumulation_is_bit_identical": 18,
+    "test_gpu_parity.py::test_chained_stages_are_bit_identical": 45,
+    "test_gpu_rkc.py::test_rkc_chained_stage_is_bit_identical": 1,
+    # lock-step
+    "test_gpu_parity.py::test_rccl_single_rank_lockstep": 1,
+    "test_gpu_parity.py::test_lockstep_total_size_changes_the_norm": 1,
+    # RKC
+    "test_gpu_rkc.py::test_stages_golden": 5,
+    "test_gpu_rkc.py::test_published_table": 3,
+    "test_gpu_rkc.py::test_power_iteration_golden": 1,
+    # next rows
+    "test_gpu_parity.py::test_device_dense_output_large_n": 8,
+    "test_gpu_parity.py::test_device_h_start": 18,
+    "test_gpu_stiffness.py::test_diagnosis_matches_reference": 1,
+}
+
+
+def test_required_gpu_tests_are_collected():
+    res = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"),
+         "--collect-only", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+        capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    counts = {}
+    for line in res.stdout.splitlines():
+        if "::" not in line:
+            continue
+        node = line.strip().split("[")[0]
+        node = node[node.index("tests/") + len("tests/"):] if "tests/" in node else node
+        counts[node] = counts.get(node, 0) + 1
+    missing = {k: (counts.get(k, 0), v) for k, v in REQUIRED.items()
+               if counts.get(k, 0) < v}
+    assert not missing, f"GPU parity tests missing or shrunk (have, need): {missing}"

@@ -148,6 +148,21 @@ def test_atol_vector_and_rejections(name):
     ("Pr9", esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 64),
     ("BS5", esq.Diffusion3D, pb.diff3d_rhs, pb.diff3d_y0, 13),
     ("Pr7", esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 31),
+    # even grids: the vectorised + chained plugin entries (the kernels the
+    # bench runs), incl. the FSAL "last sweep also forms y_new" path, DIRECTLY
+    # against the oracle; 130 / 258 span more than one wave tile per grid row
+    ("Ts5", esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 36),
+    ("Ts5", esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 258),
+    ("Ts5", esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 130),
+    ("BS5", esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 130),
+    ("BS5", esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 48),
+    ("Pr7", esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 30),
+    ("Pr7", esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 258),
+    ("Pr8", esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 258),
+    ("Pr9", esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 130),
+    ("CK5", esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 130),
+    ("Me4", esq.Heat2D, pb.heat2d_rhs, pb.heat2d_y0, 36),
+    ("CFMR7osc", esq.Brusselator2D, pb.bruss2d_rhs, pb.bruss2d_y0, 36),
 ])
 def test_pde_workloads(name, rhs, cpu, y0f, N):
     """the BASELINE.json workloads at small N, 5 steps, device RHS"""
@@ -564,6 +579,146 @@ def test_device_h_start(case, mode):
         want = abs(h_start(fun, a, b, y_arr, np.asarray(fun(a, y_arr)),
                            cls.order_secondary, rtol_v, atol_v))
         assert_allclose(s.h_abs, want, rtol=1e-11)
+
+
+# ----------------------------------------- solve_ivp end to end, device RHS
+@pytest.mark.parametrize("name", ["Ts5", "BS5", "Pr8"])
+def test_solve_ivp_device_rhs_t_eval_and_events(name):
+    """plain `solve_ivp(DeviceRHS, ..., method=<class>, t_eval=..., events=...)`
+    (reference tests/test_ivp.py:369-541, 757-782 with a device RHS):
+    default first step (device h_start), lazy `solver.y` mirror, device-resident
+    interpolant (n = 6400 >= 4096) for t_eval and the event root-finder"""
+    N = 80
+    y0 = pb.heat2d_y0(N, seed=7)
+    t_eval = np.array([0.0, 2e-5, 7e-5, 1e-4])
+
+    def event(t, y):                       # the centre value decays through 0.9
+        return y[(N // 2) * N + N // 2] - 0.9
+    event.terminal = False
+    kw = dict(rtol=1e-5, atol=1e-8, t_eval=t_eval, events=event)
+    got = solve_ivp(esq.Heat2D(N), (0.0, 1e-4), y0, method=DEV[name], **kw)
+    ref = solve_ivp(pb.heat2d_rhs(N), (0.0, 1e-4), y0,
+                    method=rk_oracle.METHODS[name], **kw)
+    assert got.success and ref.success
+    assert got.nfev == ref.nfev and got.t.shape == ref.t.shape
+    assert_allclose(got.y, ref.y, rtol=1e-8, atol=1e-11)
+    assert len(got.t_events[0]) == len(ref.t_events[0])
+    assert_allclose(got.t_events[0], ref.t_events[0], rtol=1e-7)
+
+
+# ---------------------------------------------------- user-compiled RHS plugin
+PLUGIN_SRC = r'''
+#include <hip/hip_runtime.h>
+// f_i = -k * y_i + cos(t)  -- a user plugin following include/extensisq_amd.h
+__global__ void k_user(const double* y, double* f, size_t n, double k, double c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = -k * y[i] + c;
+}
+extern "C" int user_rhs(void* user, double t, const double* y, double* f, size_t n,
+                        void* stream) {
+    const double k = *(const double*)user;
+    hipLaunchKernelGGL(k_user, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, y, f, n, k, cos(t));
+    return (int)hipGetLastError();
+}
+'''
+
+
+def test_user_plugin_compiled_with_hipcc(tmp_path):
+    """INTEGRATION.md §4: a user's own `esq_rhs_fn`, built with hipcc and passed
+    as a C function pointer through `CFunctionRHS`"""
+    import ctypes
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = tmp_path / "user_rhs.hip"
+    so = tmp_path / "libuser_rhs.so"
+    src.write_text(PLUGIN_SRC)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-fPIC", "-shared",
+                    "-ffp-contract=off", str(src), "-o", str(so)], check=True)
+    lib = ctypes.CDLL(str(so))
+    kval = ctypes.c_double(0.75)
+    n = 3001
+    rhs = esq.CFunctionRHS(ctypes.cast(lib.user_rhs, ctypes.c_void_p).value,
+                           ctypes.addressof(kval), n)
+    y0 = np.linspace(-1.0, 2.0, n)
+    cpu = lambda t, y: -0.75 * y + np.cos(t)  # noqa: E731
+    assert_allclose(rhs(0.3, y0), cpu(0.3, y0), rtol=1e-15)
+    got = solve_ivp(rhs, (0.0, 2.0), y0, method=esq.Pr7, rtol=1e-7, atol=1e-10)
+    ref = solve_ivp(cpu, (0.0, 2.0), y0, method=rk_oracle.Pr7, rtol=1e-7,
+                    atol=1e-10)
+    assert got.nfev == ref.nfev
+    # step sizes follow the (cancelling) error norms: ~1e-7 relative agreement
+    assert_allclose(got.t, ref.t, rtol=1e-6)
+    assert_allclose(got.y[:, -1], ref.y[:, -1], rtol=1e-7, atol=1e-11)
+
+
+# -------------------------------------------------- CKdisc (variable order)
+@pytest.mark.parametrize("case", ["readme", "duffing", "rational_bwd", "complex",
+                                  "sawtooth", "kink", "bruss1d"])
+def test_ckdisc_golden(golden_dir, case):
+    """variable-order Cash-Karp on the device (reference cash.py:253-395): every
+    order assessment is one fused `esq_rk_custom_sol_err` pass; trajectories,
+    accepted orders and dense output against the reference's run"""
+    from test_oracle_golden import _ckdisc_check
+    with open(os.path.join(golden_dir, "ckdisc_traces.json")) as fh:
+        gold = json.load(fh)
+    _ckdisc_check(esq.CKdisc, case, gold, esq.NFS, 1e-7)
+
+
+def test_ckdisc_device_rhs_matches_oracle():
+    n = 5000
+    rng = np.random.default_rng(8)
+    lam = -rng.random(n) * 3
+    y0 = rng.standard_normal(n)
+    kw = dict(rtol=1e-5, atol=1e-8)
+    d = esq.CKdisc(esq.DiagonalLinear(lam, 1.0), 0.0, y0, 2.0, **kw)
+    o = rk_oracle.CKdisc(lambda t, y: lam * y + np.sin(t), 0.0, y0, 2.0, **kw)
+    assert_allclose(d.h_abs, o.h_abs, rtol=1e-11)
+    for _ in range(6):
+        assert d.step() is None and o.step() is None
+        assert d.order_accepted == o.order_accepted
+        assert_allclose(d.t, o.t, rtol=1e-7)
+        assert_allclose(d.y, o.y, rtol=1e-7, atol=1e-10)
+    assert d.nfev == o.nfev
+    tc = np.linspace(o.t_old, o.t, 4)
+    assert_allclose(d.dense_output()(tc), o.dense_output()(tc), rtol=1e-7,
+                    atol=1e-10)
+
+
+# --------------------------------- the other BASELINE.json configs, full size
+def test_full_size_ts5_heat_step_matches_oracle():
+    """configs[1]: Ts5, 2-D heat N = 1000 (n = 1e6), two steps vs the oracle"""
+    N = 1000
+    rhs = esq.Heat2D(N)
+    y0 = pb.heat2d_y0(N)
+    h = 1.0 / rhs.spectral_radius()
+    kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+    d, o = _pair("Ts5", rhs, pb.heat2d_rhs(N), 0.0, y0, 1.0, **kw)
+    y_old = o.y
+    assert d.step() is None and o.step() is None
+    check_step(d, o.K, o.y, o.error_norm_old, o.h_abs, y_old, o.h_previous,
+               1e-3, 1e-6, k_rtol=2e-13, lipschitz=rhs.spectral_radius())
+    assert int(esq.NFS[()]) == 0
+    assert d.step() is None and o.step() is None
+    assert d.t == o.t and d.nfev == o.nfev
+    assert_allclose(d.y, o.y, rtol=1e-12, atol=1e-14)
+
+
+def test_full_size_pr9_heat_step_matches_oracle():
+    """configs[4] shard: Pr9, 2-D heat N = 2236 (n = 4 999 696), one step"""
+    N = 2236
+    rhs = esq.Heat2D(N)
+    y0 = pb.heat2d_y0(N)
+    h = 1.0 / rhs.spectral_radius()
+    kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+    d, o = _pair("Pr9", rhs, pb.heat2d_rhs(N), 0.0, y0, 1.0, **kw)
+    y_old = o.y
+    assert d.step() is None and o.step() is None
+    check_step(d, o.K, o.y, o.error_norm_old, o.h_abs, y_old, o.h_previous,
+               1e-3, 1e-6, k_rtol=2e-13, lipschitz=rhs.spectral_radius())
+    assert int(esq.NFS[()]) == 0
+    assert d.nfev == o.nfev == 18
 
 
 # ------------------------------------------------------ blocked accumulation
