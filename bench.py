@@ -4,20 +4,30 @@ fp64, 2-D Brusselator N = 2236 (n = 9 999 392) per GPU, inputs resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (N > 1: launched by torch.distributed.run, RANK /
-LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  With N > 1 every rank
-integrates its own independent IVP of the same size in LOCK-STEP: one fp64 RCCL
-all-reduce per step for the global error norm, nothing else crosses xGMI (weak
-scaling).  A "step" is one accepted 13-stage Pr8 step: 12 fused
-stage-accumulate kernels, 13 RHS kernels, 1 fused solution/error-norm kernel.
+One process per GPU.  `python bench.py --gpus N` with N > 1 is self-launching:
+the parent (which never touches a GPU) starts N fresh rank processes with RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment and relays rank 0's JSON
+line; under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus
+N` the launcher has already done that and every process is a rank.  The control
+plane (rendezvous, barrier, max-over-ranks time) is a plain TCP star
+(extensisq_amd.lockstep.ControlGroup): no PyTorch anywhere.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel class (the
-fused stage-accumulate kernels): algorithmic bytes = 8 B * (nnz(A[i,:i]) + 2) * n
-per launch, time from HIP events attached to every
-such dispatch on the solver's stream, over the timed region itself.
+With N > 1 every rank integrates its own independent IVP of the same size in
+LOCK-STEP: one fp64 RCCL all-reduce per step for the global error norm, nothing
+else crosses xGMI (weak scaling).  The no-collective variant (`replicas`) is
+timed in the same run and reported beside it.
+
+A "step" is one accepted 13-stage Pr8 step.  The timed region carries no
+events.  Right after it the same K steps are replayed with a HIP event pair on
+EVERY kernel launch (dispatch timestamps on the solver's stream); from that
+replay come the per-kernel table and `roofline`:
+    achieved = bytes the dominant kernel class MOVES (designed traffic, checked
+               against the rocprofv3 PMC counters in profiles/) / its device time
+    frac     = achieved / 8 TB/s                                   (<= 1)
+    algorithmic_gbs = SURVEY.md §8d bytes / the same time (can exceed the fabric
+               rate: blocked accumulation and chaining move fewer bytes)
 `cpu_baseline` times the NumPy oracle (the restated reference algorithm) on the
-host cores of this box, rank 0, N = 1 only, on a bounded sample of the same
-workload.
+host cores of this box, rank 0, N = 1 only, on a bounded sample of the workload.
 
 `--config ts5|pr9|rkc` runs the other BASELINE.json configs through the same
 harness (for DESIGN.md's table; the driver uses the default).
@@ -25,6 +35,8 @@ harness (for DESIGN.md's table; the driver uses the default).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,66 +59,108 @@ def parse():
     ap.add_argument("--config", default="pr8", choices=["pr8", "ts5", "pr9", "rkc"],
                     help="pr8 = the BASELINE.json metric config (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--sample-every", type=int, default=13,
-                    help="attach HIP events to every k-th launch of the dominant "
-                         "kernel class in the timed region (pseudo-random 1-in-k "
-                         "sampling; an event-carrying dispatch costs "
-                         "~6 us of queue time)")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--no-solve-ivp", action="store_true",
+                    help="skip the plain solve_ivp(...) figure (PCIe-inclusive)")
     ap.add_argument("--force-lockstep", action="store_true",
                     help="create the RCCL communicator even for one rank")
     ap.add_argument("--replicas", action="store_true",
-                    help="N > 1 without the lock-step collective: fully "
+                    help="N > 1 without the lock-step collective only: fully "
                          "independent solvers per GPU (upper bound, SURVEY.md §8e)")
+    ap.add_argument("--timeout", type=float, default=1500.0,
+                    help="self-launched ranks are stopped after this many seconds")
     ap.add_argument("--dry-run", action="store_true",
-                    help="exercise only the multi-rank control plane (gloo "
+                    help="exercise only the multi-rank control plane (spawn, "
                          "rendezvous, id exchange, barrier, max-over-ranks, JSON) "
                          "with no GPU work -- used by the CPU tests")
     return ap.parse_args()
 
 
-def gloo_exchange(dist, rank):
-    """ncclUniqueId broadcast + shard-size sum over the gloo control group"""
-    import torch
-
-    def exchange(make_id, n_local):
-        ident = [make_id() if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)
-        total = torch.tensor([int(n_local)], dtype=torch.int64)
-        dist.all_reduce(total)
-        return ident[0], int(total[0])
-    return exchange
+# ---------------------------------------------------------------------------
+# self-launch: the parent never imports the package nor touches a GPU
+# ---------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def dry_run(args, rank, world, dist):
+def spawn_ranks(args):
+    """start `args.gpus` fresh rank processes of this script, relay rank 0's
+    stdout, return non-zero if any rank fails or the time limit passes"""
+    world = args.gpus
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+            stdout=subprocess.PIPE if rank == 0 else sys.stderr, cwd=ROOT))
+    deadline = time.time() + args.timeout
+    rc = 0
+    live = set(range(world))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}", file=sys.stderr)
+        if rc != 0 or time.time() > deadline:
+            if time.time() > deadline and rc == 0:
+                rc = 124
+                print("bench.py: time limit reached", file=sys.stderr)
+            for r in live:                     # exactly the PIDs started above
+                procs[r].terminate()
+            t_kill = time.time() + 10
+            for r in live:
+                try:
+                    procs[r].wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        time.sleep(0.05)
+    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    if rc == 0:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(out)
+    return rc
+
+
+def dry_run(args, rank, world, ctl):
     """control-plane rehearsal without a GPU (tests/test_bench_cpu.py)"""
-    import torch
     n = 1000 + rank
-    ident, n_total = gloo_exchange(dist, rank)(lambda: bytes(range(128)), n) \
-        if dist is not None else (bytes(range(128)), n)
+    ident, n_total = ctl.exchange(lambda: bytes(range(128)), n)
     assert len(ident) == 128 and n_total == sum(1000 + r for r in range(world))
-    if dist is not None:
-        dist.barrier()
+    ctl.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
-        dist.barrier()
+    elapsed = ctl.allreduce([time.perf_counter() - t0], "max")[0]
+    ctl.barrier()
+    if os.environ.get("ESQ_BENCH_DRY_FAIL_RANK") == str(rank):
+        sys.exit(3)                       # a failing rank must fail the whole run
     if rank == 0:
         print(json.dumps({"metric": "dry-run", "value": n_total / elapsed,
                           "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "max_elapsed": elapsed}),
               flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    ctl.close()
 
 
 # ---------------------------------------------------------------------------
 # workloads (SURVEY.md §8d)
 # ---------------------------------------------------------------------------
+STAGE_KERNEL = ("stage-accumulate class: k_lincomb / rhs_chain (RHS sweep of the "
+                "previous stage with this stage's accumulate chained in) / "
+                "k_block_acc")
+
+
 def make_workload(name, N, rank):
     """returns a dict: device solver factory, oracle factory, byte counts"""
     import extensisq_amd as esq
@@ -122,9 +176,7 @@ def make_workload(name, N, rank):
             metric="accepted RK steps/s x state-dim (fp64), Pr8 n=1e7",
             cls=esq.Pr8, oracle="Pr8", rhs=rhs, y0=y0, kw=kw, N=N,
             cpu_problem=("bruss2d_rhs", "bruss2d_y0"),
-            bytes_per_elt_step=1040.0, klass=PROF_STAGE,
-            kernel="stage-accumulate class: k_lincomb / k_*_chain (RHS of the previous "
-                   "stage chained in) / k_block_acc")
+            bytes_per_elt_step=1040.0, klass=PROF_STAGE, kernel=STAGE_KERNEL)
     if name == "ts5":
         N = N or 1000
         rhs, y0, h = wl.ts5_heat(N, seed=1234 + rank)
@@ -135,9 +187,7 @@ def make_workload(name, N, rank):
             metric="accepted RK steps/s x state-dim (fp64), Ts5 n=1e6",
             cls=esq.Ts5, oracle="Ts5", rhs=rhs, y0=y0, kw=kw, N=N,
             cpu_problem=("heat2d_rhs", "heat2d_y0"),
-            bytes_per_elt_step=432.0, klass=PROF_STAGE,
-            kernel="stage-accumulate class: k_lincomb / k_*_chain (RHS of the previous "
-                   "stage chained in) / k_block_acc")
+            bytes_per_elt_step=432.0, klass=PROF_STAGE, kernel=STAGE_KERNEL)
     if name == "pr9":
         N = N or 2236
         rhs = esq.Heat2D(N)
@@ -150,9 +200,7 @@ def make_workload(name, N, rank):
             metric="accepted RK steps/s x state-dim (fp64), Pr9 n=5e6 per GPU",
             cls=esq.Pr9, oracle="Pr9", rhs=rhs, y0=y0, kw=kw, N=N,
             cpu_problem=("heat2d_rhs", "heat2d_y0"),
-            bytes_per_elt_step=1624.0, klass=PROF_STAGE,
-            kernel="stage-accumulate class: k_lincomb / k_*_chain (RHS of the previous "
-                   "stage chained in) / k_block_acc")
+            bytes_per_elt_step=1624.0, klass=PROF_STAGE, kernel=STAGE_KERNEL)
     N = N or 159
     rhs, y0, h, rho = wl.rkc_diffusion(N, m_target=100)
     kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-3, const_jac=True,
@@ -163,7 +211,21 @@ def make_workload(name, N, rank):
         cls=esq.SSV2stab, oracle="SSV2stab", rhs=rhs, y0=y0, kw=kw, N=N,
         cpu_problem=("diff3d_rhs", "diff3d_y0"),
         bytes_per_elt_step=None, klass=PROF_RKC,
-        kernel="k_rkc_stage (three-term Chebyshev recursion)")
+        kernel="RKC stage class: rhs_rkc (stencil sweep + three-term Chebyshev "
+               "recursion in one kernel) / k_rkc_first")
+
+
+def blas_threads():
+    """threads the NumPy BLAS really uses on this box"""
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        if pools:
+            return max(int(p["num_threads"]) for p in pools), pools[0].get(
+                "internal_api", "blas")
+    except Exception:
+        pass
+    return None, None
 
 
 def cpu_baseline(w, steps):
@@ -181,139 +243,144 @@ def cpu_baseline(w, steps):
     for _ in range(steps):
         s.step()
     dt = time.perf_counter() - t0
+    nthr, api = blas_threads()
     return {"value": y0.size * steps / dt, "unit": "state-dim*steps/s",
-            "cores": os.cpu_count(), "kind": "port",
+            "cores": nthr or 1, "host_cpus": os.cpu_count(), "blas": api,
+            "kind": "port",
             "sample": f"{steps} accepted steps of the same workload "
-                      f"(n={y0.size}) after 1 warm-up, NumPy/OpenBLAS oracle, "
-                      f"{dt / steps:.2f} s/step"}
+                      f"(n={y0.size}) after 1 warm-up, NumPy oracle, "
+                      f"{dt / steps:.2f} s/step; BLAS threads = {nthr} (gemv "
+                      f"parts), the elementwise NumPy passes and the RHS are "
+                      f"single-threaded"}
 
 
-def pmc_traffic(w):
-    """HBM bytes per stage-accumulate launch from the committed rocprofv3 PMC
-    passes of the default command (profiles/rNN_pmc_traffic.json, written by
+def pmc_traffic(config):
+    """HBM bytes per launch of the dominant kernel class from the committed
+    rocprofv3 PMC passes (profiles/rNN_pmc_traffic_<config>.json, written by
     tools/profile_bench.sh + tools/summarize_profiles.py)"""
-    if not (w["cls"].__name__ == "Pr8" and w["N"] == 2236):
-        return None, None
     pdir = os.path.join(ROOT, "profiles")
     try:
-        names = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json"))
+        names = sorted(f for f in os.listdir(pdir)
+                       if f.endswith(f"_pmc_traffic_{config}.json"))
         with open(os.path.join(pdir, names[-1])) as fh:
             data = json.load(fh)
-        return (data["stage_accumulate"]["hbm_bytes_per_launch"],
+        return (data["dominant_class"]["hbm_bytes_per_launch"],
                 f"profiles/{names[-1]}")
     except Exception:
         return None, None
 
 
+def kernel_table(dev):
+    """per-kernel rows of the profiled replay"""
+    rows = {}
+    for name, klass, launches, ms, alg, moved in dev.profile_kernels():
+        rows[name] = {
+            "class": klass, "launches": launches,
+            "avg_us": 1e3 * ms / launches if launches else None,
+            "moved_bytes_per_launch": moved / launches if launches else None,
+            "algorithmic_bytes_per_launch": alg / launches if launches else None,
+            "gbs": moved / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            "total_ms": ms, "moved_bytes": moved, "algorithmic_bytes": alg}
+    return rows
+
+
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        sys.exit("launch with torch.distributed.run for --gpus > 1")
-    dist = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as dist_mod      # control plane only (gloo)
-        # gloo announces its connections on stdout; stdout is reserved for the
-        # one JSON line, so fd 1 points at stderr while the group forms
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
-            dist_mod.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
-        dist = dist_mod
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
+    from extensisq_amd import lockstep            # no GPU call on import
+    ctl = lockstep.ControlGroup(rank, world)
     if args.dry_run:
-        return dry_run(args, rank, world, dist)
+        return dry_run(args, rank, world, ctl)
 
     import extensisq_amd as esq
-    from extensisq_amd import lockstep
     from extensisq_amd._lib import PROF_RHS, PROF_RKC, PROF_SOLERR, PROF_STAGE
 
     w = make_workload(args.config, args.grid, rank)
     n = w["y0"].size
     group = None
-    if (world > 1 and not args.replicas) or args.force_lockstep:
-        group = lockstep.init_lockstep(
-            rank, world, local, n,
-            exchange=gloo_exchange(dist, rank) if dist is not None else None)
-    solver = w["cls"](w["rhs"], 0.0, w["y0"], 1.0e9, device=local, lockstep=group,
-                      **w["kw"])
-    dev = solver._dev
-    klass = w["klass"]
+    rccl_nranks = None
+    try:
+        if (world > 1 and not args.replicas) or args.force_lockstep:
+            group = lockstep.init_lockstep(rank, world, local, n,
+                                           exchange=ctl.exchange)
+            rccl_nranks = lockstep.comm_size(group)
+            if rccl_nranks != world:
+                raise RuntimeError(f"RCCL sees {rccl_nranks} ranks, expected {world}")
 
-    def barrier():
-        dev.synchronize()
-        if dist is not None:
-            dist.barrier()
+        def timed(lock_group):
+            solver = w["cls"](w["rhs"], 0.0, w["y0"], 1.0e9, device=local,
+                              lockstep=lock_group, **w["kw"])
+            dev = solver._dev
 
-    def run(k):
-        for _ in range(k):
-            msg = solver.step()
-            if msg is not None or solver.status != "running":
-                raise RuntimeError(f"step failed: {msg}")
+            def barrier():
+                dev.synchronize()
+                ctl.barrier()
 
-    run(args.warmup)
-    # ---- timed region: exactly K accepted steps.  Every launch of the dominant
-    # kernel class carries a start/stop HIP event pair (dispatch timestamps on
-    # the solver's stream, hipExtLaunchKernelGGL): the roofline figure is
-    # measured live over the SAME K steps the throughput is quoted on.
-    dev.profile_reset()
-    dev.profile_enable([klass], every=args.sample_every)
-    nfs0, nfev0 = int(esq.NFS[()]), solver.nfev
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dev.profile_enable(None)
-    rejected = int(esq.NFS[()]) - nfs0
-    nfev_timed = solver.nfev - nfev0
-    prof = {klass: dev.profile_read(klass)}
-    moved_bytes = dev.profile_read_moved(klass)
-    # ---- the same K steps again without any event: the cost of measuring
-    barrier()
-    t1 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    elapsed_noprof = time.perf_counter() - t1
-    # ---- diagnostic pass (untimed): device time of the other kernel classes
-    others = [k for k in (PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC) if k != klass]
-    dev.profile_reset()
-    dev.profile_enable(others)
-    run(min(args.steps, 10))
-    dev.profile_enable(None)
-    for k in others:
-        prof[k] = dev.profile_read(k)
+            def run(k):
+                for _ in range(k):
+                    msg = solver.step()
+                    if msg is not None or solver.status != "running":
+                        raise RuntimeError(f"step failed: {msg}")
 
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed, elapsed_noprof], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_noprof = float(tt[0]), float(tt[1])
-        rj = torch.tensor([rejected], dtype=torch.int64)
-        dist.all_reduce(rj, op=dist.ReduceOp.MAX)
-        rejected = int(rj[0])
+            run(args.warmup)
+            nfs0, nfev0 = int(esq.NFS[()]), solver.nfev
+            # ---- timed region: exactly K accepted steps, no events attached
+            barrier()
+            t0 = time.perf_counter()
+            run(args.steps)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            rejected = int(esq.NFS[()]) - nfs0
+            nfev_timed = solver.nfev - nfev0
+            elapsed, rejected = ctl.allreduce([elapsed, rejected], "max")
+            return solver, run, barrier, elapsed, int(rejected), nfev_timed
+
+        solver, run, barrier, elapsed, rejected, nfev_timed = timed(group)
+        dev = solver._dev
+        # ---- profiled replay: the same K steps with an event pair on EVERY
+        # launch (all ranks step -- the lock-step collective needs them all)
+        dev.profile_reset()
+        dev.profile_enable([PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC], every=1)
+        barrier()
+        t1 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        elapsed_prof = time.perf_counter() - t1
+        dev.profile_enable(None)
+        table = kernel_table(dev)
+
+        replicas = None
+        if world > 1 and group is not None:
+            # the no-collective upper bound, same run (SURVEY.md §8e)
+            _s2, _r2, _b2, el2, _rj2, _nf2 = timed(None)
+            replicas = {"value": world * n * args.steps / el2,
+                        "ms_per_step": 1e3 * el2 / args.steps}
+            del _s2, _r2, _b2
+    except BaseException:
+        # a rank that dies must not leave its peers blocked in the all-reduce
+        lockstep.abort_lockstep(group)
+        raise
 
     if rank == 0:
-        ms, cnt, nbytes = prof[klass]
-        achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(w)
-
-        def klass_info(k):
-            kms, kcnt, kb = prof[k]
-            return {"gbs": kb / (kms * 1e-3) / 1e9 if kms > 0 else None,
-                    "avg_launch_us": 1e3 * kms / kcnt if kcnt else None,
-                    "launches": kcnt}
-        names = {PROF_STAGE: "stage_accumulate", PROF_RHS: "rhs_plugin",
-                 PROF_SOLERR: "solution_error", PROF_RKC: "rkc_stage"}
+        klass = w["klass"]
+        dom = [r for r in table.values() if r["class"] == klass]
+        ms = sum(r["total_ms"] for r in dom)
+        cnt = sum(r["launches"] for r in dom)
+        moved = sum(r["moved_bytes"] for r in dom)
+        alg = sum(r["algorithmic_bytes"] for r in dom)
+        achieved = moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(args.config)
+        all_moved = sum(r["moved_bytes"] for r in table.values())
+        all_ms = sum(r["total_ms"] for r in table.values())
+        for r in table.values():
+            for key in ("total_ms", "moved_bytes", "algorithmic_bytes"):
+                r.pop(key)
         out = {
             "metric": w["metric"],
             "value": world * n * args.steps / elapsed,
@@ -331,32 +398,37 @@ def main():
                 if group is not None else
                 (f"replicas x{world}: independent solvers, no collective"
                  if world > 1 else "single GPU"),
+                "rccl_nranks": rccl_nranks,
+                "replicas_no_collective": replicas,
                 "rejected_steps_in_timed_region": rejected,
                 "rhs_evaluations_in_timed_region": nfev_timed,
-                "ms_per_step_without_events": 1e3 * elapsed_noprof / args.steps,
+                "ms_per_step_profiled_replay": 1e3 * elapsed_prof / args.steps,
             },
             "roofline": {
                 "bound": "hbm", "kernel": w["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "note": "achieved = SURVEY.md algorithmic bytes / device time; "
-                        "blocked accumulation moves fewer bytes than that "
-                        "(moved_gbs), so frac may exceed what the fabric carries",
+                "definition": "bytes the class is designed to move / its device "
+                              "time (HIP events on every launch of a K-step "
+                              "replay right after the timed region)",
                 "traffic": traffic, "traffic_source": traffic_src,
-                "launches_timed": cnt, "sampled_every": args.sample_every,
+                "launches_timed": cnt,
                 "avg_launch_us": 1e3 * ms / cnt if cnt else None,
-                "algorithmic_bytes_per_launch": nbytes / cnt if cnt else None,
-                # bytes the timed launches are designed to move: below the
-                # algorithmic count where blocked accumulation reads a K row
-                # once for several stages
-                "moved_gbs": moved_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None,
-                "other_kernels": {names[k]: klass_info(k) for k in others
-                                  if prof[k][1]},
-                "whole_step_gbs": (w["bytes_per_elt_step"] * n * args.steps
-                                   / elapsed / 1e9)
+                "moved_bytes_per_launch": moved / cnt if cnt else None,
+                "algorithmic_bytes_per_launch": alg / cnt if cnt else None,
+                "algorithmic_gbs": alg / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                "device_busy_frac_replay": all_ms * 1e-3 / elapsed_prof,
+                # every kernel of the step: moved bytes / wall time of the
+                # TIMED region (launch gaps and the host controller included)
+                "whole_step_gbs": all_moved / elapsed / 1e9,
+                "whole_step_algorithmic_gbs": (
+                    w["bytes_per_elt_step"] * n * args.steps / elapsed / 1e9)
                 if w["bytes_per_elt_step"] else None,
+                "kernels": table,
             },
         }
+        if world == 1 and not args.no_solve_ivp:
+            out["config"]["solve_ivp"] = solve_ivp_figure(w, local)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps)
         else:
@@ -365,10 +437,28 @@ def main():
 
     if group is not None:
         dev.synchronize()
+        ctl.barrier()
         lockstep.destroy_lockstep(group)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctl.barrier()
+    ctl.close()
+
+
+def solve_ivp_figure(w, device, steps=8):
+    """the drop-in call itself: `solve_ivp(rhs, (0, steps*h), y0, method=cls)`
+    keeps every accepted state on the host, so each step pays an n-vector
+    device-to-host copy (PCIe-inclusive; never the headline)"""
+    from scipy.integrate import solve_ivp
+    h = w["kw"]["max_step"]
+    kw = dict(w["kw"])
+    t0 = time.perf_counter()
+    res = solve_ivp(w["rhs"], (0.0, steps * h), w["y0"],
+                    method=w["cls"], device=device, **kw)
+    dt = time.perf_counter() - t0
+    n_steps = res.t.size - 1
+    return {"ms_per_step": 1e3 * dt / max(n_steps, 1), "steps": n_steps,
+            "value": w["y0"].size * n_steps / dt,
+            "note": "wall time of the whole call incl. solver construction, "
+                    "one n-vector D2H copy per step (PCIe)"}
 
 
 if __name__ == "__main__":

@@ -11,6 +11,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libextensisq_amd.so")
 
+ABI_VERSION = 2
+OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
 PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC = range(4)
 VEC_NONE, VEC_Y, VEC_YNEW, VEC_YSTAGE, VEC_WORK = -1, -2, -3, -4, -5
@@ -84,6 +86,9 @@ SIGNATURES = {
     "esq_comm_unique_id": (C.c_int, [_vp]),
     "esq_comm_init_rank": (C.c_int, [_vpp, C.c_int, _vp, C.c_int, C.c_int]),
     "esq_comm_destroy": (C.c_int, [_vp]),
+    "esq_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "esq_comm_abort": (C.c_int, [_vp]),
+    "esq_allreduce_scalars": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "esq_rhs_diag_create": (C.c_int, [_vpp, C.c_int, _vp, C.c_size_t, C.c_double]),
     "esq_rhs_heat2d_create": (C.c_int, [_vpp, C.c_int]),
     "esq_rhs_bruss2d_create": (C.c_int, [_vpp, C.c_int, C.c_double, C.c_double,
@@ -104,6 +109,7 @@ SIGNATURES = {
     "esq_profile_sampling": (C.c_int, [_vp, C.c_int]),
     "esq_profile_read": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_long), _dp]),
     "esq_profile_read_moved": (C.c_int, [_vp, C.c_int, _dp]),
+    "esq_profile_kernels": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "esq_profile_reset": (C.c_int, [_vp]),
 }
 
@@ -129,7 +135,7 @@ def load():
         fn = getattr(lib, name)     # AttributeError if a symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.esq_abi_version() != 1:
+    if lib.esq_abi_version() != ABI_VERSION:
         raise DeviceError("libextensisq_amd.so ABI version mismatch")
     _lib = lib
     return lib

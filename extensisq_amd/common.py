@@ -14,6 +14,7 @@ There is no CPU implementation of the step in this package: without the built
 library and a GPU the constructor raises `DeviceError`.
 """
 import logging
+import os
 from math import copysign, sqrt
 from warnings import warn
 
@@ -241,11 +242,47 @@ class LockstepGroup:
     """Membership of this solver in a lock-step batch (one rank per GPU):
     `comm` is an ncclComm_t handle (see extensisq_amd.lockstep), `n_total` the
     summed state dimension of all ranks.  The C library all-reduces the error
-    sum of squares, so every rank takes the same accept/reject decision."""
+    sum of squares, so every rank takes the same accept/reject decision.
 
-    def __init__(self, comm, n_total):
+    Rank-local host scalars that feed the step size or the stage count (a
+    y-dependent spectral-radius estimate, say) go through `allreduce` so that
+    the ranks cannot leave lock-step.  `reduce_scalars(values, op)` replaces
+    the RCCL path (CPU tests pass a gloo reducer)."""
+
+    def __init__(self, comm, n_total, reduce_scalars=None):
         self.comm = comm
         self.n_total = int(n_total)
+        self._reduce = reduce_scalars
+        self.debug = os.environ.get("ESQ_LOCKSTEP_DEBUG", "0") not in ("", "0")
+
+    def allreduce(self, dev, values, op="max"):
+        """all-reduce a few floats over the group; `dev`: the solver's
+        DeviceContext (its stream and communicator carry the RCCL call)"""
+        values = [float(v) for v in values]
+        if self._reduce is not None:
+            return [float(v) for v in self._reduce(values, op)]
+        if not self.comm:
+            return values
+        import ctypes
+        from ._lib import OP_MAX, OP_MIN, OP_SUM
+        buf = (ctypes.c_double * len(values))(*values)
+        dev._chk(dev.lib.esq_allreduce_scalars(
+            dev.handle, buf, len(values),
+            {"sum": OP_SUM, "max": OP_MAX, "min": OP_MIN}[op]),
+            "esq_allreduce_scalars")
+        return list(buf)
+
+    def check_identical(self, dev, what, values):
+        """debug mode (ESQ_LOCKSTEP_DEBUG=1): every rank must hold the same
+        scalars -- max and min over the ranks coincide"""
+        if not self.debug:
+            return
+        hi = self.allreduce(dev, values, "max")
+        lo = self.allreduce(dev, values, "min")
+        if hi != lo or any(v != h for v, h in zip(values, hi)):
+            raise RuntimeError(
+                f"ranks left lock-step: {what} = {list(values)} here, "
+                f"min over ranks {lo}, max {hi}")
 
 
 class RungeKutta(OdeSolver):
@@ -675,6 +712,8 @@ class RungeKutta(OdeSolver):
                 return False, self.TOO_SMALL_STEP
             h = h_abs * self.direction
             t_new = t + h
+            if self._lockstep is not None:
+                self._lockstep.check_identical(self._dev, "(t, h)", (t, h))
             self._run_stages(1, self.n_stages, t, h)
             error_norm = self._solution_and_error(t, h)
             if error_norm < 1:

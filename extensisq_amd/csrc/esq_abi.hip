@@ -15,6 +15,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "../../include/extensisq_amd.h"
@@ -32,6 +35,18 @@ struct ProfEvent {
     int klass;
     double bytes;      // algorithmic bytes (SURVEY.md §8d definition)
     double moved;      // bytes the launch is designed to move
+    char name[40];     // kernel label for the per-kernel table (esq_profile_kernels)
+};
+struct ProfKernel {    // per-label totals since the last reset
+    int klass = 0;
+    long launches = 0;
+    double ms = 0.0, bytes = 0.0, moved = 0.0;
+};
+// pinned host slot a reduction's result lands in: the value, then the sequence
+// number of the reduction (system-scope release), polled by the host
+struct HostSlot {
+    double value;
+    unsigned long long seq;
 };
 
 }  // namespace
@@ -54,8 +69,10 @@ struct esq_ctx {
            *work = nullptr;
     double *partials = nullptr;       // kMaxPartials doubles
     double *partials2 = nullptr;      // second set (min reductions)
-    double *d_result = nullptr;       // 1 double (device)
-    double *h_result = nullptr;       // 1 double (pinned host)
+    double *d_result = nullptr;       // 8 doubles (device)
+    HostSlot *h_slot = nullptr;       // pinned, device-visible host memory
+    unsigned long long red_seq = 0;   // reductions issued so far
+    double comm_timeout_s = 120.0;    // bounded wait of a lock-step all-reduce
     // method
     int s = 0, fsal = 0;
     std::vector<double> A, B, C, E;
@@ -76,6 +93,7 @@ struct esq_ctx {
         std::vector<int> in_vec;          // previous-level partial (-1: none)
     };
     std::vector<Block> blocks;
+    int block_rows_first = -1, block_rows_count = 0;   // aux rows of the plan
     std::vector<int> stage_init;          // per stage: row of its partial or -1
     std::vector<int> stage_from;          // per stage: first column still to add
     // launch geometry
@@ -95,6 +113,7 @@ struct esq_ctx {
     long prof_cnt[ESQ_PROF_NCLASS] = {0};
     double prof_bytes[ESQ_PROF_NCLASS] = {0};
     double prof_moved[ESQ_PROF_NCLASS] = {0};
+    std::map<std::string, ProfKernel> prof_kernels;
     char err[512] = {0};
 };
 
@@ -140,10 +159,11 @@ struct Prof {
     esq_ctx *c;
     bool on, recorded;
     ProfEvent ev;
-    Prof(esq_ctx *ctx, int klass, double bytes, bool record_now = false,
-         double moved = -1.0)
+    Prof(esq_ctx *ctx, int klass, const char *name, int nt, double bytes,
+         bool record_now = false, double moved = -1.0)
         : c(ctx), on((ctx->prof_mask >> klass) & 1u), recorded(record_now) {
         ev.start = ev.stop = nullptr;
+        ev.name[0] = 0;
         if (on && ctx->prof_every > 1) {
             // pseudo-random 1-in-`every` sampling: a fixed stride would alias
             // with the number of launches per step (e.g. 14 for Pr8, stride 7)
@@ -169,6 +189,8 @@ struct Prof {
         ev.klass = klass;
         ev.bytes = bytes;
         ev.moved = moved < 0.0 ? bytes : moved;
+        if (nt >= 0) snprintf(ev.name, sizeof(ev.name), "%s<%d>", name, nt);
+        else snprintf(ev.name, sizeof(ev.name), "%s", name);
         if (recorded) (void)hipEventRecord(ev.start, c->stream);
     }
     void cancel() {            // the launch did not happen: return the events
@@ -196,6 +218,12 @@ void prof_drain(esq_ctx *c) {
             c->prof_cnt[ev.klass] += 1;
             c->prof_bytes[ev.klass] += ev.bytes;
             c->prof_moved[ev.klass] += ev.moved;
+            ProfKernel &pk = c->prof_kernels[ev.name];
+            pk.klass = ev.klass;
+            pk.launches += 1;
+            pk.ms += ms;
+            pk.bytes += ev.bytes;
+            pk.moved += ev.moved;
         }
         c->prof_pool.push_back(ev.start);
         c->prof_pool.push_back(ev.stop);
@@ -295,6 +323,8 @@ struct Rccl {
     int (*GetUniqueId)(void *) = nullptr;
     void *CommInitRank = nullptr;   // int (*)(ncclComm_t*, int, ncclUniqueId, int)
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -314,6 +344,8 @@ int rccl_load() {
     g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *,
                                 hipStream_t))dlsym(lib, "ncclAllReduce");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    g_rccl.CommAbort = (int (*)(void *))dlsym(lib, "ncclCommAbort");
+    g_rccl.CommCount = (int (*)(void *, int *))dlsym(lib, "ncclCommCount");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy ||
         !g_rccl.AllReduce)
         return ESQ_ESTATE;
@@ -336,18 +368,55 @@ struct StdoutToStderr {
 };
 constexpr int kNcclFloat64 = 8;   // ncclDouble
 constexpr int kNcclSum = 0;       // ncclSum
+constexpr int kNcclMax = 2;       // ncclMax
 constexpr int kNcclMin = 3;       // ncclMin
+
+// Wait until the reduction numbered `seq` has landed in the pinned host slot.
+// The GPU writes the slot itself (no copy engine, no stream-sync wake-up: the
+// 8-byte D2H copy + hipStreamSynchronize pair cost ~15 us of every step), the
+// host spins on it.  The stream is queried now and then so that a faulted
+// kernel surfaces as an error instead of a hang; `timeout_s` > 0 bounds the
+// wait (lock-step: a peer that died never arrives at the all-reduce).
+int wait_slot(esq_ctx *c, unsigned long long seq, double timeout_s) {
+    volatile unsigned long long *flag = &c->h_slot->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spins = 1;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+        if ((spins & 0xfff) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                // everything on the stream has finished: the slot is written
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+                return fail(c, ESQ_ESTATE, "reduction %llu finished without a result", seq);
+            }
+            if (q != hipErrorNotReady)
+                return fail(c, (int)q, "stream failed while waiting for a reduction: %s",
+                            hipGetErrorString(q));
+            if (timeout_s > 0.0) {
+                const double el = std::chrono::duration<double>(
+                    std::chrono::steady_clock::now() - t0).count();
+                if (el > timeout_s) return ESQ_ETIMEOUT;
+            }
+        }
+    }
+}
 
 // partials -> one double on the host (all-reduced over the communicator if set)
 int finish_reduction(esq_ctx *c, double *out, bool take_min = false,
-                     const double *partials = nullptr) {
+                     const double *partials = nullptr, int count = -1) {
     if (!partials) partials = c->partials;
+    if (count < 0) count = (int)c->grid_reduce;
+    ResultSink rs;
+    rs.seq = ++c->red_seq;
+    rs.dev = c->comm ? c->d_result : nullptr;
+    rs.host_value = c->comm ? nullptr : &c->h_slot->value;
+    rs.host_seq = &c->h_slot->seq;
     if (take_min)
         hipLaunchKernelGGL(k_final_min, dim3(1), dim3(1024), 0, c->stream,
-                           partials, (int)c->grid_reduce, c->d_result);
+                           partials, count, rs);
     else
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(1024), 0, c->stream,
-                           partials, (int)c->grid_reduce, c->d_result);
+                           partials, count, rs);
     HIPCHK(c, hipGetLastError());
     if (c->comm) {
         int r = g_rccl.AllReduce(c->d_result, c->d_result, 1, kNcclFloat64,
@@ -356,17 +425,29 @@ int finish_reduction(esq_ctx *c, double *out, bool take_min = false,
         if (r != 0)
             return fail(c, 1000 + r, "ncclAllReduce failed: %s",
                         g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        rs.host_value = &c->h_slot->value;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream,
+                           c->d_result, rs);
+        HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_result, c->d_result, sizeof(double),
-                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (out) *out = *c->h_result;
+    int w = wait_slot(c, rs.seq, c->comm ? c->comm_timeout_s : 0.0);
+    if (w == ESQ_ETIMEOUT) {
+        // a peer never reached the collective: abort the communicator so that
+        // this rank (and, through RCCL, the others) fails instead of hanging
+        if (c->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+        c->comm = nullptr;
+        return fail(c, ESQ_ETIMEOUT, "lock-step all-reduce did not complete within "
+                    "%.0f s (a peer rank failed?); communicator aborted",
+                    c->comm_timeout_s);
+    }
+    if (w) return w;
+    if (out) *out = c->h_slot->value;
     return 0;
 }
 
 int call_rhs(esq_ctx *c, double t, const double *src, double *dst) {
     if (!c->rhs) return fail(c, ESQ_ESTATE, "no device RHS set (esq_set_rhs)");
-    Prof p(c, ESQ_PROF_RHS, 16.0 * (double)c->len, /*record_now=*/true);
+    Prof p(c, ESQ_PROF_RHS, "rhs_plugin", -1, 16.0 * (double)c->len, /*record_now=*/true);
     int r = c->rhs(c->rhs_user, t, src, dst, c->len, (void *)c->stream);
     if (r != 0) return fail(c, ESQ_ERHS, "RHS plugin returned %d", r);
     return 0;
@@ -446,15 +527,11 @@ int plan_words(const std::vector<double> &A, int s, const std::vector<int> &boun
     return total;
 }
 
-// One process per GPU is the intended use (a context never changes device), but
-// a process MAY hold contexts on several devices (threads driving one context
-// each): once that happens every entry point re-selects the context's device.
-bool g_multi_device = false;
-int g_first_device = -1;
-#define ENTER(c)                                                  \
-    do {                                                          \
-        if (g_multi_device) (void)hipSetDevice((c)->device);      \
-    } while (0)
+// One process per GPU is the intended use, but a process MAY hold contexts on
+// several devices and drive a context from any thread: hipSetDevice is
+// per-thread state and costs well under a microsecond, so every entry point
+// selects the context's device unconditionally.
+#define ENTER(c) (void)hipSetDevice((c)->device)
 
 // Device-to-host copy into a caller's (pageable) buffer.  Large copies pin the
 // destination for the duration of the call: measured for 80 MB into a fresh
@@ -526,7 +603,8 @@ static int run_block(esq_ctx *c, const esq_ctx::Block &b, double h,
     }
     // algorithmic bytes: only the folded-in stage (the other partial sums are
     // booked on the stages they serve); moved bytes: its real traffic
-    Prof p(c, ESQ_PROF_STAGE, alg, false, 8.0 * (reads + no) * (double)c->len);
+    Prof p(c, ESQ_PROF_STAGE, "k_block_acc", nt, alg, false,
+           8.0 * (reads + no) * (double)c->len);
     DISPATCH_1_20(launch_block_n, nt, c, a, no, p)
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -542,8 +620,6 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     if (!c) return ESQ_ENOMEM;
     *out = c;   // returned even on failure so the caller can read the message
     c->device = device;
-    if (g_first_device < 0) g_first_device = device;
-    else if (device != g_first_device) g_multi_device = true;
     c->n = n;
     c->cplx = is_complex != 0;
     c->len = c->cplx ? 2 * n : n;
@@ -576,7 +652,11 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     c->partials = base + 5 * c->stride;
     c->partials2 = c->partials + kMaxPartials;
     c->d_result = c->partials2 + kMaxPartials;
-    HIPCHK(c, hipHostMalloc(&c->h_result, 64, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_slot, 64,
+                            hipHostMallocMapped | hipHostMallocCoherent));
+    c->h_slot->value = 0.0;
+    c->h_slot->seq = 0;
+    c->comm_timeout_s = (double)env_uint("ESQ_COMM_TIMEOUT_S", 120);
     // launch geometry: grid-stride kernels, a few resident blocks per CU
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
@@ -610,7 +690,7 @@ int esq_destroy(esq_ctx *c) {
     for (auto &e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->slab) (void)hipFree(c->slab);
     for (double *p : c->aux_slabs) (void)hipFree(p);
-    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->h_slot) (void)hipHostFree(c->h_slot);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -708,9 +788,15 @@ int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
             plan_words(c->A, s, best, &blocks);
             int count = 0;
             for (auto &bl : blocks) count += (int)bl.stages.size();
-            int first = 0;
-            int r = esq_aux_rows(c, count, &first);
-            if (r) return r;
+            // partial-sum rows: those of an earlier plan on this context are
+            // reused (a second esq_rk_set_tableau must not leak a slab)
+            int first = c->block_rows_first;
+            if (count > c->block_rows_count) {
+                int r = esq_aux_rows(c, count, &first);
+                if (r) return r;
+                c->block_rows_first = first;
+                c->block_rows_count = count;
+            }
             std::vector<int> cur(s, -1);
             for (auto &bl : blocks) {
                 for (int i : bl.stages) {
@@ -797,8 +883,8 @@ int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
     }
     const int nt = build_row_terms(c, row.data(), i, tm, c->kmap);
     if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
-    Prof p(c, ESQ_PROF_STAGE, 8.0 * (nnz_all + 2) * (double)c->len, false,
-           8.0 * (nt + 2 + (init ? 1 : 0)) * (double)c->len);
+    Prof p(c, ESQ_PROF_STAGE, "k_lincomb", nt, 8.0 * (nnz_all + 2) * (double)c->len,
+           false, 8.0 * (nt + 2 + (init ? 1 : 0)) * (double)c->len);
     return launch_lincomb(c, c->ystage, c->y, tm, nt, h, &p, init);
 }
 
@@ -861,7 +947,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
             if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
             // booked on the stage class: next stage's algorithmic bytes + the
             // RHS's 16 B; moved: ys_in, rows, init, y in; K[i], ys_out out
-            Prof p(c, ESQ_PROF_STAGE, 8.0 * (nnz_all + 4) * (double)c->len, false,
+            Prof p(c, ESQ_PROF_STAGE, "rhs_chain", nt,
+                   8.0 * (nnz_all + 4) * (double)c->len, false,
                    8.0 * (nt + 4 + (init ? 1 : 0)) * (double)c->len);
             const int r = c->rhs_chain(c->rhs_user, t + c->C[i] * h, c->ystage,
                                        c->krow[c->kmap[i]], nt, tm.p, tm.c, c_self,
@@ -888,7 +975,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
             Terms tm;
             const int nt = build_row_terms(c, row.data(), c->s, tm, c->kmap);
             if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
-            Prof p(c, ESQ_PROF_STAGE, 8.0 * (nnz_all + 4) * (double)c->len, false,
+            Prof p(c, ESQ_PROF_STAGE, "rhs_chain", nt,
+                   8.0 * (nnz_all + 4) * (double)c->len, false,
                    8.0 * (nt + 4) * (double)c->len);
             const int r = c->rhs_chain(c->rhs_user, t + c->C[i] * h, c->ystage,
                                        c->krow[c->kmap[i]], nt, tm.p, tm.c, c_self,
@@ -916,7 +1004,7 @@ int esq_rk_solution(esq_ctx *c, double h) {
     Terms tm;
     const int nt = build_row_terms(c, c->B.data(), c->s, tm, c->kmap);
     if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
-    Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
+    Prof p(c, ESQ_PROF_SOLERR, "k_lincomb", nt, 8.0 * (nt + 2) * (double)c->len);
     return launch_lincomb(c, c->ynew, c->y, tm, nt, h, &p);
 }
 
@@ -928,7 +1016,8 @@ int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
     const int nt = build_row_terms(c, c->E.data(), c->s + c->fsal, tm, c->kmap);
     if (nt < 1) return fail(c, ESQ_EINVAL, "error weights are all zero");
     {
-        Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
+        Prof p(c, ESQ_PROF_SOLERR, "k_error_norm", nt,
+               8.0 * (nt + 2) * (double)c->len);
         DISPATCH_1_20(launch_errnorm_n, nt, c, tm, h, p)
         HIPCHK(c, hipGetLastError());
     }
@@ -952,7 +1041,8 @@ int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
     const int nt = build_row_terms2(c, c->B.data(), c->s, c->E.data(), c->s, tm, c->kmap);
     if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
     {
-        Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
+        Prof p(c, ESQ_PROF_SOLERR, "k_solution_error", nt,
+               8.0 * (nt + 2) * (double)c->len);
         DISPATCH_1_20(launch_solerr_n, nt, c, tm, h, p)
         HIPCHK(c, hipGetLastError());
     }
@@ -968,7 +1058,8 @@ int esq_rk_pre_error(esq_ctx *c, double h, const double *e_pre,
     const int nt = build_row_terms2(c, b_scale_pre, rows, e_pre, rows, tm, c->kmap);
     if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
     {
-        Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 1) * (double)c->len);
+        Prof p(c, ESQ_PROF_SOLERR, "k_pre_error", nt,
+               8.0 * (nt + 1) * (double)c->len);
         DISPATCH_1_20(launch_preerr_n, nt, c, tm, h, p)
         HIPCHK(c, hipGetLastError());
     }
@@ -985,7 +1076,8 @@ int esq_rk_custom_sol_err(esq_ctx *c, double h, const double *b, const double *e
     const int nt = build_row_terms2(c, b, rows, e, rows, tm, c->kmap);
     if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
     {
-        Prof p(c, ESQ_PROF_SOLERR, 8.0 * (nt + 2) * (double)c->len);
+        Prof p(c, ESQ_PROF_SOLERR, "k_solution_error", nt,
+               8.0 * (nt + 2) * (double)c->len);
         DISPATCH_1_20(launch_solerr_n, nt, c, tm, h, p)
         HIPCHK(c, hipGetLastError());
     }
@@ -1189,7 +1281,7 @@ int esq_rkc_first_stage(esq_ctx *c, int dst, int yn, int fn, double hmus) {
     ENTER(c);
     double *d = ROW(c, dst), *a = ROW(c, yn), *f = ROW(c, fn);
     if (!d || !a || !f) return fail(c, ESQ_EINVAL, "bad row");
-    Prof p(c, ESQ_PROF_RKC, 24.0 * (double)c->len);
+    Prof p(c, ESQ_PROF_RKC, "k_rkc_first", -1, 24.0 * (double)c->len);
     hipExtLaunchKernelGGL(k_rkc_first, dim3(c->grid_stream), dim3(kBlock), 0,
                           c->stream, p.start(), p.stop(), 0, d, a, f, hmus,
                           c->len_pad / 2);
@@ -1204,7 +1296,7 @@ int esq_rkc_stage(esq_ctx *c, int dst, int fy, int yjm1, int yjm2, int yn, int f
            *y0 = ROW(c, yn), *g = ROW(c, fn);
     if (!d || !f || !a || !b || !y0 || !g) return fail(c, ESQ_EINVAL, "bad row");
     const double omn = (1.0 - mu) - nu;   // (1.0 - mu - nu), left to right
-    Prof p(c, ESQ_PROF_RKC, 48.0 * (double)c->len);
+    Prof p(c, ESQ_PROF_RKC, "k_rkc_stage", -1, 48.0 * (double)c->len);
     hipExtLaunchKernelGGL(k_rkc_stage, dim3(c->grid_stream), dim3(kBlock), 0,
                           c->stream, p.start(), p.stop(), 0, d, f, a, b, y0, g,
                           mu, nu, omn, hmus, ajm1, c->len_pad / 2);
@@ -1237,7 +1329,7 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
                    *y0 = ROW(c, yn), *g = ROW(c, fn);
             if (!d || !a || !b || !y0 || !g) return fail(c, ESQ_EINVAL, "bad row");
             const double omn = (1.0 - sc[0]) - sc[1];
-            Prof p(c, ESQ_PROF_RKC, 64.0 * (double)c->len, false,
+            Prof p(c, ESQ_PROF_RKC, "rhs_rkc", -1, 64.0 * (double)c->len, false,
                    40.0 * (double)c->len);
             r = c->rhs_rkc(c->rhs_user, sc[4], a, b, y0, g, sc[0], sc[1], omn,
                            sc[2], sc[3], d, c->len, (void *)c->stream,
@@ -1277,7 +1369,7 @@ int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
     if (!a || !b || !f || !g) return fail(c, ESQ_EINVAL, "bad row");
     if (c->cplx) return fail(c, ESQ_EINVAL, "RKC is real-only (sommeijer.py:98)");
     {
-        Prof p(c, ESQ_PROF_SOLERR, 32.0 * (double)c->len);
+        Prof p(c, ESQ_PROF_SOLERR, "k_rkc_error", -1, 32.0 * (double)c->len);
         hipExtLaunchKernelGGL(k_rkc_error, dim3(c->grid_reduce), dim3(kBlock), 0,
                            c->stream, p.start(), p.stop(), 0, a, b, f, g, h,
                            c->atol_is_vec ? c->atolv : nullptr, c->atol_s, c->rtol,
@@ -1462,6 +1554,56 @@ int esq_comm_init_rank(void **comm_out, int nranks, const void *id128, int rank,
     int r = ((init_rank_fn)g_rccl.CommInitRank)(comm_out, nranks, id, rank);
     return r ? 1000 + r : 0;
 }
+int esq_comm_count(void *comm, int *nranks_out) {
+    if (!comm || !nranks_out) return ESQ_EINVAL;
+    if (rccl_load() != 0 || !g_rccl.CommCount) return ESQ_ESTATE;
+    int r = g_rccl.CommCount(comm, nranks_out);
+    return r ? 1000 + r : 0;
+}
+int esq_comm_abort(void *comm) {
+    if (!comm) return 0;
+    StdoutToStderr guard;
+    if (rccl_load() != 0 || !g_rccl.CommAbort) return ESQ_ESTATE;
+    int r = g_rccl.CommAbort(comm);
+    return r ? 1000 + r : 0;
+}
+// all-reduce of a few host scalars over the context's communicator (identity
+// without one): the lock-step mode's rank-local scalars that feed h or the stage
+// count (spectral-radius estimates, debug cross-checks)
+int esq_allreduce_scalars(esq_ctx *c, double *inout, int count, int op) {
+    if (!c || !inout || count < 1 || count > 4) return ESQ_EINVAL;
+    ENTER(c);
+    if (!c->comm) return 0;
+    const int nccl_op = op == ESQ_OP_SUM ? kNcclSum : op == ESQ_OP_MIN ? kNcclMin
+                      : op == ESQ_OP_MAX ? kNcclMax : -1;
+    if (nccl_op < 0) return fail(c, ESQ_EINVAL, "bad reduction op %d", op);
+    double *d = c->d_result + 4;
+    HIPCHK(c, hipMemcpyAsync(d, inout, count * sizeof(double), hipMemcpyHostToDevice,
+                             c->stream));
+    int r = g_rccl.AllReduce(d, d, (size_t)count, kNcclFloat64, nccl_op, c->comm,
+                             c->stream);
+    if (r != 0)
+        return fail(c, 1000 + r, "ncclAllReduce failed: %s",
+                    g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    HIPCHK(c, hipMemcpyAsync(inout, d, count * sizeof(double), hipMemcpyDeviceToHost,
+                             c->stream));
+    // bounded wait, like finish_reduction
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady)
+            return fail(c, (int)q, "all-reduce failed: %s", hipGetErrorString(q));
+        const double el = std::chrono::duration<double>(
+            std::chrono::steady_clock::now() - t0).count();
+        if (el > c->comm_timeout_s) {
+            if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+            c->comm = nullptr;
+            return fail(c, ESQ_ETIMEOUT, "lock-step all-reduce timed out after %.0f s; "
+                        "communicator aborted", c->comm_timeout_s);
+        }
+    }
+}
 int esq_comm_destroy(void *comm) {
     if (!comm) return 0;
     StdoutToStderr guard;
@@ -1500,6 +1642,23 @@ int esq_profile_read_moved(esq_ctx *c, int klass, double *moved_bytes) {
     *moved_bytes = c->prof_moved[klass];
     return 0;
 }
+int esq_profile_kernels(esq_ctx *c, char *buf, size_t buflen) {
+    if (!c || !buf || buflen < 2) return ESQ_EINVAL;
+    ENTER(c);
+    prof_drain(c);
+    size_t used = 0;
+    buf[0] = 0;
+    for (const auto &kv : c->prof_kernels) {
+        const ProfKernel &k = kv.second;
+        const int w = snprintf(buf + used, buflen - used, "%s\t%d\t%ld\t%.9g\t%.17g\t%.17g\n",
+                               kv.first.c_str(), k.klass, k.launches, k.ms, k.bytes,
+                               k.moved);
+        if (w < 0 || (size_t)w >= buflen - used)
+            return fail(c, ESQ_EINVAL, "profile table needs a larger buffer");
+        used += (size_t)w;
+    }
+    return 0;
+}
 int esq_profile_reset(esq_ctx *c) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
@@ -1509,6 +1668,7 @@ int esq_profile_reset(esq_ctx *c) {
         c->prof_moved[k] = 0;
         c->prof_seen[k] = 0;
     }
+    c->prof_kernels.clear();
     return 0;
 }
 

@@ -202,9 +202,29 @@ __device__ __forceinline__ void block_partial(double v, double *partials) {
     }
 }
 
-// final deterministic sum of the per-block partials (one block)
+// Where a reduction's result goes: a device double (input of the lock-step
+// all-reduce) and/or a pinned host slot the host polls.  The value is stored
+// first, then -- behind a system-scope release -- the sequence number of this
+// reduction, so a host that reads seq == expected also reads the value.
+struct ResultSink {
+    double *dev;                       // may be nullptr
+    double *host_value;                // pinned host memory, may be nullptr
+    unsigned long long *host_seq;
+    unsigned long long seq;
+};
+__device__ __forceinline__ void publish(const ResultSink &rs, double v) {
+    if (rs.dev) *rs.dev = v;
+    if (rs.host_value) {
+        __hip_atomic_store(rs.host_value, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(rs.host_seq, rs.seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// final deterministic sum of the per-block partials (one block of 1024):
+// thread-strided partial sums, wave64 tree, 16 waves through LDS
 __global__ __launch_bounds__(1024) void k_final_sum(
-    const double *__restrict__ partials, int count, double *__restrict__ out) {
+    const double *__restrict__ partials, int count, ResultSink rs) {
     __shared__ double lds[16];
     double s = 0.0;
     for (int i = threadIdx.x; i < count; i += 1024) s += partials[i];
@@ -215,7 +235,14 @@ __global__ __launch_bounds__(1024) void k_final_sum(
         double t = lds[0];
 #pragma unroll
         for (int w = 1; w < 16; ++w) t += lds[w];
-        *out = t;
+        publish(rs, t);
+    }
+}
+// after the lock-step all-reduce: device double -> host slot
+__global__ void k_publish(const double *__restrict__ src, ResultSink rs) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        rs.dev = nullptr;
+        publish(rs, *src);
     }
 }
 
@@ -527,7 +554,7 @@ __global__ __launch_bounds__(kBlock) void k_log_etol(
     }
 }
 __global__ __launch_bounds__(1024) void k_final_min(
-    const double *__restrict__ partials, int count, double *__restrict__ out) {
+    const double *__restrict__ partials, int count, ResultSink rs) {
     __shared__ double lds[16];
     double m = INFINITY;
     for (int i = threadIdx.x; i < count; i += 1024) m = fmin(m, partials[i]);
@@ -539,7 +566,7 @@ __global__ __launch_bounds__(1024) void k_final_min(
         double t = lds[0];
 #pragma unroll
         for (int w = 1; w < 16; ++w) t = fmin(t, lds[w]);
-        *out = t;
+        publish(rs, t);
     }
 }
 // next perturbation direction (common.py:700-714):

@@ -174,6 +174,19 @@ class DeviceContext:
                   "esq_profile_read")
         return ms.value, cnt.value, by.value
 
+    def profile_kernels(self):
+        """per-kernel rows since the last reset:
+        (name, class, launches, total_ms, algorithmic_bytes, moved_bytes)"""
+        buf = C.create_string_buffer(1 << 16)
+        self._chk(self.lib.esq_profile_kernels(self.handle, buf, len(buf)),
+                  "esq_profile_kernels")
+        rows = []
+        for line in buf.value.decode().splitlines():
+            name, klass, launches, ms, alg, moved = line.split("\t")
+            rows.append((name, int(klass), int(launches), float(ms), float(alg),
+                         float(moved)))
+        return rows
+
     def profile_read_moved(self, klass):
         mv = C.c_double()
         self._chk(self.lib.esq_profile_read_moved(self.handle, klass,
@@ -199,7 +212,8 @@ class DeviceRHS:
 
     def __init__(self):
         self._bound = {}       # device -> (fn, user)
-        self._host_ctx = None
+        self._host_ctx = {}    # device -> DeviceContext of __call__
+        self._last_device = 0
 
     def _create(self, lib, device):
         raise NotImplementedError
@@ -216,6 +230,7 @@ class DeviceRHS:
         if ctx.n != self.n:
             raise ValueError(f"RHS is for n={self.n}, solver state has n={ctx.n}")
         key = ctx.device
+        self._last_device = key
         if key not in self._bound:
             self._bound[key] = self._create(ctx.lib, ctx.device)
         return self._bound[key]
@@ -224,10 +239,14 @@ class DeviceRHS:
         y = np.asarray(y)
         if y.ndim != 1:
             raise ValueError("device RHS plugins take one state vector")
-        if self._host_ctx is None:
-            self._host_ctx = DeviceContext(self.n, 2, self.is_complex)
-            self._host_ctx.set_rhs(self)
-        ctx = self._host_ctx
+        # evaluate on the device this RHS was last bound to (a rank with
+        # LOCAL_RANK != 0 must not allocate on GPU 0)
+        device = self._last_device
+        ctx = self._host_ctx.get(device)
+        if ctx is None:
+            ctx = DeviceContext(self.n, 2, self.is_complex, device)
+            ctx.set_rhs(self)
+            self._host_ctx[device] = ctx
         ctx.upload(SLOT_Y, 0, y)
         ctx._chk(ctx.lib.esq_rk_eval_rhs(ctx.handle, 0, float(t), SLOT_Y, 0),
                  "esq_rk_eval_rhs")
@@ -235,9 +254,9 @@ class DeviceRHS:
 
     def close(self):
         lib = _lib.load()
-        if self._host_ctx is not None:
-            self._host_ctx.close()
-            self._host_ctx = None
+        for ctx in self._host_ctx.values():
+            ctx.close()
+        self._host_ctx = {}
         for fn, user in self._bound.values():
             if user:
                 lib.esq_rhs_free(user)
@@ -372,7 +391,7 @@ class CFunctionRHS(DeviceRHS):
         return self._fn, None if self._user is None else self._user
 
     def close(self):
-        if self._host_ctx is not None:
-            self._host_ctx.close()
-            self._host_ctx = None
+        for ctx in self._host_ctx.values():
+            ctx.close()
+        self._host_ctx = {}
         self._bound = {}

@@ -82,6 +82,109 @@ def rendezvous(rank, world_size, n_local, make_id, addr=None, port=None,
     return payload[8:], total
 
 
+class ControlGroup:
+    """Host-side control plane of a multi-rank run (bench.py, tests): a TCP star
+    on MASTER_ADDR:MASTER_PORT+1 with rank 0 at the centre.  It carries what the
+    data path never does -- the 128-byte ncclUniqueId, shard sizes, barriers and
+    max-over-ranks timings -- so neither the package nor the benchmark needs
+    PyTorch.  Every call is collective (all ranks, same order)."""
+
+    _OPS = {"sum": sum, "max": max, "min": min}
+
+    def __init__(self, rank, world_size, addr=None, port=None, timeout=300.0):
+        self.rank, self.world = int(rank), int(world_size)
+        self._peers = []          # rank 0: sockets of ranks 1..world-1, by rank
+        self._sock = None         # other ranks: socket to rank 0
+        if self.world == 1:
+            return
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port or int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            by_rank = {}
+            try:
+                for _ in range(self.world - 1):
+                    conn, _a = srv.accept()
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    (peer,) = struct.unpack("<q", _recv_exact(conn, 8))
+                    by_rank[peer] = conn
+            finally:
+                srv.close()
+            self._peers = [by_rank[r] for r in range(1, self.world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    sock = socket.create_connection((addr, port), timeout=timeout)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            sock.sendall(struct.pack("<q", self.rank))
+            self._sock = sock
+
+    # -- framing: 8-byte length + payload
+    @staticmethod
+    def _send(sock, payload):
+        sock.sendall(struct.pack("<q", len(payload)) + payload)
+
+    @staticmethod
+    def _recv(sock):
+        (size,) = struct.unpack("<q", _recv_exact(sock, 8))
+        return _recv_exact(sock, size) if size else b""
+
+    def allreduce(self, values, op="sum"):
+        """element-wise reduction of a list of floats over all ranks"""
+        values = [float(v) for v in values]
+        if self.world == 1:
+            return values
+        fmt = "<%dd" % len(values)
+        if self.rank == 0:
+            rows = [values] + [list(struct.unpack(fmt, self._recv(c)))
+                               for c in self._peers]
+            out = [self._OPS[op](col) for col in zip(*rows)]
+            blob = struct.pack(fmt, *out)
+            for c in self._peers:
+                self._send(c, blob)
+            return out
+        self._send(self._sock, struct.pack(fmt, *values))
+        return list(struct.unpack(fmt, self._recv(self._sock)))
+
+    def broadcast(self, payload=None):
+        """bytes from rank 0 to everyone"""
+        if self.world == 1:
+            return payload
+        if self.rank == 0:
+            for c in self._peers:
+                self._send(c, payload)
+            return payload
+        return self._recv(self._sock)
+
+    def barrier(self):
+        self.allreduce([0.0])
+
+    def exchange(self, make_id, n_local):
+        """the `exchange` hook of `init_lockstep`: ncclUniqueId from rank 0 and
+        the summed shard size"""
+        ident = self.broadcast(make_id() if self.rank == 0 else None)
+        total = self.allreduce([float(n_local)], "sum")[0]
+        return ident, int(round(total))
+
+    def close(self):
+        for c in self._peers:
+            c.close()
+        if self._sock is not None:
+            self._sock.close()
+        self._peers, self._sock = [], None
+
+
 def _rccl_unique_id():
     buf = C.create_string_buffer(_ID_BYTES)
     _lib.check(_lib.load().esq_comm_unique_id(buf), None, "esq_comm_unique_id")
@@ -94,8 +197,8 @@ def init_lockstep(rank, world_size, device, n_local, addr=None, port=None,
     to pass as `lockstep=` to a solver constructor.
 
     `exchange(make_id, n_local) -> (id_bytes, n_total)` may replace the built-in
-    TCP rendezvous (bench.py passes one that rides on its torch.distributed
-    gloo group, so no second port is needed)."""
+    one-shot TCP rendezvous (bench.py passes `ControlGroup.exchange`, which rides
+    on its persistent control connections)."""
     lib = _lib.load()
     if exchange is not None:
         ident, n_total = exchange(_rccl_unique_id, n_local)
@@ -107,6 +210,22 @@ def init_lockstep(rank, world_size, device, n_local, addr=None, port=None,
     _lib.check(lib.esq_comm_init_rank(C.byref(comm), world_size, buf, rank,
                                       device), None, "esq_comm_init_rank")
     return LockstepGroup(comm, n_total)
+
+
+def comm_size(group):
+    """number of ranks RCCL reports for the group's communicator"""
+    out = C.c_int(0)
+    _lib.check(_lib.load().esq_comm_count(group.comm, C.byref(out)), None,
+               "esq_comm_count")
+    return out.value
+
+
+def abort_lockstep(group):
+    """ncclCommAbort: called by a rank that fails outside a collective so that
+    its peers' pending all-reduce errors out instead of blocking"""
+    if group is not None and group.comm:
+        _lib.load().esq_comm_abort(group.comm)
+        group.comm = None
 
 
 def destroy_lockstep(group):

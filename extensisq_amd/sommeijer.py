@@ -120,6 +120,7 @@ class SSV2stab(OdeSolver):
         self._r = dict(yn=0, fn=1, w=[2, 3, 4], yold=5, fold=6, V=7)
         self._have_V = False
         self._n_norm = self.n
+        self._lockstep = lockstep
         if lockstep is not None:
             self._dev._chk(self._lib.esq_set_comm(self._ctx, lockstep.comm),
                            "esq_set_comm")
@@ -278,6 +279,21 @@ class SSV2stab(OdeSolver):
                 self._dev.upload(SLOT_K, v, vec)
         return None
 
+    def _spectral_radius(self, t):
+        """spectral radius for the next step (ref sommeijer.py:174-204): the
+        user's `rho_jac(t, y)` or the power iteration.  In a lock-step batch
+        every rank sees only its own shard's `y`, so a y-dependent bound
+        differs from rank to rank; the batch uses the LARGEST one (the spectral
+        radius of the block-diagonal Jacobian of the concatenated system) --
+        otherwise the ranks would choose different m and h.  The power
+        iteration needs no exchange: its norms are all-reduced sums already."""
+        if self.rho_jac is None:
+            return self._rho(t)
+        sprad = self.rho_jac(t, self.y)
+        if self._lockstep is not None:
+            sprad = self._lockstep.allreduce(self._dev, [sprad], "max")[0]
+        return sprad
+
     # ------------------------------------------------------------------ step
     def _step_impl(self):
         """ref sommeijer.py:162-271 (subroutine RKCLOW of rkc.f)"""
@@ -286,13 +302,10 @@ class SSV2stab(OdeSolver):
         r = self._r
         while True:
             if self.newspc:
-                if self.rho_jac is not None:
-                    self.sprad = self.rho_jac(t, self.y)
-                else:
-                    self.sprad = self._rho(t)
-                    if self.sprad is None:
-                        return False, ("The method to estimate the spectral "
-                                       "radius of the Jacobian did not converge")
+                self.sprad = self._spectral_radius(t)
+                if self.sprad is None:
+                    return False, ("The method to estimate the spectral "
+                                   "radius of the Jacobian did not converge")
                 self.jacatt = True
             if absh is None:
                 absh = self._init_step_size(t)
@@ -311,6 +324,8 @@ class SSV2stab(OdeSolver):
             h = self.direction * absh
             hmin = max(self.sqrtmin,
                        13.3 * self.uround * (abs(t) + absh) * (m ** 2 - 1))
+            if self._lockstep is not None:
+                self._lockstep.check_identical(self._dev, "(t, h, m)", (t, h, m))
             yrow = self._stages(t, h, m)
             fyrow = next(w for w in r["w"] if w != yrow)
             self._eval_rhs(fyrow, t + h, yrow)

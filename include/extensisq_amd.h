@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ESQ_ABI_VERSION 1
+#define ESQ_ABI_VERSION 2
 
 /* error codes (negative = misuse) */
 #define ESQ_EINVAL   (-1)   /* bad argument (row/slot out of range, NULL, ...) */
@@ -42,6 +42,7 @@ extern "C" {
 #define ESQ_ENOMEM   (-3)   /* host allocation failed                          */
 #define ESQ_ERHS     (-4)   /* the RHS plugin returned non-zero                */
 #define ESQ_ENOTSUP  (-5)   /* optional plugin entry cannot handle this case   */
+#define ESQ_ETIMEOUT (-6)   /* a lock-step collective did not complete in time */
 
 /* vector slots of a context (row is ignored unless slot == ESQ_SLOT_K) */
 #define ESQ_SLOT_K       0  /* stage derivatives K[row], row < n_rows          */
@@ -295,6 +296,22 @@ int  esq_comm_unique_id(void *id128_out);              /* 128-byte ncclUniqueId 
 int  esq_comm_init_rank(void **comm_out, int nranks, const void *id128, int rank,
                         int device);
 int  esq_comm_destroy(void *comm);
+/* number of ranks RCCL reports for the communicator (bench.py echoes it) */
+int  esq_comm_count(void *comm, int *nranks_out);
+/* ncclCommAbort: a rank that fails outside a collective calls this before it
+ * exits so that its peers' pending all-reduce ends with an error instead of
+ * blocking.  The library itself aborts the communicator when an all-reduce does
+ * not complete within ESQ_COMM_TIMEOUT_S (default 120 s) and returns
+ * ESQ_ETIMEOUT. */
+int  esq_comm_abort(void *comm);
+/* all-reduce `count` (<= 4) host doubles in place over the context's
+ * communicator; a no-op without one.  Used for the rank-local scalars that feed
+ * the step size or the stage count (SSV2stab's spectral radius,
+ * sommeijer.py:174-204) so that all ranks stay in lock-step. */
+#define ESQ_OP_SUM 0
+#define ESQ_OP_MAX 1
+#define ESQ_OP_MIN 2
+int  esq_allreduce_scalars(esq_ctx *ctx, double *inout, int count, int op);
 
 /* ---- built-in device RHS plugins (synthetic workloads of BASELINE.json) --- */
 /* each *_create returns an opaque `user` pointer to pass with the matching
@@ -358,6 +375,10 @@ int  esq_profile_read(esq_ctx *ctx, int klass, double *total_ms, long *launches,
  * algorithmic bytes except where blocked accumulation reads K rows once for
  * several stages) */
 int  esq_profile_read_moved(esq_ctx *ctx, int klass, double *moved_bytes);
+/* per-kernel table since the last reset, one line per kernel label:
+ *   name \t class \t launches \t total_ms \t algorithmic_bytes \t moved_bytes \n
+ * (NUL-terminated text in buf; bench.py's `roofline.kernels`) */
+int  esq_profile_kernels(esq_ctx *ctx, char *buf, size_t buflen);
 int  esq_profile_reset(esq_ctx *ctx);
 
 #ifdef __cplusplus

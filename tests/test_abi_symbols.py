@@ -37,7 +37,7 @@ def test_python_binding_covers_the_header():
     from extensisq_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     bound = _lib.load()
-    assert bound.esq_abi_version() == 1
+    assert bound.esq_abi_version() == _lib.ABI_VERSION
 
 
 def test_misuse_is_reported_not_crashing(lib):

@@ -41,7 +41,7 @@ def traces(golden_dir):
 def test_library_is_the_hip_build():
     from extensisq_amd import _lib
     lib = _lib.load()
-    assert lib.esq_abi_version() == 1
+    assert lib.esq_abi_version() == _lib.ABI_VERSION
     assert os.path.basename(_lib.LIB_PATH) == "libextensisq_amd.so"
 
 

@@ -1,11 +1,19 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 outputs of tools/profile_bench.sh (gpurun_out/prof_*)
-into small tracked files under profiles/:
-    profiles/rNN_kernel_stats.csv      rocprofv3 --kernel-trace --stats summary
-    profiles/rNN_pmc_traffic.json      per-kernel HBM traffic from the PMC passes
-Usage: python tools/summarize_profiles.py r01
+into small tracked files under profiles/ and print the roofline figure they give:
+    profiles/rNN_kernel_stats_<config>.csv   rocprofv3 --kernel-trace --stats summary
+    profiles/rNN_pmc_traffic_<config>.json   per-kernel HBM traffic (PMC passes) +
+                                             the dominant class's bytes, time, rate
+    profiles/rNN_bench_<config>.json         bench.py's JSON line of the same command
+Usage: python tools/summarize_profiles.py r02 [config ...]      (default: pr8)
+
 FETCH_SIZE is doubled (gfx950 reports exactly half of the bytes of wide coalesced
 reads, MI355X_MICROARCH.md §HBM); WRITE_SIZE is exact; both are in KiB.
+
+Kernel names are folded onto the labels of bench.py's `roofline.kernels` table so
+that the two sources can be laid side by side: the figure printed here
+(PMC bytes / rocprof kernel time / 8 TB/s) must agree with bench.py's
+`roofline.frac` (designed bytes / event time / 8 TB/s).
 """
 import collections
 import csv
@@ -18,59 +26,118 @@ import sys
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
+PEAK = 8.0e12
+
+STAGE = ("k_lincomb", "k_block_acc", "rhs_chain", "rhs+stage", "rhs+block")
+RKC = ("rhs_rkc", "k_rkc_first", "k_rkc_stage")
+
+
+def label(name):
+    """rocprof kernel name -> bench.py kernel label"""
+    m = re.search(r"k_(bruss2d|heat2d|diff3d)_sweep<.*Epi(\w+)<(\d+)", name)
+    if m:                                   # fused sweeps (round 2)
+        return f"rhs+{m.group(2).lower()}<{m.group(3)}>"
+    m = re.search(r"k_(bruss2d|heat2d)_chain<(\d+)>", name)
+    if m:
+        return f"rhs_chain<{m.group(2)}>"
+    m = re.search(r"k_(heat2d|diff3d)_v2<\d+, (true|false)>", name)
+    if m:
+        return "rhs_rkc" if m.group(2) == "true" else "rhs_plugin"
+    if re.search(r"k_(bruss2d|heat2d|diff3d|diag)", name):
+        return "rhs_plugin"
+    m = re.search(r"(k_[a-z0-9_]+)<(\d+)", name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.search(r"(k_[a-z0-9_]+)", name)
+    return m.group(1) if m else name[:40]
 
 
 def mean_counter(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        agg[label(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
-def short(name):
-    m = re.search(r"(k_[a-z0-9_]+(<[^>(]*>)?)", name)
-    return m.group(1) if m else name[:40]
-
-
-def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    os.makedirs(P, exist_ok=True)
-    shutil.copy(os.path.join(G, "prof_stats", "bench_kernel_stats.csv"),
-                os.path.join(P, f"{tag}_kernel_stats.csv"))
-    fetch = mean_counter(os.path.join(G, "prof_fetch", "bench_counter_collection.csv"))
-    write = mean_counter(os.path.join(G, "prof_write", "bench_counter_collection.csv"))
-    stats = {r["Name"]: r for r in csv.DictReader(
-        open(os.path.join(G, "prof_stats", "bench_kernel_stats.csv")))}
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- "
-                      "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+def one(tag, cfg):
+    stats_csv = os.path.join(G, f"prof_{cfg}_stats", "bench_kernel_stats.csv")
+    shutil.copy(stats_csv, os.path.join(P, f"{tag}_kernel_stats_{cfg}.csv"))
+    bench = None
+    try:
+        with open(os.path.join(G, f"prof_{cfg}_bench.json")) as fh:
+            bench = json.loads(fh.read().strip().splitlines()[-1])
+        with open(os.path.join(P, f"{tag}_bench_{cfg}.json"), "w") as fh:
+            json.dump(bench, fh, indent=1)
+    except Exception as exc:                               # noqa: BLE001
+        print(f"[{cfg}] no bench JSON: {exc}")
+    fetch = mean_counter(os.path.join(G, f"prof_{cfg}_fetch",
+                                      "bench_counter_collection.csv"))
+    write = mean_counter(os.path.join(G, f"prof_{cfg}_write",
+                                      "bench_counter_collection.csv"))
+    stats = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(stats_csv)):
+        if "rocclr" in r["Name"]:
+            continue
+        s = stats[label(r["Name"])]
+        s[0] += int(r["Calls"])
+        s[1] += float(r["TotalDurationNs"])
+    out = {"command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- "
+                      f"python3 bench.py --config {cfg} --steps 3 --warmup 1; "
+                      f"kernel times: rocprofv3 --kernel-trace --stats -- python3 "
+                      f"bench.py --config {cfg} --steps 20 --warmup 5",
            "note": "bytes per launch; fetch = 2 x FETCH_SIZE KiB (gfx950 "
                    "correction), write = WRITE_SIZE KiB",
            "kernels": {}}
-    st_bytes = st_launch = 0.0
-    st_ns = st_calls = 0.0
-    for k in sorted(fetch):
-        if "rocclr" in k:
-            continue
-        f_b = 2.0 * fetch[k][0] * 1024.0
+    dom = STAGE if cfg != "rkc" else RKC
+    d_bytes = d_ns = d_calls = 0.0
+    all_bytes = all_ns = 0.0
+    events = (bench or {}).get("roofline", {}).get("kernels", {})
+    for k in sorted(stats):
+        calls, ns = stats[k]
+        f_b = 2.0 * fetch.get(k, (0.0, 0))[0] * 1024.0
         w_b = write.get(k, (0.0, 0))[0] * 1024.0
-        rec = {"fetch_bytes": f_b, "write_bytes": w_b, "hbm_bytes": f_b + w_b,
-               "launches_sampled": fetch[k][1]}
-        if k in stats:
-            rec["avg_ns_kernel_trace"] = float(stats[k]["AverageNs"])
-            rec["calls_kernel_trace"] = int(stats[k]["Calls"])
-        out["kernels"][short(k)] = rec
-        if ("k_lincomb" in k or "k_block_acc" in k or "_chain<" in k) and k in stats:
-            st_bytes += (f_b + w_b) * int(stats[k]["Calls"])
-            st_launch += int(stats[k]["Calls"])
-            st_ns += float(stats[k]["TotalDurationNs"])
-            st_calls += int(stats[k]["Calls"])
-    out["stage_accumulate"] = {
-        "hbm_bytes_per_launch": st_bytes / st_launch if st_launch else None,
-        "avg_launch_ns_kernel_trace": st_ns / st_calls if st_calls else None,
+        rec = {"calls_kernel_trace": calls, "avg_ns_kernel_trace": ns / calls,
+               "fetch_bytes": f_b, "write_bytes": w_b, "hbm_bytes": f_b + w_b,
+               "gbs": (f_b + w_b) / (ns / calls) if calls else None}
+        if k in events:
+            rec["bench_avg_us_events"] = events[k]["avg_us"]
+            rec["bench_designed_bytes"] = events[k]["moved_bytes_per_launch"]
+        out["kernels"][k] = rec
+        all_bytes += (f_b + w_b) * calls
+        all_ns += ns
+        if k.split("<")[0] in dom:
+            d_bytes += (f_b + w_b) * calls
+            d_ns += ns
+            d_calls += calls
+    out["dominant_class"] = {
+        "members": [k for k in out["kernels"] if k.split("<")[0] in dom],
+        "hbm_bytes_per_launch": d_bytes / d_calls if d_calls else None,
+        "avg_launch_ns_kernel_trace": d_ns / d_calls if d_calls else None,
+        "gbs_pmc": d_bytes / d_ns if d_ns else None,
+        "frac_of_8TBs_pmc": d_bytes / d_ns * 1e9 / PEAK if d_ns else None,
     }
-    with open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w") as fh:
+    out["all_kernels"] = {"gbs_pmc": all_bytes / all_ns if all_ns else None,
+                          "frac_of_8TBs_pmc": all_bytes / all_ns * 1e9 / PEAK
+                          if all_ns else None}
+    if bench:
+        out["bench_roofline"] = {k: bench["roofline"].get(k) for k in (
+            "achieved", "frac", "avg_launch_us", "moved_bytes_per_launch",
+            "algorithmic_gbs", "whole_step_gbs")}
+        out["bench_value"] = bench["value"]
+        out["bench_ms_per_step"] = bench["ms_per_step"]
+    with open(os.path.join(P, f"{tag}_pmc_traffic_{cfg}.json"), "w") as fh:
         json.dump(out, fh, indent=1)
-    print(json.dumps(out["stage_accumulate"]))
+    print(f"[{cfg}] dominant class from profiles/: "
+          f"{json.dumps(out['dominant_class'])}")
+    if bench:
+        print(f"[{cfg}] bench.py roofline: {json.dumps(out['bench_roofline'])}")
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    os.makedirs(P, exist_ok=True)
+    for cfg in (sys.argv[2:] or ["pr8"]):
+        one(tag, cfg)
 
 
 if __name__ == "__main__":
