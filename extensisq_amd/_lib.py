@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libextensisq_amd.so")
 
 ABI_VERSION = 2
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
+EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
+FUSE_ALL = 0x1e
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
 PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC = range(4)
 VEC_NONE, VEC_Y, VEC_YNEW, VEC_YSTAGE, VEC_WORK = -1, -2, -3, -4, -5
@@ -38,7 +40,7 @@ SIGNATURES = {
     "esq_rk_set_tableau": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "esq_set_tol": (C.c_int, [_vp, C.c_double, _vp, C.c_size_t]),
     "esq_set_rhs": (C.c_int, [_vp, _vp, _vp]),
-    "esq_set_rhs_chain": (C.c_int, [_vp, _vp]),
+    "esq_set_rhs_fused": (C.c_int, [_vp, _vp, C.c_int]),
     "esq_set_rhs_rkc": (C.c_int, [_vp, _vp]),
     "esq_rk_stage_accumulate": (C.c_int, [_vp, C.c_int, C.c_double]),
     "esq_rk_block_plan": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int,
@@ -51,7 +53,7 @@ SIGNATURES = {
     "esq_rk_pre_error": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _dp]),
     "esq_rk_custom_sol_err": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, C.c_int,
                                         _dp]),
-    "esq_rk_accept": (C.c_int, [_vp, C.c_double, C.c_int]),
+    "esq_rk_accept": (C.c_int, [_vp, C.c_double, C.c_int, C.c_double]),
     "esq_rk_error_vector": (C.c_int, [_vp, C.c_double, C.c_int]),
     "esq_rk_row_id": (C.c_int, [_vp, C.c_int, C.c_int]),
     "esq_rk_download_last_K": (C.c_int, [_vp, C.c_int, _vp]),
@@ -101,10 +103,9 @@ SIGNATURES = {
     "esq_rhs_diff3d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
     "esq_rhs_heat2d_rkc": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp] + [C.c_double] * 5 + [_vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_diff3d_rkc": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp] + [C.c_double] * 5 + [_vp, C.c_size_t, _vp, _vp, _vp]),
-    "esq_rhs_bruss2d_chain": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp,
-                                        C.c_double, _vp, C.c_size_t, _vp, _vp, _vp]),
-    "esq_rhs_heat2d_chain": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp,
-                                        C.c_double, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_bruss2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_heat2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_diag_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_profile_enable": (C.c_int, [_vp, C.c_int]),
     "esq_profile_sampling": (C.c_int, [_vp, C.c_int]),
     "esq_profile_read": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_long), _dp]),

@@ -64,7 +64,7 @@ class BS5(RungeKutta):
             h_abs *= self._reject_factor(error_norm)
             NFS[()] += 1
             self.jflstp += 1
-        self._finish_step(t_new, h)
+        self._finish_step(t_new, h, h_abs)
         self.h_previous = h
         self.h_abs = h_abs
         self.error_norm_old = error_norm

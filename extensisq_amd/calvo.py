@@ -48,7 +48,7 @@ class CFMR7osc(RungeKutta):
             self.jflstp += 1
             if np.isnan(error_norm) or np.isinf(error_norm):
                 return False, "Overflow or underflow encountered."
-        self._finish_step(t_new, h)
+        self._finish_step(t_new, h, h_abs)
         self.h_previous = h
         self.h_abs = h_abs
         self.error_norm_old = error_norm

@@ -68,7 +68,9 @@ class CKdisc(RungeKutta):
                 esttol = E2 / quit[1]
                 if E2 < twiddle[1] * quit[1]:
                     self._run_stages(4, 6, t, h)
-                    E4 = self._pair_norm(h, self.B, self.E, 6, True) ** (1 / 5)
+                    # the tableau's own pair: `_comp_sol_err` of the base class
+                    # (fused into the last stage's sweep where the plugin can)
+                    E4 = self._solution_and_error(t, h) ** (1 / 5)
                     E4 = E4 or 1e-160
                     esttol = E4
                     if E4 < 1:
@@ -114,7 +116,7 @@ class CKdisc(RungeKutta):
             NFS[()] += 1
         # the derivative at the accepted point (next first stage, interpolation)
         t_new = t + h
-        self._finish_step(t_new, h)
+        self._finish_step(t_new, h, h_abs)
         self.order_accepted = order_accepted
         self.h_previous = h
         self.h_abs = h_abs

@@ -614,21 +614,27 @@ class RungeKutta(OdeSolver):
         self.standard_sc = True
 
     # ------------------------------------------------------- host controller
-    def _reassess_stepsize(self, t, y=None):
+    def _limit_step(self, t, h_abs):
         """clip to [min_step, max_step]; look ahead over the last two steps
-        (ref common.py:310-331)"""
-        h_abs = self.h_abs
+        (ref common.py:310-331).  Pure: returns (h_abs, min_step, reset_sc)."""
+        reset = False
         min_step = max(self.h_min_a * (abs(t) + h_abs), self.h_min_b)
         if not (min_step <= h_abs <= self.max_step):
             h_abs = min(self.max_step, max(min_step, h_abs))
-            self.standard_sc = True
+            reset = True
         remaining = abs(self.t_bound - t)
         if remaining < 2 * h_abs:
             if remaining > h_abs:
                 h_abs = max(0.5 * remaining, min_step)
-                self.standard_sc = True
+                reset = True
             else:
                 h_abs = remaining
+        return h_abs, min_step, reset
+
+    def _reassess_stepsize(self, t, y=None):
+        h_abs, min_step, reset = self._limit_step(t, self.h_abs)
+        if reset:
+            self.standard_sc = True
         return h_abs, min_step
 
     def _accept_factor(self, error_norm, h, rejected_before):
@@ -687,18 +693,29 @@ class RungeKutta(OdeSolver):
             sumsq = self._dev.rk_solution_error_sumsq(t, h)
         return self._rms_from_sumsq(sumsq)
 
-    def _finish_step(self, t_new, h):
+    _prelaunch = os.environ.get("ESQ_PRELAUNCH", "1") != "0"
+
+    def _finish_step(self, t_new, h, h_abs_next=None):
         """end-point derivative of non-FSAL pairs, then pointer rotation on the
-        device (ref common.py:289-303)"""
+        device (ref common.py:289-303).  `h_abs_next`: the step size the
+        controller has just chosen; the library then forms the NEXT step's
+        first stage argument right away (in the end-point sweep itself, or in a
+        kernel that runs while this host code is between steps).  The next
+        `_run_stages` uses it only if it asks for exactly that step."""
         end_eval = 0
-        if not self.FSAL:
-            if self._device_rhs is not None:
+        h_next = 0.0
+        if self._device_rhs is not None:
+            if not self.FSAL:
                 end_eval = 1
                 self.nfev += 1
-            else:
-                y_new = self._dev.download(SLOT_YNEW)
-                self._dev.upload(SLOT_K, self.n_stages, self.fun(t_new, y_new))
-        self._chk(self._lib.esq_rk_accept(self._ctx, t_new, end_eval),
+            if h_abs_next is not None and self._prelaunch:
+                h_lim, min_step, _ = self._limit_step(t_new, h_abs_next)
+                if h_lim >= min_step:
+                    h_next = h_lim * self.direction
+        elif not self.FSAL:
+            y_new = self._dev.download(SLOT_YNEW)
+            self._dev.upload(SLOT_K, self.n_stages, self.fun(t_new, y_new))
+        self._chk(self._lib.esq_rk_accept(self._ctx, t_new, end_eval, h_next),
                   "esq_rk_accept")
         self._invalidate_mirrors()
 
@@ -725,7 +742,7 @@ class RungeKutta(OdeSolver):
             self.jflstp += 1
             if np.isnan(error_norm) or np.isinf(error_norm):
                 return False, "Overflow or underflow encountered."
-        self._finish_step(t_new, h)
+        self._finish_step(t_new, h, h_abs)
         self.h_previous = h
         self.h_abs = h_abs
         self.error_norm_old = error_norm

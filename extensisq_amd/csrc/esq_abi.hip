@@ -29,6 +29,7 @@ namespace {
 
 constexpr size_t kPadDoubles = 512;   // 4 KiB
 constexpr int kFixedSlots = 5;        // Y, YNEW, YSTAGE, ATOL, WORK
+constexpr int kPartialsCap = 1 << 17; // one partial per workgroup of a sweep
 
 struct ProfEvent {
     hipEvent_t start, stop;
@@ -67,7 +68,8 @@ struct esq_ctx {
     std::vector<int> kmap_last;       // mapping of the step just accepted
     double *y = nullptr, *ynew = nullptr, *ystage = nullptr, *atolv = nullptr,
            *work = nullptr;
-    double *partials = nullptr;       // kMaxPartials doubles
+    double *partials = nullptr;       // kPartialsCap doubles (own kernels use
+                                      // <= kMaxPartials, fused sweeps their grid)
     double *partials2 = nullptr;      // second set (min reductions)
     double *d_result = nullptr;       // 8 doubles (device)
     HostSlot *h_slot = nullptr;       // pinned, device-visible host memory
@@ -81,9 +83,15 @@ struct esq_ctx {
     bool atol_is_vec = false;
     esq_rhs_fn rhs = nullptr;
     void *rhs_user = nullptr;
-    esq_rhs_chain_fn rhs_chain = nullptr;   // optional RHS + next-accumulate entry
+    esq_rhs_fused_fn rhs_fused = nullptr;   // optional RHS + epilogue entry
+    int fuse_mask = 0;                      // epilogue kinds the library may request
     esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
-    bool ynew_ready = false;                // YNEW already formed by the last stage's chained sweep
+    bool ynew_ready = false;     // YNEW already formed by the last stage's sweep
+    bool solerr_ready = false;   // ... and the error partial sums too
+    int red_count = 0;           // partials written by the last reducing sweep
+    // first stage argument of the NEXT step, formed at accept time
+    bool pre_valid = false;
+    double pre_h = 0.0;
     // blocked accumulation plan (esq_rk_set_tableau)
     struct Block {
         int J = 0, prev = 0;              // columns [prev, J) of A
@@ -531,7 +539,15 @@ int plan_words(const std::vector<double> &A, int s, const std::vector<int> &boun
 // several devices and drive a context from any thread: hipSetDevice is
 // per-thread state and costs well under a microsecond, so every entry point
 // selects the context's device unconditionally.
-#define ENTER(c) (void)hipSetDevice((c)->device)
+// The first stage argument formed ahead of time by esq_rk_accept lives in
+// YSTAGE until the next esq_rk_stages: any entry point that may write a vector
+// drops it (ENTER); the read-only ones keep it (ENTER_KEEP).
+#define ENTER_KEEP(c) (void)hipSetDevice((c)->device)
+#define ENTER(c)                             \
+    do {                                     \
+        (void)hipSetDevice((c)->device);     \
+        (c)->pre_valid = false;              \
+    } while (0)
 
 // Device-to-host copy into a caller's (pageable) buffer.  Large copies pin the
 // destination for the duration of the call: measured for 80 MB into a fresh
@@ -633,7 +649,7 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t nvec = (size_t)n_rows + kFixedSlots;
-    const size_t slab_doubles = nvec * c->stride + 2 * kMaxPartials + 64;
+    const size_t slab_doubles = nvec * c->stride + kPartialsCap + kMaxPartials + 64;
     HIPCHK(c, hipMalloc(&c->slab, slab_doubles * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(c->slab, 0, slab_doubles * sizeof(double), c->stream));
     c->krow.resize(n_rows);
@@ -650,7 +666,7 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     c->atolv = base + 3 * c->stride;
     c->work = base + 4 * c->stride;
     c->partials = base + 5 * c->stride;
-    c->partials2 = c->partials + kMaxPartials;
+    c->partials2 = c->partials + kPartialsCap;
     c->d_result = c->partials2 + kMaxPartials;
     HIPCHK(c, hipHostMalloc((void **)&c->h_slot, 64,
                             hipHostMallocMapped | hipHostMallocCoherent));
@@ -700,7 +716,7 @@ const char *esq_last_error(const esq_ctx *c) { return c ? c->err : "null context
 
 int esq_synchronize(esq_ctx *c) {
     if (!c) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -719,7 +735,7 @@ int esq_upload(esq_ctx *c, int slot, int row, const double *host) {
 }
 int esq_download(esq_ctx *c, int slot, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     double *d = slot_ptr(c, slot, row);
     if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
     const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
@@ -841,7 +857,8 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     ENTER(c);
     c->rhs = fn;
     c->rhs_user = user;
-    c->rhs_chain = nullptr;
+    c->rhs_fused = nullptr;
+    c->fuse_mask = 0;
     c->rhs_rkc = nullptr;
     return 0;
 }
@@ -851,10 +868,11 @@ int esq_set_rhs_rkc(esq_ctx *c, esq_rhs_rkc_fn fn) {
     c->rhs_rkc = fn;
     return 0;
 }
-int esq_set_rhs_chain(esq_ctx *c, esq_rhs_chain_fn fn) {
+int esq_set_rhs_fused(esq_ctx *c, esq_rhs_fused_fn fn, int fuse_mask) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
-    c->rhs_chain = fn;
+    c->rhs_fused = fn;
+    c->fuse_mask = fn ? fuse_mask : 0;
     return 0;
 }
 
@@ -909,87 +927,247 @@ int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row
     return call_rhs(c, t, src, dst);
 }
 
+}  // extern "C"
+
+namespace {
+
+// coefficient row of stage i as the stage kernels use it: columns below the
+// stage's blocked-accumulation boundary are in its stored partial sum, column
+// `skip` (if >= 0) comes from registers.  Returns the number of rows to read.
+int stage_terms(esq_ctx *c, int i, int skip, Terms &tm, const double **init,
+                int *nnz_all, double *c_skip) {
+    const int from = c->stage_from[i];
+    *init = c->stage_init[i] >= 0 ? c->krow[c->stage_init[i]] : nullptr;
+    const double *row = &c->A[(size_t)i * c->s];
+    int nt = 0, nnz = 0;
+    if (c_skip) *c_skip = 0.0;
+    for (int j = 0; j < i; ++j) {
+        if (row[j] == 0.0) continue;
+        ++nnz;
+        if (j < from) continue;
+        if (j == skip) { if (c_skip) *c_skip = row[j]; continue; }
+        if (nt >= kMaxTerms) return -1;
+        tm.p[nt] = c->krow[c->kmap[j]];
+        tm.c[nt] = row[j];
+        ++nt;
+    }
+    for (int j = nt; j < kMaxTerms; ++j) { tm.p[j] = nullptr; tm.c[j] = 0.0; }
+    *nnz_all = nnz;
+    return nt;
+}
+
+void epi_common(esq_ctx *c, esq_epilogue &e, int kind) {
+    memset(&e, 0, sizeof(e));
+    e.kind = kind;
+    e.atol_vec = c->atol_is_vec ? c->atolv : nullptr;
+    e.atol_s = c->atol_s;
+    e.rtol = c->rtol;
+    e.n_valid = c->n;
+    e.partials = c->partials;
+    e.partials_cap = kPartialsCap;
+    e.partials_used = &c->red_count;
+}
+
+// one fused sweep; returns 0, ESQ_ENOTSUP (caller falls back) or an error
+int run_fused(esq_ctx *c, double t, const double *y_in, double *f_out,
+              const esq_epilogue &e, Prof &p) {
+    const int r = c->rhs_fused(c->rhs_user, t, y_in, f_out, &e, c->len,
+                               (void *)c->stream, (void *)p.start(),
+                               (void *)p.stop());
+    if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
+    if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "fused RHS entry returned %d", r); }
+    return 0;
+}
+bool may_fuse(const esq_ctx *c, int kind) {
+    return c->rhs_fused && ((c->fuse_mask >> kind) & 1);
+}
+
+// RHS sweep of stage i + the accumulate of stage nx = i + 1 (ESQ_EPI_STAGE)
+int sweep_next_stage(esq_ctx *c, int i, double t, double h) {
+    const int nx = i + 1;
+    esq_epilogue e;
+    epi_common(c, e, ESQ_EPI_STAGE);
+    Terms tm;
+    int nnz_all = 0;
+    const int nt = stage_terms(c, nx, i, tm, &e.init, &nnz_all, &e.c_self);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    e.nt = nt;
+    for (int j = 0; j < nt; ++j) { e.rows[j] = tm.p[j]; e.c[j] = tm.c[j]; }
+    e.y = c->y;
+    e.h = h;
+    e.out = c->work;
+    e.f_store_nt = 1;      // K_i is consumed from registers, not re-read soon
+    // booked on the stage class: next stage's algorithmic bytes + the RHS's
+    // 16 B; moved: ys_in, rows, init, y in; K[i], ys_out out
+    Prof p(c, ESQ_PROF_STAGE, "rhs+stage", nt, 8.0 * (nnz_all + 4) * (double)c->len,
+           false, 8.0 * (nt + 4 + (e.init ? 1 : 0)) * (double)c->len);
+    const int r = run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
+    if (r == 0) std::swap(c->ystage, c->work);   // double buffer
+    return r;
+}
+
+// RHS sweep of stage i = J - 1 + the blocked accumulation at boundary J with
+// K_i as the block's last column (ESQ_EPI_BLOCK)
+int sweep_block(esq_ctx *c, const esq_ctx::Block &b, int i, double t, double h,
+                bool *made_ystage) {
+    esq_epilogue e;
+    epi_common(c, e, ESQ_EPI_BLOCK);
+    const int no = (int)b.stages.size();
+    int nt = 0;
+    for (int col : b.cols) {
+        if (col == i) continue;
+        if (nt >= ESQ_EPI_MAX_ROWS) return ESQ_ENOTSUP;
+        e.rows[nt] = c->krow[c->kmap[col]];
+        for (int o = 0; o < no; ++o)
+            e.w[nt][o] = c->A[(size_t)b.stages[o] * c->s + col];
+        ++nt;
+    }
+    e.nt = nt;
+    e.no = no;
+    double reads = nt + 1;                       // rows + the sweep's input
+    for (int o = 0; o < no; ++o) {
+        e.w_self[o] = c->A[(size_t)b.stages[o] * c->s + i];
+        e.out_o[o] = c->krow[b.out_vec[o]];
+        e.init_o[o] = b.in_vec[o] >= 0 ? c->krow[b.in_vec[o]] : nullptr;
+        if (e.init_o[o]) reads += 1;
+    }
+    e.h = h;
+    double alg = 16.0 * (double)c->len;          // the RHS itself
+    *made_ystage = false;
+    if (no > 0 && b.stages[0] == b.J && c->stage_init[b.J] == b.out_vec[0] &&
+        c->stage_from[b.J] == b.J) {
+        e.y = c->y;
+        e.out_o[0] = c->work;
+        reads += 1;
+        int nnz_all = 0;
+        for (int j = 0; j < b.J; ++j) nnz_all += c->A[(size_t)b.J * c->s + j] != 0.0;
+        alg += 8.0 * (nnz_all + 2) * (double)c->len;   // the boundary stage's booking
+        *made_ystage = true;
+    }
+    e.f_store_nt = 1;
+    Prof p(c, ESQ_PROF_STAGE, "rhs+block", nt, alg, false,
+           8.0 * (reads + no + 1) * (double)c->len);
+    const int r = run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
+    if (r == 0 && *made_ystage) std::swap(c->ystage, c->work);
+    if (r != 0) *made_ystage = false;
+    return r;
+}
+
+// FSAL pairs: RHS sweep of the last stage also forms y_new (ESQ_EPI_STAGE)
+int sweep_ynew(esq_ctx *c, int i, double t, double h) {
+    esq_epilogue e;
+    epi_common(c, e, ESQ_EPI_STAGE);
+    int nt = 0, nnz_all = 0;
+    for (int j = 0; j < c->s; ++j) {
+        if (c->B[j] == 0.0) continue;
+        ++nnz_all;
+        if (j == i) { e.c_self = c->B[j]; continue; }
+        e.rows[nt] = c->krow[c->kmap[j]];
+        e.c[nt] = c->B[j];
+        ++nt;
+    }
+    e.nt = nt;
+    e.y = c->y;
+    e.h = h;
+    e.out = c->ynew;
+    e.f_store_nt = 1;
+    Prof p(c, ESQ_PROF_STAGE, "rhs+stage", nt, 8.0 * (nnz_all + 4) * (double)c->len,
+           false, 8.0 * (nt + 4) * (double)c->len);
+    return run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
+}
+
+// non-FSAL pairs: RHS sweep of the last stage + y_new + error partial sums
+int sweep_solerr(esq_ctx *c, int i, double t, double h) {
+    esq_epilogue e;
+    epi_common(c, e, ESQ_EPI_SOLERR);
+    int nt = 0;
+    for (int j = 0; j < c->s; ++j) {
+        const double bj = c->B[j], ej = c->E[j];
+        if (j == i) { e.c_self = bj; e.e_self = ej; continue; }
+        if (bj == 0.0 && ej == 0.0) continue;
+        if (nt >= ESQ_EPI_MAX_ROWS) return ESQ_ENOTSUP;
+        e.rows[nt] = c->krow[c->kmap[j]];
+        e.c[nt] = bj;
+        e.e[nt] = ej;
+        ++nt;
+    }
+    e.nt = nt;
+    e.y = c->y;
+    e.h = h;
+    e.out = c->ynew;
+    e.f_store_nt = 0;      // K_{s-1} is read by the dense output / next block only
+    // booked: the RHS's 16 B + the fused solution/error pass (rows incl. the
+    // fresh one + y + y_new); moved: ys_in, rows, y in; K_i, y_new out
+    Prof p(c, ESQ_PROF_SOLERR, "rhs+solerr", nt, 8.0 * (nt + 1 + 2 + 2) * (double)c->len,
+           false, 8.0 * (nt + 4) * (double)c->len);
+    return run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
+}
+
+}  // namespace
+
+extern "C" {
+
 int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     if (!c) return ESQ_EINVAL;
+    // YSTAGE may already hold the first stage's argument (esq_rk_accept)
+    bool ready = i_from == 1 && c->pre_valid && c->pre_h == h;
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (i_from < 1 || i_to > c->s || i_from > i_to)
         return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
-    bool ready = false;     // YSTAGE already holds the argument of stage i
     c->ynew_ready = false;
+    c->solerr_ready = false;
+    bool block_done = false;   // the block at boundary i already ran in a sweep
     for (int i = i_from; i < i_to; ++i) {
         if (!ready) {
-            const int r = esq_rk_stage_accumulate(c, i, h);
-            if (r) return r;
+            if (block_done) {
+                // partial sums are in place; only the stage kernel is left
+                const double *init = nullptr;
+                Terms tm;
+                int nnz_all = 0;
+                const int nt = stage_terms(c, i, -1, tm, &init, &nnz_all, nullptr);
+                if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+                Prof p(c, ESQ_PROF_STAGE, "k_lincomb", nt,
+                       8.0 * (nnz_all + 2) * (double)c->len, false,
+                       8.0 * (nt + 2 + (init ? 1 : 0)) * (double)c->len);
+                const int r = launch_lincomb(c, c->ystage, c->y, tm, nt, h, &p, init);
+                if (r) return r;
+            } else {
+                const int r = esq_rk_stage_accumulate(c, i, h);
+                if (r) return r;
+            }
         }
         ready = false;
-        // chained form: this stage's RHS also forms the NEXT stage's argument
-        // (not across a blocked-accumulation boundary: its block kernel needs
-        // K[i] in memory first)
-        bool boundary_next = false;
-        for (const auto &b : c->blocks) boundary_next |= (b.J == i + 1);
-        if (c->rhs_chain && i + 1 < i_to && !boundary_next) {
-            const int nx = i + 1;
-            const int from = c->stage_from[nx];
-            const double *init =
-                c->stage_init[nx] >= 0 ? c->krow[c->stage_init[nx]] : nullptr;
-            std::vector<double> row(c->A.begin() + (size_t)nx * c->s,
-                                    c->A.begin() + (size_t)nx * c->s + nx);
-            int nnz_all = 0;
-            for (int j = 0; j < nx; ++j) {
-                nnz_all += row[j] != 0.0;
-                if (j < from) row[j] = 0.0;
-            }
-            const double c_self = row[i];
-            row[i] = 0.0;                      // K[i] comes from registers
-            Terms tm;
-            const int nt = build_row_terms(c, row.data(), nx, tm, c->kmap);
-            if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
-            // booked on the stage class: next stage's algorithmic bytes + the
-            // RHS's 16 B; moved: ys_in, rows, init, y in; K[i], ys_out out
-            Prof p(c, ESQ_PROF_STAGE, "rhs_chain", nt,
-                   8.0 * (nnz_all + 4) * (double)c->len, false,
-                   8.0 * (nt + 4 + (init ? 1 : 0)) * (double)c->len);
-            const int r = c->rhs_chain(c->rhs_user, t + c->C[i] * h, c->ystage,
-                                       c->krow[c->kmap[i]], nt, tm.p, tm.c, c_self,
-                                       init, c->y, h, c->work, c->len,
-                                       (void *)c->stream, (void *)p.start(),
-                                       (void *)p.stop());
-            if (r == 0) {
-                std::swap(c->ystage, c->work);   // double buffer
-                ready = true;
-                continue;
-            }
-            if (r != ESQ_ENOTSUP)
-                return fail(c, ESQ_ERHS, "chained RHS returned %d", r);
-            p.cancel();
+        block_done = false;
+        const esq_ctx::Block *bnext = nullptr;
+        for (const auto &b : c->blocks)
+            if (b.J == i + 1) bnext = &b;
+        if (i + 1 < i_to && !bnext && may_fuse(c, ESQ_EPI_STAGE)) {
+            // this stage's RHS sweep also forms the NEXT stage's argument
+            const int r = sweep_next_stage(c, i, t, h);
+            if (r == 0) { ready = true; continue; }
+            if (r != ESQ_ENOTSUP) return r;
         }
-        // FSAL pairs: the LAST stage's sweep also forms y_new = y + h*sum b_j K_j
-        // (K_{s-1} from registers); esq_rk_solution_error then skips that kernel
-        if (c->rhs_chain && c->fsal && i == c->s - 1 && i_to == c->s) {
-            std::vector<double> row(c->B.begin(), c->B.begin() + c->s);
-            int nnz_all = 0;
-            for (int j = 0; j < c->s; ++j) nnz_all += row[j] != 0.0;
-            const double c_self = row[i];
-            row[i] = 0.0;
-            Terms tm;
-            const int nt = build_row_terms(c, row.data(), c->s, tm, c->kmap);
-            if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
-            Prof p(c, ESQ_PROF_STAGE, "rhs_chain", nt,
-                   8.0 * (nnz_all + 4) * (double)c->len, false,
-                   8.0 * (nt + 4) * (double)c->len);
-            const int r = c->rhs_chain(c->rhs_user, t + c->C[i] * h, c->ystage,
-                                       c->krow[c->kmap[i]], nt, tm.p, tm.c, c_self,
-                                       nullptr, c->y, h, c->ynew, c->len,
-                                       (void *)c->stream, (void *)p.start(),
-                                       (void *)p.stop());
-            if (r == 0) {
-                c->ynew_ready = true;
-                continue;
+        if (i + 1 < i_to && bnext && may_fuse(c, ESQ_EPI_BLOCK)) {
+            // ... or runs the blocked accumulation at the column boundary
+            bool made = false;
+            const int r = sweep_block(c, *bnext, i, t, h, &made);
+            if (r == 0) { ready = made; block_done = !made; continue; }
+            if (r != ESQ_ENOTSUP) return r;
+        }
+        if (i == c->s - 1 && i_to == c->s) {
+            if (c->fsal && may_fuse(c, ESQ_EPI_STAGE)) {
+                // FSAL pairs: the LAST stage's sweep also forms y_new
+                const int r = sweep_ynew(c, i, t, h);
+                if (r == 0) { c->ynew_ready = true; continue; }
+                if (r != ESQ_ENOTSUP) return r;
             }
-            if (r != ESQ_ENOTSUP)
-                return fail(c, ESQ_ERHS, "chained RHS returned %d", r);
-            p.cancel();
+            if (!c->fsal && !c->cplx && may_fuse(c, ESQ_EPI_SOLERR)) {
+                // others: ... y_new and the error partial sums
+                const int r = sweep_solerr(c, i, t, h);
+                if (r == 0) { c->ynew_ready = c->solerr_ready = true; continue; }
+                if (r != ESQ_ENOTSUP) return r;
+            }
         }
         const int r = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
         if (r) return r;
@@ -1026,17 +1204,50 @@ int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
 
 int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
+    const bool ynew_ready = c->ynew_ready, solerr_ready = c->solerr_ready;
     ENTER(c);
+    c->ynew_ready = c->solerr_ready = false;
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (c->fsal) {
         int r = 0;
-        if (!c->ynew_ready) r = esq_rk_solution(c, h);
-        c->ynew_ready = false;
+        if (!ynew_ready) r = esq_rk_solution(c, h);
         if (r) return r;
+        if (!c->cplx && may_fuse(c, ESQ_EPI_ERRNORM)) {
+            // K[s] = f(t + h, y_new) and the error norm in ONE sweep
+            esq_epilogue e;
+            epi_common(c, e, ESQ_EPI_ERRNORM);
+            int nt = 0;
+            bool ok = true;
+            for (int j = 0; j < c->s; ++j) {
+                if (c->E[j] == 0.0) continue;
+                if (nt >= ESQ_EPI_MAX_ROWS) { ok = false; break; }
+                e.rows[nt] = c->krow[c->kmap[j]];
+                e.e[nt] = c->E[j];
+                ++nt;
+            }
+            if (ok) {
+                e.nt = nt;
+                e.e_self = c->E[c->s];
+                e.y = c->y;
+                e.h = h;
+                e.f_store_nt = 0;     // K[s] is the next step's K[0]
+                // booked: RHS 16 B + error pass (rows incl. K[s], y, y_new);
+                // moved: y_new, rows, y in; K[s] out
+                Prof p(c, ESQ_PROF_SOLERR, "rhs+errnorm", nt,
+                       8.0 * (nt + 1 + 2 + 2) * (double)c->len, false,
+                       8.0 * (nt + 3) * (double)c->len);
+                r = run_fused(c, t + h, c->ynew, c->krow[c->kmap[c->s]], e, p);
+                if (r == 0) return finish_reduction(c, sumsq_out, false, c->partials,
+                                                    c->red_count);
+                if (r != ESQ_ENOTSUP) return r;
+            }
+        }
         r = call_rhs(c, t + h, c->ynew, c->krow[c->kmap[c->s]]);
         if (r) return r;
         return esq_rk_error_norm(c, h, sumsq_out);
     }
+    if (solerr_ready)
+        return finish_reduction(c, sumsq_out, false, c->partials, c->red_count);
     Terms2 tm;
     const int nt = build_row_terms2(c, c->B.data(), c->s, c->E.data(), c->s, tm, c->kmap);
     if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
@@ -1084,17 +1295,51 @@ int esq_rk_custom_sol_err(esq_ctx *c, double h, const double *b, const double *e
     return finish_reduction(c, sumsq_out);
 }
 
-int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval) {
+int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    // the next step's first stage argument can be formed now: stage 1 reads
+    // nothing but y and K[0]
+    const bool want_pre = h_next != 0.0 && c->s >= 2 && c->rhs != nullptr;
+    bool pre_done = false;
     if (!c->fsal && with_end_eval) {
-        int r = call_rhs(c, t_new, c->ynew, c->krow[c->kmap[c->s]]);
-        if (r) return r;
+        int r = ESQ_ENOTSUP;
+        if (want_pre && may_fuse(c, ESQ_EPI_STAGE)) {
+            // K[s] = f(t_new, y_new) and YSTAGE = y_new + h_next*a_10*K[s] in
+            // ONE sweep (K[s] becomes K[0], y_new becomes y below)
+            esq_epilogue e;
+            epi_common(c, e, ESQ_EPI_STAGE);
+            e.nt = 0;
+            e.c_self = c->A[(size_t)c->s];          // A[1][0]
+            e.y = nullptr;                          // base = the sweep's input
+            e.h = h_next;
+            e.out = c->ystage;
+            e.f_store_nt = 0;                       // K[0] of the next step
+            const int nnz = e.c_self != 0.0 ? 1 : 0;
+            Prof p(c, ESQ_PROF_STAGE, "rhs+stage", 0, 8.0 * (nnz + 4) * (double)c->len,
+                   false, 8.0 * 3 * (double)c->len);
+            r = run_fused(c, t_new, c->ynew, c->krow[c->kmap[c->s]], e, p);
+            if (r == 0) pre_done = true;
+            else if (r != ESQ_ENOTSUP) return r;
+        }
+        if (r == ESQ_ENOTSUP) {
+            r = call_rhs(c, t_new, c->ynew, c->krow[c->kmap[c->s]]);
+            if (r) return r;
+        }
     }
     c->kmap_last = c->kmap;
     std::swap(c->kmap[0], c->kmap[c->s]);
     std::swap(c->y, c->ynew);
+    if (want_pre && !pre_done) {
+        // stage 1's accumulate, launched now: it runs while the host controller
+        // is between steps
+        const int r = esq_rk_stage_accumulate(c, 1, h_next);
+        if (r) return r;
+        pre_done = true;
+    }
+    c->pre_valid = pre_done;
+    c->pre_h = h_next;
     return 0;
 }
 
@@ -1111,12 +1356,12 @@ int esq_rk_error_vector(esq_ctx *c, double h, int last_step) {
 
 int esq_rk_row_id(esq_ctx *c, int logical_row, int last_step) {
     if (!c || logical_row < 0 || logical_row >= c->n_rows) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     return last_step ? c->kmap_last[logical_row] : c->kmap[logical_row];
 }
 int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
     return d2h(c, host, c->krow[c->kmap_last[row]], c->len * sizeof(double));
 }
@@ -1168,7 +1413,7 @@ extern "C" {
 int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
                      int from_end, esq_dense **out) {
     if (!c || !P || !out) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     if (rows < 1 || rows > c->n_rows || p < 1 || p > kMaxCols)
         return fail(c, ESQ_EINVAL, "bad interpolant shape (%d, %d)", rows, p);
     esq_dense *d = new (std::nothrow) esq_dense();
@@ -1530,7 +1775,7 @@ int esq_hs_select(esq_ctx *c, int yp, int spy, int src, double fill) {
 // ---- lock-step ------------------------------------------------------------------
 int esq_set_comm(esq_ctx *c, void *nccl_comm) {
     if (!c) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     if (nccl_comm && rccl_load() != 0) return fail(c, ESQ_ESTATE, "cannot load librccl");
     c->comm = nccl_comm;
     return 0;
@@ -1572,7 +1817,7 @@ int esq_comm_abort(void *comm) {
 // count (spectral-radius estimates, debug cross-checks)
 int esq_allreduce_scalars(esq_ctx *c, double *inout, int count, int op) {
     if (!c || !inout || count < 1 || count > 4) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     if (!c->comm) return 0;
     const int nccl_op = op == ESQ_OP_SUM ? kNcclSum : op == ESQ_OP_MIN ? kNcclMin
                       : op == ESQ_OP_MAX ? kNcclMax : -1;
@@ -1615,21 +1860,21 @@ int esq_comm_destroy(void *comm) {
 // ---- measurement ----------------------------------------------------------------
 int esq_profile_enable(esq_ctx *c, int class_mask) {
     if (!c) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     if (!class_mask) prof_drain(c);
     c->prof_mask = (unsigned)class_mask;
     return 0;
 }
 int esq_profile_sampling(esq_ctx *c, int every) {
     if (!c || every < 1) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     c->prof_every = (unsigned)every;
     return 0;
 }
 int esq_profile_read(esq_ctx *c, int klass, double *total_ms, long *launches,
                      double *bytes) {
     if (!c || klass < 0 || klass >= ESQ_PROF_NCLASS) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     prof_drain(c);
     if (total_ms) *total_ms = c->prof_ms[klass];
     if (launches) *launches = c->prof_cnt[klass];
@@ -1644,7 +1889,7 @@ int esq_profile_read_moved(esq_ctx *c, int klass, double *moved_bytes) {
 }
 int esq_profile_kernels(esq_ctx *c, char *buf, size_t buflen) {
     if (!c || !buf || buflen < 2) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     prof_drain(c);
     size_t used = 0;
     buf[0] = 0;
@@ -1661,7 +1906,7 @@ int esq_profile_kernels(esq_ctx *c, char *buf, size_t buflen) {
 }
 int esq_profile_reset(esq_ctx *c) {
     if (!c) return ESQ_EINVAL;
-    ENTER(c);
+    ENTER_KEEP(c);
     prof_drain(c);
     for (int k = 0; k < ESQ_PROF_NCLASS; ++k) {
         c->prof_ms[k] = 0; c->prof_cnt[k] = 0; c->prof_bytes[k] = 0;

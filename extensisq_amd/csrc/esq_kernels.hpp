@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include "esq_epilogue.hpp"
 #include "esq_terms.hpp"
 
 namespace esq {
@@ -64,7 +65,6 @@ __global__ __launch_bounds__(kBlock) void k_lincomb(
 // words per element and step; Pr9, J = 8, 13: 154 -> 109).  The arithmetic is
 // the SAME ascending-j FMA chain, cut at J: results are bit-identical.
 // ---------------------------------------------------------------------------
-constexpr int kMaxOut = 12;
 struct BlockArgs {
     const double *p[kMaxTerms];        // K rows of the block (non-zero columns)
     double w[kMaxTerms][kMaxOut];      // a_ij for output stage o, 0 = skip
@@ -178,30 +178,6 @@ __global__ __launch_bounds__(kBlock) void k_horner(double *__restrict__ out,
     }
 }
 
-// ---------------------------------------------------------------------------
-// block reduction: wave64 shuffle tree -> LDS across the 4 waves -> one
-// partial per block (fixed order => bitwise reproducible for a given grid).
-// NaN/Inf propagate through plain adds.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ void block_partial(double v, double *partials) {
-    __shared__ double lds[kBlock / 64];
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) lds[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = lds[0];
-#pragma unroll
-        for (int w = 1; w < kBlock / 64; ++w) s += lds[w];
-        partials[blockIdx.x] = s;
-    }
-}
-
 // Where a reduction's result goes: a device double (input of the lock-step
 // all-reduce) and/or a pinned host slot the host polls.  The value is stored
 // first, then -- behind a system-scope release -- the sequence number of this
@@ -246,43 +222,6 @@ __global__ void k_publish(const double *__restrict__ src, ResultSink rs) {
     }
 }
 
-// np.maximum propagates NaN, fmax drops it: keep NumPy's semantics
-__device__ __forceinline__ double pmax(double a, double b) {
-    double m = fmax(a, b);
-    m = (a != a) ? a : m;
-    return (b != b) ? b : m;
-}
-// weights: scale = atol + rtol * max(|a|, |b|)         common.py:57-61
-// CPLX: one double2 is one complex element, |.| = hypot (NumPy's complex abs)
-template <bool CPLX>
-__device__ __forceinline__ double ratio_sq(double2 err, double2 ya, double2 yb,
-                                           const double *atol_vec,
-                                           double atol_s, double rtol, size_t i,
-                                           size_t n_valid) {
-    if (CPLX) {
-        if (i >= n_valid) return 0.0;
-        const double at = atol_vec ? atol_vec[i] : atol_s;
-        const double sc = at + rtol * pmax(hypot(ya.x, ya.y), hypot(yb.x, yb.y));
-        const double rx = err.x / sc, ry = err.y / sc;
-        return rx * rx + ry * ry;
-    } else {
-        const size_t e0 = 2 * i;
-        double s = 0.0;
-        if (e0 < n_valid) {
-            const double at = atol_vec ? atol_vec[e0] : atol_s;
-            const double sc = at + rtol * pmax(fabs(ya.x), fabs(yb.x));
-            const double r = err.x / sc;
-            s = r * r;
-        }
-        if (e0 + 1 < n_valid) {
-            const double at = atol_vec ? atol_vec[e0 + 1] : atol_s;
-            const double sc = at + rtol * pmax(fabs(ya.y), fabs(yb.y));
-            const double r = err.y / sc;
-            s += r * r;
-        }
-        return s;
-    }
-}
 // ---------------------------------------------------------------------------
 // Non-FSAL fused pass: y_new = y + h*sum b_j K_j ; err = h*sum e_j K_j ;
 // partial sum of |err/scale|^2.  Each K row is read ONCE for both sums.

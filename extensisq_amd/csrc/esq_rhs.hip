@@ -18,6 +18,7 @@
 #include <hip/hip_ext.h>
 
 #include "../../include/extensisq_amd.h"
+#include "esq_epilogue.hpp"
 #include "esq_terms.hpp"
 
 namespace {
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d(
 // order is identical to the scalar kernels (and to oracle/problems.py).
 // ---------------------------------------------------------------------------
 using esq::v2d;
+using RkcEpi = esq::EpiRkc;
 
 template <bool PERIODIC>
 struct RowWin {
@@ -152,242 +154,113 @@ struct RowWin {
     }
 };
 
-template <int R, bool NTS>
-__global__ __launch_bounds__(kBlock) void k_bruss2d_v2(
-    const double *__restrict__ y, double *__restrict__ f, int N, double d,
-    double A, double B, unsigned nblocks, unsigned bpr) {
-    // tiles are WAVE-granular (64 column pairs x R rows): `bpr` counts the
-    // 64-pair segments per row, so a ragged row end idles < 64 lanes
+// ---------------------------------------------------------------------------
+// SWEEPS.  One wave tile = 64 column pairs of ONE grid row; all three window
+// rows are requested up front, together with the epilogue's operands, so every
+// load of the thread is in flight before the first use.  `Epi` (esq_epilogue.hpp)
+// says what happens to the fresh derivative: store only (EpiNone), next stage
+// argument (EpiStage), blocked accumulation (EpiBlock), solution + error norm
+// (EpiSolErr), FSAL error norm (EpiErrNorm), Chebyshev recursion (EpiRkc).
+// The epilogues are pointwise: nothing is recomputed on halos.
+// ---------------------------------------------------------------------------
+template <class Epi>
+__global__ __launch_bounds__(kBlock) void k_bruss2d_sweep(
+    const double *__restrict__ ys, double *__restrict__ f, Epi epi, int N,
+    double d, double A, double B, unsigned nblocks, unsigned wpr) {
     const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
-    const int i0 = (int)(tile / bpr) * R;
-    const size_t NN = (size_t)N * N;
-    RowWin<true> U, V;
-    U.f = y; V.f = y + NN;
-    U.N = V.N = N;
-    U.npairs = V.npairs = (unsigned)N / 2;
-    U.pair = V.pair = (tile % bpr) * 64 + (threadIdx.x & 63);
-    U.live = V.live = U.pair < U.npairs;
-    if (i0 >= N) return;
-    // all R + 2 rows of the window are requested up front (independent loads:
-    // one memory round trip per tile instead of one per row)
-    double2 ur[R + 2], vr[R + 2];
-#pragma unroll
-    for (int r = 0; r < R + 2; ++r) {
-        ur[r] = U.row(i0 - 1 + r);
-        vr[r] = V.row(i0 - 1 + r);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = i0 + r;
-        if (i >= N) break;                       // uniform across the wave
-        const double2 uu = ur[r], uc = ur[r + 1], ud = ur[r + 2];
-        const double2 vu = vr[r], vc = vr[r + 1], vd = vr[r + 2];
+    const int i = (int)(tile / wpr);
+    double local = 0.0;
+    if (i < N) {                                           // wave-uniform
+        const size_t NN = (size_t)N * N;
+        RowWin<true> U, V;
+        U.f = ys; V.f = ys + NN;
+        U.N = V.N = N;
+        U.npairs = V.npairs = (unsigned)N / 2;
+        U.pair = V.pair = (tile % wpr) * 64 + (threadIdx.x & 63);
+        U.live = V.live = U.pair < U.npairs;
+        const size_t k2 = ((size_t)i * N) / 2 + (U.live ? U.pair : 0);   // N even
+        const size_t v2 = NN / 2 + k2;
+        typename Epi::In cu, cv;
+        epi.load(cu, k2);
+        epi.load(cv, v2);
+        const double2 uu = U.row(i - 1), uc = U.row(i), ud = U.row(i + 1);
+        const double2 vu = V.row(i - 1), vc = V.row(i), vd = V.row(i + 1);
         double ul, urt, vl, vrt;
         U.sides(i, uc, ul, urt);
         V.sides(i, vc, vl, vrt);
-        // .x : neighbours (left = ul, right = uc.y); .y : (left = uc.x, right = urt)
-        double2 lapu, lapv, fu, fv;
-        lapu.x = ((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x;
-        lapu.y = ((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y;
-        lapv.x = ((vu.x + vd.x) + (vl + vc.y)) - 4.0 * vc.x;
-        lapv.y = ((vu.y + vd.y) + (vc.x + vrt)) - 4.0 * vc.y;
-        const double uuvx = uc.x * uc.x * vc.x, uuvy = uc.y * uc.y * vc.y;
-        fu.x = ((A + uuvx) - (B + 1.0) * uc.x) + d * lapu.x;
-        fu.y = ((A + uuvy) - (B + 1.0) * uc.y) + d * lapu.y;
-        fv.x = (B * uc.x - uuvx) + d * lapv.x;
-        fv.y = (B * uc.y - uuvy) + d * lapv.y;
+        double2 fu, fv;
+        {
+            const double lapx = ((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x;
+            const double lapy = ((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y;
+            const double lvx = ((vu.x + vd.x) + (vl + vc.y)) - 4.0 * vc.x;
+            const double lvy = ((vu.y + vd.y) + (vc.x + vrt)) - 4.0 * vc.y;
+            const double uuvx = uc.x * uc.x * vc.x, uuvy = uc.y * uc.y * vc.y;
+            fu.x = ((A + uuvx) - (B + 1.0) * uc.x) + d * lapx;
+            fu.y = ((A + uuvy) - (B + 1.0) * uc.y) + d * lapy;
+            fv.x = (B * uc.x - uuvx) + d * lvx;
+            fv.y = (B * uc.y - uuvy) + d * lvy;
+        }
         if (U.live) {
-            const size_t k = (size_t)i * N + 2 * (size_t)U.pair;
-            if (NTS) {
-                v2d a, b;
-                a.x = fu.x; a.y = fu.y; b.x = fv.x; b.y = fv.y;
-                __builtin_nontemporal_store(a, reinterpret_cast<v2d *>(f + k));
-                __builtin_nontemporal_store(b, reinterpret_cast<v2d *>(f + NN + k));
-            } else {
-                *reinterpret_cast<double2 *>(f + k) = fu;
-                *reinterpret_cast<double2 *>(f + NN + k) = fv;
-            }
+            epi.store_f(f, k2, fu);
+            epi.store_f(f, v2, fv);
+            epi.finish(cu, fu, uc, k2, local);
+            epi.finish(cv, fv, vc, v2, local);
         }
     }
+    if (Epi::kReduce) esq::block_partial(local, epi.red.partials);
 }
 
-// Optional RKC epilogue: instead of storing f(y_{j-1}) the sweep finishes the
-// Chebyshev recursion of that stage,
-//   y_j = mu*y_{j-1} + nu*y_{j-2} + (1-mu-nu)*y_n + hmus*(f - ajm1*f_n)
-// (sommeijer.py:312-313, same operation order as k_rkc_stage), so the derivative
-// never goes to memory: 40 instead of 64 bytes per element and stage.
-struct RkcEpi {
-    const double *yjm2, *yn, *fn;
-    double *out;
-    double mu, nu, omn, hmus, ajm1;
-    __device__ __forceinline__ double apply(double yjm1, double b, double c0,
-                                            double g, double fy) const {
-        return __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(mu, yjm1), __dmul_rn(nu, b)),
-                                   __dmul_rn(omn, c0)),
-                         __dmul_rn(hmus, __dsub_rn(fy, __dmul_rn(ajm1, g))));
-    }
-};
-
-template <int R, bool RKC>
-__global__ __launch_bounds__(kBlock) void k_heat2d_v2(
-    const double *__restrict__ u, double *__restrict__ f, int N, double c,
-    unsigned nblocks, unsigned bpr, RkcEpi epi) {
+template <class Epi>
+__global__ __launch_bounds__(kBlock) void k_heat2d_sweep(
+    const double *__restrict__ ys, double *__restrict__ f, Epi epi, int N,
+    double c, unsigned nblocks, unsigned wpr) {
     const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
-    const int i0 = (int)(tile / bpr) * R;
-    RowWin<false> U;
-    U.f = u;
-    U.N = N;
-    U.npairs = (unsigned)N / 2;
-    U.pair = (tile % bpr) * 64 + (threadIdx.x & 63);
-    U.live = U.pair < U.npairs;
-    if (i0 >= N) return;
-    double2 ur[R + 2];
-#pragma unroll
-    for (int r = 0; r < R + 2; ++r) ur[r] = U.row(i0 - 1 + r);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = i0 + r;
-        if (i >= N) break;
-        const double2 uu = ur[r], uc = ur[r + 1], ud = ur[r + 2];
+    const int i = (int)(tile / wpr);
+    double local = 0.0;
+    if (i < N) {
+        RowWin<false> U;
+        U.f = ys;
+        U.N = N;
+        U.npairs = (unsigned)N / 2;
+        U.pair = (tile % wpr) * 64 + (threadIdx.x & 63);
+        U.live = U.pair < U.npairs;
+        const size_t k2 = ((size_t)i * N) / 2 + (U.live ? U.pair : 0);
+        typename Epi::In cu;
+        epi.load(cu, k2);
+        const double2 uu = U.row(i - 1), uc = U.row(i), ud = U.row(i + 1);
         double ul, urt;
         U.sides(i, uc, ul, urt);
         double2 out;
         out.x = c * (((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x);
         out.y = c * (((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y);
         if (U.live) {
-            const size_t k = (size_t)i * N + 2 * (size_t)U.pair;
-            if (RKC) {
-                const double2 b = *reinterpret_cast<const double2 *>(epi.yjm2 + k);
-                const double2 c0 = *reinterpret_cast<const double2 *>(epi.yn + k);
-                const double2 g = *reinterpret_cast<const double2 *>(epi.fn + k);
-                double2 yj;
-                yj.x = epi.apply(uc.x, b.x, c0.x, g.x, out.x);
-                yj.y = epi.apply(uc.y, b.y, c0.y, g.y, out.y);
-                *reinterpret_cast<double2 *>(epi.out + k) = yj;
-            } else {
-                *reinterpret_cast<double2 *>(f + k) = out;
-            }
+            epi.store_f(f, k2, out);
+            epi.finish(cu, out, uc, k2, local);
         }
     }
+    if (Epi::kReduce) esq::block_partial(local, epi.red.partials);
 }
 
-// ---------------------------------------------------------------------------
-// CHAINED stage: K_i = f(t, ys_in) AND, from the value still in registers, the
-// argument of the NEXT stage
-//     ys_out = y + h * (init + sum_j c_j K_j + c_self * K_i)
-// in one sweep.  The next stage's accumulate is pointwise, so nothing is recomputed on halos: this is the plain one-row stencil
-// kernel plus NT + 2 streaming loads and one more store per element.  The next
-// stage kernel (and its re-read of K_i) disappears.  Same ascending-j FMA chain
-// with K_i last (it has the largest column index), so results are bit-identical.
-// ---------------------------------------------------------------------------
-struct ChainArgs {
-    esq::Terms tm;                 // rows j < i of the next stage (non-zero a)
-    const double *init;            // its leading partial sum or nullptr
-    const double *y;
-    double *ys_out;
-    double c_self, h;
-};
-// operands of one chain element, requested BEFORE the stencil is evaluated so
-// that all loads of the thread are in flight together (they are independent of
-// the stencil, but the compiler may not move them above the stores to f)
-template <int NT>
-struct ChainIn {
-    double2 v[NT > 0 ? NT : 1], yb, acc0;
-    __device__ __forceinline__ void load(const ChainArgs &ca, size_t i2) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) v[j] = esq::ld2_nt(ca.tm.p[j], i2);
-        yb = esq::ld2(ca.y, i2);
-        acc0 = ca.init ? esq::ld2_nt(ca.init, i2) : make_double2(0.0, 0.0);
+// f = lam*y + forcing, pointwise: the same epilogues on a grid-stride loop
+// (lam holds exactly n doubles; the state vectors are zero-padded to a multiple
+// of 512, and the padding must stay zero)
+template <class Epi>
+__global__ __launch_bounds__(kBlock) void k_diag_sweep(
+    const double *__restrict__ y, double *__restrict__ f, Epi epi,
+    const double *__restrict__ lam, double forcing, size_t n, size_t n2) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    double local = 0.0;
+    for (size_t i2 = (size_t)blockIdx.x * kBlock + threadIdx.x; i2 < n2; i2 += stride) {
+        typename Epi::In in;
+        epi.load(in, i2);
+        const double2 yc = esq::ld2(y, i2);
+        double2 fy = make_double2(0.0, 0.0);
+        if (2 * i2 < n) fy.x = lam[2 * i2] * yc.x + forcing;
+        if (2 * i2 + 1 < n) fy.y = lam[2 * i2 + 1] * yc.y + forcing;
+        epi.store_f(f, i2, fy);
+        epi.finish(in, fy, yc, i2, local);
     }
-    __device__ __forceinline__ double2 finish(const ChainArgs &ca,
-                                              double2 fresh) const {
-        double2 acc = acc0;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            acc.x = fma(ca.tm.c[j], v[j].x, acc.x);
-            acc.y = fma(ca.tm.c[j], v[j].y, acc.y);
-        }
-        if (ca.c_self != 0.0) {                       // uniform
-            acc.x = fma(ca.c_self, fresh.x, acc.x);
-            acc.y = fma(ca.c_self, fresh.y, acc.y);
-        }
-        return make_double2(__dadd_rn(yb.x, __dmul_rn(ca.h, acc.x)),
-                            __dadd_rn(yb.y, __dmul_rn(ca.h, acc.y)));
-    }
-};
-
-template <int NT>
-__global__ __launch_bounds__(kBlock) void k_bruss2d_chain(
-    const double *__restrict__ ys, double *__restrict__ f, ChainArgs ca, int N,
-    double d, double A, double B, unsigned nblocks, unsigned wpr) {
-    const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
-    const int i = (int)(tile / wpr);
-    if (i >= N) return;
-    const size_t NN = (size_t)N * N;
-    RowWin<true> U, V;
-    U.f = ys; V.f = ys + NN;
-    U.N = V.N = N;
-    U.npairs = V.npairs = (unsigned)N / 2;
-    U.pair = V.pair = (tile % wpr) * 64 + (threadIdx.x & 63);
-    U.live = V.live = U.pair < U.npairs;
-    const size_t k2 = ((size_t)i * N) / 2 + (U.live ? U.pair : 0);   // N even
-    const size_t v2 = NN / 2 + k2;
-    ChainIn<NT> cu, cv;
-    cu.load(ca, k2);
-    cv.load(ca, v2);
-    const double2 uu = U.row(i - 1), uc = U.row(i), ud = U.row(i + 1);
-    const double2 vu = V.row(i - 1), vc = V.row(i), vd = V.row(i + 1);
-    double ul, urt, vl, vrt;
-    U.sides(i, uc, ul, urt);
-    V.sides(i, vc, vl, vrt);
-    double2 fu, fv;
-    {
-        const double lapx = ((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x;
-        const double lapy = ((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y;
-        const double lvx = ((vu.x + vd.x) + (vl + vc.y)) - 4.0 * vc.x;
-        const double lvy = ((vu.y + vd.y) + (vc.x + vrt)) - 4.0 * vc.y;
-        const double uuvx = uc.x * uc.x * vc.x, uuvy = uc.y * uc.y * vc.y;
-        fu.x = ((A + uuvx) - (B + 1.0) * uc.x) + d * lapx;
-        fu.y = ((A + uuvy) - (B + 1.0) * uc.y) + d * lapy;
-        fv.x = (B * uc.x - uuvx) + d * lvx;
-        fv.y = (B * uc.y - uuvy) + d * lvy;
-    }
-    if (!U.live) return;
-    const double2 su = cu.finish(ca, fu), sv = cv.finish(ca, fv);
-    // K_i is not re-read by the next stage (it was consumed from registers):
-    // stream it out so that ys_in / ys_out / y keep the Infinity Cache
-    esq::st2_nt(f, k2, fu);
-    esq::st2_nt(f, v2, fv);
-    esq::st2(ca.ys_out, k2, su);
-    esq::st2(ca.ys_out, v2, sv);
-}
-
-template <int NT>
-__global__ __launch_bounds__(kBlock) void k_heat2d_chain(
-    const double *__restrict__ ys, double *__restrict__ f, ChainArgs ca, int N,
-    double c, unsigned nblocks, unsigned wpr) {
-    const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
-    const int i = (int)(tile / wpr);
-    if (i >= N) return;
-    RowWin<false> U;
-    U.f = ys;
-    U.N = N;
-    U.npairs = (unsigned)N / 2;
-    U.pair = (tile % wpr) * 64 + (threadIdx.x & 63);
-    U.live = U.pair < U.npairs;
-    const size_t k2 = ((size_t)i * N) / 2 + (U.live ? U.pair : 0);
-    ChainIn<NT> cu;
-    cu.load(ca, k2);
-    const double2 uu = U.row(i - 1), uc = U.row(i), ud = U.row(i + 1);
-    double ul, urt;
-    U.sides(i, uc, ul, urt);
-    double2 out;
-    out.x = c * (((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x);
-    out.y = c * (((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y);
-    if (!U.live) return;
-    const double2 su = cu.finish(ca, out);
-    esq::st2_nt(f, k2, out);
-    esq::st2(ca.ys_out, k2, su);
+    if (Epi::kReduce) esq::block_partial(local, epi.red.partials);
 }
 
 // 3-D diffusion, Dirichlet 0, 7-point
@@ -458,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void k_diff3d_v2(
                 c * ((((below + above) + (b0 + b1)) + (c0 + c1)) - 6.0 * centre);
             const size_t k = (size_t)i * NN + p;
             if (RKC)
-                epi.out[k] = epi.apply(centre, epi.yjm2[k], epi.yn[k], epi.fn[k], fy);
+                epi.out[k] = epi.one(centre, epi.yjm2[k], epi.yn[k], epi.fn[k], fy);
             else
                 f[k] = fy;
         }
@@ -474,6 +347,148 @@ int make(void **out, Rhs proto) {
     *r = proto;
     *out = r;
     return 0;
+}
+
+// ---- launch geometry of the 2-D sweeps: one wave tile per 64 column pairs
+struct Geo2d {
+    unsigned wpr, grid;
+};
+Geo2d geo2d(int N) {
+    Geo2d g;
+    g.wpr = (N / 2 + 63) / 64;                                  // wave tiles per row
+    const unsigned tiles = g.wpr * (unsigned)N;
+    const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
+    g.grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+    return g;
+}
+esq::RedArgs red_of(const esq_epilogue *e) {
+    esq::RedArgs r;
+    r.atol_vec = e->atol_vec;
+    r.atol_s = e->atol_s;
+    r.rtol = e->rtol;
+    r.n_valid = e->n_valid;
+    r.partials = e->partials;
+    return r;
+}
+template <int NT>
+esq::EpiStage<NT> make_stage(const esq_epilogue *e) {
+    esq::EpiStage<NT> s;
+    for (int j = 0; j < esq::kMaxTerms; ++j) {
+        s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
+        s.tm.c[j] = j < e->nt ? e->c[j] : 0.0;
+    }
+    s.init = e->init; s.y = e->y; s.out = e->out;
+    s.c_self = e->c_self; s.h = e->h; s.f_nt = e->f_store_nt;
+    s.red = red_of(e);
+    return s;
+}
+template <int NT>
+esq::EpiBlock<NT> make_block(const esq_epilogue *e) {
+    esq::EpiBlock<NT> s;
+    for (int j = 0; j < esq::kMaxTerms; ++j) {
+        s.p[j] = j < e->nt ? e->rows[j] : nullptr;
+        for (int o = 0; o < esq::kMaxOut; ++o)
+            s.w[j][o] = (j < e->nt && o < e->no) ? e->w[j][o] : 0.0;
+    }
+    for (int o = 0; o < esq::kMaxOut; ++o) {
+        s.w_self[o] = o < e->no ? e->w_self[o] : 0.0;
+        s.init[o] = o < e->no ? e->init_o[o] : nullptr;
+        s.out[o] = o < e->no ? e->out_o[o] : nullptr;
+    }
+    s.y = e->y; s.h = e->h; s.no = e->no; s.f_nt = e->f_store_nt;
+    s.red = red_of(e);
+    return s;
+}
+template <int NT>
+esq::EpiSolErr<NT> make_solerr(const esq_epilogue *e) {
+    esq::EpiSolErr<NT> s;
+    for (int j = 0; j < esq::kMaxTerms; ++j) {
+        s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
+        s.tm.b[j] = j < e->nt ? e->c[j] : 0.0;
+        s.tm.e[j] = j < e->nt ? e->e[j] : 0.0;
+    }
+    s.b_self = e->c_self; s.e_self = e->e_self;
+    s.y = e->y; s.ynew = e->out; s.h = e->h; s.f_nt = e->f_store_nt;
+    s.red = red_of(e);
+    return s;
+}
+template <int NT>
+esq::EpiErrNorm<NT> make_errnorm(const esq_epilogue *e) {
+    esq::EpiErrNorm<NT> s;
+    for (int j = 0; j < esq::kMaxTerms; ++j) {
+        s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
+        s.tm.c[j] = j < e->nt ? e->e[j] : 0.0;
+    }
+    s.e_self = e->e_self; s.y = e->y; s.h = e->h; s.f_nt = e->f_store_nt;
+    s.red = red_of(e);
+    return s;
+}
+
+// Dispatch (kind, nt) -> LAUNCH(EpiType, epi_value).  Row counts beyond the
+// instantiated ranges fall back (ESQ_ENOTSUP): stage rows <= 16, block rows
+// <= 8 (the fresh column comes on top), solution/error rows <= 16.
+#define EPI_CASE(MAKE, T, K) case K: { auto ep = MAKE<K>(epi); LAUNCH(T<K>, ep); } break;
+#define EPI_DISPATCH()                                                               \
+    switch (epi->kind) {                                                             \
+        case ESQ_EPI_STAGE:                                                          \
+            if (!epi->out) return ESQ_EINVAL;                                        \
+            switch (epi->nt) {                                                       \
+                EPI_CASE(make_stage, esq::EpiStage, 0) EPI_CASE(make_stage, esq::EpiStage, 1)   \
+                EPI_CASE(make_stage, esq::EpiStage, 2) EPI_CASE(make_stage, esq::EpiStage, 3)   \
+                EPI_CASE(make_stage, esq::EpiStage, 4) EPI_CASE(make_stage, esq::EpiStage, 5)   \
+                EPI_CASE(make_stage, esq::EpiStage, 6) EPI_CASE(make_stage, esq::EpiStage, 7)   \
+                EPI_CASE(make_stage, esq::EpiStage, 8) EPI_CASE(make_stage, esq::EpiStage, 9)   \
+                EPI_CASE(make_stage, esq::EpiStage, 10) EPI_CASE(make_stage, esq::EpiStage, 11) \
+                EPI_CASE(make_stage, esq::EpiStage, 12) EPI_CASE(make_stage, esq::EpiStage, 13) \
+                EPI_CASE(make_stage, esq::EpiStage, 14) EPI_CASE(make_stage, esq::EpiStage, 15) \
+                EPI_CASE(make_stage, esq::EpiStage, 16)                              \
+                default: return ESQ_ENOTSUP;                                         \
+            }                                                                        \
+            break;                                                                   \
+        case ESQ_EPI_BLOCK:                                                          \
+            if (epi->no < 1 || epi->no > ESQ_EPI_MAX_OUT) return ESQ_EINVAL;         \
+            switch (epi->nt) {                                                       \
+                EPI_CASE(make_block, esq::EpiBlock, 0) EPI_CASE(make_block, esq::EpiBlock, 1)   \
+                EPI_CASE(make_block, esq::EpiBlock, 2) EPI_CASE(make_block, esq::EpiBlock, 3)   \
+                EPI_CASE(make_block, esq::EpiBlock, 4) EPI_CASE(make_block, esq::EpiBlock, 5)   \
+                EPI_CASE(make_block, esq::EpiBlock, 6) EPI_CASE(make_block, esq::EpiBlock, 7)   \
+                EPI_CASE(make_block, esq::EpiBlock, 8)                               \
+                default: return ESQ_ENOTSUP;                                         \
+            }                                                                        \
+            break;                                                                   \
+        case ESQ_EPI_SOLERR:                                                         \
+            if (!epi->out || !epi->y || !epi->partials) return ESQ_EINVAL;           \
+            switch (epi->nt) {                                                       \
+                EPI_CASE(make_solerr, esq::EpiSolErr, 0) EPI_CASE(make_solerr, esq::EpiSolErr, 1)   \
+                EPI_CASE(make_solerr, esq::EpiSolErr, 2) EPI_CASE(make_solerr, esq::EpiSolErr, 3)   \
+                EPI_CASE(make_solerr, esq::EpiSolErr, 4) EPI_CASE(make_solerr, esq::EpiSolErr, 5)   \
+                EPI_CASE(make_solerr, esq::EpiSolErr, 6) EPI_CASE(make_solerr, esq::EpiSolErr, 7)   \
+                EPI_CASE(make_solerr, esq::EpiSolErr, 8) EPI_CASE(make_solerr, esq::EpiSolErr, 9)   \
+                EPI_CASE(make_solerr, esq::EpiSolErr, 10) EPI_CASE(make_solerr, esq::EpiSolErr, 11) \
+                EPI_CASE(make_solerr, esq::EpiSolErr, 12) EPI_CASE(make_solerr, esq::EpiSolErr, 13) \
+                EPI_CASE(make_solerr, esq::EpiSolErr, 14) EPI_CASE(make_solerr, esq::EpiSolErr, 15) \
+                EPI_CASE(make_solerr, esq::EpiSolErr, 16)                            \
+                default: return ESQ_ENOTSUP;                                         \
+            }                                                                        \
+            break;                                                                   \
+        case ESQ_EPI_ERRNORM:                                                        \
+            if (!epi->y || !epi->partials) return ESQ_EINVAL;                        \
+            switch (epi->nt) {                                                       \
+                EPI_CASE(make_errnorm, esq::EpiErrNorm, 0) EPI_CASE(make_errnorm, esq::EpiErrNorm, 1)   \
+                EPI_CASE(make_errnorm, esq::EpiErrNorm, 2) EPI_CASE(make_errnorm, esq::EpiErrNorm, 3)   \
+                EPI_CASE(make_errnorm, esq::EpiErrNorm, 4) EPI_CASE(make_errnorm, esq::EpiErrNorm, 5)   \
+                EPI_CASE(make_errnorm, esq::EpiErrNorm, 6) EPI_CASE(make_errnorm, esq::EpiErrNorm, 7)   \
+                EPI_CASE(make_errnorm, esq::EpiErrNorm, 8) EPI_CASE(make_errnorm, esq::EpiErrNorm, 9)   \
+                EPI_CASE(make_errnorm, esq::EpiErrNorm, 10) EPI_CASE(make_errnorm, esq::EpiErrNorm, 11) \
+                EPI_CASE(make_errnorm, esq::EpiErrNorm, 12)                          \
+                default: return ESQ_ENOTSUP;                                         \
+            }                                                                        \
+            break;                                                                   \
+        default: return ESQ_ENOTSUP;                                                 \
+    }
+
+bool reduces(const esq_epilogue *epi) {
+    return epi->kind == ESQ_EPI_SOLERR || epi->kind == ESQ_EPI_ERRNORM;
 }
 
 }  // namespace
@@ -543,13 +558,10 @@ int esq_rhs_heat2d(void *user, double t, const double *y, double *f, size_t n,
     if (!r || r->kind != HEAT2D || n != r->n) return ESQ_EINVAL;
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
     if (r->N % 2 == 0 && r->N >= 4 && rhs_variant() != 1) {
-        constexpr int R = 1;
-        const unsigned wpr = (r->N / 2 + 63) / 64;              // wave tiles per row
-        const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
-        const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
-        const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
-        hipLaunchKernelGGL((k_heat2d_v2<R, false>), dim3(grid), dim3(kBlock), 0,
-                           (hipStream_t)stream, y, f, r->N, c, grid, wpr, RkcEpi{});
+        const Geo2d g = geo2d(r->N);
+        esq::EpiNone ep{};
+        hipLaunchKernelGGL((k_heat2d_sweep<esq::EpiNone>), dim3(g.grid), dim3(kBlock),
+                           0, (hipStream_t)stream, y, f, ep, r->N, c, g.grid, g.wpr);
         return (int)hipGetLastError();
     }
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;
@@ -566,21 +578,11 @@ int esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
     if (!r || r->kind != BRUSS2D || n != r->n) return ESQ_EINVAL;
     const double d = r->alpha * ((double)r->N * (double)r->N);
     if (r->N % 2 == 0 && r->N >= 4 && rhs_variant() != 1) {
-        const unsigned wpr = (r->N / 2 + 63) / 64;              // wave tiles per row
-        const int v = rhs_variant();
-        const int R = (v == 8 || v == 4 || v == 3 || v == 2) ? v : 1;
-        const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
-        const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
-        const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
-#define LAUNCH_BR(RR)                                                           \
-    hipLaunchKernelGGL((k_bruss2d_v2<RR, false>), dim3(grid), dim3(kBlock), 0,  \
-                       (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, wpr)
-        if (R == 1) LAUNCH_BR(1);
-        else if (R == 8) LAUNCH_BR(8);
-        else if (R == 4) LAUNCH_BR(4);
-        else if (R == 3) LAUNCH_BR(3);
-        else LAUNCH_BR(2);
-#undef LAUNCH_BR
+        const Geo2d g = geo2d(r->N);
+        esq::EpiNone ep{};
+        hipLaunchKernelGGL((k_bruss2d_sweep<esq::EpiNone>), dim3(g.grid), dim3(kBlock),
+                           0, (hipStream_t)stream, y, f, ep, r->N, d, r->a, r->b,
+                           g.grid, g.wpr);
         return (int)hipGetLastError();
     }
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;
@@ -595,80 +597,71 @@ int esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
                            (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, bpr);
     return (int)hipGetLastError();
 }
-static void fill_chain(ChainArgs &ca, int nt, const double *const *rows,
-                       const double *coef, double c_self, const double *init,
-                       const double *y, double h, double *ys_out) {
-    for (int j = 0; j < esq::kMaxTerms; ++j) {
-        ca.tm.p[j] = j < nt ? rows[j] : nullptr;
-        ca.tm.c[j] = j < nt ? coef[j] : 0.0;
-    }
-    ca.init = init;
-    ca.y = y;
-    ca.ys_out = ys_out;
-    ca.c_self = c_self;
-    ca.h = h;
-}
-#define CHAIN_CASES(LAUNCH)                                                     \
-    switch (nt) {                                                               \
-        case 0: LAUNCH(0); break;   case 1: LAUNCH(1); break;                   \
-        case 2: LAUNCH(2); break;   case 3: LAUNCH(3); break;                   \
-        case 4: LAUNCH(4); break;   case 5: LAUNCH(5); break;                   \
-        case 6: LAUNCH(6); break;   case 7: LAUNCH(7); break;                   \
-        case 8: LAUNCH(8); break;   case 9: LAUNCH(9); break;                   \
-        case 10: LAUNCH(10); break; case 11: LAUNCH(11); break;                 \
-        case 12: LAUNCH(12); break; case 13: LAUNCH(13); break;                 \
-        case 14: LAUNCH(14); break; case 15: LAUNCH(15); break;                 \
-        case 16: LAUNCH(16); break;                                             \
-        default: return ESQ_ENOTSUP;                                            \
-    }
 
-int esq_rhs_bruss2d_chain(void *user, double t, const double *ys_in, double *f,
-                          int nt, const double *const *rows, const double *coef,
-                          double c_self, const double *init, const double *y,
-                          double h, double *ys_out, size_t n, void *stream,
+int esq_rhs_bruss2d_fused(void *user, double t, const double *y_in, double *f,
+                          const esq_epilogue *epi, size_t n, void *stream,
                           void *start_event, void *stop_event) {
     (void)t;
     Rhs *r = (Rhs *)user;
-    if (!r || r->kind != BRUSS2D || n != r->n) return ESQ_EINVAL;
+    if (!r || r->kind != BRUSS2D || n != r->n || !epi) return ESQ_EINVAL;
     if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
-    ChainArgs ca;
-    fill_chain(ca, nt, rows, coef, c_self, init, y, h, ys_out);
-    const unsigned wpr = (r->N / 2 + 63) / 64;
-    const unsigned tiles = wpr * (unsigned)r->N;
-    const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
-    const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+    const Geo2d g = geo2d(r->N);
+    if (reduces(epi)) {
+        if ((int)g.grid > epi->partials_cap) return ESQ_ENOTSUP;
+        if (epi->partials_used) *epi->partials_used = (int)g.grid;
+    }
     const double d = r->alpha * ((double)r->N * (double)r->N);
-#define LAUNCH(K)                                                               \
-    hipExtLaunchKernelGGL((k_bruss2d_chain<K>), dim3(grid), dim3(kBlock), 0,    \
+#define LAUNCH(T, EP)                                                           \
+    hipExtLaunchKernelGGL((k_bruss2d_sweep<T>), dim3(g.grid), dim3(kBlock), 0,  \
                           (hipStream_t)stream, (hipEvent_t)start_event,         \
-                          (hipEvent_t)stop_event, 0, ys_in, f, ca, r->N, d,     \
-                          r->a, r->b, grid, wpr)
-    CHAIN_CASES(LAUNCH)
+                          (hipEvent_t)stop_event, 0, y_in, f, EP, r->N, d,      \
+                          r->a, r->b, g.grid, g.wpr)
+    EPI_DISPATCH()
 #undef LAUNCH
     return (int)hipGetLastError();
 }
-int esq_rhs_heat2d_chain(void *user, double t, const double *ys_in, double *f,
-                         int nt, const double *const *rows, const double *coef,
-                         double c_self, const double *init, const double *y,
-                         double h, double *ys_out, size_t n, void *stream,
+int esq_rhs_heat2d_fused(void *user, double t, const double *y_in, double *f,
+                         const esq_epilogue *epi, size_t n, void *stream,
                          void *start_event, void *stop_event) {
     (void)t;
     Rhs *r = (Rhs *)user;
-    if (!r || r->kind != HEAT2D || n != r->n) return ESQ_EINVAL;
+    if (!r || r->kind != HEAT2D || n != r->n || !epi) return ESQ_EINVAL;
     if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
-    ChainArgs ca;
-    fill_chain(ca, nt, rows, coef, c_self, init, y, h, ys_out);
-    const unsigned wpr = (r->N / 2 + 63) / 64;
-    const unsigned tiles = wpr * (unsigned)r->N;
-    const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
-    const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+    const Geo2d g = geo2d(r->N);
+    if (reduces(epi)) {
+        if ((int)g.grid > epi->partials_cap) return ESQ_ENOTSUP;
+        if (epi->partials_used) *epi->partials_used = (int)g.grid;
+    }
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
-#define LAUNCH(K)                                                               \
-    hipExtLaunchKernelGGL((k_heat2d_chain<K>), dim3(grid), dim3(kBlock), 0,     \
+#define LAUNCH(T, EP)                                                           \
+    hipExtLaunchKernelGGL((k_heat2d_sweep<T>), dim3(g.grid), dim3(kBlock), 0,   \
                           (hipStream_t)stream, (hipEvent_t)start_event,         \
-                          (hipEvent_t)stop_event, 0, ys_in, f, ca, r->N, c, grid, \
-                          wpr)
-    CHAIN_CASES(LAUNCH)
+                          (hipEvent_t)stop_event, 0, y_in, f, EP, r->N, c,      \
+                          g.grid, g.wpr)
+    EPI_DISPATCH()
+#undef LAUNCH
+    return (int)hipGetLastError();
+}
+int esq_rhs_diag_fused(void *user, double t, const double *y_in, double *f,
+                       const esq_epilogue *epi, size_t n, void *stream,
+                       void *start_event, void *stop_event) {
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != DIAG || n != r->n || !epi) return ESQ_EINVAL;
+    const double forcing = r->amp != 0.0 ? r->amp * sin(t) : 0.0;
+    // the state vectors are padded to a multiple of 512 doubles
+    const size_t n_pad = ((n + 511) / 512) * 512, n2 = n_pad / 2;
+    size_t blocks = (n2 + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    if (reduces(epi)) {
+        if ((int)blocks > epi->partials_cap) return ESQ_ENOTSUP;
+        if (epi->partials_used) *epi->partials_used = (int)blocks;
+    }
+#define LAUNCH(T, EP)                                                           \
+    hipExtLaunchKernelGGL((k_diag_sweep<T>), dim3((unsigned)blocks), dim3(kBlock), \
+                          0, (hipStream_t)stream, (hipEvent_t)start_event,      \
+                          (hipEvent_t)stop_event, 0, y_in, f, EP, r->lam_dev,   \
+                          forcing, n, n2)
+    EPI_DISPATCH()
 #undef LAUNCH
     return (int)hipGetLastError();
 }
@@ -676,7 +669,7 @@ int esq_rhs_heat2d_chain(void *user, double t, const double *ys_in, double *f,
 static RkcEpi make_epi(const double *yjm2, const double *yn, const double *fn,
                        double mu, double nu, double omn, double hmus, double ajm1,
                        double *out) {
-    RkcEpi e;
+    RkcEpi e{};
     e.yjm2 = yjm2; e.yn = yn; e.fn = fn; e.out = out;
     e.mu = mu; e.nu = nu; e.omn = omn; e.hmus = hmus; e.ajm1 = ajm1;
     return e;
@@ -689,17 +682,13 @@ int esq_rhs_heat2d_rkc(void *user, double t, const double *yjm1, const double *y
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != HEAT2D || n != r->n) return ESQ_EINVAL;
     if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
-    constexpr int R = 1;
-    const unsigned wpr = (r->N / 2 + 63) / 64;
-    const unsigned tiles = wpr * (unsigned)((r->N + R - 1) / R);
-    const unsigned nblocks = (tiles + kBlock / 64 - 1) / (kBlock / 64);
-    const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+    const Geo2d g = geo2d(r->N);
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
-    hipExtLaunchKernelGGL((k_heat2d_v2<R, true>), dim3(grid), dim3(kBlock), 0,
-                          (hipStream_t)stream, (hipEvent_t)start_event,
-                          (hipEvent_t)stop_event, 0, yjm1, (double *)nullptr, r->N,
-                          c, grid, wpr,
-                          make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out));
+    hipExtLaunchKernelGGL((k_heat2d_sweep<esq::EpiRkc>), dim3(g.grid), dim3(kBlock),
+                          0, (hipStream_t)stream, (hipEvent_t)start_event,
+                          (hipEvent_t)stop_event, 0, yjm1, (double *)nullptr,
+                          make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out),
+                          r->N, c, g.grid, g.wpr);
     return (int)hipGetLastError();
 }
 int esq_rhs_diff3d_rkc(void *user, double t, const double *yjm1, const double *yjm2,

@@ -114,18 +114,29 @@ class DeviceContext:
         self._rhs_keepalive = (rhs, fn)
         self._chk(self.lib.esq_set_rhs(self.handle, C.cast(fn, C.c_void_p), user),
                   "esq_set_rhs")
-        # chained entry: RHS of stage i + accumulate of stage i+1 in one kernel.
-        # Bit-identical; measured Pr8/Brusselator 1.40 -> 1.35 ms/step, Pr9/heat
-        # 1.10 -> 1.02, Ts5/heat 0.107 -> 0.097 (K_i must be streamed out with
-        # non-temporal stores, or the four live vectors of the sweep overflow
-        # the Infinity Cache at n = 1e7).  ESQ_CHAIN=1 / 0 forces it on / off.
-        chain = rhs._chain_entry(self.lib)
+        # fused entry: every RHS sweep also does the Runge-Kutta arithmetic that
+        # follows it (next stage argument, blocked accumulation, solution + error
+        # norm) while the derivative is in registers -- bit-identical K rows and
+        # states, one kernel per RHS evaluation.  ESQ_CHAIN=0 / 1 switches the
+        # entry off / forces it on; ESQ_FUSE=stage,block,solerr,errnorm (any
+        # subset, default all) selects the epilogue kinds for A/B runs.
+        fused = rhs._fused_entry(self.lib)
         want = os.environ.get("ESQ_CHAIN", "")
-        use_chain = (want == "1") or (want != "0" and rhs._chain_default)
-        if chain is not None and use_chain:
-            self._chk(self.lib.esq_set_rhs_chain(self.handle,
-                                                 C.cast(chain, C.c_void_p)),
-                      "esq_set_rhs_chain")
+        use = (want == "1") or (want != "0" and rhs._fuse_default)
+        if fused is not None and use:
+            kinds = {"stage": _lib.EPI_STAGE, "block": _lib.EPI_BLOCK,
+                     "solerr": _lib.EPI_SOLERR, "errnorm": _lib.EPI_ERRNORM}
+            sel = os.environ.get("ESQ_FUSE", "")
+            mask = _lib.FUSE_ALL
+            if sel:
+                mask = 0
+                for name in sel.split(","):
+                    if name.strip() not in kinds:
+                        raise ValueError(f"ESQ_FUSE: unknown epilogue {name!r}")
+                    mask |= 1 << kinds[name.strip()]
+            self._chk(self.lib.esq_set_rhs_fused(self.handle,
+                                                 C.cast(fused, C.c_void_p), mask),
+                      "esq_set_rhs_fused")
         # RKC entry: derivative + Chebyshev recursion in one sweep
         rkc = rhs._rkc_entry(self.lib)
         if rkc is not None and os.environ.get("ESQ_RKC_CHAIN", "1") != "0":
@@ -208,7 +219,7 @@ class DeviceRHS:
 
     n = None
     is_complex = False
-    _chain_default = False     # use the chained entry unless ESQ_CHAIN says otherwise
+    _fuse_default = False      # use the fused entry unless ESQ_CHAIN says otherwise
 
     def __init__(self):
         self._bound = {}       # device -> (fn, user)
@@ -218,8 +229,8 @@ class DeviceRHS:
     def _create(self, lib, device):
         raise NotImplementedError
 
-    def _chain_entry(self, lib):
-        """optional `esq_rhs_chain_fn` of this plugin"""
+    def _fused_entry(self, lib):
+        """optional `esq_rhs_fused_fn` of this plugin"""
         return None
 
     def _rkc_entry(self, lib):
@@ -271,15 +282,15 @@ class DeviceRHS:
 
 class _Builtin(DeviceRHS):
     _symbol = None
-    _symbol_chain = None
+    _symbol_fused = None
     _symbol_rkc = None
 
     def _rkc_entry(self, lib):
         return getattr(lib, self._symbol_rkc) if self._symbol_rkc else None
 
 
-    def _chain_entry(self, lib):
-        return getattr(lib, self._symbol_chain) if self._symbol_chain else None
+    def _fused_entry(self, lib):
+        return getattr(lib, self._symbol_fused) if self._symbol_fused else None
 
     def _make_user(self, lib, device):
         raise NotImplementedError
@@ -293,6 +304,8 @@ class _Builtin(DeviceRHS):
 class DiagonalLinear(_Builtin):
     """f = lam * y + amp * sin(t)   (lam: vector of n reals)"""
     _symbol = "esq_rhs_diag"
+    _symbol_fused = "esq_rhs_diag_fused"
+    _fuse_default = True
 
     def __init__(self, lam, forcing_amp=0.0):
         super().__init__()
@@ -312,9 +325,9 @@ class Heat2D(_Builtin):
     """5-point heat equation on an N x N interior grid, Dirichlet 0
     (BASELINE.json configs[1], configs[4]); twin of oracle/problems.py."""
     _symbol = "esq_rhs_heat2d"
-    _symbol_chain = "esq_rhs_heat2d_chain"
+    _symbol_fused = "esq_rhs_heat2d_fused"
     _symbol_rkc = "esq_rhs_heat2d_rkc"
-    _chain_default = True
+    _fuse_default = True
 
     def __init__(self, N):
         super().__init__()
@@ -335,8 +348,8 @@ class Brusselator2D(_Builtin):
     """2-D Brusselator reaction-diffusion, periodic, y = [u.ravel(), v.ravel()]
     (BASELINE.json configs[2], the north-star workload)."""
     _symbol = "esq_rhs_bruss2d"
-    _symbol_chain = "esq_rhs_bruss2d_chain"
-    _chain_default = True
+    _symbol_fused = "esq_rhs_bruss2d_fused"
+    _fuse_default = True
 
     def __init__(self, N, alpha=0.1, a=1.0, b=3.4):
         super().__init__()

@@ -64,23 +64,76 @@ typedef int (*esq_rhs_fn)(void *user, double t, const double *y_dev,
                           double *f_dev, size_t n, void *hip_stream);
 
 /*
- * OPTIONAL chained entry of a plugin: enqueue BOTH
- *     f_dev  = fun(t, ys_in)
- *     ys_out = y_dev + h * (init + sum_{j<nt} coef[j]*rows[j] + c_self*f_dev)
- * i.e. this stage's derivative and, from the value still in registers, the NEXT
- * stage's argument (its accumulate is pointwise, nothing is recomputed).  init
- * may be NULL; the FMA chain runs over j ascending and adds c_self*f_dev last
- * (skipped if c_self == 0), then *h, then +y: bit-identical to the separate
- * kernels.  start/stop are hipEvent_t or NULL (dispatch timestamps for
- * esq_profile_*).  Return ESQ_ENOTSUP to fall back to esq_rhs_fn +
- * stage_accumulate.
+ * OPTIONAL fused entry of a plugin: enqueue ONE sweep that evaluates
+ *     f_dev = fun(t, y_in)
+ * and, while the derivative is still in registers, applies a POINTWISE epilogue
+ * to it -- the Runge-Kutta arithmetic that follows every RHS evaluation
+ * (common.py:343-356).  The separate streaming kernel and its re-read of f_dev
+ * disappear; nothing is recomputed on stencil halos because the epilogue is
+ * pointwise.  `kind` selects the epilogue (device side: csrc/esq_epilogue.hpp,
+ * which a plugin author includes and instantiates in the sweep kernel):
+ *
+ *   ESQ_EPI_STAGE    out = base + h*(init + sum_{j<nt} c[j]*rows[j] + c_self*f)
+ *                    base = y, or y_in itself when y == NULL.  The argument of
+ *                    the next stage (common.py:355), y_new of an FSAL pair
+ *                    (:343), or -- with y == NULL -- the end-point evaluation
+ *                    K[s] = fun(t+h, y_new) chained with the NEXT step's first
+ *                    stage argument y_new + h_next*a_10*K[s] (:289-291, 355).
+ *   ESQ_EPI_BLOCK    blocked accumulation (see esq_rk_stage_accumulate) with f
+ *                    as the block's last column:
+ *                    out_o[o] = init_o[o] + sum_j w[j][o]*rows[j] + w_self[o]*f;
+ *                    if y != NULL output 0 is y + h*(that sum) instead.
+ *   ESQ_EPI_SOLERR   y_new = y + h*(sum c[j]*rows[j] + c_self*f)  -> out
+ *                    err   = h*(sum e[j]*rows[j] + e_self*f)
+ *                    partials[block] = sum |err/(atol + rtol*max(|y|,|y_new|))|^2
+ *                    (`_comp_sol_err`, common.py:341-351, non-FSAL pairs)
+ *   ESQ_EPI_ERRNORM  FSAL pairs: y_in is y_new, f is K[s];
+ *                    err = h*(sum e[j]*rows[j] + e_self*f), scale from y and
+ *                    y_in, partial sums as above      (common.py:348-351)
+ *
+ * The FMA chains run over j ascending and take f last; products with h and the
+ * final add are rounded separately: bit-identical to the stand-alone kernels.
+ * Reducing kinds write ONE partial per workgroup to partials[blockIdx.x] and
+ * report the workgroup count in *partials_used (<= partials_cap, else return
+ * ESQ_ENOTSUP).  f_store_nt != 0: f_dev is not re-read soon, stream it out.
+ * start/stop are hipEvent_t or NULL (dispatch timestamps for esq_profile_*).
+ * Return ESQ_ENOTSUP for any case the plugin does not fuse: the library falls
+ * back to esq_rhs_fn + its own kernels.
  */
-typedef int (*esq_rhs_chain_fn)(void *user, double t, const double *ys_in,
-                                double *f_dev, int nt, const double *const *rows,
-                                const double *coef, double c_self,
-                                const double *init, const double *y_dev, double h,
-                                double *ys_out, size_t n, void *hip_stream,
-                                void *start_event, void *stop_event);
+#define ESQ_EPI_STAGE    1
+#define ESQ_EPI_BLOCK    2
+#define ESQ_EPI_SOLERR   3
+#define ESQ_EPI_ERRNORM  4
+#define ESQ_EPI_MAX_ROWS 20
+#define ESQ_EPI_MAX_OUT  12
+typedef struct esq_epilogue {
+    int kind;
+    int nt;                                  /* K rows read from memory        */
+    const double *rows[ESQ_EPI_MAX_ROWS];
+    double c[ESQ_EPI_MAX_ROWS];              /* stage / solution weights       */
+    double e[ESQ_EPI_MAX_ROWS];              /* error weights                  */
+    double c_self, e_self;                   /* weights of the fresh f         */
+    const double *init;                      /* STAGE: leading partial or NULL */
+    const double *y;                         /* base state (NULL: y_in)        */
+    double h;
+    double *out;                             /* STAGE: argument; SOLERR: y_new */
+    int no;                                  /* BLOCK: number of outputs       */
+    double w[ESQ_EPI_MAX_ROWS][ESQ_EPI_MAX_OUT];
+    double w_self[ESQ_EPI_MAX_OUT];
+    const double *init_o[ESQ_EPI_MAX_OUT];
+    double *out_o[ESQ_EPI_MAX_OUT];
+    const double *atol_vec;                  /* reductions: NULL = scalar atol */
+    double atol_s, rtol;
+    size_t n_valid;                          /* elements beyond are padding    */
+    double *partials;
+    int partials_cap;
+    int *partials_used;
+    int f_store_nt;
+} esq_epilogue;
+typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
+                                double *f_dev, const esq_epilogue *epi, size_t n,
+                                void *hip_stream, void *start_event,
+                                void *stop_event);
 
 /*
  * OPTIONAL RKC entry of a plugin: enqueue ONE sweep that evaluates
@@ -129,10 +182,14 @@ int  esq_rk_set_tableau(esq_ctx *ctx, int s, const double *A, const double *B,
  * values as returned by validate_tol  common.py:30-54. */
 int  esq_set_tol(esq_ctx *ctx, double rtol, const double *atol, size_t n_atol);
 int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
-/* register (or clear) the optional chained entry: esq_rk_stages then issues ONE
- * kernel per stage (RHS of stage i + accumulate of stage i+1) wherever stage
- * i+1 lies in the requested range and is not a blocked-accumulation boundary */
-int  esq_set_rhs_chain(esq_ctx *ctx, esq_rhs_chain_fn fn);
+/* register (or clear) the optional fused entry: every RHS evaluation of a step
+ * then is ONE kernel that also does the Runge-Kutta arithmetic which follows it
+ * (next stage argument / blocked accumulation / solution + error norm).
+ * fuse_mask selects the epilogue kinds the library may request (bit k =
+ * ESQ_EPI_* value k; ESQ_FUSE_ALL for all) -- each one is bit-identical to the
+ * unfused sequence and can be switched off for A/B tests. */
+#define ESQ_FUSE_ALL 0x1e
+int  esq_set_rhs_fused(esq_ctx *ctx, esq_rhs_fused_fn fn, int fuse_mask);
 /* register (or clear) the optional RKC entry: esq_rkc_stages then issues ONE
  * kernel per Chebyshev stage (RHS + recursion) instead of two */
 int  esq_set_rhs_rkc(esq_ctx *ctx, esq_rhs_rkc_fn fn);
@@ -155,10 +212,13 @@ int  esq_rk_eval_rhs(esq_ctx *ctx, int dst_row, double t, int src_slot,
                      int src_row);
 /* for i in [i_from, i_to): stage_accumulate(i, h); K[i] = rhs(t + C[i]*h, YSTAGE)
  *                                                  common.py:241-242, 353-356
- * With a chained plugin entry (esq_set_rhs_chain) the RHS sweep of stage i also
- * forms stage i+1's argument (and, for FSAL tableaux when i_to == s, the last
- * sweep forms YNEW, which esq_rk_solution_error then does not recompute).  The
- * results are bit-identical to the one-kernel-per-operation sequence. */
+ * With a fused plugin entry (esq_set_rhs_fused) the RHS sweep of stage i also
+ * forms stage i+1's argument or runs the blocked accumulation at a column
+ * boundary; when i_to == s the last sweep forms YNEW (FSAL tableaux) or YNEW
+ * and the error partial sums (others), which esq_rk_solution_error then does
+ * not recompute.  K rows and states are bit-identical to the
+ * one-kernel-per-operation sequence; the error norm agrees to rounding (its
+ * partial sums are grouped by the sweep's workgroups). */
 int  esq_rk_stages(esq_ctx *ctx, int i_from, int i_to, double t, double h);
 /* YNEW = Y + h * sum_j B[j] K[j]                   common.py:343              */
 int  esq_rk_solution(esq_ctx *ctx, double h);
@@ -187,8 +247,14 @@ int  esq_rk_custom_sol_err(esq_ctx *ctx, double h, const double *b,
 /* Accept the attempt (common.py:289-303): non-FSAL tableaux with a device RHS
  * get K[s] = rhs(t_new, YNEW); then Y <-> YNEW are swapped and K[s] becomes the
  * new K[0] by pointer rotation (no copies).  with_end_eval = 0 skips the RHS
- * launch (host-RHS mode uploads K[s] itself before calling this). */
-int  esq_rk_accept(esq_ctx *ctx, double t_new, int with_end_eval);
+ * launch (host-RHS mode uploads K[s] itself before calling this).
+ * h_next != 0: the step size the host controller intends to use next.  The
+ * first stage argument of the next step, YSTAGE = Y + h_next*A[1][0]*K[0], is
+ * then formed right away -- by the end-point sweep itself where the plugin has
+ * a fused entry, else by a kernel that runs while the host is between steps.
+ * The next esq_rk_stages(1, ..., h) uses it iff h == h_next exactly and no call
+ * that may write a vector came in between; otherwise it is recomputed. */
+int  esq_rk_accept(esq_ctx *ctx, double t_new, int with_end_eval, double h_next);
 /* WORK = h * sum_j E[j] K[j]  (the vector `_estimate_error` returns,
  * common.py:333-336); K rows of the step just accepted if last_step != 0. */
 int  esq_rk_error_vector(esq_ctx *ctx, double h, int last_step);
@@ -342,17 +408,16 @@ int  esq_rhs_diff3d_rkc(void *user, double t, const double *yjm1,
                         double mu, double nu, double omn, double hmus, double ajm1,
                         double *y_out, size_t n, void *stream, void *start_event,
                         void *stop_event);
-/* chained entries (esq_rhs_chain_fn) of the 2-D plugins */
-int  esq_rhs_bruss2d_chain(void *user, double t, const double *ys_in, double *f,
-                           int nt, const double *const *rows, const double *coef,
-                           double c_self, const double *init, const double *y,
-                           double h, double *ys_out, size_t n, void *stream,
+/* fused entries (esq_rhs_fused_fn) */
+int  esq_rhs_bruss2d_fused(void *user, double t, const double *y_in, double *f,
+                           const esq_epilogue *epi, size_t n, void *stream,
                            void *start_event, void *stop_event);
-int  esq_rhs_heat2d_chain(void *user, double t, const double *ys_in, double *f,
-                          int nt, const double *const *rows, const double *coef,
-                          double c_self, const double *init, const double *y,
-                          double h, double *ys_out, size_t n, void *stream,
+int  esq_rhs_heat2d_fused(void *user, double t, const double *y_in, double *f,
+                          const esq_epilogue *epi, size_t n, void *stream,
                           void *start_event, void *stop_event);
+int  esq_rhs_diag_fused(void *user, double t, const double *y_in, double *f,
+                        const esq_epilogue *epi, size_t n, void *stream,
+                        void *start_event, void *stop_event);
 
 /* ---- measurement (bench.py `roofline`) ------------------------------------ */
 /* class_mask bit k = 1: every launch of kernel class k carries a start/stop HIP

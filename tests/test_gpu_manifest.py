@@ -42,6 +42,8 @@ REQUIRED = {
     # bit-identical restructurings, each with its on/off switch
     "test_gpu_parity.py::test_blocked_accumulation_is_bit_identical": 18,
     "test_gpu_parity.py::test_chained_stages_are_bit_identical": 45,
+    "test_gpu_parity.py::test_each_epilogue_kind_is_bit_identical": 40,
+    "test_gpu_parity.py::test_prelaunched_first_stage_is_used_only_when_valid": 4,
     "test_gpu_rkc.py::test_rkc_chained_stage_is_bit_identical": 1,
     # lock-step
     "test_gpu_parity.py::test_rccl_single_rank_lockstep": 1,

@@ -770,18 +770,23 @@ def test_blocked_accumulation_plans(monkeypatch):
 
 
 # ------------------------------------------------------------- chained stages
+def _plugin(plugin, N):
+    if plugin == "bruss":
+        return (lambda: esq.Brusselator2D(N)), pb.bruss2d_y0(N), pb.bruss2d_rho(N)
+    return (lambda: esq.Heat2D(N)), pb.heat2d_y0(N), pb.heat2d_rho(N)
+
+
 @pytest.mark.parametrize("name", ERK + ["CKdisc"])
 @pytest.mark.parametrize("plugin,N", [("bruss", 4), ("bruss", 50), ("bruss", 258),
                                       ("heat", 6), ("heat", 130)])
 def test_chained_stages_are_bit_identical(monkeypatch, name, plugin, N):
-    """ESQ_CHAIN (default on for the heat plugin): one kernel does the RHS of
-    stage i and the accumulate of stage i+1; K rows, states and error norms
-    must equal the separate-kernel path bit for bit (also combined with blocked
-    accumulation, whose boundaries are never chained across)"""
-    if plugin == "bruss":
-        mk, y0, rho = (lambda: esq.Brusselator2D(N)), pb.bruss2d_y0(N), pb.bruss2d_rho(N)
-    else:
-        mk, y0, rho = (lambda: esq.Heat2D(N)), pb.heat2d_y0(N), pb.heat2d_rho(N)
+    """ESQ_CHAIN (default on): every RHS sweep also does the Runge-Kutta
+    arithmetic that follows it (all epilogue kinds, first stage of the next
+    step formed at accept time); K rows and states must equal the
+    one-kernel-per-operation path bit for bit (also combined with blocked
+    accumulation), the error norm to rounding (its partial sums are grouped by
+    the sweep's workgroups instead of the grid-stride blocks)"""
+    mk, y0, rho = _plugin(plugin, N)
     h = 0.4 / rho
     kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
     cls = getattr(esq, name)
@@ -790,15 +795,86 @@ def test_chained_stages_are_bit_identical(monkeypatch, name, plugin, N):
     monkeypatch.setenv("ESQ_CHAIN", "0")
     plain = cls(mk(), 0.0, y0, 1.0, **kw)
     monkeypatch.delenv("ESQ_CHAIN")
+    chained._prelaunch, plain._prelaunch = True, False
     for _ in range(3):
-        assert chained.step() is None and plain.step() is None
-        assert chained.t == plain.t and chained.h_abs == plain.h_abs
+        assert plain.step() is None and chained.step() is None
+        assert chained.t == plain.t
+        assert_allclose(chained.h_abs, plain.h_abs, rtol=1e-12)
+        if name != "CKdisc":
+            assert_allclose(chained.error_norm_old, plain.error_norm_old, rtol=1e-12)
         assert_equal(chained.K, plain.K)
         assert_equal(chained.y, plain.y)
     assert chained.nfev == plain.nfev
     sd, sp = chained.dense_output(), plain.dense_output()
     tc = np.linspace(plain.t_old, plain.t, 3)
     assert_equal(sd(tc), sp(tc))
+
+
+@pytest.mark.parametrize("fuse", ["stage", "stage,block", "stage,solerr",
+                                  "stage,errnorm", "block,solerr,errnorm"])
+@pytest.mark.parametrize("name,plugin,N", [
+    ("Pr8", "bruss", 50), ("Pr8", "bruss", 258), ("Pr9", "heat", 130),
+    ("Pr7", "heat", 36), ("Ts5", "heat", 258), ("Ts5", "bruss", 48),
+    ("BS5", "heat", 130), ("CFMR7osc", "bruss", 36)])
+def test_each_epilogue_kind_is_bit_identical(monkeypatch, fuse, name, plugin, N):
+    """ESQ_FUSE selects the epilogue kinds one by one: (a) next stage argument,
+    (b) blocked accumulation inside the boundary stage's sweep, (c) solution +
+    error norm inside the last stage's sweep, FSAL error norm inside the
+    end-point sweep -- each must leave K rows and states bit-identical"""
+    mk, y0, rho = _plugin(plugin, N)
+    h = 0.4 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
+    cls = getattr(esq, name)
+    monkeypatch.setenv("ESQ_FUSE", fuse)
+    fused = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_FUSE")
+    monkeypatch.setenv("ESQ_CHAIN", "0")
+    plain = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_CHAIN")
+    for _ in range(3):
+        assert fused.step() is None and plain.step() is None
+        assert fused.t == plain.t
+        assert_allclose(fused.error_norm_old, plain.error_norm_old, rtol=1e-12)
+        assert_equal(fused.K, plain.K)
+        assert_equal(fused.y, plain.y)
+    assert fused.nfev == plain.nfev
+
+
+@pytest.mark.parametrize("name", ["Pr8", "Ts5", "BS5", "Pr9"])
+def test_prelaunched_first_stage_is_used_only_when_valid(monkeypatch, name):
+    """esq_rk_accept(h_next) forms the next step's first stage argument ahead of
+    time.  It must be dropped when (1) the next step asks for another h (the
+    user changed h_abs), (2) a vector was written in between (solver.y = ...),
+    (3) the attempt is repeated after a rejection -- and used otherwise; every
+    variant must equal the run without it bit for bit"""
+    N = 48
+    mk, y0, rho = _plugin("heat", N)
+    cls = getattr(esq, name)
+    kw = dict(first_step=0.5 / rho, rtol=1e-5, atol=1e-8)
+
+    def run(prelaunch):
+        s = cls(mk(), 0.0, y0, 1.0, **kw)
+        s._prelaunch = prelaunch
+        out = []
+        for k in range(8):
+            if k == 2:
+                s.h_abs = 0.7 * s.h_abs                # (1) another step size
+            if k == 4:
+                s.y = 0.5 * s.y                        # (2) the state is replaced
+                s._chk(s._lib.esq_rk_eval_rhs(s._ctx, 0, float(s.t), 1, 0),
+                       "esq_rk_eval_rhs")                # ... and K[0] = f(t, y)
+            if k == 6:
+                s.h_abs = 40.0 * s.h_abs               # (3) forces rejections
+            assert s.step() is None
+            out.append((s.t, s.h_abs, s.y.copy(), s.K.copy()))
+        return out, int(esq.NFS[()])
+    a, nfs_a = run(True)
+    b, nfs_b = run(False)
+    assert nfs_a == nfs_b and nfs_a > 0
+    for (ta, ha, ya, Ka), (tb, hb, yb, Kb) in zip(a, b):
+        assert ta == tb and ha == hb
+        assert_equal(ya, yb)
+        assert_equal(Ka, Kb)
 
 
 @pytest.mark.parametrize("N", [2, 3, 5, 7])
