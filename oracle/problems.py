@@ -153,3 +153,38 @@ def tanh3d_problem(N=39):
         return 12.0 * inv_h2
 
     return fun, y0, rho_jac
+
+
+def combustion3d_problem(N=40, lewis=0.9, alpha=1.0, delta=20.0, rate=5.0):
+    """3-D combustion benchmark of the RKC paper as set up in the reference's
+    docs/Demo_SSV2stab.ipynb (cells 1-3): concentration c and temperature T on
+    an N^3 cell grid, mirror (Neumann) conditions on the three low faces, value 1
+    (Dirichlet) on the three high faces, mesh width 1/(N + 1/2);
+        c_t = lap c - D c exp(-delta/T),   L T_t = lap T + alpha D c exp(-delta/T)
+    with D = R exp(delta) / (alpha delta).  State y = [c.ravel(), T.ravel()].
+    Returns (fun, y0)."""
+    damkohler = rate * np.exp(delta) / (alpha * delta)
+    inv_h2 = (N + 0.5) ** 2
+    n3 = N ** 3
+    halo = [np.ones((N + 2,) * 3), np.ones((N + 2,) * 3)]   # high faces stay 1
+
+    def laplacian(field, w):
+        w[1:-1, 1:-1, 1:-1] = field
+        w[0, :, :] = w[1, :, :]
+        w[:, 0, :] = w[:, 1, :]
+        w[:, :, 0] = w[:, :, 1]
+        return inv_h2 * (-6 * w[1:-1, 1:-1, 1:-1]
+                         + w[:-2, 1:-1, 1:-1] + w[2:, 1:-1, 1:-1]
+                         + w[1:-1, :-2, 1:-1] + w[1:-1, 2:, 1:-1]
+                         + w[1:-1, 1:-1, :-2] + w[1:-1, 1:-1, 2:])
+
+    def fun(t, y):
+        c = y[:n3].reshape(N, N, N)
+        temp = y[n3:].reshape(N, N, N)
+        lap_c = laplacian(c, halo[0])
+        lap_t = laplacian(temp, halo[1])
+        react = damkohler * c * np.exp(-delta / temp)
+        return np.concatenate([(lap_c - react).reshape(-1),
+                               ((lap_t + alpha * react) / lewis).reshape(-1)])
+
+    return fun, np.ones(2 * n3)

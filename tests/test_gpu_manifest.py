@@ -50,7 +50,8 @@ REQUIRED = {
     "test_gpu_parity.py::test_lockstep_total_size_changes_the_norm": 1,
     # RKC
     "test_gpu_rkc.py::test_stages_golden": 5,
-    "test_gpu_rkc.py::test_published_table": 3,
+    "test_gpu_rkc.py::test_published_table": 6,
+    "test_gpu_rkc.py::test_published_combustion_table": 4,
     "test_gpu_rkc.py::test_power_iteration_golden": 1,
     # next rows
     "test_gpu_parity.py::test_device_dense_output_large_n": 8,

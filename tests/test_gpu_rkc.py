@@ -40,6 +40,9 @@ def test_stages_golden(golden_dir, m, mode):
     (1e-1, (6, 1, 402, 132)),      # docs/Demo_SSV2stab.ipynb:350-356
     (1e-2, (15, 4, 729, 85)),
     (1e-3, (27, 2, 786, 40)),
+    (1e-4, (57, 0, 1087, 26)),
+    (1e-5, (129, 1, 1682, 20)),
+    (1e-6, (262, 0, 2445, 12)),
 ])
 def test_published_table(golden_dir, tol, expect):
     """3-D tanh heat problem (n = 59 319), host-RHS mode"""
@@ -53,6 +56,28 @@ def test_published_table(golden_dir, tol, expect):
     assert got == expect
     assert_allclose(res.t, gold["t"], rtol=1e-9)
     assert_allclose(res.y[::5000, -1], gold["y_probe"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("tol,expect", [
+    (1e-4, (51, 1, 525, 21, 36)),  # docs/Demo_SSV2stab.ipynb:207-211:
+    (1e-5, (124, 0, 781, 27, 29)),  # steps (failed) / f-evals / f-sigma / s-max
+    (1e-6, (270, 0, 1270, 39, 20)),
+    (1e-7, (581, 0, 2147, 65, 14)),
+])
+def test_published_combustion_table(golden_dir, tol, expect):
+    """3-D combustion problem (n = 128 000), host-RHS mode, spectral radius by
+    the device-resident power iteration: the published integer table and the
+    reference's accepted times"""
+    with open(os.path.join(golden_dir, "rkc_traces.json")) as fh:
+        gold = json.load(fh)[f"combustion_tol{tol:.0e}"]
+    fun, y0 = pb.combustion3d_problem(40)
+    res = solve_ivp(fun, (0, 0.3), y0, method=esq.SSV2stab, rtol=tol, atol=tol)
+    nfs = int(dev_rkc.nrejct[()])
+    got = (int(res.t.size - 1 + nfs), nfs, int(res.nfev),
+           int(dev_rkc.nfesig[()]), int(dev_rkc.maxm[()]))
+    assert got == expect
+    assert_allclose(res.t, gold["t"], rtol=1e-8)
+    assert_allclose(res.y[::4001, -1], gold["y_probe"], rtol=1e-6)
 
 
 @pytest.mark.parametrize("mode", ["host_rhs", "device_rhs"])

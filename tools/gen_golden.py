@@ -168,7 +168,7 @@ def gen_rkc():
 
     traces = {}
     fun3, y03, rho3 = pb.tanh3d_problem(39)
-    for tol in (1e-1, 1e-2, 1e-3):
+    for tol in (1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-6):   # Demo_SSV2stab.ipynb:350-356
         res = solve_ivp(fun3, (0, 0.7), y03, method=ref.SSV2stab, rtol=tol,
                         atol=tol, const_jac=True, rho_jac=rho3)
         nfs = int(ref.NFS[()])
@@ -177,6 +177,20 @@ def gen_rkc():
             "nfev": int(res.nfev), "maxm": int(maxm[()]),
             "t": [float(v) for v in res.t],
             "y_probe": [float(v) for v in res.y[::5000, -1]],
+        }
+    # combustion table (Demo_SSV2stab.ipynb:207-211): rho_jac=None, so the
+    # spectral radius comes from the power iteration (f-sigma column)
+    func, y0c = pb.combustion3d_problem(40)
+    for tol in (1e-4, 1e-5, 1e-6, 1e-7):
+        res = solve_ivp(func, (0, 0.3), y0c, method=ref.SSV2stab, rtol=tol,
+                        atol=tol)
+        nfs = int(ref.NFS[()])
+        traces[f"combustion_tol{tol:.0e}"] = {
+            "steps": int(res.t.size - 1 + nfs), "nfs": nfs,
+            "nfev": int(res.nfev), "maxm": int(maxm[()]),
+            "nfesig": int(nfesig[()]),
+            "t": [float(v) for v in res.t],
+            "y_probe": [float(v) for v in res.y[::4001, -1]],
         }
     # power-iteration branch (rho_jac=None) on a small 2-D heat problem
     N = 24
@@ -193,8 +207,8 @@ def gen_rkc():
     }
     with open(os.path.join(GOLD, "rkc_traces.json"), "w") as fh:
         json.dump(traces, fh)
-    print("rkc:", {k: (v["steps"], v["nfs"], v["nfev"], v["maxm"])
-                   for k, v in traces.items()})
+    print("rkc:", {k: (v["steps"], v["nfs"], v["nfev"], v["maxm"],
+                       v.get("nfesig")) for k, v in traces.items()})
 
 
 def gen_lockstep():
