@@ -15,6 +15,7 @@ ABI_VERSION = 2
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
 FUSE_ALL = 0x1e
+CREATE_HOST_SLAB = 1
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
 PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC = range(4)
 VEC_NONE, VEC_Y, VEC_YNEW, VEC_YSTAGE, VEC_WORK = -1, -2, -3, -4, -5
@@ -30,6 +31,7 @@ _vpp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "esq_abi_version": (C.c_int, []),
     "esq_create": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int]),
+    "esq_create2": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "esq_destroy": (C.c_int, [_vp]),
     "esq_last_error": (C.c_char_p, [_vp]),
     "esq_synchronize": (C.c_int, [_vp]),

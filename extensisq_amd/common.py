@@ -343,7 +343,8 @@ class RungeKutta(OdeSolver):
         # at least 5 K rows: rows 1..4 are the work vectors of the device
         # starting-step estimate (they are free until the first step)
         self._dev = DeviceContext(
-            self.n, max(self.n_stages + 1 + self._extra_rows, 5), is_cplx, device)
+            self.n, max(self.n_stages + 1 + self._extra_rows, 5), is_cplx, device,
+            host_rhs=self._device_rhs is None and lockstep is None)
         self._lib = self._dev.lib
         self._ctx = self._dev.handle
         self._dev.set_tableau(self.A, self.B, self.C, self.E, self.FSAL)

@@ -62,6 +62,13 @@ struct esq_ctx {
     bool cplx = false;
     hipStream_t stream = nullptr;
     double *slab = nullptr;
+    // small host-RHS problems: the slab is pinned, device-mapped HOST memory --
+    // kernels read and write it over PCIe, uploads and downloads are plain
+    // memcpy calls (no copy engine, no stream synchronisation)
+    bool host_slab = false;
+    double *slab_host = nullptr;      // host address of slab[0]
+    size_t slab_doubles = 0;
+    bool idle = true;                 // nothing enqueued since the last wait
     std::vector<double *> aux_slabs;   // lazily added work rows (esq_aux_rows)
     std::vector<double *> krow;       // physical K rows
     std::vector<int> kmap;            // logical -> physical (step in flight)
@@ -449,6 +456,7 @@ int finish_reduction(esq_ctx *c, double *out, bool take_min = false,
                     c->comm_timeout_s);
     }
     if (w) return w;
+    c->idle = true;        // the final-sum kernel was the last thing enqueued
     if (out) *out = c->h_slot->value;
     return 0;
 }
@@ -547,13 +555,46 @@ int plan_words(const std::vector<double> &A, int s, const std::vector<int> &boun
     do {                                     \
         (void)hipSetDevice((c)->device);     \
         (c)->pre_valid = false;              \
+        (c)->idle = false;                   \
     } while (0)
+
+// ---- host-slab mode ------------------------------------------------------------
+bool in_host_slab(const esq_ctx *c, const void *dev) {
+    const double *p = (const double *)dev;
+    return c->host_slab && p >= c->slab && p < c->slab + c->slab_doubles;
+}
+double *host_of(const esq_ctx *c, const void *dev) {
+    return c->slab_host + ((const double *)dev - c->slab);
+}
+// every kernel enqueued so far has finished (its writes to the pinned slab are
+// visible to the host): a one-thread kernel bumps the pinned sequence number
+// behind them, the host spins on it
+int host_wait(esq_ctx *c, bool already_idle) {
+    if (already_idle) return 0;
+    ResultSink rs;
+    rs.seq = ++c->red_seq;
+    rs.dev = nullptr;
+    rs.host_value = &c->h_slot->value;
+    rs.host_seq = &c->h_slot->seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, c->d_result, rs);
+    HIPCHK(c, hipGetLastError());
+    const int w = wait_slot(c, rs.seq, 0.0);
+    if (w) return w;
+    c->idle = true;
+    return 0;
+}
 
 // Device-to-host copy into a caller's (pageable) buffer.  Large copies pin the
 // destination for the duration of the call: measured for 80 MB into a fresh
 // NumPy array 4.3 ms (register 2.8 + copy 1.5 at 54 GB/s) against 6.5-7 ms for
 // the staged pageable copy.
-int d2h(esq_ctx *c, void *host, const void *dev, size_t bytes) {
+int d2h(esq_ctx *c, void *host, const void *dev, size_t bytes, bool was_idle = false) {
+    if (in_host_slab(c, dev)) {
+        const int w = host_wait(c, was_idle);
+        if (w) return w;
+        memcpy(host, host_of(c, dev), bytes);
+        return 0;
+    }
     bool pinned = false;
     if (bytes >= ((size_t)8 << 20))
         pinned = hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess;
@@ -562,6 +603,22 @@ int d2h(esq_ctx *c, void *host, const void *dev, size_t bytes) {
     if (pinned) (void)hipHostUnregister(host);
     if (e != hipSuccess)
         return fail(c, (int)e, "device-to-host copy failed: %s", hipGetErrorString(e));
+    c->idle = true;
+    return 0;
+}
+// host-to-device copy of a caller's buffer, synchronous
+int h2d(esq_ctx *c, void *dev, const void *host, size_t bytes, bool was_idle) {
+    if (in_host_slab(c, dev)) {
+        // no kernel may still be reading the row that is overwritten
+        const int w = host_wait(c, was_idle);
+        if (w) return w;
+        memcpy(host_of(c, dev), host, bytes);
+        c->idle = true;
+        return 0;
+    }
+    HIPCHK(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->idle = true;
     return 0;
 }
 
@@ -631,6 +688,10 @@ extern "C" {
 int esq_abi_version(void) { return ESQ_ABI_VERSION; }
 
 int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) {
+    return esq_create2(out, device, n, n_rows, is_complex, 0);
+}
+int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
+                int flags) {
     if (!out || n_rows < 1 || n_rows > 64) return ESQ_EINVAL;
     esq_ctx *c = new (std::nothrow) esq_ctx();
     if (!c) return ESQ_ENOMEM;
@@ -650,8 +711,17 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t nvec = (size_t)n_rows + kFixedSlots;
     const size_t slab_doubles = nvec * c->stride + kPartialsCap + kMaxPartials + 64;
-    HIPCHK(c, hipMalloc(&c->slab, slab_doubles * sizeof(double)));
-    HIPCHK(c, hipMemsetAsync(c->slab, 0, slab_doubles * sizeof(double), c->stream));
+    c->slab_doubles = slab_doubles;
+    c->host_slab = (flags & ESQ_CREATE_HOST_SLAB) != 0;
+    if (c->host_slab) {
+        HIPCHK(c, hipHostMalloc((void **)&c->slab_host, slab_doubles * sizeof(double),
+                                hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->slab_host, 0, slab_doubles * sizeof(double));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->slab, c->slab_host, 0));
+    } else {
+        HIPCHK(c, hipMalloc(&c->slab, slab_doubles * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->slab, 0, slab_doubles * sizeof(double), c->stream));
+    }
     c->krow.resize(n_rows);
     c->kmap.resize(n_rows);
     for (int r = 0; r < n_rows; ++r) {
@@ -704,7 +774,11 @@ int esq_destroy(esq_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &ev : c->prof_live) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
     for (auto &e : c->prof_pool) (void)hipEventDestroy(e);
-    if (c->slab) (void)hipFree(c->slab);
+    if (c->host_slab) {
+        if (c->slab_host) (void)hipHostFree(c->slab_host);
+    } else if (c->slab) {
+        (void)hipFree(c->slab);
+    }
     for (double *p : c->aux_slabs) (void)hipFree(p);
     if (c->h_slot) (void)hipHostFree(c->h_slot);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -718,20 +792,19 @@ int esq_synchronize(esq_ctx *c) {
     if (!c) return ESQ_EINVAL;
     ENTER_KEEP(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->idle = true;
     return 0;
 }
 size_t esq_vector_len(const esq_ctx *c) { return c ? c->len : 0; }
 
 int esq_upload(esq_ctx *c, int slot, int row, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    const bool was_idle = c->idle;
     ENTER(c);
     double *d = slot_ptr(c, slot, row);
     if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
     const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
-    HIPCHK(c, hipMemcpyAsync(d, host, cnt * sizeof(double), hipMemcpyHostToDevice,
-                             c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return h2d(c, d, host, cnt * sizeof(double), was_idle);
 }
 int esq_download(esq_ctx *c, int slot, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
@@ -739,7 +812,7 @@ int esq_download(esq_ctx *c, int slot, int row, double *host) {
     double *d = slot_ptr(c, slot, row);
     if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
     const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
-    return d2h(c, host, d, cnt * sizeof(double));
+    return d2h(c, host, d, cnt * sizeof(double), c->idle);
 }
 int esq_copy(esq_ctx *c, int dst_slot, int dst_row, int src_slot, int src_row) {
     if (!c) return ESQ_EINVAL;
@@ -747,7 +820,7 @@ int esq_copy(esq_ctx *c, int dst_slot, int dst_row, int src_slot, int src_row) {
     double *d = slot_ptr(c, dst_slot, dst_row), *s = slot_ptr(c, src_slot, src_row);
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad slot/row");
     HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),
-                             hipMemcpyDeviceToDevice, c->stream));
+                             hipMemcpyDefault, c->stream));
     return 0;
 }
 
@@ -846,10 +919,7 @@ int esq_set_tol(esq_ctx *c, double rtol, const double *atol, size_t n_atol) {
     }
     if (n_atol != c->n) return fail(c, ESQ_EINVAL, "atol has %zu entries, n = %zu", n_atol, c->n);
     c->atol_is_vec = true;
-    HIPCHK(c, hipMemcpyAsync(c->atolv, atol, c->n * sizeof(double),
-                             hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return h2d(c, c->atolv, atol, c->n * sizeof(double), false);
 }
 
 int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
@@ -1363,7 +1433,7 @@ int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
     ENTER_KEEP(c);
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
-    return d2h(c, host, c->krow[c->kmap_last[row]], c->len * sizeof(double));
+    return d2h(c, host, c->krow[c->kmap_last[row]], c->len * sizeof(double), c->idle);
 }
 
 int esq_rk_dense_stage(esq_ctx *c, int row, const double *a, int count, double h) {
@@ -1385,13 +1455,10 @@ int esq_rk_dense_eval(esq_ctx *c, int row, double t) {
 }
 int esq_rk_upload_last_K(esq_ctx *c, int row, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    const bool was_idle = c->idle;
     ENTER(c);
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
-    HIPCHK(c, hipMemcpyAsync(c->krow[c->kmap_last[row]], host,
-                             c->len * sizeof(double), hipMemcpyHostToDevice,
-                             c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return h2d(c, c->krow[c->kmap_last[row]], host, c->len * sizeof(double), was_idle);
 }
 
 // ---- device-resident interpolant ------------------------------------------------
@@ -1458,7 +1525,7 @@ int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
     // base state: after esq_rk_accept, Y is the new state, YNEW the pre-step one
     const double *base = from_end ? c->y : c->ynew;
     e = hipMemcpyAsync(d->mem + (size_t)p * d->len_pad, base,
-                       d->len_pad * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+                       d->len_pad * sizeof(double), hipMemcpyDefault, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1711,7 +1778,7 @@ int esq_vec_copy(esq_ctx *c, int dst, int src) {
     double *d = ROW(c, dst), *s = ROW(c, src);
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad vector id");
     HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),
-                             hipMemcpyDeviceToDevice, c->stream));
+                             hipMemcpyDefault, c->stream));
     return 0;
 }
 int esq_vec_eval_rhs(esq_ctx *c, int dst, double t, int src) {
@@ -1723,20 +1790,19 @@ int esq_vec_eval_rhs(esq_ctx *c, int dst, double t, int src) {
 }
 int esq_vec_upload(esq_ctx *c, int dst, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    const bool was_idle = c->idle;
     ENTER(c);
     double *d = ROW(c, dst);
     if (!d) return fail(c, ESQ_EINVAL, "bad vector id %d", dst);
-    HIPCHK(c, hipMemcpyAsync(d, host, c->len * sizeof(double),
-                             hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return h2d(c, d, host, c->len * sizeof(double), was_idle);
 }
 int esq_vec_download(esq_ctx *c, int src, double *host) {
     if (!c || !host) return ESQ_EINVAL;
-    ENTER(c);
+    const bool was_idle = c->idle;
+    ENTER_KEEP(c);
     double *s = ROW(c, src);
     if (!s) return fail(c, ESQ_EINVAL, "bad vector id %d", src);
-    return d2h(c, host, s, c->len * sizeof(double));
+    return d2h(c, host, s, c->len * sizeof(double), was_idle);
 }
 int esq_hs_log_etol(esq_ctx *c, int y, double *sum_out, double *min_out) {
     if (!c || !sum_out || !min_out) return ESQ_EINVAL;

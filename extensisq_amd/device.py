@@ -100,16 +100,24 @@ _warm = WarmBuffers()
 class DeviceContext:
     """Thin owner of one `esq_ctx` (one device, one stream, one HBM slab)."""
 
-    def __init__(self, n, n_rows, is_complex=False, device=0):
+    # host-RHS problems up to this many doubles per vector keep their vectors
+    # in pinned, device-mapped host memory (ESQ_HOST_SLAB=0 switches it off)
+    HOST_SLAB_MAX_DOUBLES = 8192
+
+    def __init__(self, n, n_rows, is_complex=False, device=0, host_rhs=False):
         self.lib = _lib.load()
         self.n = int(n)
         self.n_rows = int(n_rows)
         self.is_complex = bool(is_complex)
         self.dtype = np.complex128 if is_complex else np.float64
         self.device = int(device)
+        doubles = self.n * (2 if is_complex else 1)
+        self.host_slab = (bool(host_rhs) and doubles <= self.HOST_SLAB_MAX_DOUBLES
+                          and os.environ.get("ESQ_HOST_SLAB", "1") != "0")
         handle = C.c_void_p()
-        code = self.lib.esq_create(C.byref(handle), self.device, self.n,
-                                   self.n_rows, int(self.is_complex))
+        code = self.lib.esq_create2(
+            C.byref(handle), self.device, self.n, self.n_rows,
+            int(self.is_complex), _lib.CREATE_HOST_SLAB if self.host_slab else 0)
         self.handle = handle
         if code != 0:
             msg = self.lib.esq_last_error(handle) if handle else b""

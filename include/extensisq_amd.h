@@ -156,6 +156,16 @@ int  esq_abi_version(void);
  * Replaces `self.K = np.empty((n_stages + 1, n))`  common.py:216 and the
  * per-step temporaries of common.py:343-356. */
 int  esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex);
+/* flags: ESQ_CREATE_HOST_SLAB -- small problems whose RHS is a host callable
+ * (the reference's own tests live at n <= 400): every vector of the context is
+ * pinned, device-mapped HOST memory.  The kernels are the same; the per-stage
+ * download of the stage argument and upload of the derivative become plain
+ * memcpy calls (completion is signalled through the pinned result slot), which
+ * removes two copy-engine round trips per stage.  Meant for vectors of at most
+ * a few thousand doubles: kernels then read their operands over PCIe. */
+#define ESQ_CREATE_HOST_SLAB 1
+int  esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
+                 int flags);
 int  esq_destroy(esq_ctx *ctx);
 const char *esq_last_error(const esq_ctx *ctx);
 int  esq_synchronize(esq_ctx *ctx);

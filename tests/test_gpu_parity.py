@@ -897,3 +897,64 @@ def test_plugin_fallback_paths_small_and_odd_grids(N):
         assert d.step() is None and o.step() is None
     assert d.status == "finished"
     assert_allclose(d.y, o.y, rtol=1e-7, atol=1e-11)
+
+
+# ------------------------------------------------------- small host-RHS problems
+@pytest.mark.parametrize("name", ERK + ["CKdisc", "SSV2stab"])
+def test_host_slab_mode_is_bit_identical(monkeypatch, name):
+    """small problems with a Python RHS keep their vectors in pinned,
+    device-mapped host memory (ESQ_CREATE_HOST_SLAB): same kernels, uploads and
+    downloads become memcpy -- the run must equal the device-slab run bit for bit"""
+    cls = getattr(esq, name)
+    fun, t_span, y0, kw = CASES["bruss1d"]
+
+    def run(flag):
+        monkeypatch.setenv("ESQ_HOST_SLAB", flag)
+        s = cls(fun, t_span[0], y0, t_span[1], **kw)
+        assert s._dev.host_slab == (flag == "1")
+        out = []
+        for _ in range(6):
+            assert s.step() is None
+            out.append((s.t, s.y.copy()))
+        dense = s.dense_output()(0.5 * (s.t_old + s.t))
+        return out, dense, s.nfev
+    a, da, na = run("1")
+    b, db, nb = run("0")
+    assert na == nb
+    for (ta, ya), (tb, yb) in zip(a, b):
+        assert ta == tb
+        assert_equal(ya, yb)
+    assert_equal(da, db)
+
+
+def test_host_slab_mode_is_faster_for_small_host_rhs(monkeypatch, capsys):
+    """n = 400, Python RHS (the regime of the reference's own tests): wall time
+    per Pr8 step with the pinned host slab against the device slab (and the
+    NumPy oracle for scale).  The host slab must not be slower."""
+    import time
+    n = 400
+    rng = np.random.default_rng(0)
+    lam = -rng.random(n)
+    y0 = rng.standard_normal(n)
+    fun = lambda t, y: lam * y          # noqa: E731
+    kw = dict(first_step=1e-3, max_step=1e-3, rtol=1e-6, atol=1e-9,
+              nfev_stiff_detect=0)
+
+    def per_step(make, steps=200):
+        s = make()
+        for _ in range(20):
+            s.step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.step()
+        return (time.perf_counter() - t0) / steps
+    monkeypatch.setenv("ESQ_HOST_SLAB", "1")
+    t_host = per_step(lambda: esq.Pr8(fun, 0.0, y0, 1e9, **kw))
+    monkeypatch.setenv("ESQ_HOST_SLAB", "0")
+    t_dev = per_step(lambda: esq.Pr8(fun, 0.0, y0, 1e9, **kw))
+    t_ora = per_step(lambda: rk_oracle.Pr8(fun, 0.0, y0, 1e9, **kw))
+    with capsys.disabled():
+        print(f"\n[small-n] Pr8 n=400 host RHS: host slab {1e6 * t_host:.0f} us/step, "
+              f"device slab {1e6 * t_dev:.0f} us/step, NumPy oracle "
+              f"{1e6 * t_ora:.0f} us/step")
+    assert t_host < 1.1 * t_dev
