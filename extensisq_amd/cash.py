@@ -46,74 +46,105 @@ class CKdisc(RungeKutta):
             ctypes.byref(out)), "esq_rk_custom_sol_err")
         return self._rms_from_sumsq(out.value)
 
+    # The ladder: stage pairs (1), (2, 3), (4, 5); after each of the first two an
+    # embedded pair of order 2 / 3 is assessed, after the last the 5(4) pair of
+    # the tableau itself.  (rows of K involved, root that makes the norm
+    # comparable between the orders)
+    _LADDER = ((2, 1 / 2), (4, 1 / 3), (6, 1 / 5))
+    _ORDER_OF_FALLBACK = (1, 2)        # `order_accepted` of fallback level 0 / 1
+
+    def _climb(self, t, h):
+        """Evaluate stage pairs for the step size h while the assessed errors
+        promise that the fifth-order step will succeed (gates
+        `E < twiddle * quit`, ref cash.py:277-303).  Returns the assessed,
+        order-normalised errors [E1, E2, E4] as far as the climb got."""
+        est = []
+        first = 1
+        for level, (rows, root) in enumerate(self._LADDER):
+            self._run_stages(first, rows, t, h)
+            first = rows
+            if level < 2:
+                e = self._pair_norm(h, self.B_assess[level], self.E_assess[level],
+                                    rows, False) ** root
+                est.append(e)
+                if not e < self.twiddle[level] * self.quit[level]:
+                    break
+            else:
+                # the tableau's own pair: `_comp_sol_err` of the base class
+                # (fused into the last stage's sweep where the plugin can)
+                est.append(self._solution_and_error(t, h) ** root or 1e-160)
+        return est
+
+    def _tune_quit(self, est):
+        """after an accepted fifth-order step (ref cash.py:318-326)"""
+        for j in (0, 1):
+            q = est[j] / est[2]
+            q = min(q, 10 * self.quit[j]) if q > self.quit[j] else \
+                max(q, 2 / 3 * self.quit[j])
+            self.quit[j] = max(1., min(10000., q))
+
+    def _tune_twiddle(self, est):
+        """after a failed fifth-order step (ref cash.py:334-339)"""
+        for j in (0, 1):
+            ratio = est[j] / self.quit[j]
+            if ratio < self.twiddle[j]:
+                self.twiddle[j] = max(1.1, ratio)
+
+    def _descend(self, est, h):
+        """The climb did not end in an accepted fifth-order step: try the
+        lower-order solutions over the shortened step, highest first
+        (ref cash.py:341-375).  Level 1 (third order) is only looked at after a
+        failed fifth-order attempt, level 0 (second order) whenever the first
+        gate was passed.  Returns ("accept", level), ("shrink", 0) -- non-smooth
+        behaviour, retry with the shortened step -- or ("reject", None)."""
+        depth = len(est)
+        for level in (1, 0):
+            reached = depth == 3 if level == 1 else depth >= 2
+            if not reached or not est[level] < 1:
+                continue
+            rows = self._LADDER[level][0]
+            if self._pair_norm(h, self.B_fallback[level], self.E_fallback[level],
+                               rows, True) < 1:
+                return "accept", level
+            if level == 0:
+                return "shrink", 0
+        return "reject", None
+
     def _step_impl(self):
-        """ref cash.py:253-395"""
+        """variable-order step (ref cash.py:253-395)"""
         t = self.t
-        twiddle, quit = self.twiddle, self.quit
         h_abs, min_step = self._reassess_stepsize(t)
-        order_accepted = 0
         rejected = False
-        while not order_accepted:
+        while True:
             if h_abs < min_step:
                 return False, self.TOO_SMALL_STEP
             h = h_abs * self.direction
-            self._run_stages(1, 2, t, h)
-            E1 = self._pair_norm(h, self.B_assess[0], self.E_assess[0], 2,
-                                 False) ** (1 / 2)
-            esttol = E1 / quit[0]
-            if E1 < twiddle[0] * quit[0]:
-                self._run_stages(2, 4, t, h)
-                E2 = self._pair_norm(h, self.B_assess[1], self.E_assess[1], 4,
-                                     False) ** (1 / 3)
-                esttol = E2 / quit[1]
-                if E2 < twiddle[1] * quit[1]:
-                    self._run_stages(4, 6, t, h)
-                    # the tableau's own pair: `_comp_sol_err` of the base class
-                    # (fused into the last stage's sweep where the plugin can)
-                    E4 = self._solution_and_error(t, h) ** (1 / 5)
-                    E4 = E4 or 1e-160
-                    esttol = E4
-                    if E4 < 1:
-                        order_accepted = 4
-                        factor = min(self.max_factor, SAFETY / E4)
-                        if rejected:
-                            factor = min(1.0, factor)
-                        h_abs *= factor
-                        q = [E1 / E4, E2 / E4]
-                        for j in (0, 1):
-                            if q[j] > quit[j]:
-                                q[j] = min(q[j], 10 * quit[j])
-                            else:
-                                q[j] = max(q[j], 2 / 3 * quit[j])
-                            quit[j] = max(1., min(10000., q[j]))
-                        break
-                    if np.isnan(E4) or np.isinf(E4):
-                        return False, "Overflow or underflow encountered."
-                    for i, e in enumerate((E1, E2)):
-                        ratio = e / quit[i]
-                        if ratio < twiddle[i]:
-                            twiddle[i] = max(1.1, ratio)
-                    if E2 < 1:
-                        if self._pair_norm(h, self.B_fallback[1],
-                                           self.E_fallback[1], 4, True) < 1:
-                            order_accepted = 2
-                            h_abs *= self.C_fallback[1]
-                            h = h_abs * self.direction
-                            break
-                if E1 < 1:
-                    if self._pair_norm(h, self.B_fallback[0], self.E_fallback[0],
-                                       2, True) < 1:
-                        order_accepted = 1
-                        h_abs *= self.C_fallback[0]
-                        h = h_abs * self.direction
-                        break
-                    rejected = True
-                    h_abs *= self.C_fallback[0]
-                    NFS[()] += 1
-                    continue
+            est = self._climb(t, h)
+            if len(est) == 3:
+                if est[2] < 1:                       # fifth order accepted
+                    order_accepted = 4
+                    factor = min(self.max_factor, SAFETY / est[2])
+                    h_abs *= min(1.0, factor) if rejected else factor
+                    self._tune_quit(est)
+                    break
+                if np.isnan(est[2]) or np.isinf(est[2]):
+                    return False, "Overflow or underflow encountered."
+                self._tune_twiddle(est)
+            verdict, level = self._descend(est, h)
+            if verdict == "accept":
+                # the fallback solution belongs to the SHORTENED step
+                order_accepted = self._ORDER_OF_FALLBACK[level]
+                h_abs *= self.C_fallback[level]
+                h = h_abs * self.direction
+                break
             rejected = True
-            h_abs *= max(self.min_factor, SAFETY / esttol)
             NFS[()] += 1
+            if verdict == "shrink":
+                h_abs *= self.C_fallback[0]
+            else:
+                depth = len(est)
+                esttol = est[-1] / self.quit[depth - 1] if depth < 3 else est[-1]
+                h_abs *= max(self.min_factor, SAFETY / esttol)
         # the derivative at the accepted point (next first stage, interpolation)
         t_new = t + h
         self._finish_step(t_new, h, h_abs)

@@ -347,35 +347,41 @@ class SSV2stab(OdeSolver):
             self.newspc = not self.jacatt
             self.absh = absh
 
-        # accepted: rotate the roles instead of copying W (ref :245-251)
-        t += h
+        self._advance(t + h, h, absh, hmin, err, yrow, fyrow)
+        return True, None
+
+    def _advance(self, t_new, h, absh, hmin, err, yrow, fyrow):
+        """book-keeping of an accepted step (ref sommeijer.py:245-270)"""
+        # when to look at the spectral radius again: with a user bound at every
+        # step, else every 25 steps -- unless the Jacobian is constant
         self.jacatt = self.const_jac
         self.nstsig = (self.nstsig + 1) % 25
-        self.newspc = False
-        if self.rho_jac is not None or self.nstsig == 0:
-            self.newspc = not self.jacatt
-        spare = [w for w in r["w"] if w not in (yrow, fyrow)]
-        r["w"] = spare + [r["yold"], r["fold"]]
+        refresh = self.rho_jac is not None or self.nstsig == 0
+        self.newspc = refresh and not self.jacatt
+        # the result rows become (yn, fn), the old (yn, fn) are kept for the
+        # interpolant, what is left is work space: roles move, data do not
+        r = self._r
+        idle = [w for w in r["w"] if w not in (yrow, fyrow)]
+        r["w"] = idle + [r["yold"], r["fold"]]
         r["yold"], r["fold"] = r["yn"], r["fn"]
         r["yn"], r["fn"] = yrow, fyrow
         self._y_host = None
-
-        fac = 10.0
-        if self.hold is None:
-            temp2 = err ** (1 / 3)
-            if 0.8 < fac * temp2:
-                fac = 0.8 / temp2
-        else:
-            temp1 = 0.8 * absh * self.errold ** (1 / 3)
-            temp2 = abs(self.hold) * err ** (2 / 3)
-            if temp1 < fac * temp2:
-                fac = temp1 / temp2
-        absh = max(0.1, fac) * absh
-        self.absh = max(hmin, min(self.max_step, absh))
+        self.absh = max(hmin, min(self.max_step, self._predicted_step(err, absh)))
         self.errold = err
         self.hold = h
-        self.t = t
-        return True, None
+        self.t = t_new
+
+    def _predicted_step(self, err, absh):
+        """next step size: the asymptotic estimate on the first step, afterwards
+        the predictive controller that also uses the previous step and error;
+        growth capped at 10, shrinkage at 0.1 (ref sommeijer.py:252-265)"""
+        if self.hold is None:
+            num, den = 0.8, err ** (1 / 3)
+        else:
+            num = 0.8 * absh * self.errold ** (1 / 3)
+            den = abs(self.hold) * err ** (2 / 3)
+        factor = num / den if num < 10.0 * den else 10.0     # den == 0: err == 0
+        return max(0.1, factor) * absh
 
     def _dense_output_impl(self):
         """cubic Hermite through (y_old, f_old), (y, f)  (ref :400-406)"""
