@@ -99,6 +99,9 @@ struct esq_ctx {
     // first stage argument of the NEXT step, formed at accept time
     bool pre_valid = false;
     double pre_h = 0.0;
+    // which sweeps stream the fresh derivative out with non-temporal stores
+    // (ESQ_EPI_NT bits: 0 stage, 1 block, 2 solerr, 3 end-point, 4 FSAL errnorm)
+    unsigned epi_nt = 0x3;
     // blocked accumulation plan (esq_rk_set_tableau)
     struct Block {
         int J = 0, prev = 0;              // columns [prev, J) of A
@@ -743,6 +746,7 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     c->h_slot->value = 0.0;
     c->h_slot->seq = 0;
     c->comm_timeout_s = (double)env_uint("ESQ_COMM_TIMEOUT_S", 120);
+    c->epi_nt = env_uint("ESQ_EPI_NT", 0x3);
     // launch geometry: grid-stride kernels, a few resident blocks per CU
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
@@ -872,6 +876,18 @@ int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
                     const int w = plan_words(c->A, s, {b1, b2, b3}, nullptr);
                     if (w >= 0 && w < best_words) { best_words = w; best = {b1, b2, b3}; }
                 }
+        // ESQ_BLOCK_BOUNDS="6,10": override the boundaries (tuning experiments)
+        if (const char *ov = getenv("ESQ_BLOCK_BOUNDS")) {
+            std::vector<int> forced;
+            for (const char *q = ov; *q;) {
+                char *end = nullptr;
+                const long v = strtol(q, &end, 10);
+                if (end == q) break;
+                if (v >= 2 && v < s) forced.push_back((int)v);
+                q = *end ? end + 1 : end;
+            }
+            if (plan_words(c->A, s, forced, nullptr) >= 0) best = forced;
+        }
         if (!best.empty()) {
             std::vector<esq_ctx::Block> blocks;
             plan_words(c->A, s, best, &blocks);
@@ -1066,7 +1082,7 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h) {
     e.y = c->y;
     e.h = h;
     e.out = c->work;
-    e.f_store_nt = 1;      // K_i is consumed from registers, not re-read soon
+    e.f_store_nt = c->epi_nt & 1;   // K_i is consumed from registers, not re-read soon
     // booked on the stage class: next stage's algorithmic bytes + the RHS's
     // 16 B; moved: ys_in, rows, init, y in; K[i], ys_out out
     Prof p(c, ESQ_PROF_STAGE, "rhs+stage", nt, 8.0 * (nnz_all + 4) * (double)c->len,
@@ -1114,7 +1130,7 @@ int sweep_block(esq_ctx *c, const esq_ctx::Block &b, int i, double t, double h,
         alg += 8.0 * (nnz_all + 2) * (double)c->len;   // the boundary stage's booking
         *made_ystage = true;
     }
-    e.f_store_nt = 1;
+    e.f_store_nt = (c->epi_nt >> 1) & 1;
     Prof p(c, ESQ_PROF_STAGE, "rhs+block", nt, alg, false,
            8.0 * (reads + no + 1) * (double)c->len);
     const int r = run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
@@ -1140,7 +1156,7 @@ int sweep_ynew(esq_ctx *c, int i, double t, double h) {
     e.y = c->y;
     e.h = h;
     e.out = c->ynew;
-    e.f_store_nt = 1;
+    e.f_store_nt = c->epi_nt & 1;
     Prof p(c, ESQ_PROF_STAGE, "rhs+stage", nt, 8.0 * (nnz_all + 4) * (double)c->len,
            false, 8.0 * (nt + 4) * (double)c->len);
     return run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
@@ -1165,7 +1181,7 @@ int sweep_solerr(esq_ctx *c, int i, double t, double h) {
     e.y = c->y;
     e.h = h;
     e.out = c->ynew;
-    e.f_store_nt = 0;      // K_{s-1} is read by the dense output / next block only
+    e.f_store_nt = (c->epi_nt >> 2) & 1;   // K_{s-1}: next read by the dense output
     // booked: the RHS's 16 B + the fused solution/error pass (rows incl. the
     // fresh one + y + y_new); moved: ys_in, rows, y in; K_i, y_new out
     Prof p(c, ESQ_PROF_SOLERR, "rhs+solerr", nt, 8.0 * (nt + 1 + 2 + 2) * (double)c->len,
@@ -1300,7 +1316,7 @@ int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
                 e.e_self = c->E[c->s];
                 e.y = c->y;
                 e.h = h;
-                e.f_store_nt = 0;     // K[s] is the next step's K[0]
+                e.f_store_nt = (c->epi_nt >> 4) & 1;   // K[s] is the next step's K[0]
                 // booked: RHS 16 B + error pass (rows incl. K[s], y, y_new);
                 // moved: y_new, rows, y in; K[s] out
                 Prof p(c, ESQ_PROF_SOLERR, "rhs+errnorm", nt,
@@ -1385,7 +1401,7 @@ int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
             e.y = nullptr;                          // base = the sweep's input
             e.h = h_next;
             e.out = c->ystage;
-            e.f_store_nt = 0;                       // K[0] of the next step
+            e.f_store_nt = (c->epi_nt >> 3) & 1;    // K[0] of the next step
             const int nnz = e.c_self != 0.0 ? 1 : 0;
             Prof p(c, ESQ_PROF_STAGE, "rhs+stage", 0, 8.0 * (nnz + 4) * (double)c->len,
                    false, 8.0 * 3 * (double)c->len);
