@@ -1,0 +1,156 @@
+// esq_plugin.hpp -- host-side helper for authors of device RHS plugins with a
+// fused entry (esq_rhs_fused_fn, include/extensisq_amd.h).
+//
+// The library describes the epilogue it wants as a plain C struct
+// (`esq_epilogue`); the plugin's sweep kernel is a template over the matching
+// device-side type of esq_epilogue.hpp.  `esq::dispatch_epilogue` converts one
+// into the other and hands it to a generic callable that launches the kernel:
+//
+//     template <class Epi> __global__ void my_sweep(const double* y, double* f, Epi epi, ...);
+//
+//     extern "C" int my_rhs_fused(void* user, double t, const double* y, double* f,
+//                                 const esq_epilogue* epi, size_t n, void* stream,
+//                                 void* start_event, void* stop_event) {
+//         const unsigned grid = ...;
+//         if (esq::epilogue_reduces(epi)) {            // one partial per workgroup
+//             if ((int)grid > epi->partials_cap) return ESQ_ENOTSUP;
+//             *epi->partials_used = (int)grid;
+//         }
+//         const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
+//             hipExtLaunchKernelGGL((my_sweep<decltype(ep)>), dim3(grid), dim3(256), 0,
+//                                   (hipStream_t)stream, (hipEvent_t)start_event,
+//                                   (hipEvent_t)stop_event, 0, y, f, ep, ...);
+//         });
+//         return rc ? rc : (int)hipGetLastError();
+//     }
+//
+// Row counts beyond the instantiated ranges (stage / solution rows <= 16, block
+// rows <= 8 besides the fresh column, FSAL error rows <= 12) return ESQ_ENOTSUP:
+// the library then falls back to esq_rhs_fn + its own kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/extensisq_amd.h"
+#include "esq_epilogue.hpp"
+
+namespace esq {
+
+inline bool epilogue_reduces(const esq_epilogue *epi) {
+    return epi->kind == ESQ_EPI_SOLERR || epi->kind == ESQ_EPI_ERRNORM;
+}
+inline RedArgs red_of(const esq_epilogue *e) {
+    RedArgs r;
+    r.atol_vec = e->atol_vec;
+    r.atol_s = e->atol_s;
+    r.rtol = e->rtol;
+    r.n_valid = e->n_valid;
+    r.partials = e->partials;
+    return r;
+}
+template <int NT>
+EpiStage<NT> make_stage(const esq_epilogue *e) {
+    EpiStage<NT> s;
+    for (int j = 0; j < kMaxTerms; ++j) {
+        s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
+        s.tm.c[j] = j < e->nt ? e->c[j] : 0.0;
+    }
+    s.init = e->init; s.y = e->y; s.out = e->out;
+    s.c_self = e->c_self; s.h = e->h; s.f_nt = e->f_store_nt;
+    s.red = red_of(e);
+    return s;
+}
+template <int NT>
+EpiBlock<NT> make_block(const esq_epilogue *e) {
+    EpiBlock<NT> s;
+    for (int j = 0; j < kMaxTerms; ++j) {
+        s.p[j] = j < e->nt ? e->rows[j] : nullptr;
+        for (int o = 0; o < kMaxOut; ++o)
+            s.w[j][o] = (j < e->nt && o < e->no) ? e->w[j][o] : 0.0;
+    }
+    for (int o = 0; o < kMaxOut; ++o) {
+        s.w_self[o] = o < e->no ? e->w_self[o] : 0.0;
+        s.init[o] = o < e->no ? e->init_o[o] : nullptr;
+        s.out[o] = o < e->no ? e->out_o[o] : nullptr;
+    }
+    s.y = e->y; s.h = e->h; s.no = e->no; s.f_nt = e->f_store_nt;
+    s.red = red_of(e);
+    return s;
+}
+template <int NT>
+EpiSolErr<NT> make_solerr(const esq_epilogue *e) {
+    EpiSolErr<NT> s;
+    for (int j = 0; j < kMaxTerms; ++j) {
+        s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
+        s.tm.b[j] = j < e->nt ? e->c[j] : 0.0;
+        s.tm.e[j] = j < e->nt ? e->e[j] : 0.0;
+    }
+    s.b_self = e->c_self; s.e_self = e->e_self;
+    s.y = e->y; s.ynew = e->out; s.h = e->h; s.f_nt = e->f_store_nt;
+    s.red = red_of(e);
+    return s;
+}
+template <int NT>
+EpiErrNorm<NT> make_errnorm(const esq_epilogue *e) {
+    EpiErrNorm<NT> s;
+    for (int j = 0; j < kMaxTerms; ++j) {
+        s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
+        s.tm.c[j] = j < e->nt ? e->e[j] : 0.0;
+    }
+    s.e_self = e->e_self; s.y = e->y; s.h = e->h; s.f_nt = e->f_store_nt;
+    s.red = red_of(e);
+    return s;
+}
+
+// (kind, nt) -> launch(device-side epilogue object).  Returns 0 after the call,
+// ESQ_EINVAL for an inconsistent description, ESQ_ENOTSUP outside the
+// instantiated ranges.
+#define ESQ_EPI_CASE_(MAKE, K) case K: launch(MAKE<K>(epi)); return 0;
+#define ESQ_EPI_CASES_0_8_(MAKE)                                                 \
+    ESQ_EPI_CASE_(MAKE, 0) ESQ_EPI_CASE_(MAKE, 1) ESQ_EPI_CASE_(MAKE, 2)         \
+    ESQ_EPI_CASE_(MAKE, 3) ESQ_EPI_CASE_(MAKE, 4) ESQ_EPI_CASE_(MAKE, 5)         \
+    ESQ_EPI_CASE_(MAKE, 6) ESQ_EPI_CASE_(MAKE, 7) ESQ_EPI_CASE_(MAKE, 8)
+#define ESQ_EPI_CASES_9_12_(MAKE)                                                \
+    ESQ_EPI_CASE_(MAKE, 9) ESQ_EPI_CASE_(MAKE, 10) ESQ_EPI_CASE_(MAKE, 11)       \
+    ESQ_EPI_CASE_(MAKE, 12)
+#define ESQ_EPI_CASES_13_16_(MAKE)                                               \
+    ESQ_EPI_CASE_(MAKE, 13) ESQ_EPI_CASE_(MAKE, 14) ESQ_EPI_CASE_(MAKE, 15)      \
+    ESQ_EPI_CASE_(MAKE, 16)
+template <class Launch>
+int dispatch_epilogue(const esq_epilogue *epi, Launch &&launch) {
+    if (!epi || epi->nt < 0) return ESQ_EINVAL;
+    switch (epi->kind) {
+        case ESQ_EPI_STAGE:
+            if (!epi->out) return ESQ_EINVAL;
+            switch (epi->nt) {
+                ESQ_EPI_CASES_0_8_(make_stage) ESQ_EPI_CASES_9_12_(make_stage)
+                ESQ_EPI_CASES_13_16_(make_stage)
+                default: return ESQ_ENOTSUP;
+            }
+        case ESQ_EPI_BLOCK:
+            if (epi->no < 1 || epi->no > ESQ_EPI_MAX_OUT) return ESQ_EINVAL;
+            switch (epi->nt) {
+                ESQ_EPI_CASES_0_8_(make_block)
+                default: return ESQ_ENOTSUP;
+            }
+        case ESQ_EPI_SOLERR:
+            if (!epi->out || !epi->y || !epi->partials) return ESQ_EINVAL;
+            switch (epi->nt) {
+                ESQ_EPI_CASES_0_8_(make_solerr) ESQ_EPI_CASES_9_12_(make_solerr)
+                ESQ_EPI_CASES_13_16_(make_solerr)
+                default: return ESQ_ENOTSUP;
+            }
+        case ESQ_EPI_ERRNORM:
+            if (!epi->y || !epi->partials) return ESQ_EINVAL;
+            switch (epi->nt) {
+                ESQ_EPI_CASES_0_8_(make_errnorm) ESQ_EPI_CASES_9_12_(make_errnorm)
+                default: return ESQ_ENOTSUP;
+            }
+        default: return ESQ_ENOTSUP;
+    }
+}
+#undef ESQ_EPI_CASE_
+#undef ESQ_EPI_CASES_0_8_
+#undef ESQ_EPI_CASES_9_12_
+#undef ESQ_EPI_CASES_13_16_
+
+}  // namespace esq

@@ -19,6 +19,7 @@
 
 #include "../../include/extensisq_amd.h"
 #include "esq_epilogue.hpp"
+#include "esq_plugin.hpp"
 #include "esq_terms.hpp"
 
 namespace {
@@ -361,135 +362,6 @@ Geo2d geo2d(int N) {
     g.grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
     return g;
 }
-esq::RedArgs red_of(const esq_epilogue *e) {
-    esq::RedArgs r;
-    r.atol_vec = e->atol_vec;
-    r.atol_s = e->atol_s;
-    r.rtol = e->rtol;
-    r.n_valid = e->n_valid;
-    r.partials = e->partials;
-    return r;
-}
-template <int NT>
-esq::EpiStage<NT> make_stage(const esq_epilogue *e) {
-    esq::EpiStage<NT> s;
-    for (int j = 0; j < esq::kMaxTerms; ++j) {
-        s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
-        s.tm.c[j] = j < e->nt ? e->c[j] : 0.0;
-    }
-    s.init = e->init; s.y = e->y; s.out = e->out;
-    s.c_self = e->c_self; s.h = e->h; s.f_nt = e->f_store_nt;
-    s.red = red_of(e);
-    return s;
-}
-template <int NT>
-esq::EpiBlock<NT> make_block(const esq_epilogue *e) {
-    esq::EpiBlock<NT> s;
-    for (int j = 0; j < esq::kMaxTerms; ++j) {
-        s.p[j] = j < e->nt ? e->rows[j] : nullptr;
-        for (int o = 0; o < esq::kMaxOut; ++o)
-            s.w[j][o] = (j < e->nt && o < e->no) ? e->w[j][o] : 0.0;
-    }
-    for (int o = 0; o < esq::kMaxOut; ++o) {
-        s.w_self[o] = o < e->no ? e->w_self[o] : 0.0;
-        s.init[o] = o < e->no ? e->init_o[o] : nullptr;
-        s.out[o] = o < e->no ? e->out_o[o] : nullptr;
-    }
-    s.y = e->y; s.h = e->h; s.no = e->no; s.f_nt = e->f_store_nt;
-    s.red = red_of(e);
-    return s;
-}
-template <int NT>
-esq::EpiSolErr<NT> make_solerr(const esq_epilogue *e) {
-    esq::EpiSolErr<NT> s;
-    for (int j = 0; j < esq::kMaxTerms; ++j) {
-        s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
-        s.tm.b[j] = j < e->nt ? e->c[j] : 0.0;
-        s.tm.e[j] = j < e->nt ? e->e[j] : 0.0;
-    }
-    s.b_self = e->c_self; s.e_self = e->e_self;
-    s.y = e->y; s.ynew = e->out; s.h = e->h; s.f_nt = e->f_store_nt;
-    s.red = red_of(e);
-    return s;
-}
-template <int NT>
-esq::EpiErrNorm<NT> make_errnorm(const esq_epilogue *e) {
-    esq::EpiErrNorm<NT> s;
-    for (int j = 0; j < esq::kMaxTerms; ++j) {
-        s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
-        s.tm.c[j] = j < e->nt ? e->e[j] : 0.0;
-    }
-    s.e_self = e->e_self; s.y = e->y; s.h = e->h; s.f_nt = e->f_store_nt;
-    s.red = red_of(e);
-    return s;
-}
-
-// Dispatch (kind, nt) -> LAUNCH(EpiType, epi_value).  Row counts beyond the
-// instantiated ranges fall back (ESQ_ENOTSUP): stage rows <= 16, block rows
-// <= 8 (the fresh column comes on top), solution/error rows <= 16.
-#define EPI_CASE(MAKE, T, K) case K: { auto ep = MAKE<K>(epi); LAUNCH(T<K>, ep); } break;
-#define EPI_DISPATCH()                                                               \
-    switch (epi->kind) {                                                             \
-        case ESQ_EPI_STAGE:                                                          \
-            if (!epi->out) return ESQ_EINVAL;                                        \
-            switch (epi->nt) {                                                       \
-                EPI_CASE(make_stage, esq::EpiStage, 0) EPI_CASE(make_stage, esq::EpiStage, 1)   \
-                EPI_CASE(make_stage, esq::EpiStage, 2) EPI_CASE(make_stage, esq::EpiStage, 3)   \
-                EPI_CASE(make_stage, esq::EpiStage, 4) EPI_CASE(make_stage, esq::EpiStage, 5)   \
-                EPI_CASE(make_stage, esq::EpiStage, 6) EPI_CASE(make_stage, esq::EpiStage, 7)   \
-                EPI_CASE(make_stage, esq::EpiStage, 8) EPI_CASE(make_stage, esq::EpiStage, 9)   \
-                EPI_CASE(make_stage, esq::EpiStage, 10) EPI_CASE(make_stage, esq::EpiStage, 11) \
-                EPI_CASE(make_stage, esq::EpiStage, 12) EPI_CASE(make_stage, esq::EpiStage, 13) \
-                EPI_CASE(make_stage, esq::EpiStage, 14) EPI_CASE(make_stage, esq::EpiStage, 15) \
-                EPI_CASE(make_stage, esq::EpiStage, 16)                              \
-                default: return ESQ_ENOTSUP;                                         \
-            }                                                                        \
-            break;                                                                   \
-        case ESQ_EPI_BLOCK:                                                          \
-            if (epi->no < 1 || epi->no > ESQ_EPI_MAX_OUT) return ESQ_EINVAL;         \
-            switch (epi->nt) {                                                       \
-                EPI_CASE(make_block, esq::EpiBlock, 0) EPI_CASE(make_block, esq::EpiBlock, 1)   \
-                EPI_CASE(make_block, esq::EpiBlock, 2) EPI_CASE(make_block, esq::EpiBlock, 3)   \
-                EPI_CASE(make_block, esq::EpiBlock, 4) EPI_CASE(make_block, esq::EpiBlock, 5)   \
-                EPI_CASE(make_block, esq::EpiBlock, 6) EPI_CASE(make_block, esq::EpiBlock, 7)   \
-                EPI_CASE(make_block, esq::EpiBlock, 8)                               \
-                default: return ESQ_ENOTSUP;                                         \
-            }                                                                        \
-            break;                                                                   \
-        case ESQ_EPI_SOLERR:                                                         \
-            if (!epi->out || !epi->y || !epi->partials) return ESQ_EINVAL;           \
-            switch (epi->nt) {                                                       \
-                EPI_CASE(make_solerr, esq::EpiSolErr, 0) EPI_CASE(make_solerr, esq::EpiSolErr, 1)   \
-                EPI_CASE(make_solerr, esq::EpiSolErr, 2) EPI_CASE(make_solerr, esq::EpiSolErr, 3)   \
-                EPI_CASE(make_solerr, esq::EpiSolErr, 4) EPI_CASE(make_solerr, esq::EpiSolErr, 5)   \
-                EPI_CASE(make_solerr, esq::EpiSolErr, 6) EPI_CASE(make_solerr, esq::EpiSolErr, 7)   \
-                EPI_CASE(make_solerr, esq::EpiSolErr, 8) EPI_CASE(make_solerr, esq::EpiSolErr, 9)   \
-                EPI_CASE(make_solerr, esq::EpiSolErr, 10) EPI_CASE(make_solerr, esq::EpiSolErr, 11) \
-                EPI_CASE(make_solerr, esq::EpiSolErr, 12) EPI_CASE(make_solerr, esq::EpiSolErr, 13) \
-                EPI_CASE(make_solerr, esq::EpiSolErr, 14) EPI_CASE(make_solerr, esq::EpiSolErr, 15) \
-                EPI_CASE(make_solerr, esq::EpiSolErr, 16)                            \
-                default: return ESQ_ENOTSUP;                                         \
-            }                                                                        \
-            break;                                                                   \
-        case ESQ_EPI_ERRNORM:                                                        \
-            if (!epi->y || !epi->partials) return ESQ_EINVAL;                        \
-            switch (epi->nt) {                                                       \
-                EPI_CASE(make_errnorm, esq::EpiErrNorm, 0) EPI_CASE(make_errnorm, esq::EpiErrNorm, 1)   \
-                EPI_CASE(make_errnorm, esq::EpiErrNorm, 2) EPI_CASE(make_errnorm, esq::EpiErrNorm, 3)   \
-                EPI_CASE(make_errnorm, esq::EpiErrNorm, 4) EPI_CASE(make_errnorm, esq::EpiErrNorm, 5)   \
-                EPI_CASE(make_errnorm, esq::EpiErrNorm, 6) EPI_CASE(make_errnorm, esq::EpiErrNorm, 7)   \
-                EPI_CASE(make_errnorm, esq::EpiErrNorm, 8) EPI_CASE(make_errnorm, esq::EpiErrNorm, 9)   \
-                EPI_CASE(make_errnorm, esq::EpiErrNorm, 10) EPI_CASE(make_errnorm, esq::EpiErrNorm, 11) \
-                EPI_CASE(make_errnorm, esq::EpiErrNorm, 12)                          \
-                default: return ESQ_ENOTSUP;                                         \
-            }                                                                        \
-            break;                                                                   \
-        default: return ESQ_ENOTSUP;                                                 \
-    }
-
-bool reduces(const esq_epilogue *epi) {
-    return epi->kind == ESQ_EPI_SOLERR || epi->kind == ESQ_EPI_ERRNORM;
-}
 
 }  // namespace
 
@@ -606,19 +478,18 @@ int esq_rhs_bruss2d_fused(void *user, double t, const double *y_in, double *f,
     if (!r || r->kind != BRUSS2D || n != r->n || !epi) return ESQ_EINVAL;
     if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
     const Geo2d g = geo2d(r->N);
-    if (reduces(epi)) {
+    if (esq::epilogue_reduces(epi)) {
         if ((int)g.grid > epi->partials_cap) return ESQ_ENOTSUP;
         if (epi->partials_used) *epi->partials_used = (int)g.grid;
     }
     const double d = r->alpha * ((double)r->N * (double)r->N);
-#define LAUNCH(T, EP)                                                           \
-    hipExtLaunchKernelGGL((k_bruss2d_sweep<T>), dim3(g.grid), dim3(kBlock), 0,  \
-                          (hipStream_t)stream, (hipEvent_t)start_event,         \
-                          (hipEvent_t)stop_event, 0, y_in, f, EP, r->N, d,      \
-                          r->a, r->b, g.grid, g.wpr)
-    EPI_DISPATCH()
-#undef LAUNCH
-    return (int)hipGetLastError();
+    const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
+        hipExtLaunchKernelGGL((k_bruss2d_sweep<decltype(ep)>), dim3(g.grid),
+                              dim3(kBlock), 0, (hipStream_t)stream,
+                              (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
+                              y_in, f, ep, r->N, d, r->a, r->b, g.grid, g.wpr);
+    });
+    return rc ? rc : (int)hipGetLastError();
 }
 int esq_rhs_heat2d_fused(void *user, double t, const double *y_in, double *f,
                          const esq_epilogue *epi, size_t n, void *stream,
@@ -628,19 +499,18 @@ int esq_rhs_heat2d_fused(void *user, double t, const double *y_in, double *f,
     if (!r || r->kind != HEAT2D || n != r->n || !epi) return ESQ_EINVAL;
     if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
     const Geo2d g = geo2d(r->N);
-    if (reduces(epi)) {
+    if (esq::epilogue_reduces(epi)) {
         if ((int)g.grid > epi->partials_cap) return ESQ_ENOTSUP;
         if (epi->partials_used) *epi->partials_used = (int)g.grid;
     }
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
-#define LAUNCH(T, EP)                                                           \
-    hipExtLaunchKernelGGL((k_heat2d_sweep<T>), dim3(g.grid), dim3(kBlock), 0,   \
-                          (hipStream_t)stream, (hipEvent_t)start_event,         \
-                          (hipEvent_t)stop_event, 0, y_in, f, EP, r->N, c,      \
-                          g.grid, g.wpr)
-    EPI_DISPATCH()
-#undef LAUNCH
-    return (int)hipGetLastError();
+    const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
+        hipExtLaunchKernelGGL((k_heat2d_sweep<decltype(ep)>), dim3(g.grid),
+                              dim3(kBlock), 0, (hipStream_t)stream,
+                              (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
+                              y_in, f, ep, r->N, c, g.grid, g.wpr);
+    });
+    return rc ? rc : (int)hipGetLastError();
 }
 int esq_rhs_diag_fused(void *user, double t, const double *y_in, double *f,
                        const esq_epilogue *epi, size_t n, void *stream,
@@ -652,18 +522,17 @@ int esq_rhs_diag_fused(void *user, double t, const double *y_in, double *f,
     const size_t n_pad = ((n + 511) / 512) * 512, n2 = n_pad / 2;
     size_t blocks = (n2 + kBlock - 1) / kBlock;
     if (blocks > 2048) blocks = 2048;
-    if (reduces(epi)) {
+    if (esq::epilogue_reduces(epi)) {
         if ((int)blocks > epi->partials_cap) return ESQ_ENOTSUP;
         if (epi->partials_used) *epi->partials_used = (int)blocks;
     }
-#define LAUNCH(T, EP)                                                           \
-    hipExtLaunchKernelGGL((k_diag_sweep<T>), dim3((unsigned)blocks), dim3(kBlock), \
-                          0, (hipStream_t)stream, (hipEvent_t)start_event,      \
-                          (hipEvent_t)stop_event, 0, y_in, f, EP, r->lam_dev,   \
-                          forcing, n, n2)
-    EPI_DISPATCH()
-#undef LAUNCH
-    return (int)hipGetLastError();
+    const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
+        hipExtLaunchKernelGGL((k_diag_sweep<decltype(ep)>), dim3((unsigned)blocks),
+                              dim3(kBlock), 0, (hipStream_t)stream,
+                              (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
+                              y_in, f, ep, r->lam_dev, forcing, n, n2);
+    });
+    return rc ? rc : (int)hipGetLastError();
 }
 
 static RkcEpi make_epi(const double *yjm2, const double *yn, const double *fn,

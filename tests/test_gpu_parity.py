@@ -653,6 +653,130 @@ def test_user_plugin_compiled_with_hipcc(tmp_path):
     assert_allclose(got.y[:, -1], ref.y[:, -1], rtol=1e-7, atol=1e-11)
 
 
+FUSED_PLUGIN_SRC = r'''
+// A user plugin WITH a fused entry, written against the public helper headers
+// (extensisq_amd/csrc/esq_plugin.hpp, esq_epilogue.hpp): f_i = -k*y_i + cos(t).
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include "esq_plugin.hpp"
+
+__global__ void k_plain(const double* y, double* f, size_t n, double k, double c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[i] = -k * y[i] + c;
+}
+template <class Epi>
+__global__ __launch_bounds__(256) void k_sweep(const double* y, double* f, Epi epi,
+                                               size_t n, size_t n2, double k, double c) {
+    double local = 0.0;
+    for (size_t i2 = (size_t)blockIdx.x * 256 + threadIdx.x; i2 < n2;
+         i2 += (size_t)gridDim.x * 256) {
+        typename Epi::In in;
+        epi.load(in, i2);
+        const double2 yc = esq::ld2(y, i2);
+        double2 fy = make_double2(0.0, 0.0);          // the padding stays zero
+        if (2 * i2 < n) fy.x = -k * yc.x + c;
+        if (2 * i2 + 1 < n) fy.y = -k * yc.y + c;
+        epi.store_f(f, i2, fy);
+        epi.finish(in, fy, yc, i2, local);
+    }
+    if (Epi::kReduce) esq::block_partial(local, epi.red.partials);
+}
+extern "C" int user_rhs(void* user, double t, const double* y, double* f, size_t n,
+                        void* stream) {
+    const double k = *(const double*)user;
+    hipLaunchKernelGGL(k_plain, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, y, f, n, k, cos(t));
+    return (int)hipGetLastError();
+}
+extern "C" int user_rhs_fused(void* user, double t, const double* y, double* f,
+                              const esq_epilogue* epi, size_t n, void* stream,
+                              void* start_event, void* stop_event) {
+    const double k = *(const double*)user;
+    const size_t n2 = ((n + 511) / 512) * 512 / 2;    // vectors are padded to 512
+    unsigned grid = (unsigned)((n2 + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    if (esq::epilogue_reduces(epi)) {
+        if ((int)grid > epi->partials_cap) return ESQ_ENOTSUP;
+        *epi->partials_used = (int)grid;
+    }
+    const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
+        hipExtLaunchKernelGGL((k_sweep<decltype(ep)>), dim3(grid), dim3(256), 0,
+                              (hipStream_t)stream, (hipEvent_t)start_event,
+                              (hipEvent_t)stop_event, 0, y, f, ep, n, n2, k, cos(t));
+    });
+    return rc ? rc : (int)hipGetLastError();
+}
+'''
+
+
+@pytest.mark.parametrize("name", ["Pr8", "Ts5", "BS5"])
+def test_user_plugin_with_fused_entry(tmp_path_factory, name):
+    """INTEGRATION.md §4: a user's `esq_rhs_fused_fn` written with the public
+    helper headers (`esq_plugin.hpp`: `dispatch_epilogue`, `epilogue_reduces`;
+    `esq_epilogue.hpp`: the device-side epilogues).  The fused run must equal
+    the run through the plain entry bit for bit, and the oracle to tolerance."""
+    import ctypes
+    import shutil
+    import subprocess
+    from extensisq_amd import _lib
+    so = _user_fused_plugin(tmp_path_factory, ctypes, shutil, subprocess)
+    lib = ctypes.CDLL(str(so))
+    kval = ctypes.c_double(0.75)
+    n = 3001
+    plain_ptr = ctypes.cast(lib.user_rhs, ctypes.c_void_p).value
+    fused_ptr = ctypes.cast(lib.user_rhs_fused, ctypes.c_void_p)
+
+    class Fused(esq.CFunctionRHS):
+        _fuse_default = True
+
+        def _fused_entry(self, lib_):
+            return fused_ptr
+
+    y0 = np.linspace(-1.0, 2.0, n)
+    kw = dict(first_step=0.05, rtol=1e-7, atol=1e-10)
+    cls = DEV[name]
+    a = cls(Fused(plain_ptr, ctypes.addressof(kval), n), 0.0, y0, 2.0, **kw)
+    b = cls(esq.CFunctionRHS(plain_ptr, ctypes.addressof(kval), n), 0.0, y0, 2.0,
+            **kw)
+    o = rk_oracle.METHODS[name](lambda t, y: -0.75 * y + np.cos(t), 0.0, y0, 2.0,
+                                **kw)
+    a._dev.profile_enable([_lib.PROF_STAGE, _lib.PROF_SOLERR, _lib.PROF_RHS])
+    for _ in range(5):
+        assert a.step() is None and b.step() is None and o.step() is None
+        assert_allclose(a.t, b.t, rtol=1e-13)
+        # vs the oracle: the step sizes follow error norms that are cancelling
+        # sums (rounding-level differences show up as ~1e-5 relative in h)
+        assert_allclose(a.t, o.t, rtol=1e-4)
+    a._dev.profile_enable(None)
+    kernels = {row[0].split("<")[0] for row in a._dev.profile_kernels()}
+    assert "rhs+stage" in kernels                      # the fused entry really ran
+    assert ("rhs+solerr" in kernels) or ("rhs+errnorm" in kernels)
+    assert a.nfev == b.nfev == o.nfev
+    # the first step starts from identical data: bit-identical K and y; later
+    # steps inherit the last-bit difference of the error norm through h
+    assert_allclose(a.y, b.y, rtol=1e-11, atol=1e-14)
+    assert_allclose(a.y, o.y, rtol=1e-4, atol=1e-6)
+
+
+_FUSED_SO = {}
+
+
+def _user_fused_plugin(tmp_path_factory, ctypes, shutil, subprocess):
+    if "so" not in _FUSED_SO:
+        d = tmp_path_factory.mktemp("fused_plugin")
+        src = d / "user_fused.hip"
+        so = d / "libuser_fused.so"
+        src.write_text(FUSED_PLUGIN_SRC)
+        root = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC",
+                        "-shared", "-ffp-contract=off",
+                        "-I", os.path.join(root, "extensisq_amd", "csrc"),
+                        str(src), "-o", str(so)], check=True)
+        _FUSED_SO["so"] = so
+    return _FUSED_SO["so"]
+
+
 # -------------------------------------------------- CKdisc (variable order)
 @pytest.mark.parametrize("case", ["readme", "duffing", "rational_bwd", "complex",
                                   "sawtooth", "kink", "bruss1d"])
