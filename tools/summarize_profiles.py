@@ -28,7 +28,7 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 PEAK = 8.0e12
 
-STAGE = ("k_lincomb", "k_block_acc", "rhs_chain", "rhs+stage", "rhs+block")
+STAGE = ("k_lincomb", "k_block_acc", "rhs+stage", "rhs+block")
 RKC = ("rhs_rkc", "k_rkc_first", "k_rkc_stage")
 
 
@@ -37,9 +37,6 @@ def label(name):
     m = re.search(r"k_(bruss2d|heat2d|diff3d)_sweep<.*Epi(\w+)<(\d+)", name)
     if m:                                   # fused sweeps (round 2)
         return f"rhs+{m.group(2).lower()}<{m.group(3)}>"
-    m = re.search(r"k_(bruss2d|heat2d)_chain<(\d+)>", name)
-    if m:
-        return f"rhs_chain<{m.group(2)}>"
     m = re.search(r"k_(heat2d|diff3d)_v2<\d+, (true|false)>", name)
     if m:
         return "rhs_rkc" if m.group(2) == "true" else "rhs_plugin"
