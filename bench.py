@@ -89,12 +89,13 @@ def spawn_ranks(args):
     """start `args.gpus` fresh rank processes of this script, relay rank 0's
     stdout, return non-zero if any rank fails or the time limit passes"""
     world = args.gpus
-    port = free_port()
+    port, ctl_port = free_port(), free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ)
         env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ESQ_CTL_PORT=str(ctl_port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(
             [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,

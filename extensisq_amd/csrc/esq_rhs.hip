@@ -286,8 +286,7 @@ __global__ __launch_bounds__(kBlock) void k_diff3d(const double *__restrict__ u,
     f[k] = c * ((((a0 + a1) + (b0 + b1)) + (c0 + c1)) - 6.0 * uc);
 }
 
-// ESQ_RHS_VARIANT: 1 = scalar kernels, 2/3/4/8 = rows per wave tile of the
-// vectorised sweeps (default: one row -- measured fastest, most waves in flight)
+// ESQ_RHS_VARIANT=1: scalar kernels instead of the vectorised sweeps (tests)
 int rhs_variant() {
     static const int v = getenv("ESQ_RHS_VARIANT") ? atoi(getenv("ESQ_RHS_VARIANT")) : 0;
     return v;

@@ -90,6 +90,8 @@ class ControlGroup:
     PyTorch.  Every call is collective (all ranks, same order)."""
 
     _OPS = {"sum": sum, "max": max, "min": min}
+    _MAGIC = b"ESQCTL02"
+    _PORT_SPAN = 16
 
     def __init__(self, rank, world_size, addr=None, port=None, timeout=300.0):
         self.rank, self.world = int(rank), int(world_size)
@@ -98,36 +100,74 @@ class ControlGroup:
         if self.world == 1:
             return
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
-        port = int(port or int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        port = int(port or os.environ.get("ESQ_CTL_PORT") or
+                   int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        # the launcher owns MASTER_PORT; the ports behind it may be taken too:
+        # rank 0 binds the first free one of a small range, the others find it by
+        # a handshake (magic + world size + their rank)
+        ports = range(port, port + self._PORT_SPAN)
         if self.rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
+            srv = None
+            for cand in ports:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    srv.bind((addr, cand))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise OSError(f"ControlGroup: no free port in {ports}")
             srv.listen(self.world)
             srv.settimeout(timeout)
             by_rank = {}
             try:
-                for _ in range(self.world - 1):
+                while len(by_rank) < self.world - 1:
                     conn, _a = srv.accept()
                     conn.settimeout(timeout)
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    (peer,) = struct.unpack("<q", _recv_exact(conn, 8))
+                    try:
+                        hello = _recv_exact(conn, 24)
+                    except (OSError, ConnectionError):
+                        conn.close()
+                        continue
+                    magic, world, peer = struct.unpack("<8sqq", hello)
+                    if magic != self._MAGIC or world != self.world or \
+                            not 0 < peer < self.world or peer in by_rank:
+                        conn.close()                  # a stranger: not ours
+                        continue
+                    conn.sendall(self._MAGIC)
                     by_rank[peer] = conn
             finally:
                 srv.close()
             self._peers = [by_rank[r] for r in range(1, self.world)]
         else:
             deadline = time.time() + timeout
-            while True:
-                try:
-                    sock = socket.create_connection((addr, port), timeout=timeout)
-                    break
-                except OSError:
+            sock = None
+            while sock is None:
+                for cand in ports:
+                    try:
+                        trial = socket.create_connection((addr, cand), timeout=5.0)
+                    except OSError:
+                        continue
+                    try:
+                        trial.settimeout(5.0)
+                        trial.sendall(struct.pack("<8sqq", self._MAGIC, self.world,
+                                                  self.rank))
+                        if _recv_exact(trial, 8) == self._MAGIC:
+                            sock = trial
+                            break
+                    except (OSError, ConnectionError):
+                        pass
+                    trial.close()
+                if sock is None:
                     if time.time() > deadline:
-                        raise
+                        raise TimeoutError("ControlGroup: rank 0 not found on "
+                                           f"{addr}:{ports.start}-{ports.stop - 1}")
                     time.sleep(0.05)
+            sock.settimeout(timeout)
             sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            sock.sendall(struct.pack("<q", self.rank))
             self._sock = sock
 
     # -- framing: 8-byte length + payload

@@ -86,6 +86,31 @@ def test_control_group(world):
         assert blob == b"x" * 300
 
 
+def test_control_group_skips_a_taken_port():
+    """the port behind MASTER_PORT may belong to somebody else: a foreign
+    listener sits on the first port of the range, the group must form on the
+    next one"""
+    port = free_port()
+    squatter = socket.socket()
+    squatter.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    squatter.bind(("127.0.0.1", port))
+    squatter.listen(8)
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_control_group_worker, args=(r, 2, port, q))
+                 for r in range(2)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert [g[2] for g in got] == [2001, 2001]
+    finally:
+        squatter.close()
+
+
 def _lockstep_worker(rank, world, port, q):
     import sys
     sys.path.insert(0, ROOT)
