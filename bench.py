@@ -292,6 +292,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ESQ_BENCH_ONE_DEVICE"):
+        local = 0       # rehearsal of the multi-rank flow on a one-GPU box (--replicas)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
     from extensisq_amd import lockstep            # no GPU call on import
