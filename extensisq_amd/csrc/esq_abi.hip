@@ -69,6 +69,8 @@ struct esq_ctx {
     double *slab_host = nullptr;      // host address of slab[0]
     size_t slab_doubles = 0;
     bool idle = true;                 // nothing enqueued since the last wait
+    bool self_valid = false;          // the last kernel enqueued publishes self_seq
+    unsigned long long self_seq = 0;
     std::vector<double *> aux_slabs;   // lazily added work rows (esq_aux_rows)
     std::vector<double *> krow;       // physical K rows
     std::vector<int> kmap;            // logical -> physical (step in flight)
@@ -272,9 +274,37 @@ void launch_lincomb_n(esq_ctx *c, double *out, const double *base,
         default: launch_lincomb_p<NT, 0, 0>(c, out, base, init, tm, h, p); break;
     }
 }
+template <int NT>
+void launch_lincomb_small(esq_ctx *c, double *out, const double *base,
+                          const double *init, const Terms &tm, double h,
+                          const Prof *p) {
+    ResultSink rs;
+    rs.seq = ++c->red_seq;
+    rs.dev = nullptr;
+    rs.host_value = &c->h_slot->value;
+    rs.host_seq = &c->h_slot->seq;
+    hipExtLaunchKernelGGL((k_lincomb_small<NT>), dim3(1), dim3(kBlock), 0, c->stream,
+                          p ? p->start() : nullptr, p ? p->stop() : nullptr, 0, out,
+                          base, init, tm, h, c->len_pad / 2, rs);
+    c->self_seq = rs.seq;
+    c->self_valid = true;
+}
 int launch_lincomb(esq_ctx *c, double *out, const double *base, const Terms &tm,
                    int nt, double h, const Prof *p = nullptr,
                    const double *init = nullptr) {
+    if (c->host_slab && c->len_pad / 2 <= 4096) {
+        // small host-RHS problem: one workgroup, completion signalled in-kernel
+#define CASE(N) case N: launch_lincomb_small<N>(c, out, base, init, tm, h, p); break;
+        switch (nt) {
+            CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+            CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
+            CASE(17) CASE(18) CASE(19) CASE(20)
+            default: return fail(c, ESQ_EINVAL, "too many terms: %d", nt);
+        }
+#undef CASE
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
 #define CASE(N) case N: launch_lincomb_n<N>(c, out, base, init, tm, h, p); break;
     switch (nt) {
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -559,6 +589,7 @@ int plan_words(const std::vector<double> &A, int s, const std::vector<int> &boun
         (void)hipSetDevice((c)->device);     \
         (c)->pre_valid = false;              \
         (c)->idle = false;                   \
+        (c)->self_valid = false;             \
     } while (0)
 
 // ---- host-slab mode ------------------------------------------------------------
@@ -574,6 +605,13 @@ double *host_of(const esq_ctx *c, const void *dev) {
 // behind them, the host spins on it
 int host_wait(esq_ctx *c, bool already_idle) {
     if (already_idle) return 0;
+    if (c->self_valid) {               // the last kernel signals its own completion
+        c->self_valid = false;
+        const int w = wait_slot(c, c->self_seq, 0.0);
+        if (w) return w;
+        c->idle = true;
+        return 0;
+    }
     ResultSink rs;
     rs.seq = ++c->red_seq;
     rs.dev = nullptr;

@@ -18,6 +18,25 @@
 
 namespace esq {
 
+// Where a reduction's result goes: a device double (input of the lock-step
+// all-reduce) and/or a pinned host slot the host polls.  The value is stored
+// first, then -- behind a system-scope release -- the sequence number of this
+// reduction, so a host that reads seq == expected also reads the value.
+struct ResultSink {
+    double *dev;                       // may be nullptr
+    double *host_value;                // pinned host memory, may be nullptr
+    unsigned long long *host_seq;
+    unsigned long long seq;
+};
+__device__ __forceinline__ void publish(const ResultSink &rs, double v) {
+    if (rs.dev) *rs.dev = v;
+    if (rs.host_value) {
+        __hip_atomic_store(rs.host_value, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(rs.host_seq, rs.seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 // ---------------------------------------------------------------------------
 // out = base + h * sum_j c_j * v_j        (base may be nullptr -> 0)
 // Evaluation order follows the reference: the weighted sum first (ascending j,
@@ -54,6 +73,33 @@ __global__ __launch_bounds__(kBlock) void k_lincomb(
         r.y = __dadd_rn(yb.y, __dmul_rn(h, acc.y));
         if (STP) st2_nt(out, i, r); else st2(out, i, r);
     }
+}
+
+// Single-workgroup form for the host-slab mode (small host-RHS problems): the
+// same arithmetic; when the sweep is complete the workgroup itself bumps the
+// pinned sequence number the host is spinning on -- no completion kernel, no
+// stream synchronisation between the kernel and the host's memcpy of `out`.
+template <int NT>
+__global__ __launch_bounds__(kBlock) void k_lincomb_small(
+    double *__restrict__ out, const double *__restrict__ base,
+    const double *__restrict__ init, Terms tm, double h, size_t n2, ResultSink rs) {
+    for (size_t i = threadIdx.x; i < n2; i += kBlock) {
+        double2 v[NT > 0 ? NT : 1];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j] = ld2(tm.p[j], i);
+        const double2 yb = base ? ld2(base, i) : make_double2(0.0, 0.0);
+        double2 acc = init ? ld2(init, i) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc.x = fma(tm.c[j], v[j].x, acc.x);
+            acc.y = fma(tm.c[j], v[j].y, acc.y);
+        }
+        st2(out, i, make_double2(__dadd_rn(yb.x, __dmul_rn(h, acc.x)),
+                                 __dadd_rn(yb.y, __dmul_rn(h, acc.y))));
+    }
+    __threadfence_system();            // every thread's stores, before the flag
+    __syncthreads();
+    if (threadIdx.x == 0) publish(rs, 0.0);
 }
 
 // ---------------------------------------------------------------------------
@@ -178,25 +224,6 @@ __global__ __launch_bounds__(kBlock) void k_horner(double *__restrict__ out,
     }
 }
 
-// Where a reduction's result goes: a device double (input of the lock-step
-// all-reduce) and/or a pinned host slot the host polls.  The value is stored
-// first, then -- behind a system-scope release -- the sequence number of this
-// reduction, so a host that reads seq == expected also reads the value.
-struct ResultSink {
-    double *dev;                       // may be nullptr
-    double *host_value;                // pinned host memory, may be nullptr
-    unsigned long long *host_seq;
-    unsigned long long seq;
-};
-__device__ __forceinline__ void publish(const ResultSink &rs, double v) {
-    if (rs.dev) *rs.dev = v;
-    if (rs.host_value) {
-        __hip_atomic_store(rs.host_value, v, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(rs.host_seq, rs.seq, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
 // final deterministic sum of the per-block partials (one block of 1024):
 // thread-strided partial sums, wave64 tree, 16 waves through LDS
 __global__ __launch_bounds__(1024) void k_final_sum(
