@@ -12,6 +12,8 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+# a fresh box runs its first seconds of GPU work measurably slower: warm it up
+python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp > /dev/null 2>&1
 for CFG in "${@:-pr8}"; do
     python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-solve-ivp \
         > $OUT/prof_${CFG}_bench.json 2> $OUT/prof_${CFG}_bench.err
