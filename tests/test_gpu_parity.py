@@ -471,7 +471,22 @@ def test_rccl_single_rank_lockstep():
         assert r.step() is None and s.step() is None
         assert r.t == s.t
     assert_equal(r.y, s.y)
-    del a, r
+    # host scalars through RCCL (esq_allreduce_scalars): the debug cross-check
+    # of (t, h[, m]) and the batch maximum of a user spectral-radius bound
+    assert lockstep.comm_size(group) == 1
+    assert group.allreduce(a._dev, [1.5, -2.0], "max") == [1.5, -2.0]
+    assert group.allreduce(a._dev, [1.5, -2.0], "sum") == [1.5, -2.0]
+    group.debug = True
+    rho = 8.0 * (N + 1) ** 2
+    u = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 1e-3, rtol=1e-4, atol=1e-6,
+                     lockstep=group, rho_jac=lambda t, y: rho + float(np.max(y)))
+    v = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 1e-3, rtol=1e-4, atol=1e-6,
+                     rho_jac=lambda t, y: rho + float(np.max(y)))
+    for _ in range(3):
+        assert u.step() is None and v.step() is None and a.step() is None
+        assert u.t == v.t and u.sprad == v.sprad
+    group.debug = False
+    del a, r, u
     lockstep.destroy_lockstep(group)
 
 
