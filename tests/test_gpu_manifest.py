@@ -29,6 +29,7 @@ REQUIRED = {
     "test_gpu_parity.py::test_full_size_ts5_heat_step_matches_oracle": 1,
     "test_gpu_parity.py::test_full_size_pr9_heat_step_matches_oracle": 1,
     "test_gpu_parity.py::test_full_size_linearity_and_exactness": 1,
+    "test_gpu_parity.py::test_full_size_fused_equals_unfused": 3,
     "test_gpu_rkc.py::test_full_size_rkc_diffusion_step_matches_oracle": 1,
     # the scipy surface and the boundary
     "test_gpu_parity.py::test_solve_ivp_device_rhs_t_eval_and_events": 3,

@@ -425,6 +425,36 @@ def test_full_size_pr8_step_matches_oracle():
     assert d.nfev == o.nfev == 14
 
 
+@pytest.mark.parametrize("name,plugin,N", [("Pr8", "bruss", 2236), ("Ts5", "heat", 1000),
+                                           ("Pr9", "heat", 2236)])
+def test_full_size_fused_equals_unfused(monkeypatch, name, plugin, N):
+    """size-independent property at the BASELINE.json sizes: the fully fused
+    step (one kernel per RHS evaluation, ~10 000 workgroup partials in the error
+    norm, first stage formed at accept time) and the one-kernel-per-operation
+    step give bit-identical states and stage derivatives"""
+    if plugin == "bruss":
+        mk, y0, rho = (lambda: esq.Brusselator2D(N)), pb.bruss2d_y0(N), pb.bruss2d_rho(N)
+    else:
+        mk, y0, rho = (lambda: esq.Heat2D(N)), pb.heat2d_y0(N), pb.heat2d_rho(N)
+    h = 1.0 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+    cls = DEV[name]
+    fused = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_CHAIN", "0")
+    plain = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_CHAIN")
+    plain._prelaunch = False
+    for _ in range(3):
+        assert fused.step() is None and plain.step() is None
+        assert fused.t == plain.t
+        assert_allclose(fused.error_norm_old, plain.error_norm_old, rtol=1e-11)
+    assert_equal(fused.y, plain.y)
+    s = cls.n_stages
+    for row in (1, s // 2, s - 1, s):
+        assert_equal(fused._dev.download_last_K(row), plain._dev.download_last_K(row))
+    assert fused.nfev == plain.nfev
+
+
 def test_full_size_linearity_and_exactness():
     """size-independent properties at n = 1e7: for f = lam*y the Pr8 step is
     linear in y0 (step(a*y0) == a*step(y0) with atol scaled alike) and the
