@@ -15,6 +15,7 @@ ABI_VERSION = 2
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
 FUSE_ALL = 0x1e
+FUSE_SRC = 0x20
 CREATE_HOST_SLAB = 1
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
 PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC = range(4)

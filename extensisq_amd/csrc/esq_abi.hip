@@ -94,6 +94,8 @@ struct esq_ctx {
     void *rhs_user = nullptr;
     esq_rhs_fused_fn rhs_fused = nullptr;   // optional RHS + epilogue entry
     int fuse_mask = 0;                      // epilogue kinds the library may request
+    bool src_declined = false;              // the plugin returned ENOTSUP for ESQ_FUSE_SRC
+    bool src_pays = false;                  // working set inside the Infinity Cache
     esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
     bool ynew_ready = false;     // YNEW already formed by the last stage's sweep
     bool solerr_ready = false;   // ... and the error partial sums too
@@ -796,6 +798,12 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     // the stage argument stay on-die (2 workgroups per CU); a working set that
     // fits is left to the cache (plain loads, 8 workgroups per CU).
     const bool fits_mall = slab_doubles * sizeof(double) <= (size_t)160 << 20;
+    // The first sweep of a step may form its own input from y and K[0]
+    // (ESQ_FUSE_SRC): one launch and 16 B per element less, but a second row
+    // window through L2.  Measured (profiles/r02_experiments.md): Ts5 at n = 1e6
+    // 0.0834 -> 0.0778 ms/step, Pr8 at n = 1e7 unchanged, Pr9 at n = 5e6 +0.8 %:
+    // used where the working set is cache-resident.  ESQ_SRC=0|1 overrides.
+    c->src_pays = env_uint("ESQ_SRC", fits_mall ? 1 : 0) != 0;
     const unsigned per_cu = env_uint("ESQ_BLOCKS_PER_CU", fits_mall ? 8 : 2);
     c->stage_policy = (int)env_uint("ESQ_STAGE_POLICY", fits_mall ? 0 : 10);
     size_t g = (size_t)cus * per_cu;
@@ -997,6 +1005,7 @@ int esq_set_rhs_fused(esq_ctx *c, esq_rhs_fused_fn fn, int fuse_mask) {
     ENTER(c);
     c->rhs_fused = fn;
     c->fuse_mask = fn ? fuse_mask : 0;
+    c->src_declined = false;
     return 0;
 }
 
@@ -1106,8 +1115,10 @@ bool may_fuse(const esq_ctx *c, int kind) {
     return c->rhs_fused && ((c->fuse_mask >> kind) & 1);
 }
 
-// RHS sweep of stage i + the accumulate of stage nx = i + 1 (ESQ_EPI_STAGE)
-int sweep_next_stage(esq_ctx *c, int i, double t, double h) {
+// RHS sweep of stage i + the accumulate of stage nx = i + 1 (ESQ_EPI_STAGE).
+// from_state (stage 1 only): the sweep forms its own input y + h*a_10*K[0] on
+// the fly instead of reading YSTAGE (ESQ_FUSE_SRC)
+int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = false) {
     const int nx = i + 1;
     esq_epilogue e;
     epi_common(c, e, ESQ_EPI_STAGE);
@@ -1121,6 +1132,21 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h) {
     e.h = h;
     e.out = c->work;
     e.f_store_nt = c->epi_nt & 1;   // K_i is consumed from registers, not re-read soon
+    if (from_state) {
+        if (nt > 1 || e.init) return ESQ_ENOTSUP;
+        e.in_base = c->y;
+        e.in_row = c->krow[c->kmap[0]];
+        e.in_c = c->A[(size_t)c->s];                 // A[1][0]
+        e.in_h = h;
+        // booked: stage 1's accumulate (1 + 2 words) + the RHS + stage 2's
+        // accumulate; moved: y and K[0] in (stage 2's row K[0] is the same
+        // vector), K[1] and the argument of stage 2 out
+        Prof p(c, ESQ_PROF_STAGE, "rhs1+stage", nt,
+               8.0 * (3 + nnz_all + 4) * (double)c->len, false, 8.0 * 4 * (double)c->len);
+        const int r = run_fused(c, t + c->C[i] * h, nullptr, c->krow[c->kmap[i]], e, p);
+        if (r == 0) std::swap(c->ystage, c->work);
+        return r;
+    }
     // booked on the stage class: next stage's algorithmic bytes + the RHS's
     // 16 B; moved: ys_in, rows, init, y in; K[i], ys_out out
     Prof p(c, ESQ_PROF_STAGE, "rhs+stage", nt, 8.0 * (nnz_all + 4) * (double)c->len,
@@ -1128,6 +1154,10 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h) {
     const int r = run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
     if (r == 0) std::swap(c->ystage, c->work);   // double buffer
     return r;
+}
+bool may_use_src(const esq_ctx *c) {
+    return c->src_pays && may_fuse(c, ESQ_EPI_STAGE) && (c->fuse_mask & ESQ_FUSE_SRC) &&
+           !c->src_declined;
 }
 
 // RHS sweep of stage i = J - 1 + the blocked accumulation at boundary J with
@@ -1243,6 +1273,18 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     c->solerr_ready = false;
     bool block_done = false;   // the block at boundary i already ran in a sweep
     for (int i = i_from; i < i_to; ++i) {
+        if (i == 1 && !ready && i + 1 < i_to && may_use_src(c)) {
+            // the first sweep forms its own input from y and K[0]: no stage-1
+            // kernel, no stage argument in memory
+            bool boundary = false;
+            for (const auto &b : c->blocks) boundary |= (b.J == 2);
+            if (!boundary) {
+                const int r = sweep_next_stage(c, 1, t, h, /*from_state=*/true);
+                if (r == 0) { ready = true; continue; }
+                if (r != ESQ_ENOTSUP) return r;
+                c->src_declined = true;
+            }
+        }
         if (!ready) {
             if (block_done) {
                 // partial sums are in place; only the stage kernel is left
@@ -1425,7 +1467,8 @@ int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     // the next step's first stage argument can be formed now: stage 1 reads
     // nothing but y and K[0]
-    const bool want_pre = h_next != 0.0 && c->s >= 2 && c->rhs != nullptr;
+    const bool want_pre = h_next != 0.0 && c->s >= 2 && c->rhs != nullptr &&
+                          !(may_use_src(c) && c->s >= 3);
     bool pre_done = false;
     if (!c->fsal && with_end_eval) {
         int r = ESQ_ENOTSUP;

@@ -119,9 +119,42 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d(
 using esq::v2d;
 using RkcEpi = esq::EpiRkc;
 
-template <bool PERIODIC>
+// Where a sweep takes its input from: a vector in memory (SrcPlain), or -- for
+// the FIRST stage of a step -- the stage argument formed on the fly from the
+// state and the first stage derivative,
+//     ys = y + h * (c * K0)            (common.py:355, stage 1: one term)
+// with exactly the operations of k_lincomb / EpiStage (fma(c, K0, 0), then *h,
+// then +y, each rounded), so the derivative is bit-identical.  The argument is
+// then never written to nor read from memory: the end-point sweep of the
+// previous step need not produce it, the first sweep reads y and K0 (which its
+// epilogue needs anyway) instead of a third vector.  Unlike the general
+// "stage argument inside the stencil sweep" (rejected: 12-term rows on halos)
+// this costs one extra row window of ONE vector, served by L1/L2.
+struct SrcPlain {
+    const double *__restrict__ f;
+    __device__ __forceinline__ double2 ld2(size_t e2) const {
+        return reinterpret_cast<const double2 *>(f)[e2];
+    }
+    __device__ __forceinline__ double ld(size_t e) const { return f[e]; }
+};
+struct SrcAxpy {
+    const double *__restrict__ y, *__restrict__ k;
+    double c, h;
+    __device__ __forceinline__ double one(double yy, double kk) const {
+        return __dadd_rn(yy, __dmul_rn(h, fma(c, kk, 0.0)));
+    }
+    __device__ __forceinline__ double2 ld2(size_t e2) const {
+        const double2 a = reinterpret_cast<const double2 *>(y)[e2];
+        const double2 b = reinterpret_cast<const double2 *>(k)[e2];
+        return make_double2(one(a.x, b.x), one(a.y, b.y));
+    }
+    __device__ __forceinline__ double ld(size_t e) const { return one(y[e], k[e]); }
+};
+
+template <bool PERIODIC, class Src>
 struct RowWin {
-    const double *__restrict__ f;   // field base
+    Src src;
+    size_t base;                    // offset of the field inside the state (doubles)
     int N;
     unsigned pair, npairs;          // this thread's column pair
     bool live;                      // pair < npairs
@@ -134,7 +167,7 @@ struct RowWin {
             return make_double2(0.0, 0.0);
         }
         if (!live) return make_double2(0.0, 0.0);
-        return *reinterpret_cast<const double2 *>(f + (size_t)i * N + 2 * (size_t)pair);
+        return src.ld2((base + (size_t)i * N) / 2 + pair);       // N even
     }
     // left neighbour of .x and right neighbour of .y in row i (centre c given)
     __device__ __forceinline__ void sides(int i, double2 c, double &lf,
@@ -143,14 +176,14 @@ struct RowWin {
         lf = __shfl_up(c.y, 1, 64);
         rt = __shfl_down(c.x, 1, 64);
         if (!live) return;
-        const double *r = f + (size_t)i * N;
+        const size_t r = base + (size_t)i * N;
         if (lane == 0 || pair == 0) {
-            if (pair > 0) lf = r[2 * (size_t)pair - 1];
-            else lf = PERIODIC ? r[N - 1] : 0.0;
+            if (pair > 0) lf = src.ld(r + 2 * (size_t)pair - 1);
+            else lf = PERIODIC ? src.ld(r + N - 1) : 0.0;
         }
         if (lane == 63 || pair + 1 >= npairs) {
-            if (pair + 1 < npairs) rt = r[2 * (size_t)pair + 2];
-            else rt = PERIODIC ? r[0] : 0.0;
+            if (pair + 1 < npairs) rt = src.ld(r + 2 * (size_t)pair + 2);
+            else rt = PERIODIC ? src.ld(r) : 0.0;
         }
     }
 };
@@ -164,17 +197,18 @@ struct RowWin {
 // (EpiSolErr), FSAL error norm (EpiErrNorm), Chebyshev recursion (EpiRkc).
 // The epilogues are pointwise: nothing is recomputed on halos.
 // ---------------------------------------------------------------------------
-template <class Epi>
+template <class Epi, class Src>
 __global__ __launch_bounds__(kBlock) void k_bruss2d_sweep(
-    const double *__restrict__ ys, double *__restrict__ f, Epi epi, int N,
+    Src ys, double *__restrict__ f, Epi epi, int N,
     double d, double A, double B, unsigned nblocks, unsigned wpr) {
     const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
     const int i = (int)(tile / wpr);
     double local = 0.0;
     if (i < N) {                                           // wave-uniform
         const size_t NN = (size_t)N * N;
-        RowWin<true> U, V;
-        U.f = ys; V.f = ys + NN;
+        RowWin<true, Src> U, V;
+        U.src = V.src = ys;
+        U.base = 0; V.base = NN;
         U.N = V.N = N;
         U.npairs = V.npairs = (unsigned)N / 2;
         U.pair = V.pair = (tile % wpr) * 64 + (threadIdx.x & 63);
@@ -211,16 +245,17 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d_sweep(
     if (Epi::kReduce) esq::block_partial(local, epi.red.partials);
 }
 
-template <class Epi>
+template <class Epi, class Src>
 __global__ __launch_bounds__(kBlock) void k_heat2d_sweep(
-    const double *__restrict__ ys, double *__restrict__ f, Epi epi, int N,
+    Src ys, double *__restrict__ f, Epi epi, int N,
     double c, unsigned nblocks, unsigned wpr) {
     const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
     const int i = (int)(tile / wpr);
     double local = 0.0;
     if (i < N) {
-        RowWin<false> U;
-        U.f = ys;
+        RowWin<false, Src> U;
+        U.src = ys;
+        U.base = 0;
         U.N = N;
         U.npairs = (unsigned)N / 2;
         U.pair = (tile % wpr) * 64 + (threadIdx.x & 63);
@@ -245,16 +280,16 @@ __global__ __launch_bounds__(kBlock) void k_heat2d_sweep(
 // f = lam*y + forcing, pointwise: the same epilogues on a grid-stride loop
 // (lam holds exactly n doubles; the state vectors are zero-padded to a multiple
 // of 512, and the padding must stay zero)
-template <class Epi>
+template <class Epi, class Src>
 __global__ __launch_bounds__(kBlock) void k_diag_sweep(
-    const double *__restrict__ y, double *__restrict__ f, Epi epi,
+    Src y, double *__restrict__ f, Epi epi,
     const double *__restrict__ lam, double forcing, size_t n, size_t n2) {
     const size_t stride = (size_t)gridDim.x * kBlock;
     double local = 0.0;
     for (size_t i2 = (size_t)blockIdx.x * kBlock + threadIdx.x; i2 < n2; i2 += stride) {
         typename Epi::In in;
         epi.load(in, i2);
-        const double2 yc = esq::ld2(y, i2);
+        const double2 yc = y.ld2(i2);
         double2 fy = make_double2(0.0, 0.0);
         if (2 * i2 < n) fy.x = lam[2 * i2] * yc.x + forcing;
         if (2 * i2 + 1 < n) fy.y = lam[2 * i2 + 1] * yc.y + forcing;
@@ -349,6 +384,18 @@ int make(void **out, Rhs proto) {
     return 0;
 }
 
+// the on-the-fly first-stage input is instantiated for the epilogues a first
+// stage can have: the second stage's argument with at most one row from memory
+template <class E> constexpr bool kFirstStage = false;
+template <> constexpr bool kFirstStage<esq::EpiStage<0>> = true;
+template <> constexpr bool kFirstStage<esq::EpiStage<1>> = true;
+bool first_stage_ok(const esq_epilogue *e) {
+    return e->kind == ESQ_EPI_STAGE && e->nt <= 1 && e->in_base;
+}
+SrcAxpy axpy_of(const esq_epilogue *e) {
+    return SrcAxpy{e->in_base, e->in_row, e->in_c, e->in_h};
+}
+
 // ---- launch geometry of the 2-D sweeps: one wave tile per 64 column pairs
 struct Geo2d {
     unsigned wpr, grid;
@@ -431,8 +478,8 @@ int esq_rhs_heat2d(void *user, double t, const double *y, double *f, size_t n,
     if (r->N % 2 == 0 && r->N >= 4 && rhs_variant() != 1) {
         const Geo2d g = geo2d(r->N);
         esq::EpiNone ep{};
-        hipLaunchKernelGGL((k_heat2d_sweep<esq::EpiNone>), dim3(g.grid), dim3(kBlock),
-                           0, (hipStream_t)stream, y, f, ep, r->N, c, g.grid, g.wpr);
+        hipLaunchKernelGGL((k_heat2d_sweep<esq::EpiNone, SrcPlain>), dim3(g.grid),
+                           dim3(kBlock), 0, (hipStream_t)stream, SrcPlain{y}, f, ep, r->N, c, g.grid, g.wpr);
         return (int)hipGetLastError();
     }
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;
@@ -451,8 +498,8 @@ int esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
     if (r->N % 2 == 0 && r->N >= 4 && rhs_variant() != 1) {
         const Geo2d g = geo2d(r->N);
         esq::EpiNone ep{};
-        hipLaunchKernelGGL((k_bruss2d_sweep<esq::EpiNone>), dim3(g.grid), dim3(kBlock),
-                           0, (hipStream_t)stream, y, f, ep, r->N, d, r->a, r->b,
+        hipLaunchKernelGGL((k_bruss2d_sweep<esq::EpiNone, SrcPlain>), dim3(g.grid),
+                           dim3(kBlock), 0, (hipStream_t)stream, SrcPlain{y}, f, ep, r->N, d, r->a, r->b,
                            g.grid, g.wpr);
         return (int)hipGetLastError();
     }
@@ -482,11 +529,24 @@ int esq_rhs_bruss2d_fused(void *user, double t, const double *y_in, double *f,
         if (epi->partials_used) *epi->partials_used = (int)g.grid;
     }
     const double d = r->alpha * ((double)r->N * (double)r->N);
+    if (epi->in_row && !first_stage_ok(epi)) return ESQ_ENOTSUP;
     const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
-        hipExtLaunchKernelGGL((k_bruss2d_sweep<decltype(ep)>), dim3(g.grid),
+        using E = decltype(ep);
+        if constexpr (kFirstStage<E>) {
+            if (epi->in_row) {
+                hipExtLaunchKernelGGL((k_bruss2d_sweep<E, SrcAxpy>), dim3(g.grid),
+                                      dim3(kBlock), 0, (hipStream_t)stream,
+                                      (hipEvent_t)start_event, (hipEvent_t)stop_event,
+                                      0, axpy_of(epi), f, ep, r->N, d, r->a, r->b,
+                                      g.grid, g.wpr);
+                return;
+            }
+        }
+        hipExtLaunchKernelGGL((k_bruss2d_sweep<E, SrcPlain>), dim3(g.grid),
                               dim3(kBlock), 0, (hipStream_t)stream,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
-                              y_in, f, ep, r->N, d, r->a, r->b, g.grid, g.wpr);
+                              SrcPlain{y_in}, f, ep, r->N, d, r->a, r->b, g.grid,
+                              g.wpr);
     });
     return rc ? rc : (int)hipGetLastError();
 }
@@ -503,11 +563,22 @@ int esq_rhs_heat2d_fused(void *user, double t, const double *y_in, double *f,
         if (epi->partials_used) *epi->partials_used = (int)g.grid;
     }
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
+    if (epi->in_row && !first_stage_ok(epi)) return ESQ_ENOTSUP;
     const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
-        hipExtLaunchKernelGGL((k_heat2d_sweep<decltype(ep)>), dim3(g.grid),
+        using E = decltype(ep);
+        if constexpr (kFirstStage<E>) {
+            if (epi->in_row) {
+                hipExtLaunchKernelGGL((k_heat2d_sweep<E, SrcAxpy>), dim3(g.grid),
+                                      dim3(kBlock), 0, (hipStream_t)stream,
+                                      (hipEvent_t)start_event, (hipEvent_t)stop_event,
+                                      0, axpy_of(epi), f, ep, r->N, c, g.grid, g.wpr);
+                return;
+            }
+        }
+        hipExtLaunchKernelGGL((k_heat2d_sweep<E, SrcPlain>), dim3(g.grid),
                               dim3(kBlock), 0, (hipStream_t)stream,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
-                              y_in, f, ep, r->N, c, g.grid, g.wpr);
+                              SrcPlain{y_in}, f, ep, r->N, c, g.grid, g.wpr);
     });
     return rc ? rc : (int)hipGetLastError();
 }
@@ -525,11 +596,22 @@ int esq_rhs_diag_fused(void *user, double t, const double *y_in, double *f,
         if ((int)blocks > epi->partials_cap) return ESQ_ENOTSUP;
         if (epi->partials_used) *epi->partials_used = (int)blocks;
     }
+    if (epi->in_row && !first_stage_ok(epi)) return ESQ_ENOTSUP;
     const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
-        hipExtLaunchKernelGGL((k_diag_sweep<decltype(ep)>), dim3((unsigned)blocks),
+        using E = decltype(ep);
+        if constexpr (kFirstStage<E>) {
+            if (epi->in_row) {
+                hipExtLaunchKernelGGL((k_diag_sweep<E, SrcAxpy>), dim3((unsigned)blocks),
+                                      dim3(kBlock), 0, (hipStream_t)stream,
+                                      (hipEvent_t)start_event, (hipEvent_t)stop_event,
+                                      0, axpy_of(epi), f, ep, r->lam_dev, forcing, n, n2);
+                return;
+            }
+        }
+        hipExtLaunchKernelGGL((k_diag_sweep<E, SrcPlain>), dim3((unsigned)blocks),
                               dim3(kBlock), 0, (hipStream_t)stream,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
-                              y_in, f, ep, r->lam_dev, forcing, n, n2);
+                              SrcPlain{y_in}, f, ep, r->lam_dev, forcing, n, n2);
     });
     return rc ? rc : (int)hipGetLastError();
 }
@@ -552,9 +634,9 @@ int esq_rhs_heat2d_rkc(void *user, double t, const double *yjm1, const double *y
     if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
     const Geo2d g = geo2d(r->N);
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
-    hipExtLaunchKernelGGL((k_heat2d_sweep<esq::EpiRkc>), dim3(g.grid), dim3(kBlock),
-                          0, (hipStream_t)stream, (hipEvent_t)start_event,
-                          (hipEvent_t)stop_event, 0, yjm1, (double *)nullptr,
+    hipExtLaunchKernelGGL((k_heat2d_sweep<esq::EpiRkc, SrcPlain>), dim3(g.grid),
+                          dim3(kBlock), 0, (hipStream_t)stream, (hipEvent_t)start_event,
+                          (hipEvent_t)stop_event, 0, SrcPlain{yjm1}, (double *)nullptr,
                           make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out),
                           r->N, c, g.grid, g.wpr);
     return (int)hipGetLastError();

@@ -207,22 +207,26 @@ class DeviceContext:
         # follows it (next stage argument, blocked accumulation, solution + error
         # norm) while the derivative is in registers -- bit-identical K rows and
         # states, one kernel per RHS evaluation.  ESQ_CHAIN=0 / 1 switches the
-        # entry off / forces it on; ESQ_FUSE=stage,block,solerr,errnorm (any
-        # subset, default all) selects the epilogue kinds for A/B runs.
+        # entry off / forces it on; ESQ_FUSE=stage,block,solerr,errnorm,src (any
+        # subset, default all) selects the epilogue kinds for A/B runs ("src":
+        # the first sweep of a step forms its own input from y and K[0]).
         fused = rhs._fused_entry(self.lib)
         want = os.environ.get("ESQ_CHAIN", "")
         use = (want == "1") or (want != "0" and rhs._fuse_default)
         if fused is not None and use:
-            kinds = {"stage": _lib.EPI_STAGE, "block": _lib.EPI_BLOCK,
-                     "solerr": _lib.EPI_SOLERR, "errnorm": _lib.EPI_ERRNORM}
+            kinds = {"stage": 1 << _lib.EPI_STAGE, "block": 1 << _lib.EPI_BLOCK,
+                     "solerr": 1 << _lib.EPI_SOLERR,
+                     "errnorm": 1 << _lib.EPI_ERRNORM, "src": _lib.FUSE_SRC}
             sel = os.environ.get("ESQ_FUSE", "")
-            mask = _lib.FUSE_ALL
+            mask = _lib.FUSE_ALL | (_lib.FUSE_SRC if rhs._fuse_src else 0)
             if sel:
                 mask = 0
                 for name in sel.split(","):
                     if name.strip() not in kinds:
                         raise ValueError(f"ESQ_FUSE: unknown epilogue {name!r}")
-                    mask |= 1 << kinds[name.strip()]
+                    mask |= kinds[name.strip()]
+                if not rhs._fuse_src:
+                    mask &= ~_lib.FUSE_SRC
             self._chk(self.lib.esq_set_rhs_fused(self.handle,
                                                  C.cast(fused, C.c_void_p), mask),
                       "esq_set_rhs_fused")
@@ -309,6 +313,7 @@ class DeviceRHS:
     n = None
     is_complex = False
     _fuse_default = False      # use the fused entry unless ESQ_CHAIN says otherwise
+    _fuse_src = False          # the fused entry accepts the on-the-fly first-stage input
 
     def __init__(self):
         self._bound = {}       # device -> (fn, user)
@@ -370,6 +375,7 @@ class DeviceRHS:
 
 
 class _Builtin(DeviceRHS):
+    _fuse_src = True
     _symbol = None
     _symbol_fused = None
     _symbol_rkc = None

@@ -129,6 +129,15 @@ typedef struct esq_epilogue {
     int partials_cap;
     int *partials_used;
     int f_store_nt;
+    /* ON-THE-FLY INPUT (first stage of a step; requested only from plugins
+     * registered with ESQ_FUSE_SRC): if in_row != NULL the sweep's input is not
+     * y_in (which is then NULL) but
+     *     in_base + in_h * (in_c * in_row)        rounded like ESQ_EPI_STAGE,
+     * evaluated where the sweep needs it (halos included; one term, so this is
+     * one more row window of ONE vector, served by L1/L2).  The first stage
+     * argument is then never written to nor read from memory. */
+    const double *in_base, *in_row;
+    double in_c, in_h;
 } esq_epilogue;
 typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
                                 double *f_dev, const esq_epilogue *epi, size_t n,
@@ -199,6 +208,7 @@ int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
  * ESQ_EPI_* value k; ESQ_FUSE_ALL for all) -- each one is bit-identical to the
  * unfused sequence and can be switched off for A/B tests. */
 #define ESQ_FUSE_ALL 0x1e
+#define ESQ_FUSE_SRC 0x20    /* the entry also accepts the on-the-fly input    */
 int  esq_set_rhs_fused(esq_ctx *ctx, esq_rhs_fused_fn fn, int fuse_mask);
 /* register (or clear) the optional RKC entry: esq_rkc_stages then issues ONE
  * kernel per Chebyshev stage (RHS + recursion) instead of two */

@@ -439,7 +439,10 @@ def test_full_size_fused_equals_unfused(monkeypatch, name, plugin, N):
     h = 1.0 / rho
     kw = dict(first_step=h, max_step=h, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
     cls = DEV[name]
+    if name == "Pr9":
+        monkeypatch.setenv("ESQ_SRC", "1")      # the on-the-fly first stage at full size
     fused = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_SRC", raising=False)
     monkeypatch.setenv("ESQ_CHAIN", "0")
     plain = cls(mk(), 0.0, y0, 1.0, **kw)
     monkeypatch.delenv("ESQ_CHAIN")
@@ -980,7 +983,8 @@ def test_chained_stages_are_bit_identical(monkeypatch, name, plugin, N):
 
 
 @pytest.mark.parametrize("fuse", ["stage", "stage,block", "stage,solerr",
-                                  "stage,errnorm", "block,solerr,errnorm"])
+                                  "stage,errnorm", "block,solerr,errnorm",
+                                  "stage,src", "stage,block,solerr,errnorm,src"])
 @pytest.mark.parametrize("name,plugin,N", [
     ("Pr8", "bruss", 50), ("Pr8", "bruss", 258), ("Pr9", "heat", 130),
     ("Pr7", "heat", 36), ("Ts5", "heat", 258), ("Ts5", "bruss", 48),
@@ -989,14 +993,17 @@ def test_each_epilogue_kind_is_bit_identical(monkeypatch, fuse, name, plugin, N)
     """ESQ_FUSE selects the epilogue kinds one by one: (a) next stage argument,
     (b) blocked accumulation inside the boundary stage's sweep, (c) solution +
     error norm inside the last stage's sweep, FSAL error norm inside the
-    end-point sweep -- each must leave K rows and states bit-identical"""
+    end-point sweep, "src": the first sweep of a step forms its own input from
+    y and K[0] -- each must leave K rows and states bit-identical"""
     mk, y0, rho = _plugin(plugin, N)
     h = 0.4 / rho
     kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
     cls = getattr(esq, name)
     monkeypatch.setenv("ESQ_FUSE", fuse)
+    monkeypatch.setenv("ESQ_SRC", "1")          # "src" at any size
     fused = cls(mk(), 0.0, y0, 1.0, **kw)
     monkeypatch.delenv("ESQ_FUSE")
+    monkeypatch.delenv("ESQ_SRC")
     monkeypatch.setenv("ESQ_CHAIN", "0")
     plain = cls(mk(), 0.0, y0, 1.0, **kw)
     monkeypatch.delenv("ESQ_CHAIN")
@@ -1020,6 +1027,8 @@ def test_prelaunched_first_stage_is_used_only_when_valid(monkeypatch, name):
     mk, y0, rho = _plugin("heat", N)
     cls = getattr(esq, name)
     kw = dict(first_step=0.5 / rho, rtol=1e-5, atol=1e-8)
+    # without "src" (with it the first sweep needs no stage argument at all)
+    monkeypatch.setenv("ESQ_FUSE", "stage,block,solerr,errnorm")
 
     def run(prelaunch):
         s = cls(mk(), 0.0, y0, 1.0, **kw)

@@ -28,15 +28,16 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 PEAK = 8.0e12
 
-STAGE = ("k_lincomb", "k_block_acc", "rhs+stage", "rhs+block")
+STAGE = ("k_lincomb", "k_block_acc", "rhs+stage", "rhs1+stage", "rhs+block")
 RKC = ("rhs_rkc", "k_rkc_first", "k_rkc_stage")
 
 
 def label(name):
     """rocprof kernel name -> bench.py kernel label"""
-    m = re.search(r"k_(bruss2d|heat2d|diff3d)_sweep<.*Epi(\w+)<(\d+)", name)
+    m = re.search(r"k_(bruss2d|heat2d|diff3d|diag)_sweep<.*Epi(\w+)<(\d+)", name)
     if m:                                   # fused sweeps (round 2)
-        return f"rhs+{m.group(2).lower()}<{m.group(3)}>"
+        first = "1" if "SrcAxpy" in name else ""
+        return f"rhs{first}+{m.group(2).lower()}<{m.group(3)}>"
     m = re.search(r"k_(heat2d|diff3d)_v2<\d+, (true|false)>", name)
     if m:
         return "rhs_rkc" if m.group(2) == "true" else "rhs_plugin"
