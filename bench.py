@@ -302,7 +302,14 @@ def main():
         return dry_run(args, rank, world, ctl)
 
     import extensisq_amd as esq
-    from extensisq_amd._lib import PROF_RHS, PROF_RKC, PROF_SOLERR, PROF_STAGE
+    from extensisq_amd._lib import (PROF_RHS, PROF_RKC, PROF_SOLERR, PROF_STAGE,
+                                    device_count)
+    visible = device_count()
+    if visible < 1:
+        raise RuntimeError("no GPU visible to this rank")
+    if local >= visible:
+        # the launcher restricted this rank's visibility (one GPU per rank)
+        local = local % visible
 
     w = make_workload(args.config, args.grid, rank)
     n = w["y0"].size

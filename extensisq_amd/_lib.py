@@ -31,6 +31,7 @@ _vpp = C.POINTER(C.c_void_p)
 # name -> (restype, argtypes); every symbol include/extensisq_amd.h declares
 SIGNATURES = {
     "esq_abi_version": (C.c_int, []),
+    "esq_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "esq_create": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int]),
     "esq_create2": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "esq_destroy": (C.c_int, [_vp]),
@@ -154,6 +155,13 @@ def check(code, ctx=None, what=""):
         msg = raw.decode(errors="replace") if raw else ""
     raise DeviceError(f"{what or 'libextensisq_amd'} failed with code {code}"
                       + (f": {msg}" if msg else ""))
+
+
+def device_count():
+    """GPUs visible to this process"""
+    out = C.c_int(0)
+    check(load().esq_device_count(C.byref(out)), None, "esq_device_count")
+    return out.value
 
 
 def as_ptr(arr):

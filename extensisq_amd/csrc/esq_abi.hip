@@ -730,6 +730,12 @@ extern "C" {
 
 int esq_abi_version(void) { return ESQ_ABI_VERSION; }
 
+int esq_device_count(int *count_out) {
+    if (!count_out) return ESQ_EINVAL;
+    const hipError_t e = hipGetDeviceCount(count_out);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) {
     return esq_create2(out, device, n, n_rows, is_complex, 0);
 }

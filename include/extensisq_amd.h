@@ -160,6 +160,8 @@ typedef int (*esq_rhs_rkc_fn)(void *user, double t, const double *yjm1,
 
 /* ---- lifecycle ---------------------------------------------------------- */
 int  esq_abi_version(void);
+/* devices this process can see (a launcher may restrict each rank to one) */
+int  esq_device_count(int *count_out);
 /* n: state dimension (complex elements if is_complex); n_rows: rows of K
  * (n_stages + 1, plus extra rows for BS5's interpolants / RKC work vectors).
  * Replaces `self.K = np.empty((n_stages + 1, n))`  common.py:216 and the
