@@ -21,6 +21,7 @@ REQUIRED = {
     "test_gpu_parity.py::test_device_rhs_step_sizes": 80,
     "test_gpu_parity.py::test_atol_vector_and_rejections": 8,
     "test_gpu_parity.py::test_pde_workloads": 17,
+    "test_gpu_parity.py::test_device_rhs_long_trajectory": 16,
     "test_gpu_parity.py::test_builtin_rhs_bitwise": 15,
     "test_gpu_parity.py::test_ckdisc_device_rhs_matches_oracle": 1,
     "test_gpu_parity.py::test_plugin_fallback_paths_small_and_odd_grids": 4,
