@@ -186,6 +186,35 @@ def test_pde_workloads(name, rhs, cpu, y0f, N):
 
 
 @pytest.mark.parametrize("name", ERK)
+@pytest.mark.parametrize("case", ["bruss8", "heat8", "bruss130", "heat130"])
+def test_pde_steps_golden(golden_dir, name, case):
+    """the device RHS plugins and fused sweeps DIRECTLY against numbers recorded
+    from the real reference (tools/gen_golden.py::gen_pde): three fixed steps of
+    every ERK method on the benchmark's workloads at even grid sizes"""
+    g = np.load(os.path.join(golden_dir, "pde_steps.npz"))
+    N = int(case[-3:]) if case.endswith("130") else 8
+    if case.startswith("bruss"):
+        rhs, y0 = esq.Brusselator2D(N), pb.bruss2d_y0(N)
+    else:
+        rhs, y0 = esq.Heat2D(N), pb.heat2d_y0(N)
+    key = f"{case}/{name}"
+    h = float(g[key + "/h"])
+    s = DEV[name](rhs, 0.0, y0, 1.0, first_step=h, max_step=h, rtol=1e-3,
+                  atol=1e-6, nfev_stiff_detect=0)
+    for _ in range(3):
+        assert s.step() is None
+    small = y0.size <= 512
+    assert s.t == float(g[key + "/t"]) and s.nfev == int(g[key + "/nfev"])
+    assert int(esq.NFS[()]) == int(g[key + "/nfs"])
+    y = s.y if small else s.y[::97]
+    K = s.K[:s.n_stages + s.FSAL]
+    K = K if small else K[:, ::97]
+    assert_allclose(y, g[key + "/y"], rtol=1e-13, atol=1e-15)
+    assert_allclose(K, g[key + "/K"], rtol=0, atol=1e-11 * np.abs(g[key + "/K"]).max())
+    assert_allclose(s.error_norm_old, g[key + "/err"][-1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ERK)
 @pytest.mark.parametrize("plugin,N,t_end", [("bruss", 10, 1.5), ("heat", 24, 0.02)])
 def test_device_rhs_long_trajectory(name, plugin, N, t_end):
     """whole adaptive integrations with a device RHS (fused sweeps, accept-time

@@ -181,3 +181,25 @@ def test_rkc_chained_stage_is_bit_identical(monkeypatch, plugin, N):
         assert a.t == b.t and a.errold == b.errold
         np.testing.assert_array_equal(a.y, b.y)
     assert a.nfev == b.nfev and a.nfev > 20
+
+
+@pytest.mark.parametrize("case", ["heat8", "heat130", "diff12"])
+def test_pde_steps_golden_rkc(golden_dir, case):
+    """SSV2stab with the device plugins (sweep + Chebyshev recursion in one kernel)
+    directly against the real reference's two steps (tools/gen_golden.py::gen_pde)"""
+    g = np.load(os.path.join(golden_dir, "pde_steps.npz"))
+    if case == "diff12":
+        rhs, y0, rho = esq.Diffusion3D(12), pb.diff3d_y0(12), 12.0 * 13 ** 2
+    else:
+        N = 8 if case == "heat8" else 130
+        rhs, y0, rho = esq.Heat2D(N), pb.heat2d_y0(N), pb.heat2d_rho(N)
+    s = esq.SSV2stab(rhs, 0.0, y0, 1.0, rtol=1e-4, atol=1e-7, first_step=40.0 / rho,
+                     rho_jac=lambda t, y: rho, const_jac=True)
+    for _ in range(2):
+        assert s.step() is None
+    key = f"{case}/SSV2stab"
+    assert s.nfev == int(g[key + "/nfev"])
+    assert int(dev_rkc.maxm[()]) == int(g[key + "/maxm"])
+    assert_allclose(s.t, float(g[key + "/t"]), rtol=1e-12)
+    y = s.y if y0.size <= 2048 else s.y[::97]
+    assert_allclose(y, g[key + "/y"], rtol=1e-11, atol=1e-14)

@@ -260,3 +260,57 @@ def test_ckdisc_trajectory(golden_dir, case):
     with open(os.path.join(golden_dir, "ckdisc_traces.json")) as fh:
         gold = json.load(fh)
     _ckdisc_check(rk_oracle.CKdisc, case, gold, rk_oracle.NFS, 1e-9)
+
+
+# --------------------------------------------- PDE workloads (real reference) --
+PDE_CASES = {"bruss8": ("bruss2d", 8), "heat8": ("heat2d", 8),
+             "bruss130": ("bruss2d", 130), "heat130": ("heat2d", 130)}
+
+
+def pde_problem(case):
+    kind, N = PDE_CASES[case]
+    return (getattr(pb, kind + "_rhs")(N), getattr(pb, kind + "_y0")(N),
+            getattr(pb, kind + "_rho")(N), N)
+
+
+@pytest.mark.parametrize("name", ["BS5", "Ts5", "Pr7", "Pr8", "Pr9", "CK5", "Me4",
+                                  "CFMR7osc"])
+@pytest.mark.parametrize("case", list(PDE_CASES))
+def test_pde_steps_reference(golden_dir, name, case):
+    """three fixed steps on the benchmark's PDE workloads: oracle == reference"""
+    g = np.load(os.path.join(golden_dir, "pde_steps.npz"))
+    fun, y0, rho, N = pde_problem(case)
+    key = f"{case}/{name}"
+    h = float(g[key + "/h"])
+    s = rk_oracle.METHODS[name](fun, 0.0, y0, 1.0, first_step=h, max_step=h,
+                                rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+    for _ in range(3):
+        assert s.step() is None
+    small = y0.size <= 512
+    assert s.t == float(g[key + "/t"]) and s.nfev == int(g[key + "/nfev"])
+    y = s.y if small else s.y[::97]
+    K = s.K[:s.n_stages + s.FSAL]
+    K = K if small else K[:, ::97]
+    assert_allclose(y, g[key + "/y"], rtol=1e-13, atol=1e-15)
+    assert_allclose(K, g[key + "/K"], rtol=0, atol=1e-11 * np.abs(g[key + "/K"]).max())
+    assert_allclose(s.error_norm_old, g[key + "/err"][-1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["heat8", "heat130", "diff12"])
+def test_pde_steps_reference_rkc(golden_dir, case):
+    g = np.load(os.path.join(golden_dir, "pde_steps.npz"))
+    if case == "diff12":
+        fun, y0, rho = pb.diff3d_rhs(12), pb.diff3d_y0(12), 12.0 * 13 ** 2
+    else:
+        fun, y0, rho, _N = pde_problem(case)
+    s = rkc_oracle.SSV2stab(fun, 0.0, y0, 1.0, rtol=1e-4, atol=1e-7,
+                            first_step=40.0 / rho, rho_jac=lambda t, y: rho,
+                            const_jac=True)
+    for _ in range(2):
+        assert s.step() is None
+    key = f"{case}/SSV2stab"
+    assert s.nfev == int(g[key + "/nfev"])
+    assert int(rkc_oracle.maxm[()]) == int(g[key + "/maxm"])
+    assert_allclose(s.t, float(g[key + "/t"]), rtol=1e-12)
+    y = s.y if y0.size <= 2048 else s.y[::97]
+    assert_allclose(y, g[key + "/y"], rtol=1e-11, atol=1e-14)

@@ -16,6 +16,8 @@ Files written
   rkc_traces.json       G4b: SSV2stab runs on the tanh heat problem
                         (published integer table) and with the power iteration
   lockstep.npz          G5: Pr9 on 8 concatenated heat problems (lock-step ref)
+  pde_steps.npz         G7: three fixed steps of every ERK method (two of SSV2stab)
+                        on the 2-D Brusselator / heat (3-D diffusion) workloads
 
 Usage:  OPENBLAS_NUM_THREADS=1 python tools/gen_golden.py
 """
@@ -236,6 +238,53 @@ def gen_lockstep():
     print("lockstep: steps", len(ts), "nfev", s.nfev)
 
 
+def gen_pde():
+    """G7: the REAL reference on the 2-D / 3-D workloads of the benchmark at small
+    (even) grid sizes, with the NumPy right-hand sides of oracle/problems.py:
+    three fixed-size steps per method.  The device classes are compared with
+    these numbers directly -- device RHS plugins, fused sweeps -- not only
+    through the oracle."""
+    out = {}
+    cases = {"bruss8": (pb.bruss2d_rhs(8), pb.bruss2d_y0(8), pb.bruss2d_rho(8)),
+             "heat8": (pb.heat2d_rhs(8), pb.heat2d_y0(8), pb.heat2d_rho(8)),
+             "bruss130": (pb.bruss2d_rhs(130), pb.bruss2d_y0(130), pb.bruss2d_rho(130)),
+             "heat130": (pb.heat2d_rhs(130), pb.heat2d_y0(130), pb.heat2d_rho(130))}
+    for cname, (fun, y0, rho) in cases.items():
+        h = 0.5 / rho
+        small = y0.size <= 512
+        for name in ERK:
+            s = getattr(ref, name)(fun, 0.0, y0, 1.0, first_step=h, max_step=h,
+                                   rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+            errs = []
+            for _ in range(3):
+                assert s.step() is None
+                errs.append(float(s.error_norm_old))
+            key = f"{cname}/{name}"
+            out[key + "/h"] = h
+            out[key + "/t"] = s.t
+            out[key + "/err"] = np.array(errs)
+            out[key + "/nfev"] = s.nfev
+            out[key + "/nfs"] = int(ref.NFS[()])
+            out[key + "/y"] = s.y.copy() if small else s.y[::97].copy()
+            K = s.K[:s.n_stages + s.FSAL]
+            out[key + "/K"] = K.copy() if small else K[:, ::97].copy()
+    # SSV2stab on the 2-D heat and 3-D diffusion workloads, two steps
+    for cname, fun, y0, rho in (("heat8", pb.heat2d_rhs(8), pb.heat2d_y0(8), pb.heat2d_rho(8)),
+                                ("heat130", pb.heat2d_rhs(130), pb.heat2d_y0(130), pb.heat2d_rho(130)),
+                                ("diff12", pb.diff3d_rhs(12), pb.diff3d_y0(12), 12.0 * 13 ** 2)):
+        s = ref.SSV2stab(fun, 0.0, y0, 1.0, rtol=1e-4, atol=1e-7, first_step=40.0 / rho,
+                         rho_jac=lambda t, y, rho=rho: rho, const_jac=True)
+        for _ in range(2):
+            assert s.step() is None
+        key = f"{cname}/SSV2stab"
+        out[key + "/t"] = s.t
+        out[key + "/nfev"] = s.nfev
+        out[key + "/maxm"] = int(maxm[()])
+        out[key + "/y"] = s.y.copy() if y0.size <= 2048 else s.y[::97].copy()
+    np.savez_compressed(os.path.join(GOLD, "pde_steps.npz"), **out)
+    print("pde:", len(out), "arrays")
+
+
 def gen_stiffness():
     """G6: the reference's stiffness diagnosis (stiff_a, common.py:824-1103) on
     stiff / oscillatory / mild problems: every call's inputs and verdict, and
@@ -284,6 +333,7 @@ if __name__ == "__main__":
     gen_traces()
     gen_rkc()
     gen_lockstep()
+    gen_pde()
     gen_stiffness()
     gen_ckdisc()
     for f in sorted(os.listdir(GOLD)):
