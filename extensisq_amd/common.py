@@ -663,6 +663,12 @@ class RungeKutta(OdeSolver):
                    self.safety * error_norm ** self.error_exponent)
 
     def _rms_from_sumsq(self, sumsq):
+        # with an RCCL communicator the library has summed over the ranks
+        # already; a host reducer (several solvers of one process driven in
+        # lock-step, tests) sums here
+        grp = getattr(self, "_lockstep", None)
+        if grp is not None and not grp.comm and grp._reduce is not None:
+            sumsq = grp.allreduce(self._dev, [sumsq], "sum")[0]
         return (sumsq / self._n_norm) ** 0.5 if self._n_norm else np.nan
 
     # ------------------------------------------------------- device launches

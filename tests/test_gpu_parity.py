@@ -580,6 +580,65 @@ def test_rccl_single_rank_lockstep():
     lockstep.destroy_lockstep(group)
 
 
+def test_lockstep_eight_shards_on_one_gpu_equal_the_concatenated_reference(golden_dir):
+    """BASELINE.json configs[4] in miniature, on the real kernels: eight Pr9
+    solvers (eight contexts and streams on this GPU, one thread each, standing
+    in for eight ranks) integrate their own heat problem in lock-step; the
+    per-shard error sums of squares are summed by a host reducer where RCCL
+    would all-reduce them.  Every shard must take exactly the steps the REAL
+    reference took on the concatenated state (tests/golden/lockstep.npz)."""
+    import threading
+    g = np.load(os.path.join(golden_dir, "lockstep.npz"))
+    N, world = int(g["N"]), 8
+    n = N * N
+    slots = [0.0] * world
+    barrier = threading.Barrier(world)
+    local = threading.local()
+
+    def reducer(values, op):
+        # fixed-order reduction over the eight "ranks" (deterministic)
+        assert len(values) == 1
+        slots[local.rank] = values[0]
+        barrier.wait()
+        out = sum(slots) if op == "sum" else max(slots) if op == "max" else min(slots)
+        barrier.wait()
+        return [out]
+
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            local.rank = rank
+            y0 = pb.heat2d_y0(N, seed=int(g["seeds"][rank]))
+            grp = esq.LockstepGroup(None, world * n, reduce_scalars=reducer)
+            s = esq.Pr9(esq.Heat2D(N), 0.0, y0, float(g["t_end"]),
+                        first_step=float(g["h0"]), rtol=1e-6, atol=1e-9,
+                        nfev_stiff_detect=0, lockstep=grp)
+            ts, errs = [], []
+            while s.status == "running":
+                assert s.step() is None
+                ts.append(s.t)
+                errs.append(s.error_norm_old)
+            results[rank] = (ts, errs, s.y, s.nfev)
+        except BaseException as exc:       # noqa: BLE001
+            errors.append(exc)
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
+    for ts, errs, _y, nfev in results:
+        assert ts == results[0][0]                      # bitwise identical decisions
+        assert_allclose(ts, g["t"], rtol=1e-10)
+        assert_allclose(errs, g["err"], rtol=1e-6)
+        assert nfev == int(g["nfev"]) - 4               # the golden run estimated h0 itself
+    assert_allclose(np.concatenate([r[2] for r in results]), g["y_end"], rtol=1e-9,
+                    atol=1e-12)
+
+
 def test_lockstep_total_size_changes_the_norm():
     """n_total of the batch enters the RMS norm (two ranks' worth of elements
     halves the mean square when the other shard contributes nothing)"""
