@@ -181,6 +181,11 @@ class SSV2stab(OdeSolver):
                   "esq_vec_axpbmc")
 
     def _rms(self, sumsq):
+        # an RCCL communicator has summed over the ranks inside the library; a
+        # host reducer (several solvers of one process in lock-step) sums here
+        grp = getattr(self, "_lockstep", None)
+        if grp is not None and not grp.comm and grp._reduce is not None:
+            sumsq = grp.allreduce(self._dev, [sumsq], "sum")[0]
         return (sumsq / self._n_norm) ** 0.5 if self._n_norm else np.nan
 
     # ------------------------------------------------------------ first step

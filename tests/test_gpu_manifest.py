@@ -16,6 +16,7 @@ REQUIRED = {
     "test_gpu_parity.py::test_published_known_answers": 1,
     "test_gpu_parity.py::test_pde_steps_golden": 32,
     "test_gpu_rkc.py::test_pde_steps_golden_rkc": 3,
+    "test_gpu_rkc.py::test_lockstep_two_shards_with_y_dependent_spectral_radius": 1,
     "test_gpu_parity.py::test_dense_output_golden": 8,
     "test_gpu_parity.py::test_bs5_interpolants_golden": 3,
     "test_gpu_parity.py::test_ckdisc_golden": 7,

@@ -203,3 +203,74 @@ def test_pde_steps_golden_rkc(golden_dir, case):
     assert_allclose(s.t, float(g[key + "/t"]), rtol=1e-12)
     y = s.y if y0.size <= 2048 else s.y[::97]
     assert_allclose(y, g[key + "/y"], rtol=1e-11, atol=1e-14)
+
+
+def test_lockstep_two_shards_with_y_dependent_spectral_radius():
+    """SSV2stab in a lock-step batch on the real kernels: two solvers (two
+    contexts on this GPU, one thread each) with a y-dependent `rho_jac`; the
+    batch must use the larger bound and the summed error norm, i.e. reproduce
+    the oracle's run on the concatenated state (reference sommeijer.py:174-204
+    evaluates `rho_jac` on the whole state)"""
+    import threading
+    N, world = 12, 2
+    n = N * N
+
+    def rho_jac(t, y):
+        return 300.0 * (1.0 + float(np.max(np.abs(y))))
+
+    y0s = [(1.0 + r) * pb.heat2d_y0(N, seed=40 + r) for r in range(world)]
+    slots = [0.0] * world
+    barrier = threading.Barrier(world)
+    local = threading.local()
+
+    def reducer(values, op):
+        out = []
+        for v in values:
+            slots[local.rank] = v
+            barrier.wait()
+            out.append(sum(slots) if op == "sum" else max(slots) if op == "max"
+                       else min(slots))
+            barrier.wait()
+        return out
+
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            local.rank = rank
+            grp = esq.LockstepGroup(None, world * n, reduce_scalars=reducer)
+            grp.debug = True                 # cross-check (t, h, m) every step
+            s = esq.SSV2stab(esq.Heat2D(N), 0.0, y0s[rank], 2e-3, rtol=1e-4,
+                             atol=1e-7, rho_jac=rho_jac, first_step=1e-5,
+                             lockstep=grp)
+            ts = []
+            while s.status == "running":
+                assert s.step() is None
+                ts.append(s.t)
+            results[rank] = (ts, s.y, s.nfev)
+        except BaseException as exc:       # noqa: BLE001
+            errors.append(exc)
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
+    assert results[0][0] == results[1][0]
+    f1 = pb.heat2d_rhs(N)
+
+    def fun(t, y):
+        return np.concatenate([f1(t, y[k * n:(k + 1) * n]) for k in range(world)])
+
+    ref = rkc_oracle.SSV2stab(fun, 0.0, np.concatenate(y0s), 2e-3, rtol=1e-4,
+                              atol=1e-7, rho_jac=rho_jac, first_step=1e-5)
+    ts = []
+    while ref.status == "running":
+        assert ref.step() is None
+        ts.append(ref.t)
+    assert_allclose(results[0][0], ts, rtol=1e-9)
+    assert_allclose(np.concatenate([r[1] for r in results]), ref.y, rtol=1e-8,
+                    atol=1e-12)
+    assert results[0][2] == ref.nfev
