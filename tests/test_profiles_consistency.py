@@ -1,0 +1,55 @@
+"""The committed measurement evidence must be self-consistent (CPU check, no GPU):
+for every bench config the roofline figure of bench.py's JSON line
+(profiles/rNN_bench_<config>.json: designed bytes / HIP-event time) and the one
+recomputed from the rocprofv3 summaries of the same command
+(profiles/rNN_pmc_traffic_<config>.json: PMC bytes / kernel-trace time) agree,
+the fraction is a fraction (<= 1), and no kernel moves more HBM bytes than it
+was designed to (no wasted re-reads)."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
+P = os.path.join(ROOT, "profiles")
+TAG = "r02"
+
+
+@pytest.mark.parametrize("config", ["pr8", "ts5", "pr9", "rkc"])
+def test_bench_and_profiles_agree(config):
+    with open(os.path.join(P, f"{TAG}_bench_{config}.json")) as fh:
+        bench = json.load(fh)
+    with open(os.path.join(P, f"{TAG}_pmc_traffic_{config}.json")) as fh:
+        prof = json.load(fh)
+    r = bench["roofline"]
+    dom = prof["dominant_class"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.0 < dom["frac_of_8TBs_pmc"] <= 1.0
+    # same box, same command: the two routes to the figure agree
+    assert abs(r["frac"] - dom["frac_of_8TBs_pmc"]) <= 0.08 * r["frac"]
+    assert abs(r["avg_launch_us"] * 1e3 - dom["avg_launch_ns_kernel_trace"]) \
+        <= 0.06 * dom["avg_launch_ns_kernel_trace"]
+    # designed bytes vs what the fabric carried
+    assert abs(r["moved_bytes_per_launch"] - dom["hbm_bytes_per_launch"]) \
+        <= 0.10 * dom["hbm_bytes_per_launch"]
+    for name, k in prof["kernels"].items():
+        if "bench_designed_bytes" in k and k["bench_designed_bytes"] > 1e6:
+            assert k["hbm_bytes"] <= 1.12 * k["bench_designed_bytes"], name
+            assert k["hbm_bytes"] >= 0.90 * k["bench_designed_bytes"], name
+    assert bench["value"] == pytest.approx(
+        bench["config"]["n_per_gpu"] * 1e3 / bench["ms_per_step"], rel=1e-9)
+
+
+def test_headline_line_has_the_contract_fields():
+    with open(os.path.join(P, f"{TAG}_bench_pr8.json")) as fh:
+        b = json.load(fh)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline"):
+        assert key in b, key
+    assert b["dtype"] == "f64" and b["data"] == "synthetic" and b["vs_baseline"] is None
+    assert b["scaling"] == "weak" and b["higher_is_better"] is True
+    assert "workload" in b["config"] and "model" not in b["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in b["roofline"], key
