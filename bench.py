@@ -137,8 +137,9 @@ def spawn_ranks(args):
 def dry_run(args, rank, world, ctl):
     """control-plane rehearsal without a GPU (tests/test_bench_cpu.py)"""
     n = 1000 + rank
-    ident, n_total = ctl.exchange(lambda: bytes(range(128)), n)
+    ident, n_total, offset = ctl.exchange(lambda: bytes(range(128)), n)
     assert len(ident) == 128 and n_total == sum(1000 + r for r in range(world))
+    assert offset == sum(1000 + r for r in range(rank))
     ctl.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))

@@ -94,6 +94,7 @@ SIGNATURES = {
     "esq_comm_destroy": (C.c_int, [_vp]),
     "esq_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "esq_comm_abort": (C.c_int, [_vp]),
+    "esq_comm_is_aborted": (C.c_int, [_vp]),
     "esq_allreduce_scalars": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "esq_rhs_diag_create": (C.c_int, [_vpp, C.c_int, _vp, C.c_size_t, C.c_double]),
     "esq_rhs_heat2d_create": (C.c_int, [_vpp, C.c_int]),

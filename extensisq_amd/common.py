@@ -249,11 +249,39 @@ class LockstepGroup:
     the ranks cannot leave lock-step.  `reduce_scalars(values, op)` replaces
     the RCCL path (CPU tests pass a gloo reducer)."""
 
-    def __init__(self, comm, n_total, reduce_scalars=None):
+    def __init__(self, comm, n_total, reduce_scalars=None, offset=None):
         self.comm = comm
         self.n_total = int(n_total)
         self._reduce = reduce_scalars
+        # index of this shard's first element in the concatenated state (None:
+        # unknown); only the spectral-radius iteration's zero-derivative branch
+        # needs it (sommeijer.py:386-388 flips ONE element of the whole state)
+        self.offset = None if offset is None else int(offset)
         self.debug = os.environ.get("ESQ_LOCKSTEP_DEBUG", "0") not in ("", "0")
+        self._contexts = []       # DeviceContexts the communicator is set on
+
+    # -- the communicator handle may be invalidated by the library itself: a
+    #    collective that times out aborts it (esq_comm_is_aborted).  Aborting or
+    #    destroying the freed handle again would be a use-after-free in RCCL.
+    def attach(self, dev):
+        self._contexts.append(dev)
+
+    def sync_aborted(self):
+        """forget the communicator if the library has aborted it; returns True
+        if the handle is gone"""
+        for dev in self._contexts:
+            if getattr(dev, "handle", None) and dev.lib.esq_comm_is_aborted(dev.handle):
+                self.comm = None
+        return not self.comm
+
+    def host_reduce(self, dev, values, op="sum"):
+        """reduce scalars the LIBRARY computed shard-locally.  With an RCCL
+        communicator every reducing entry point has all-reduced its result
+        already (finish_reduction): identity.  With a host reducer standing in
+        for RCCL (several solvers of one process, CPU tests) reduce here."""
+        if self._reduce is not None and not self.comm:
+            return self.allreduce(dev, values, op)
+        return [float(v) for v in values]
 
     def allreduce(self, dev, values, op="max"):
         """all-reduce a few floats over the group; `dev`: the solver's
@@ -266,10 +294,14 @@ class LockstepGroup:
         import ctypes
         from ._lib import OP_MAX, OP_MIN, OP_SUM
         buf = (ctypes.c_double * len(values))(*values)
-        dev._chk(dev.lib.esq_allreduce_scalars(
-            dev.handle, buf, len(values),
-            {"sum": OP_SUM, "max": OP_MAX, "min": OP_MIN}[op]),
-            "esq_allreduce_scalars")
+        try:
+            dev._chk(dev.lib.esq_allreduce_scalars(
+                dev.handle, buf, len(values),
+                {"sum": OP_SUM, "max": OP_MAX, "min": OP_MIN}[op]),
+                "esq_allreduce_scalars")
+        except Exception:
+            self.sync_aborted()
+            raise
         return list(buf)
 
     def check_identical(self, dev, what, values):
@@ -355,6 +387,7 @@ class RungeKutta(OdeSolver):
         if lockstep is not None:
             self._dev._chk(self._lib.esq_set_comm(self._ctx, lockstep.comm),
                            "esq_set_comm")
+            lockstep.attach(self._dev)
             self._n_norm = lockstep.n_total
         self._f_host = None
         self._K_host = None
@@ -383,7 +416,21 @@ class RungeKutta(OdeSolver):
         NFS[()] = 0
 
     def _chk(self, code, what):
-        self._dev._chk(code, what)
+        try:
+            self._dev._chk(code, what)
+        except Exception:
+            if getattr(self, "_lockstep", None) is not None:
+                self._lockstep.sync_aborted()
+            raise
+
+    def _group_reduce(self, values, op="sum"):
+        """shard-local scalars from the library -> scalars of the whole batch
+        (identity outside a lock-step group and on the RCCL path, where the
+        library has reduced them already)"""
+        grp = getattr(self, "_lockstep", None)
+        if grp is None:
+            return list(values)
+        return grp.host_reduce(self._dev, values, op)
 
     # ------------------------------------------------------ starting step
     def _device_h_start(self, b):
@@ -404,7 +451,7 @@ class RungeKutta(OdeSolver):
             out = ctypes.c_double()
             self._chk(lib.esq_vec_sumsq(ctx, x, y, ctypes.byref(out)),
                       "esq_vec_sumsq")
-            return out.value
+            return self._group_reduce([out.value], "sum")[0]
 
         def rms(x, y=VEC_NONE):
             return (sumsq(x, y) / neq) ** 0.5
@@ -487,7 +534,9 @@ class RungeKutta(OdeSolver):
         tolsum, tolmin = ctypes.c_double(), ctypes.c_double()
         self._chk(lib.esq_hs_log_etol(ctx, Y, ctypes.byref(tolsum),
                                       ctypes.byref(tolmin)), "esq_hs_log_etol")
-        tolp = 10.0 ** (0.5 * (tolsum.value / neq + min(tolmin.value, big))
+        tol_sum = self._group_reduce([tolsum.value], "sum")[0]
+        tol_min = self._group_reduce([tolmin.value], "min")[0]
+        tolp = 10.0 ** (0.5 * (tol_sum / neq + min(tol_min, big))
                         / (self.order_secondary + 1))
         h = absdx
         if ydpb == 0.0 and fbnd == 0.0:
@@ -666,9 +715,7 @@ class RungeKutta(OdeSolver):
         # with an RCCL communicator the library has summed over the ranks
         # already; a host reducer (several solvers of one process driven in
         # lock-step, tests) sums here
-        grp = getattr(self, "_lockstep", None)
-        if grp is not None and not grp.comm and grp._reduce is not None:
-            sumsq = grp.allreduce(self._dev, [sumsq], "sum")[0]
+        sumsq = self._group_reduce([sumsq], "sum")[0]
         return (sumsq / self._n_norm) ** 0.5 if self._n_norm else np.nan
 
     # ------------------------------------------------------- device launches

@@ -1,0 +1,368 @@
+// esq_aux.hip -- off the per-step hot loop: device-resident dense output
+// (common.py:358-368, 766-790), Runge-Kutta-Chebyshev launches
+// (sommeijer.py:273-329), vector plumbing of the power iteration and of the
+// starting-step estimate (common.py:519-763).
+#include "esq_internal.hpp"
+#include "esq_aux_kernels.hpp"
+
+using namespace esqi;
+
+struct esq_dense {
+    int device = 0;
+    size_t len = 0, len_pad = 0;
+    int np = 0;
+    unsigned grid = 0;
+    double *mem = nullptr;      // (np + 2) vectors: Qh columns, base, scratch
+    hipStream_t stream = nullptr;
+};
+template <int NT>
+void launch_dense_n(esq_ctx *c, const DenseArgs &a, int np, double scale) {
+    hipLaunchKernelGGL(k_dense_q<NT>, dim3(c->grid_stream), dim3(kBlock), 0,
+                       c->stream, a, np, scale, c->len_pad / 2);
+}
+extern "C" {
+int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
+                     int from_end, esq_dense **out) {
+    if (!c || !P || !out) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    if (rows < 1 || rows > c->n_rows || p < 1 || p > kMaxCols)
+        return fail(c, ESQ_EINVAL, "bad interpolant shape (%d, %d)", rows, p);
+    esq_dense *d = new (std::nothrow) esq_dense();
+    if (!d) return ESQ_ENOMEM;
+    d->device = c->device;
+    d->len = c->len;
+    d->len_pad = c->len_pad;
+    d->np = p;
+    d->grid = c->grid_stream;
+    hipError_t e = hipMalloc(&d->mem, (size_t)(p + 2) * d->len_pad * sizeof(double));
+    if (e != hipSuccess) {
+        delete d;
+        return fail(c, (int)e, "hipMalloc for the interpolant failed: %s",
+                    hipGetErrorString(e));
+    }
+    e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipFree(d->mem); delete d; return fail(c, (int)e, "stream"); }
+    DenseArgs a;
+    int nt = 0;
+    for (int j = 0; j < rows; ++j) {
+        bool any = false;
+        for (int k = 0; k < p; ++k) any = any || P[(size_t)j * p + k] != 0.0;
+        if (!any) continue;
+        if (nt >= kMaxTerms) { esq_dense_destroy(d); return fail(c, ESQ_EINVAL, "too many rows"); }
+        a.p[nt] = c->krow[c->kmap_last[j]];
+        for (int k = 0; k < kMaxCols; ++k) a.w[nt][k] = k < p ? P[(size_t)j * p + k] : 0.0;
+        ++nt;
+    }
+    for (int j = nt; j < kMaxTerms; ++j) {
+        a.p[j] = nullptr;
+        for (int k = 0; k < kMaxCols; ++k) a.w[j][k] = 0.0;
+    }
+    for (int k = 0; k < kMaxCols; ++k) a.q[k] = k < p ? d->mem + (size_t)k * d->len_pad : nullptr;
+    if (nt < 1) { esq_dense_destroy(d); return fail(c, ESQ_EINVAL, "P is all zero"); }
+    switch (nt) {
+#define CASE(N) case N: launch_dense_n<N>(c, a, p, h); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
+        CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17)
+        CASE(18) CASE(19) CASE(20)
+#undef CASE
+    }
+    // base state: after esq_rk_accept, Y is the new state, YNEW the pre-step one
+    const double *base = from_end ? c->y : c->ynew;
+    e = hipMemcpyAsync(d->mem + (size_t)p * d->len_pad, base,
+                       d->len_pad * sizeof(double), hipMemcpyDefault, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        esq_dense_destroy(d);
+        return fail(c, (int)e, "interpolant build failed: %s", hipGetErrorString(e));
+    }
+    *out = d;
+    return 0;
+}
+int esq_dense_eval(esq_dense *d, double x, double *host_out) {
+    if (!d || !host_out) return ESQ_EINVAL;
+    hipError_t e = hipSetDevice(d->device);
+    if (e != hipSuccess) return (int)e;
+    HornerArgs a;
+    for (int k = 0; k < kMaxCols; ++k)
+        a.q[k] = k < d->np ? d->mem + (size_t)k * d->len_pad : nullptr;
+    double *base = d->mem + (size_t)d->np * d->len_pad;
+    double *scratch = d->mem + (size_t)(d->np + 1) * d->len_pad;
+    hipLaunchKernelGGL(k_horner, dim3(d->grid), dim3(kBlock), 0, d->stream,
+                       scratch, base, a, d->np, x, d->len_pad / 2);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(host_out, scratch, d->len * sizeof(double),
+                       hipMemcpyDeviceToHost, d->stream);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamSynchronize(d->stream);
+}
+int esq_dense_download(esq_dense *d, double *Qh_host) {
+    if (!d || !Qh_host) return ESQ_EINVAL;
+    hipError_t e = hipSetDevice(d->device);
+    if (e != hipSuccess) return (int)e;
+    for (int k = 0; k < d->np; ++k) {
+        e = hipMemcpyAsync(Qh_host + (size_t)k * d->len, d->mem + (size_t)k * d->len_pad,
+                           d->len * sizeof(double), hipMemcpyDeviceToHost, d->stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return (int)hipStreamSynchronize(d->stream);
+}
+int esq_dense_destroy(esq_dense *d) {
+    if (!d) return 0;
+    (void)hipSetDevice(d->device);
+    if (d->stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
+    if (d->mem) (void)hipFree(d->mem);
+    delete d;
+    return 0;
+}
+
+// ---- RKC ----------------------------------------------------------------------
+// vector ids of the esq_rkc_* / esq_vec_* family: r >= 0 is a PHYSICAL K row,
+// ESQ_VEC_Y ... ESQ_VEC_WORK name the fixed slots
+static double *vec_ptr(esq_ctx *c, int r) {
+    if (r >= 0) return r < c->n_rows ? c->krow[r] : nullptr;
+    switch (r) {
+        case ESQ_VEC_Y: return c->y;
+        case ESQ_VEC_YNEW: return c->ynew;
+        case ESQ_VEC_YSTAGE: return c->ystage;
+        case ESQ_VEC_WORK: return c->work;
+        default: return nullptr;
+    }
+}
+#define ROW(c, r) vec_ptr((c), (r))
+
+int esq_rkc_first_stage(esq_ctx *c, int dst, int yn, int fn, double hmus) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *d = ROW(c, dst), *a = ROW(c, yn), *f = ROW(c, fn);
+    if (!d || !a || !f) return fail(c, ESQ_EINVAL, "bad row");
+    Prof p(c, ESQ_PROF_RKC, "k_rkc_first", -1, 24.0 * (double)c->len);
+    hipExtLaunchKernelGGL(k_rkc_first, dim3(c->grid_stream), dim3(kBlock), 0,
+                          c->stream, p.start(), p.stop(), 0, d, a, f, hmus,
+                          c->len_pad / 2);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int esq_rkc_stage(esq_ctx *c, int dst, int fy, int yjm1, int yjm2, int yn, int fn,
+                  double mu, double nu, double hmus, double ajm1) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *d = ROW(c, dst), *f = ROW(c, fy), *a = ROW(c, yjm1), *b = ROW(c, yjm2),
+           *y0 = ROW(c, yn), *g = ROW(c, fn);
+    if (!d || !f || !a || !b || !y0 || !g) return fail(c, ESQ_EINVAL, "bad row");
+    const double omn = (1.0 - mu) - nu;   // (1.0 - mu - nu), left to right
+    Prof p(c, ESQ_PROF_RKC, "k_rkc_stage", -1, 48.0 * (double)c->len);
+    hipExtLaunchKernelGGL(k_rkc_stage, dim3(c->grid_stream), dim3(kBlock), 0,
+                          c->stream, p.start(), p.stop(), 0, d, f, a, b, y0, g,
+                          mu, nu, omn, hmus, ajm1, c->len_pad / 2);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int esq_rkc_eval_rhs(esq_ctx *c, int dst, double t, int src) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *d = ROW(c, dst), *s = ROW(c, src);
+    if (!d || !s) return fail(c, ESQ_EINVAL, "bad row");
+    return call_rhs(c, t, s, d);
+}
+int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
+                   double hmus1, int m, const double *scalars, int *y_row_out) {
+    if (!c || !y_row_out || m < 1 || (m > 1 && !scalars)) return ESQ_EINVAL;
+    ENTER(c);
+    // rotation instead of the reference's two full copies per stage:
+    //   jm1 = first-stage result, jm2 = yn; every stage writes into a free row
+    int r = esq_rkc_first_stage(c, w0, yn, fn, hmus1);
+    if (r) return r;
+    int jm1 = w0, jm2 = yn, free_a = w1, free_b = w2;
+    int ycur = w0;
+    for (int j = 2; j <= m; ++j) {
+        const double *sc = scalars + 5 * (size_t)(j - 2);
+        bool done = false;
+        if (c->rhs_rkc) {
+            // ONE sweep: derivative of yjm1 and the recursion, no fy in memory
+            double *d = ROW(c, free_a), *a = ROW(c, jm1), *b = ROW(c, jm2),
+                   *y0 = ROW(c, yn), *g = ROW(c, fn);
+            if (!d || !a || !b || !y0 || !g) return fail(c, ESQ_EINVAL, "bad row");
+            const double omn = (1.0 - sc[0]) - sc[1];
+            Prof p(c, ESQ_PROF_RKC, "rhs_rkc", -1, 64.0 * (double)c->len, false,
+                   40.0 * (double)c->len);
+            r = c->rhs_rkc(c->rhs_user, sc[4], a, b, y0, g, sc[0], sc[1], omn,
+                           sc[2], sc[3], d, c->len, (void *)c->stream,
+                           (void *)p.start(), (void *)p.stop());
+            if (r == 0) done = true;
+            else if (r != ESQ_ENOTSUP)
+                return fail(c, ESQ_ERHS, "RKC plugin entry returned %d", r);
+            else p.cancel();
+        }
+        if (!done) {
+            // fy = rhs(t_stage, yjm1) into free_a, combination overwrites free_a
+            r = esq_rkc_eval_rhs(c, free_a, sc[4], jm1);
+            if (r) return r;
+            r = esq_rkc_stage(c, free_a, free_a, jm1, jm2, yn, fn, sc[0], sc[1],
+                              sc[2], sc[3]);
+            if (r) return r;
+        }
+        ycur = free_a;
+        // shift: jm2 <- jm1, jm1 <- new; the old jm2 row becomes free
+        const int old_jm2 = jm2;
+        jm2 = jm1;
+        jm1 = ycur;
+        if (old_jm2 == yn) {      // yn is never recycled
+            free_a = free_b;
+        } else {
+            free_a = old_jm2;
+        }
+    }
+    *y_row_out = ycur;
+    return 0;
+}
+int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
+                       double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
+    double *a = ROW(c, y), *b = ROW(c, yn), *f = ROW(c, fn), *g = ROW(c, fy);
+    if (!a || !b || !f || !g) return fail(c, ESQ_EINVAL, "bad row");
+    if (c->cplx) return fail(c, ESQ_EINVAL, "RKC is real-only (sommeijer.py:98)");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, "k_rkc_error", -1, 32.0 * (double)c->len);
+        hipExtLaunchKernelGGL(k_rkc_error, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, p.start(), p.stop(), 0, a, b, f, g, h,
+                           c->atol_is_vec ? c->atolv : nullptr, c->atol_s, c->rtol,
+                           c->len_pad / 2, c->n, c->partials);
+        HIPCHK(c, hipGetLastError());
+    }
+    return finish_reduction(c, sumsq_out);
+}
+int esq_vec_sumsq(esq_ctx *c, int x, int y, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
+    double *a = ROW(c, x), *b = y != ESQ_VEC_NONE ? ROW(c, y) : nullptr;
+    if (!a || (y != ESQ_VEC_NONE && !b)) return fail(c, ESQ_EINVAL, "bad row");
+    hipLaunchKernelGGL(k_sumsq, dim3(c->grid_reduce), dim3(kBlock), 0, c->stream,
+                       a, b, c->len_pad / 2, c->partials);
+    HIPCHK(c, hipGetLastError());
+    return finish_reduction(c, sumsq_out);
+}
+int esq_vec_axpbmc(esq_ctx *c, int dst, int a, double alpha, int b, int cc) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *d = ROW(c, dst), *pa = a != ESQ_VEC_NONE ? ROW(c, a) : nullptr,
+           *pb = ROW(c, b), *pc = cc != ESQ_VEC_NONE ? ROW(c, cc) : nullptr;
+    if (!d || !pb || (a != ESQ_VEC_NONE && !pa) || (cc != ESQ_VEC_NONE && !pc))
+        return fail(c, ESQ_EINVAL, "bad row");
+    hipLaunchKernelGGL(k_axpbmc, dim3(c->grid_stream), dim3(kBlock), 0, c->stream,
+                       d, pa, alpha, pb, pc, c->len_pad / 2);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int esq_vec_wdiff_sumsq(esq_ctx *c, int a, int b, int w, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
+    double *pa = ROW(c, a), *pb = ROW(c, b), *pw = ROW(c, w);
+    if (!pa || !pb || !pw) return fail(c, ESQ_EINVAL, "bad row");
+    hipLaunchKernelGGL(k_wdiff_sumsq, dim3(c->grid_reduce), dim3(kBlock), 0,
+                       c->stream, pa, pb, pw, c->atol_is_vec ? c->atolv : nullptr,
+                       c->atol_s, c->rtol, c->len_pad / 2, c->n, c->partials);
+    HIPCHK(c, hipGetLastError());
+    return finish_reduction(c, sumsq_out);
+}
+
+int esq_vec_wdot(esq_ctx *c, int a, int b, int y1, int y2, double floor_,
+                 double *out) {
+    if (!c || !out) return ESQ_EINVAL;
+    ENTER(c);
+    double *pa = ROW(c, a), *pb = ROW(c, b), *p1 = ROW(c, y1), *p2 = ROW(c, y2);
+    if (!pa || !pb || !p1 || !p2) return fail(c, ESQ_EINVAL, "bad vector id");
+    if (c->cplx)
+        hipLaunchKernelGGL(k_wdot<true>, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, pa, pb, p1, p2, floor_, c->len_pad / 2, c->n,
+                           c->partials);
+    else
+        hipLaunchKernelGGL(k_wdot<false>, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, pa, pb, p1, p2, floor_, c->len_pad / 2, c->n,
+                           c->partials);
+    HIPCHK(c, hipGetLastError());
+    return finish_reduction(c, out);
+}
+int esq_vec_fill(esq_ctx *c, int dst, double value, double value_im) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *d = ROW(c, dst);
+    if (!d) return fail(c, ESQ_EINVAL, "bad vector id %d", dst);
+    if (c->cplx)
+        hipLaunchKernelGGL(k_fill<true>, dim3(c->grid_stream), dim3(kBlock), 0,
+                           c->stream, d, value, value_im, c->len_pad / 2, c->n);
+    else
+        hipLaunchKernelGGL(k_fill<false>, dim3(c->grid_stream), dim3(kBlock), 0,
+                           c->stream, d, value, value_im, c->len_pad / 2, c->n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+int esq_vec_copy(esq_ctx *c, int dst, int src) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *d = ROW(c, dst), *s = ROW(c, src);
+    if (!d || !s) return fail(c, ESQ_EINVAL, "bad vector id");
+    HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),
+                             hipMemcpyDefault, c->stream));
+    return 0;
+}
+int esq_vec_eval_rhs(esq_ctx *c, int dst, double t, int src) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *d = ROW(c, dst), *s = ROW(c, src);
+    if (!d || !s) return fail(c, ESQ_EINVAL, "bad vector id");
+    return call_rhs(c, t, s, d);
+}
+int esq_vec_upload(esq_ctx *c, int dst, const double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    const bool was_idle = c->idle;
+    ENTER(c);
+    double *d = ROW(c, dst);
+    if (!d) return fail(c, ESQ_EINVAL, "bad vector id %d", dst);
+    return h2d(c, d, host, c->len * sizeof(double), was_idle);
+}
+int esq_vec_download(esq_ctx *c, int src, double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    const bool was_idle = c->idle;
+    ENTER_KEEP(c);
+    double *s = ROW(c, src);
+    if (!s) return fail(c, ESQ_EINVAL, "bad vector id %d", src);
+    return d2h(c, host, s, c->len * sizeof(double), was_idle);
+}
+int esq_hs_log_etol(esq_ctx *c, int y, double *sum_out, double *min_out) {
+    if (!c || !sum_out || !min_out) return ESQ_EINVAL;
+    ENTER(c);
+    double *py = ROW(c, y);
+    if (!py) return fail(c, ESQ_EINVAL, "bad vector id %d", y);
+    const double *av = c->atol_is_vec ? c->atolv : nullptr;
+    if (c->cplx)
+        hipLaunchKernelGGL(k_log_etol<true>, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, py, av, c->atol_s, c->rtol, c->len_pad / 2,
+                           c->n, c->partials, c->partials2);
+    else
+        hipLaunchKernelGGL(k_log_etol<false>, dim3(c->grid_reduce), dim3(kBlock), 0,
+                           c->stream, py, av, c->atol_s, c->rtol, c->len_pad / 2,
+                           c->n, c->partials, c->partials2);
+    HIPCHK(c, hipGetLastError());
+    int r = finish_reduction(c, sum_out);
+    if (r) return r;
+    return finish_reduction(c, min_out, /*take_min=*/true, c->partials2);
+}
+int esq_hs_select(esq_ctx *c, int yp, int spy, int src, double fill) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *a = ROW(c, yp), *b = ROW(c, spy), *s = ROW(c, src);
+    if (!a || !b || !s) return fail(c, ESQ_EINVAL, "bad vector id");
+    if (c->cplx)
+        hipLaunchKernelGGL(k_hs_select<true>, dim3(c->grid_stream), dim3(kBlock), 0,
+                           c->stream, a, b, s, fill, c->len_pad / 2, c->n);
+    else
+        hipLaunchKernelGGL(k_hs_select<false>, dim3(c->grid_stream), dim3(kBlock), 0,
+                           c->stream, a, b, s, fill, c->len_pad / 2, c->n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,655 @@
+// esq_core.hip -- context lifecycle, data movement, the reduction tail (partials
+// -> pinned host slot, all-reduced over the lock-step communicator if one is
+// set), RHS binding and the profiling API of libextensisq_amd.so
+// (include/extensisq_amd.h).  Rotation of K rows and the y <-> y_new exchange
+// are pointer swaps on the host; kernels receive row pointers and coefficients
+// by value in their kernel arguments.
+#include <unistd.h>
+
+#include <chrono>
+
+#include "esq_internal.hpp"
+
+namespace esq {
+
+// final deterministic sum of the per-block partials (one block of 1024):
+// thread-strided partial sums, wave64 tree, 16 waves through LDS
+__global__ __launch_bounds__(1024) void k_final_sum(
+    const double *__restrict__ partials, int count, ResultSink rs) {
+    __shared__ double lds[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += 1024) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t += lds[w];
+        publish(rs, t);
+    }
+}
+// after the lock-step all-reduce: device double -> host slot
+__global__ void k_publish(const double *__restrict__ src, ResultSink rs) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        rs.dev = nullptr;
+        publish(rs, *src);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_final_min(
+    const double *__restrict__ partials, int count, ResultSink rs) {
+    __shared__ double lds[16];
+    double m = INFINITY;
+    for (int i = threadIdx.x; i < count; i += 1024) m = fmin(m, partials[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t = fmin(t, lds[w]);
+        publish(rs, t);
+    }
+}
+
+
+// lock-step scalars: pinned host doubles -> device (input of the all-reduce) ...
+__global__ void k_load_scalars(const double *__restrict__ host_vals,
+                               double *__restrict__ dev, int count) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < count)
+        dev[threadIdx.x] = __hip_atomic_load(host_vals + threadIdx.x, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... and back: the reduced values, then -- behind a system-scope release -- the
+// sequence number the host is polling
+__global__ void k_publish_scalars(const double *__restrict__ dev,
+                                  double *__restrict__ host_vals, int count,
+                                  unsigned long long *host_seq,
+                                  unsigned long long seq) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int i = 0; i < count; ++i)
+        __hip_atomic_store(host_vals + i, dev[i], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace esq
+
+namespace esqi {
+
+int fail(esq_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof(c->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+double *slot_ptr(esq_ctx *c, int slot, int row, bool logical) {
+    switch (slot) {
+        case ESQ_SLOT_K:
+            if (row < 0 || row >= c->n_rows) return nullptr;
+            return c->krow[logical ? c->kmap[row] : row];
+        case ESQ_SLOT_Y: return c->y;
+        case ESQ_SLOT_YNEW: return c->ynew;
+        case ESQ_SLOT_YSTAGE: return c->ystage;
+        case ESQ_SLOT_ATOL: return c->atolv;
+        case ESQ_SLOT_WORK: return c->work;
+        default: return nullptr;
+    }
+}
+
+// ---- profiling -------------------------------------------------------------
+Prof::Prof(esq_ctx *ctx, int klass, const char *name, int nt, double bytes,
+           bool record_now, double moved)
+    : c(ctx), on((ctx->prof_mask >> klass) & 1u), recorded(record_now) {
+    ev.start = ev.stop = nullptr;
+    ev.name[0] = 0;
+    if (on && ctx->prof_every > 1) {
+        // pseudo-random 1-in-`every` sampling: a fixed stride would alias
+        // with the number of launches per step (e.g. 14 for Pr8, stride 7)
+        unsigned x = (unsigned)(ctx->prof_seen[klass]++) * 2654435761u;
+        x ^= x >> 15;
+        x *= 2246822519u;
+        x ^= x >> 13;
+        on = (x % ctx->prof_every) == 0;
+    }
+    if (!on) return;
+    auto take = [&]() {
+        hipEvent_t e;
+        if (!c->prof_pool.empty()) {
+            e = c->prof_pool.back();
+            c->prof_pool.pop_back();
+        } else {
+            (void)hipEventCreate(&e);
+        }
+        return e;
+    };
+    ev.start = take();
+    ev.stop = take();
+    ev.klass = klass;
+    ev.bytes = bytes;
+    ev.moved = moved < 0.0 ? bytes : moved;
+    if (nt >= 0) snprintf(ev.name, sizeof(ev.name), "%s<%d>", name, nt);
+    else snprintf(ev.name, sizeof(ev.name), "%s", name);
+    if (recorded) (void)hipEventRecord(ev.start, c->stream);
+}
+void Prof::cancel() {
+    if (!on) return;
+    c->prof_pool.push_back(ev.start);
+    c->prof_pool.push_back(ev.stop);
+    on = false;
+}
+Prof::~Prof() {
+    if (!on) return;
+    if (recorded) (void)hipEventRecord(ev.stop, c->stream);
+    c->prof_live.push_back(ev);
+}
+
+void prof_drain(esq_ctx *c) {
+    if (c->prof_live.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &ev : c->prof_live) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) {
+            c->prof_ms[ev.klass] += ms;
+            c->prof_cnt[ev.klass] += 1;
+            c->prof_bytes[ev.klass] += ev.bytes;
+            c->prof_moved[ev.klass] += ev.moved;
+            ProfKernel &pk = c->prof_kernels[ev.name];
+            pk.klass = ev.klass;
+            pk.launches += 1;
+            pk.ms += ms;
+            pk.bytes += ev.bytes;
+            pk.moved += ev.moved;
+        }
+        c->prof_pool.push_back(ev.start);
+        c->prof_pool.push_back(ev.stop);
+    }
+    c->prof_live.clear();
+}
+
+// Wait until the reduction numbered `seq` has landed in the pinned host slot.
+// The GPU writes the slot itself (no copy engine, no stream-sync wake-up: the
+// 8-byte D2H copy + hipStreamSynchronize pair cost ~15 us of every step), the
+// host spins on it.  The stream is queried now and then so that a faulted
+// kernel surfaces as an error instead of a hang; `timeout_s` > 0 bounds the
+// wait (lock-step: a peer that died never arrives at the all-reduce).
+int wait_slot(esq_ctx *c, unsigned long long seq, double timeout_s) {
+    volatile unsigned long long *flag = &c->h_slot->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spins = 1;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+        if ((spins & 0xfff) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                // everything on the stream has finished: the slot is written
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+                return fail(c, ESQ_ESTATE, "reduction %llu finished without a result", seq);
+            }
+            if (q != hipErrorNotReady)
+                return fail(c, (int)q, "stream failed while waiting for a reduction: %s",
+                            hipGetErrorString(q));
+            if (timeout_s > 0.0) {
+                const double el = std::chrono::duration<double>(
+                    std::chrono::steady_clock::now() - t0).count();
+                if (el > timeout_s) return ESQ_ETIMEOUT;
+            }
+        }
+    }
+}
+
+ResultSink next_sink(esq_ctx *c, bool to_host_value) {
+    ResultSink rs;
+    rs.seq = ++c->red_seq;
+    rs.dev = nullptr;
+    rs.host_value = to_host_value ? &c->h_slot->value : nullptr;
+    rs.host_seq = &c->h_slot->seq;
+    return rs;
+}
+void launch_load_scalars(esq_ctx *c, double *dev, int count) {
+    hipLaunchKernelGGL(k_load_scalars, dim3(1), dim3(64), 0, c->stream,
+                       c->h_slot->vals, dev, count);
+}
+void launch_publish_scalars(esq_ctx *c, const double *dev, int count,
+                            unsigned long long seq) {
+    hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, c->stream, dev,
+                       c->h_slot->vals, count, &c->h_slot->seq, seq);
+}
+
+// partials -> one double on the host (all-reduced over the communicator if set)
+int finish_reduction(esq_ctx *c, double *out, bool take_min, const double *partials,
+                     int count) {
+    if (!partials) partials = c->partials;
+    if (count < 0) count = (int)c->grid_reduce;
+    ResultSink rs = next_sink(c, !c->comm);
+    rs.dev = c->comm ? c->d_result : nullptr;
+    if (take_min)
+        hipLaunchKernelGGL(k_final_min, dim3(1), dim3(1024), 0, c->stream,
+                           partials, count, rs);
+    else
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(1024), 0, c->stream,
+                           partials, count, rs);
+    HIPCHK(c, hipGetLastError());
+    if (c->comm) {
+        int r = g_rccl.AllReduce(c->d_result, c->d_result, 1, kNcclFloat64,
+                                 take_min ? kNcclMin : kNcclSum, c->comm,
+                                 c->stream);
+        if (r != 0)
+            return fail(c, 1000 + r, "ncclAllReduce failed: %s",
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        rs.host_value = &c->h_slot->value;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream,
+                           c->d_result, rs);
+        HIPCHK(c, hipGetLastError());
+    }
+    int w = wait_slot(c, rs.seq, c->comm ? c->comm_timeout_s : 0.0);
+    if (w == ESQ_ETIMEOUT) {
+        // a peer never reached the collective
+        abort_comm(c);
+        return fail(c, ESQ_ETIMEOUT, "lock-step all-reduce did not complete within "
+                    "%.0f s (a peer rank failed?); communicator aborted",
+                    c->comm_timeout_s);
+    }
+    if (w) return w;
+    c->idle = true;        // the final-sum kernel was the last thing enqueued
+    if (out) *out = c->h_slot->value;
+    return 0;
+}
+
+int call_rhs(esq_ctx *c, double t, const double *src, double *dst) {
+    if (!c->rhs) return fail(c, ESQ_ESTATE, "no device RHS set (esq_set_rhs)");
+    Prof p(c, ESQ_PROF_RHS, "rhs_plugin", -1, 16.0 * (double)c->len, /*record_now=*/true);
+    c->self_valid = false;     // a plugin kernel does not signal its own completion
+    int r = c->rhs(c->rhs_user, t, src, dst, c->len, (void *)c->stream);
+    if (r != 0) return fail(c, ESQ_ERHS, "RHS plugin returned %d", r);
+    return 0;
+}
+
+int build_row_terms(esq_ctx *c, const double *coef, int count, Terms &tm,
+                    const std::vector<int> &map) {
+    int nt = 0;
+    for (int j = 0; j < count; ++j) {
+        if (coef[j] == 0.0) continue;
+        if (nt >= kMaxTerms) return -1;
+        tm.p[nt] = c->krow[map[j]];
+        tm.c[nt] = coef[j];
+        ++nt;
+    }
+    for (int j = nt; j < kMaxTerms; ++j) { tm.p[j] = nullptr; tm.c[j] = 0.0; }
+    return nt;
+}
+int build_row_terms2(esq_ctx *c, const double *b, int nb, const double *e, int ne,
+                     Terms2 &tm, const std::vector<int> &map) {
+    int nt = 0;
+    const int count = nb > ne ? nb : ne;
+    for (int j = 0; j < count; ++j) {
+        const double bj = j < nb ? b[j] : 0.0, ej = j < ne ? e[j] : 0.0;
+        if (bj == 0.0 && ej == 0.0) continue;
+        if (nt >= kMaxTerms) return -1;
+        tm.p[nt] = c->krow[map[j]];
+        tm.b[nt] = bj;
+        tm.e[nt] = ej;
+        ++nt;
+    }
+    for (int j = nt; j < kMaxTerms; ++j) { tm.p[j] = nullptr; tm.b[j] = tm.e[j] = 0.0; }
+    return nt;
+}
+
+// ---- host-slab mode ------------------------------------------------------------
+static bool in_host_slab(const esq_ctx *c, const void *dev) {
+    const double *p = (const double *)dev;
+    return c->host_slab && p >= c->slab && p < c->slab + c->slab_doubles;
+}
+static double *host_of(const esq_ctx *c, const void *dev) {
+    return c->slab_host + ((const double *)dev - c->slab);
+}
+// every kernel enqueued so far has finished (its writes to the pinned slab are
+// visible to the host): a one-thread kernel bumps the pinned sequence number
+// behind them, the host spins on it
+int host_wait(esq_ctx *c, bool already_idle) {
+    if (already_idle) return 0;
+    if (c->self_valid) {               // the last kernel signals its own completion
+        c->self_valid = false;
+        const int w = wait_slot(c, c->self_seq, 0.0);
+        if (w) return w;
+        c->idle = true;
+        return 0;
+    }
+    const ResultSink rs = next_sink(c, true);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, c->d_result, rs);
+    HIPCHK(c, hipGetLastError());
+    const int w = wait_slot(c, rs.seq, 0.0);
+    if (w) return w;
+    c->idle = true;
+    return 0;
+}
+
+
+// Device-to-host copy into a caller's (pageable) buffer.  Large copies pin the
+// destination for the duration of the call: measured for 80 MB into a fresh
+// NumPy array 4.3 ms (register 2.8 + copy 1.5 at 54 GB/s) against 6.5-7 ms for
+// the staged pageable copy.
+int d2h(esq_ctx *c, void *host, const void *dev, size_t bytes, bool was_idle) {
+    if (in_host_slab(c, dev)) {
+        const int w = host_wait(c, was_idle);
+        if (w) return w;
+        memcpy(host, host_of(c, dev), bytes);
+        return 0;
+    }
+    bool pinned = false;
+    if (bytes >= ((size_t)8 << 20))
+        pinned = hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess;
+    hipError_t e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (pinned) (void)hipHostUnregister(host);
+    if (e != hipSuccess)
+        return fail(c, (int)e, "device-to-host copy failed: %s", hipGetErrorString(e));
+    c->idle = true;
+    return 0;
+}
+// host-to-device copy of a caller's buffer, synchronous
+int h2d(esq_ctx *c, void *dev, const void *host, size_t bytes, bool was_idle) {
+    if (in_host_slab(c, dev)) {
+        // no kernel may still be reading the row that is overwritten
+        const int w = host_wait(c, was_idle);
+        if (w) return w;
+        memcpy(host_of(c, dev), host, bytes);
+        c->idle = true;
+        return 0;
+    }
+    HIPCHK(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->idle = true;
+    return 0;
+}
+
+unsigned env_uint(const char *name, unsigned dflt) {
+    const char *s = getenv(name);
+    if (!s || !*s) return dflt;
+    char *end = nullptr;
+    long v = strtol(s, &end, 10);
+    return (end != s && v >= 0) ? (unsigned)v : dflt;
+}
+
+
+}  // namespace esqi
+
+using namespace esqi;
+
+extern "C" {
+
+int esq_abi_version(void) { return ESQ_ABI_VERSION; }
+
+int esq_device_count(int *count_out) {
+    if (!count_out) return ESQ_EINVAL;
+    const hipError_t e = hipGetDeviceCount(count_out);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) {
+    return esq_create2(out, device, n, n_rows, is_complex, 0);
+}
+int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
+                int flags) {
+    if (!out || n_rows < 1 || n_rows > 64) return ESQ_EINVAL;
+    esq_ctx *c = new (std::nothrow) esq_ctx();
+    if (!c) return ESQ_ENOMEM;
+    *out = c;   // returned even on failure so the caller can read the message
+    c->device = device;
+    c->n = n;
+    c->cplx = is_complex != 0;
+    c->len = c->cplx ? 2 * n : n;
+    c->len_pad = ((c->len + kPadDoubles - 1) / kPadDoubles) * kPadDoubles;
+    if (c->len_pad == 0) c->len_pad = kPadDoubles;
+    // ESQ_ROW_STAGGER: extra bytes between consecutive vectors (HBM channel
+    // de-aliasing experiments); must be a multiple of 16
+    const size_t stagger = (env_uint("ESQ_ROW_STAGGER", 0) / 16) * 2;
+    c->stride = c->len_pad + stagger;
+    c->n_rows = n_rows;
+    HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t nvec = (size_t)n_rows + kFixedSlots;
+    const size_t slab_doubles = nvec * c->stride + kPartialsCap + kMaxPartials + 64;
+    c->slab_doubles = slab_doubles;
+    c->host_slab = (flags & ESQ_CREATE_HOST_SLAB) != 0;
+    if (c->host_slab) {
+        HIPCHK(c, hipHostMalloc((void **)&c->slab_host, slab_doubles * sizeof(double),
+                                hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->slab_host, 0, slab_doubles * sizeof(double));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->slab, c->slab_host, 0));
+    } else {
+        HIPCHK(c, hipMalloc(&c->slab, slab_doubles * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->slab, 0, slab_doubles * sizeof(double), c->stream));
+    }
+    c->krow.resize(n_rows);
+    c->kmap.resize(n_rows);
+    for (int r = 0; r < n_rows; ++r) {
+        c->krow[r] = c->slab + (size_t)r * c->stride;
+        c->kmap[r] = r;
+    }
+    c->kmap_last = c->kmap;
+    double *base = c->slab + (size_t)n_rows * c->stride;
+    c->y = base;
+    c->ynew = base + c->stride;
+    c->ystage = base + 2 * c->stride;
+    c->atolv = base + 3 * c->stride;
+    c->work = base + 4 * c->stride;
+    c->partials = base + 5 * c->stride;
+    c->partials2 = c->partials + kPartialsCap;
+    c->d_result = c->partials2 + kMaxPartials;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_slot, 128,
+                            hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_slot, 0, sizeof(HostSlot));
+    c->comm_timeout_s = (double)env_uint("ESQ_COMM_TIMEOUT_S", 120);
+    c->epi_nt = env_uint("ESQ_EPI_NT", 0x3);
+    c->skip_dead = env_uint("ESQ_DEAD_STORE", 1) != 0;
+    // launch geometry: grid-stride kernels, a few resident blocks per CU
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    const unsigned cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const size_t n2 = c->len_pad / 2;
+    const size_t need = (n2 + kBlock - 1) / kBlock;
+    // Cache policy (measured): a working set beyond the 256 MiB
+    // Infinity Cache streams its K rows with non-temporal loads so that y and
+    // the stage argument stay on-die (2 workgroups per CU); a working set that
+    // fits is left to the cache (plain loads, 8 workgroups per CU).
+    const bool fits_mall = slab_doubles * sizeof(double) <= (size_t)160 << 20;
+    // The first sweep of a step may form its own input from y and K[0]
+    // (ESQ_FUSE_SRC): one launch and 16 B per element less, but a second row
+    // window through L2.  Measured (profiles/r02_experiments.md): Ts5 at n = 1e6
+    // 0.0834 -> 0.0778 ms/step, Pr8 at n = 1e7 unchanged, Pr9 at n = 5e6 +0.8 %:
+    // used where the working set is cache-resident.  ESQ_SRC=0|1 overrides.
+    c->src_pays = env_uint("ESQ_SRC", fits_mall ? 1 : 0) != 0;
+    const unsigned per_cu = env_uint("ESQ_BLOCKS_PER_CU", fits_mall ? 8 : 2);
+    c->stage_policy = (int)env_uint("ESQ_STAGE_POLICY", fits_mall ? 0 : 10);
+    size_t g = (size_t)cus * per_cu;
+    if (g > need) g = need;
+    if (g < 1) g = 1;
+    c->grid_stream = (unsigned)g;
+    c->grid_reduce = (unsigned)(g > (size_t)kMaxPartials ? kMaxPartials : g);
+    size_t gb = (size_t)cus * env_uint("ESQ_BLOCK_BPC", 16);
+    if (gb > need) gb = need;
+    c->grid_block = (unsigned)(gb < 1 ? 1 : gb);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int esq_destroy(esq_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &ev : c->prof_live) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
+    for (auto &e : c->prof_pool) (void)hipEventDestroy(e);
+    if (c->host_slab) {
+        if (c->slab_host) (void)hipHostFree(c->slab_host);
+    } else if (c->slab) {
+        (void)hipFree(c->slab);
+    }
+    for (double *p : c->aux_slabs) (void)hipFree(p);
+    if (c->h_slot) (void)hipHostFree(c->h_slot);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+const char *esq_last_error(const esq_ctx *c) { return c ? c->err : "null context"; }
+
+int esq_synchronize(esq_ctx *c) {
+    if (!c) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->idle = true;
+    return 0;
+}
+size_t esq_vector_len(const esq_ctx *c) { return c ? c->len : 0; }
+
+int esq_upload(esq_ctx *c, int slot, int row, const double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    const bool was_idle = c->idle;
+    ENTER(c);
+    double *d = slot_ptr(c, slot, row);
+    if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
+    const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
+    return h2d(c, d, host, cnt * sizeof(double), was_idle);
+}
+int esq_download(esq_ctx *c, int slot, int row, double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    double *d = slot_ptr(c, slot, row);
+    if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
+    const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
+    return d2h(c, host, d, cnt * sizeof(double), c->idle);
+}
+int esq_copy(esq_ctx *c, int dst_slot, int dst_row, int src_slot, int src_row) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *d = slot_ptr(c, dst_slot, dst_row), *s = slot_ptr(c, src_slot, src_row);
+    if (!d || !s) return fail(c, ESQ_EINVAL, "bad slot/row");
+    HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),
+                             hipMemcpyDefault, c->stream));
+    return 0;
+}
+
+int esq_set_tol(esq_ctx *c, double rtol, const double *atol, size_t n_atol) {
+    if (!c || !atol) return ESQ_EINVAL;
+    ENTER(c);
+    c->rtol = rtol;
+    if (n_atol == 1) {
+        c->atol_s = atol[0];
+        c->atol_is_vec = false;
+        return 0;
+    }
+    if (n_atol != c->n) return fail(c, ESQ_EINVAL, "atol has %zu entries, n = %zu", n_atol, c->n);
+    c->atol_is_vec = true;
+    return h2d(c, c->atolv, atol, c->n * sizeof(double), false);
+}
+
+int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    c->rhs = fn;
+    c->rhs_user = user;
+    c->rhs_fused = nullptr;
+    c->fuse_mask = 0;
+    c->rhs_rkc = nullptr;
+    return 0;
+}
+int esq_set_rhs_rkc(esq_ctx *c, esq_rhs_rkc_fn fn) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    c->rhs_rkc = fn;
+    return 0;
+}
+int esq_set_rhs_fused(esq_ctx *c, esq_rhs_fused_fn fn, int fuse_mask) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    c->rhs_fused = fn;
+    c->fuse_mask = fn ? fuse_mask : 0;
+    c->src_declined = false;
+    return 0;
+}
+
+int esq_aux_rows(esq_ctx *c, int count, int *first_id) {
+    if (!c || !first_id || count < 1 || count > 32) return ESQ_EINVAL;
+    ENTER(c);
+    double *mem = nullptr;
+    const size_t bytes = (size_t)count * c->stride * sizeof(double);
+    HIPCHK(c, hipMalloc(&mem, bytes));
+    HIPCHK(c, hipMemsetAsync(mem, 0, bytes, c->stream));
+    c->aux_slabs.push_back(mem);
+    *first_id = c->n_rows;
+    for (int r = 0; r < count; ++r) {
+        c->krow.push_back(mem + (size_t)r * c->stride);
+        c->kmap.push_back(c->n_rows + r);
+        c->kmap_last.push_back(c->n_rows + r);
+    }
+    c->n_rows += count;
+    return 0;
+}
+
+// ---- measurement ----------------------------------------------------------------
+int esq_profile_enable(esq_ctx *c, int class_mask) {
+    if (!c) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    if (!class_mask) prof_drain(c);
+    c->prof_mask = (unsigned)class_mask;
+    return 0;
+}
+int esq_profile_sampling(esq_ctx *c, int every) {
+    if (!c || every < 1) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    c->prof_every = (unsigned)every;
+    return 0;
+}
+int esq_profile_read(esq_ctx *c, int klass, double *total_ms, long *launches,
+                     double *bytes) {
+    if (!c || klass < 0 || klass >= ESQ_PROF_NCLASS) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    prof_drain(c);
+    if (total_ms) *total_ms = c->prof_ms[klass];
+    if (launches) *launches = c->prof_cnt[klass];
+    if (bytes) *bytes = c->prof_bytes[klass];
+    return 0;
+}
+int esq_profile_read_moved(esq_ctx *c, int klass, double *moved_bytes) {
+    if (!c || !moved_bytes || klass < 0 || klass >= ESQ_PROF_NCLASS) return ESQ_EINVAL;
+    prof_drain(c);
+    *moved_bytes = c->prof_moved[klass];
+    return 0;
+}
+int esq_profile_kernels(esq_ctx *c, char *buf, size_t buflen) {
+    if (!c || !buf || buflen < 2) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    prof_drain(c);
+    size_t used = 0;
+    buf[0] = 0;
+    for (const auto &kv : c->prof_kernels) {
+        const ProfKernel &k = kv.second;
+        const int w = snprintf(buf + used, buflen - used, "%s\t%d\t%ld\t%.9g\t%.17g\t%.17g\n",
+                               kv.first.c_str(), k.klass, k.launches, k.ms, k.bytes,
+                               k.moved);
+        if (w < 0 || (size_t)w >= buflen - used)
+            return fail(c, ESQ_EINVAL, "profile table needs a larger buffer");
+        used += (size_t)w;
+    }
+    return 0;
+}
+int esq_profile_reset(esq_ctx *c) {
+    if (!c) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    prof_drain(c);
+    for (int k = 0; k < ESQ_PROF_NCLASS; ++k) {
+        c->prof_ms[k] = 0; c->prof_cnt[k] = 0; c->prof_bytes[k] = 0;
+        c->prof_moved[k] = 0;
+        c->prof_seen[k] = 0;
+    }
+    c->prof_kernels.clear();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+// esq_internal.hpp -- what the translation units of libextensisq_amd.so share:
+// the context (one device, one HIP stream, ONE HBM slab holding every vector of
+// the step, all 4-KiB aligned and padded to a multiple of 512 doubles so that
+// kernels run without tail code), error / profiling helpers and the launchers
+// that live in another unit.
+//
+//   esq_core.hip     lifecycle, data movement, reductions -> pinned slot, profiling
+//   esq_step.hip     tableau + blocked-accumulation plan, the explicit RK step
+//   esq_lincomb.hip  k_lincomb<NT, policy> launchers        (126 instantiations)
+//   esq_reduce.hip   solution/error, error-norm, pre-error and block kernels
+//   esq_aux.hip      dense output, RKC, vector plumbing, starting step
+//   esq_comm.hip     RCCL (loaded lazily), lock-step scalars
+//   esq_rhs*.hip     built-in device RHS plugins
+#pragma once
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/extensisq_amd.h"
+#include "esq_kernels.hpp"
+
+namespace esqi {
+
+using namespace esq;
+
+constexpr size_t kPadDoubles = 512;   // 4 KiB
+constexpr int kFixedSlots = 5;        // Y, YNEW, YSTAGE, ATOL, WORK
+constexpr int kPartialsCap = 1 << 17; // one partial per workgroup of a sweep
+constexpr int kSlotScalars = 4;       // esq_allreduce_scalars carries <= 4 doubles
+
+struct ProfEvent {
+    hipEvent_t start, stop;
+    int klass;
+    double bytes;      // algorithmic bytes (SURVEY.md §8d definition)
+    double moved;      // bytes the launch is designed to move
+    char name[40];     // kernel label for the per-kernel table (esq_profile_kernels)
+};
+struct ProfKernel {    // per-label totals since the last reset
+    int klass = 0;
+    long launches = 0;
+    double ms = 0.0, bytes = 0.0, moved = 0.0;
+};
+// pinned host slot a reduction's result lands in: the value(s), then the
+// sequence number of the reduction (system-scope release), polled by the host
+struct HostSlot {
+    double value;
+    unsigned long long seq;
+    double vals[kSlotScalars];     // lock-step scalars (esq_allreduce_scalars)
+};
+
+// one non-zero entry of a coefficient row
+struct Term {
+    int col;
+    double c;
+};
+
+}  // namespace esqi
+
+struct esq_ctx {
+    int device = 0;
+    size_t n = 0;          // state dimension as the user counts it
+    size_t len = 0;        // doubles per vector (n or 2n)
+    size_t len_pad = 0;    // padded doubles per vector
+    size_t stride = 0;     // doubles between consecutive vectors in the slab
+    int n_rows = 0;
+    bool cplx = false;
+    hipStream_t stream = nullptr;
+    double *slab = nullptr;
+    // small host-RHS problems: the slab is pinned, device-mapped HOST memory --
+    // kernels read and write it over PCIe, uploads and downloads are plain
+    // memcpy calls (no copy engine, no stream synchronisation)
+    bool host_slab = false;
+    double *slab_host = nullptr;      // host address of slab[0]
+    size_t slab_doubles = 0;
+    bool idle = true;                 // nothing enqueued since the last wait
+    bool self_valid = false;          // the last kernel enqueued publishes self_seq
+    unsigned long long self_seq = 0;
+    std::vector<double *> aux_slabs;  // lazily added work rows (esq_aux_rows)
+    std::vector<double *> krow;       // physical K rows
+    std::vector<int> kmap;            // logical -> physical (step in flight)
+    std::vector<int> kmap_last;       // mapping of the step just accepted
+    double *y = nullptr, *ynew = nullptr, *ystage = nullptr, *atolv = nullptr,
+           *work = nullptr;
+    double *partials = nullptr;       // kPartialsCap doubles (own kernels use
+                                      // <= kMaxPartials, fused sweeps their grid)
+    double *partials2 = nullptr;      // second set (min reductions)
+    double *d_result = nullptr;       // 8 doubles (device)
+    esqi::HostSlot *h_slot = nullptr; // pinned, device-visible host memory
+    unsigned long long red_seq = 0;   // reductions issued so far
+    double comm_timeout_s = 120.0;    // bounded wait of a lock-step all-reduce
+    // method
+    int s = 0, fsal = 0;
+    std::vector<double> A, B, C, E;
+    bool have_tab = false;
+    double rtol = 1e-3, atol_s = 1e-6;
+    bool atol_is_vec = false;
+    esq_rhs_fn rhs = nullptr;
+    void *rhs_user = nullptr;
+    esq_rhs_fused_fn rhs_fused = nullptr;   // optional RHS + epilogue entry
+    int fuse_mask = 0;                      // epilogue kinds the library may request
+    bool src_declined = false;              // the PLUGIN returned ENOTSUP for ESQ_FUSE_SRC
+    bool src_pays = false;                  // working set inside the Infinity Cache
+    esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
+    bool ynew_ready = false;     // YNEW already formed by the last stage's sweep
+    bool solerr_ready = false;   // ... and the error partial sums too
+    int red_count = 0;           // partials written by the last reducing sweep
+    // first stage argument of the NEXT step, formed at accept time
+    bool pre_valid = false;
+    double pre_h = 0.0;
+    // which sweeps stream the fresh derivative out with non-temporal stores
+    // (ESQ_EPI_NT bits: 0 stage, 1 block, 2 solerr, 3 end-point, 4 FSAL errnorm)
+    unsigned epi_nt = 0x3;
+    // blocked accumulation plan (esq_rk_set_tableau)
+    struct Block {
+        int J = 0, prev = 0;              // columns [prev, J) of A
+        std::vector<int> cols;            // non-zero columns of the block
+        std::vector<int> stages;          // later stages that use them
+        std::vector<int> out_vec;         // physical row of each stage's partial
+        std::vector<int> in_vec;          // previous-level partial (-1: none)
+    };
+    std::vector<Block> blocks;
+    int block_rows_first = -1, block_rows_count = 0;   // aux rows of the plan
+    std::vector<int> stage_init;          // per stage: row of its partial or -1
+    std::vector<int> stage_from;          // per stage: first column still to add
+    // per stage: the non-zero entries of its row of A at columns >= stage_from
+    // (what a stage kernel still has to add), and the row's total non-zero count
+    std::vector<std::vector<esqi::Term>> stage_terms;
+    std::vector<int> stage_nnz;
+    // K rows nothing reads after their own sweep (dead stores, esq_rk_set_tableau)
+    std::vector<char> row_dead;
+    bool skip_dead = true;                // ESQ_DEAD_STORE=0 stores every row
+    std::vector<char> row_stale;          // logical rows of the step in flight /
+    std::vector<char> row_stale_last;     // ... just accepted that were not stored
+    // launch geometry
+    unsigned grid_stream = 0;         // grid for streaming kernels
+    unsigned grid_reduce = 0;
+    unsigned grid_block = 0;          // grid of the (write-heavy) block kernel
+    int stage_policy = 0;             // cache policy of k_lincomb (tuning knob)
+    // lock-step
+    void *comm = nullptr;
+    bool comm_aborted = false;        // the library called ncclCommAbort itself
+    // profiling
+    unsigned prof_mask = 0;           // bit k: time launches of class k
+    unsigned prof_every = 1;          // time every prof_every-th launch of a class
+    unsigned long prof_seen[ESQ_PROF_NCLASS] = {0};
+    std::vector<esqi::ProfEvent> prof_live;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[ESQ_PROF_NCLASS] = {0};
+    long prof_cnt[ESQ_PROF_NCLASS] = {0};
+    double prof_bytes[ESQ_PROF_NCLASS] = {0};
+    double prof_moved[ESQ_PROF_NCLASS] = {0};
+    std::map<std::string, esqi::ProfKernel> prof_kernels;
+    char err[512] = {0};
+};
+
+namespace esqi {
+
+int fail(esq_ctx *c, int code, const char *fmt, ...);
+#define HIPCHK(c, call)                                                         \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess)                                                   \
+            return esqi::fail((c), (int)e_, "%s failed: %s (%s:%d)", #call,     \
+                              hipGetErrorString(e_), __FILE__, __LINE__);       \
+    } while (0)
+
+double *slot_ptr(esq_ctx *c, int slot, int row, bool logical = true);
+
+// One process per GPU is the intended use, but a process MAY hold contexts on
+// several devices and drive a context from any thread: hipSetDevice is
+// per-thread state and costs well under a microsecond, so every entry point
+// selects the context's device unconditionally.
+// The first stage argument formed ahead of time by esq_rk_accept lives in
+// YSTAGE until the next esq_rk_stages: any entry point that may write a vector
+// drops it (ENTER); the read-only ones keep it (ENTER_KEEP).
+#define ENTER_KEEP(c) (void)hipSetDevice((c)->device)
+#define ENTER(c)                             \
+    do {                                     \
+        (void)hipSetDevice((c)->device);     \
+        (c)->pre_valid = false;              \
+        (c)->idle = false;                   \
+        (c)->self_valid = false;             \
+    } while (0)
+
+// ---- profiling -------------------------------------------------------------
+// Own kernels are launched with hipExtLaunchKernelGGL(start, stop): the events
+// take the begin/end timestamps of THAT dispatch packet, no extra barrier
+// packets enter the queue (a hipEventRecord pair around each launch cost ~10 %
+// of a Pr8 step).  Opaque RHS plugins are bracketed with hipEventRecord.
+struct Prof {
+    esq_ctx *c;
+    bool on, recorded;
+    ProfEvent ev;
+    Prof(esq_ctx *ctx, int klass, const char *name, int nt, double bytes,
+         bool record_now = false, double moved = -1.0);
+    void cancel();             // the launch did not happen: return the events
+    hipEvent_t start() const { return on && !recorded ? ev.start : nullptr; }
+    hipEvent_t stop() const { return on && !recorded ? ev.stop : nullptr; }
+    ~Prof();
+};
+void prof_drain(esq_ctx *c);
+
+// ---- esq_core.hip ------------------------------------------------------------
+unsigned env_uint(const char *name, unsigned dflt);
+int wait_slot(esq_ctx *c, unsigned long long seq, double timeout_s);
+// partials -> one double on the host (all-reduced over the communicator if set)
+int finish_reduction(esq_ctx *c, double *out, bool take_min = false,
+                     const double *partials = nullptr, int count = -1);
+int host_wait(esq_ctx *c, bool already_idle);
+int d2h(esq_ctx *c, void *host, const void *dev, size_t bytes, bool was_idle = false);
+int h2d(esq_ctx *c, void *dev, const void *host, size_t bytes, bool was_idle);
+int call_rhs(esq_ctx *c, double t, const double *src, double *dst);
+int build_row_terms(esq_ctx *c, const double *coef, int count, Terms &tm,
+                    const std::vector<int> &map);
+int build_row_terms2(esq_ctx *c, const double *b, int nb, const double *e, int ne,
+                     Terms2 &tm, const std::vector<int> &map);
+// sink of the next reduction / completion signal (bumps red_seq)
+ResultSink next_sink(esq_ctx *c, bool to_host_value);
+// lock-step: scalars in h_slot->vals -> device, and back behind a sequence number
+void launch_load_scalars(esq_ctx *c, double *dev, int count);
+void launch_publish_scalars(esq_ctx *c, const double *dev, int count,
+                            unsigned long long seq);
+
+// ---- esq_lincomb.hip ---------------------------------------------------------
+int launch_lincomb(esq_ctx *c, double *out, const double *base, const Terms &tm,
+                   int nt, double h, const Prof *p = nullptr,
+                   const double *init = nullptr);
+
+// ---- esq_reduce.hip ----------------------------------------------------------
+int launch_solerr(esq_ctx *c, const Terms2 &tm, int nt, double h, const Prof &p);
+int launch_errnorm(esq_ctx *c, const Terms &tm, int nt, double h, const Prof &p);
+int launch_preerr(esq_ctx *c, const Terms2 &tm, int nt, double h, const Prof &p);
+int launch_block(esq_ctx *c, const BlockArgs &a, int nt, int no, const Prof &p);
+
+// ---- esq_comm.hip ------------------------------------------------------------
+// RCCL, loaded lazily so that single-GPU use never pays for it
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    void *CommInitRank = nullptr;   // int (*)(ncclComm_t*, int, ncclUniqueId, int)
+    int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+extern Rccl g_rccl;
+int rccl_load();
+constexpr int kNcclFloat64 = 8;   // ncclDouble
+constexpr int kNcclSum = 0;       // ncclSum
+constexpr int kNcclMax = 2;       // ncclMax
+constexpr int kNcclMin = 3;       // ncclMin
+// a lock-step collective timed out: abort the communicator (this rank, and
+// through RCCL the others, then fail instead of hanging) and remember that the
+// handle is gone, so that the host does not abort / destroy it a second time
+void abort_comm(esq_ctx *c);
+
+}  // namespace esqi

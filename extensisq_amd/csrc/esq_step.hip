@@ -1,0 +1,753 @@
+// esq_step.hip -- the explicit Runge-Kutta step on the device: tableau and
+// blocked-accumulation plan, stage sweeps (RHS plugin + epilogue), solution and
+// error norm, accept (extensisq/common.py:222-356).  Host orchestration only;
+// the kernels are in esq_kernels.hpp / esq_epilogue.hpp / the RHS plugins.
+#include "esq_internal.hpp"
+
+using namespace esqi;
+
+namespace {
+
+// ---- blocked accumulation plan ------------------------------------------------
+// words per element and step moved by the stage kernels (+ block kernels) for a
+// set of column boundaries; returns -1 if a block needs too many outputs/rows
+int plan_words(const std::vector<double> &A, int s, const std::vector<int> &bounds,
+               std::vector<esq_ctx::Block> *out) {
+    auto nz = [&](int i, int j) { return A[(size_t)i * s + j] != 0.0; };
+    std::vector<char> has(s, 0);
+    int total = 0, prev = 0;
+    if (out) out->clear();
+    for (int J : bounds) {
+        esq_ctx::Block b;
+        b.J = J;
+        b.prev = prev;
+        std::vector<char> col(s, 0);
+        for (int i = J; i < s; ++i) {
+            bool any = false;
+            for (int j = prev; j < J; ++j)
+                if (nz(i, j)) { any = true; col[j] = 1; }
+            if (any) b.stages.push_back(i);
+        }
+        for (int j = prev; j < J; ++j)
+            if (col[j]) b.cols.push_back(j);
+        if ((int)b.stages.size() > kMaxOut || (int)b.cols.size() > kMaxTerms) return -1;
+        if (b.stages.empty()) return -1;
+        total += (int)b.cols.size();
+        for (int i : b.stages) {
+            total += 1 + (has[i] ? 1 : 0);
+            has[i] = 1;
+        }
+        if (out) out->push_back(b);
+        prev = J;
+    }
+    for (int i = 1; i < s; ++i) {
+        int last = 0;
+        for (int J : bounds)
+            if (J <= i) last = J;
+        int c = 2;
+        for (int j = last; j < i; ++j) c += nz(i, j);
+        if (last > 0 && has[i]) c += 1;
+        total += c;
+    }
+    return total;
+}
+
+// leading parts of the sums of all later stages, one pass over the block's rows
+// returns 0 on success; *made_ystage = true if the block also wrote the
+// boundary stage's argument into YSTAGE
+static int run_block(esq_ctx *c, const esq_ctx::Block &b, double h,
+                     bool *made_ystage) {
+    BlockArgs a;
+    const int nt = (int)b.cols.size(), no = (int)b.stages.size();
+    for (int j = 0; j < kMaxTerms; ++j) {
+        a.p[j] = j < nt ? c->krow[c->kmap[b.cols[j]]] : nullptr;
+        for (int o = 0; o < kMaxOut; ++o)
+            a.w[j][o] = (j < nt && o < no)
+                            ? c->A[(size_t)b.stages[o] * c->s + b.cols[j]] : 0.0;
+    }
+    double reads = nt;
+    for (int o = 0; o < kMaxOut; ++o) {
+        a.out[o] = o < no ? c->krow[b.out_vec[o]] : nullptr;
+        a.init[o] = (o < no && b.in_vec[o] >= 0) ? c->krow[b.in_vec[o]] : nullptr;
+        if (a.init[o]) reads += 1;
+    }
+    // the boundary stage J itself (always output 0 when it uses the block) has
+    // no later column to add: write its argument y + h*sum straight to YSTAGE
+    a.y = nullptr;
+    a.h = h;
+    double alg = 0.0;
+    *made_ystage = false;
+    static const bool fold = env_uint("ESQ_BLOCK_FOLD", 1) != 0;
+    if (fold && no > 0 && b.stages[0] == b.J && c->stage_init[b.J] == b.out_vec[0] &&
+        c->stage_from[b.J] == b.J) {
+        a.y = c->y;
+        a.out[0] = c->ystage;
+        reads += 1;
+        int nnz_all = 0;
+        for (int j = 0; j < b.J; ++j) nnz_all += c->A[(size_t)b.J * c->s + j] != 0.0;
+        alg = 8.0 * (nnz_all + 2) * (double)c->len;   // that stage's booking
+        *made_ystage = true;
+    }
+    // algorithmic bytes: only the folded-in stage (the other partial sums are
+    // booked on the stages they serve); moved bytes: its real traffic
+    Prof p(c, ESQ_PROF_STAGE, "k_block_acc", nt, alg, false,
+           8.0 * (reads + no) * (double)c->len);
+    c->self_valid = false;
+    return launch_block(c, a, nt, no, p);
+}
+
+// coefficient row of stage i as the stage kernels use it: columns below the
+// stage's blocked-accumulation boundary are in its stored partial sum, column
+// `skip` (if >= 0) comes from registers.  Returns the number of rows to read.
+int stage_terms(esq_ctx *c, int i, int skip, Terms &tm, const double **init,
+                int *nnz_all, double *c_skip) {
+    *init = c->stage_init[i] >= 0 ? c->krow[c->stage_init[i]] : nullptr;
+    int nt = 0;
+    if (c_skip) *c_skip = 0.0;
+    // the per-stage term lists were built once in esq_rk_set_tableau
+    for (const Term &term : c->stage_terms[i]) {
+        if (term.col == skip) { if (c_skip) *c_skip = term.c; continue; }
+        if (nt >= kMaxTerms) return -1;
+        tm.p[nt] = c->krow[c->kmap[term.col]];
+        tm.c[nt] = term.c;
+        ++nt;
+    }
+    for (int j = nt; j < kMaxTerms; ++j) { tm.p[j] = nullptr; tm.c[j] = 0.0; }
+    *nnz_all = c->stage_nnz[i];
+    return nt;
+}
+
+void epi_common(esq_ctx *c, esq_epilogue &e, int kind) {
+    memset(&e, 0, sizeof(e));
+    e.kind = kind;
+    e.atol_vec = c->atol_is_vec ? c->atolv : nullptr;
+    e.atol_s = c->atol_s;
+    e.rtol = c->rtol;
+    e.n_valid = c->n;
+    e.partials = c->partials;
+    e.partials_cap = kPartialsCap;
+    e.partials_used = &c->red_count;
+}
+
+// one fused sweep; returns 0, ESQ_ENOTSUP (caller falls back) or an error
+int run_fused(esq_ctx *c, double t, const double *y_in, double *f_out,
+              const esq_epilogue &e, Prof &p) {
+    c->self_valid = false;     // a plugin kernel does not signal its own completion
+    const int r = c->rhs_fused(c->rhs_user, t, y_in, f_out, &e, c->len,
+                               (void *)c->stream, (void *)p.start(),
+                               (void *)p.stop());
+    if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
+    if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "fused RHS entry returned %d", r); }
+    return 0;
+}
+// the library itself found a fused form not applicable (distinct from a plugin's
+// ESQ_ENOTSUP: the plugin was never asked)
+constexpr int kNotApplicable = -1000;
+bool may_fuse(const esq_ctx *c, int kind) {
+    return c->rhs_fused && ((c->fuse_mask >> kind) & 1);
+}
+
+// RHS sweep of stage i + the accumulate of stage nx = i + 1 (ESQ_EPI_STAGE).
+// from_state (stage 1 only): the sweep forms its own input y + h*a_10*K[0] on
+// the fly instead of reading YSTAGE (ESQ_FUSE_SRC)
+int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = false) {
+    const int nx = i + 1;
+    esq_epilogue e;
+    epi_common(c, e, ESQ_EPI_STAGE);
+    Terms tm;
+    int nnz_all = 0;
+    const int nt = stage_terms(c, nx, i, tm, &e.init, &nnz_all, &e.c_self);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    e.nt = nt;
+    for (int j = 0; j < nt; ++j) { e.rows[j] = tm.p[j]; e.c[j] = tm.c[j]; }
+    e.y = c->y;
+    e.h = h;
+    e.out = c->work;
+    e.f_store_nt = c->epi_nt & 1;   // K_i is consumed from registers, not re-read soon
+    if (from_state) {
+        if (nt > 1 || e.init) return kNotApplicable;   // the library's reason, not the plugin's
+        e.in_base = c->y;
+        e.in_row = c->krow[c->kmap[0]];
+        e.in_c = c->A[(size_t)c->s];                 // A[1][0]
+        e.in_h = h;
+        // booked: stage 1's accumulate (1 + 2 words) + the RHS + stage 2's
+        // accumulate; moved: y and K[0] in (stage 2's row K[0] is the same
+        // vector), K[1] and the argument of stage 2 out
+        Prof p(c, ESQ_PROF_STAGE, "rhs1+stage", nt,
+               8.0 * (3 + nnz_all + 4) * (double)c->len, false, 8.0 * 4 * (double)c->len);
+        const int r = run_fused(c, t + c->C[i] * h, nullptr, c->krow[c->kmap[i]], e, p);
+        if (r == 0) std::swap(c->ystage, c->work);
+        return r;
+    }
+    // booked on the stage class: next stage's algorithmic bytes + the RHS's
+    // 16 B; moved: ys_in, rows, init, y in; K[i], ys_out out
+    Prof p(c, ESQ_PROF_STAGE, "rhs+stage", nt, 8.0 * (nnz_all + 4) * (double)c->len,
+           false, 8.0 * (nt + 4 + (e.init ? 1 : 0)) * (double)c->len);
+    const int r = run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
+    if (r == 0) std::swap(c->ystage, c->work);   // double buffer
+    return r;
+}
+bool may_use_src(const esq_ctx *c) {
+    return c->src_pays && may_fuse(c, ESQ_EPI_STAGE) && (c->fuse_mask & ESQ_FUSE_SRC) &&
+           !c->src_declined;
+}
+
+// RHS sweep of stage i = J - 1 + the blocked accumulation at boundary J with
+// K_i as the block's last column (ESQ_EPI_BLOCK)
+int sweep_block(esq_ctx *c, const esq_ctx::Block &b, int i, double t, double h,
+                bool *made_ystage) {
+    esq_epilogue e;
+    epi_common(c, e, ESQ_EPI_BLOCK);
+    const int no = (int)b.stages.size();
+    int nt = 0;
+    for (int col : b.cols) {
+        if (col == i) continue;
+        if (nt >= ESQ_EPI_MAX_ROWS) return ESQ_ENOTSUP;
+        e.rows[nt] = c->krow[c->kmap[col]];
+        for (int o = 0; o < no; ++o)
+            e.w[nt][o] = c->A[(size_t)b.stages[o] * c->s + col];
+        ++nt;
+    }
+    e.nt = nt;
+    e.no = no;
+    double reads = nt + 1;                       // rows + the sweep's input
+    for (int o = 0; o < no; ++o) {
+        e.w_self[o] = c->A[(size_t)b.stages[o] * c->s + i];
+        e.out_o[o] = c->krow[b.out_vec[o]];
+        e.init_o[o] = b.in_vec[o] >= 0 ? c->krow[b.in_vec[o]] : nullptr;
+        if (e.init_o[o]) reads += 1;
+    }
+    e.h = h;
+    double alg = 16.0 * (double)c->len;          // the RHS itself
+    *made_ystage = false;
+    if (no > 0 && b.stages[0] == b.J && c->stage_init[b.J] == b.out_vec[0] &&
+        c->stage_from[b.J] == b.J) {
+        e.y = c->y;
+        e.out_o[0] = c->work;
+        reads += 1;
+        int nnz_all = 0;
+        for (int j = 0; j < b.J; ++j) nnz_all += c->A[(size_t)b.J * c->s + j] != 0.0;
+        alg += 8.0 * (nnz_all + 2) * (double)c->len;   // the boundary stage's booking
+        *made_ystage = true;
+    }
+    e.f_store_nt = (c->epi_nt >> 1) & 1;
+    Prof p(c, ESQ_PROF_STAGE, "rhs+block", nt, alg, false,
+           8.0 * (reads + no + 1) * (double)c->len);
+    const int r = run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
+    if (r == 0 && *made_ystage) std::swap(c->ystage, c->work);
+    if (r != 0) *made_ystage = false;
+    return r;
+}
+
+// FSAL pairs: RHS sweep of the last stage also forms y_new (ESQ_EPI_STAGE)
+int sweep_ynew(esq_ctx *c, int i, double t, double h) {
+    esq_epilogue e;
+    epi_common(c, e, ESQ_EPI_STAGE);
+    int nt = 0, nnz_all = 0;
+    for (int j = 0; j < c->s; ++j) {
+        if (c->B[j] == 0.0) continue;
+        ++nnz_all;
+        if (j == i) { e.c_self = c->B[j]; continue; }
+        if (nt >= ESQ_EPI_MAX_ROWS) return ESQ_ENOTSUP;
+        e.rows[nt] = c->krow[c->kmap[j]];
+        e.c[nt] = c->B[j];
+        ++nt;
+    }
+    e.nt = nt;
+    e.y = c->y;
+    e.h = h;
+    e.out = c->ynew;
+    e.f_store_nt = c->epi_nt & 1;
+    Prof p(c, ESQ_PROF_STAGE, "rhs+stage", nt, 8.0 * (nnz_all + 4) * (double)c->len,
+           false, 8.0 * (nt + 4) * (double)c->len);
+    return run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
+}
+
+// non-FSAL pairs: RHS sweep of the last stage + y_new + error partial sums
+int sweep_solerr(esq_ctx *c, int i, double t, double h) {
+    esq_epilogue e;
+    epi_common(c, e, ESQ_EPI_SOLERR);
+    int nt = 0;
+    for (int j = 0; j < c->s; ++j) {
+        const double bj = c->B[j], ej = c->E[j];
+        if (j == i) { e.c_self = bj; e.e_self = ej; continue; }
+        if (bj == 0.0 && ej == 0.0) continue;
+        if (nt >= ESQ_EPI_MAX_ROWS) return ESQ_ENOTSUP;
+        e.rows[nt] = c->krow[c->kmap[j]];
+        e.c[nt] = bj;
+        e.e[nt] = ej;
+        ++nt;
+    }
+    e.nt = nt;
+    e.y = c->y;
+    e.h = h;
+    e.out = c->ynew;
+    e.f_store_nt = (c->epi_nt >> 2) & 1;   // K_{s-1}: next read by the dense output
+    // booked: the RHS's 16 B + the fused solution/error pass (rows incl. the
+    // fresh one + y + y_new); moved: ys_in, rows, y in; K_i, y_new out
+    Prof p(c, ESQ_PROF_SOLERR, "rhs+solerr", nt, 8.0 * (nt + 1 + 2 + 2) * (double)c->len,
+           false, 8.0 * (nt + 4) * (double)c->len);
+    return run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
+                       const double *C, const double *E, int fsal) {
+    if (!c || !A || !B || !C || !E || s < 1) return ESQ_EINVAL;
+    ENTER(c);
+    if (s + 1 > c->n_rows)
+        return fail(c, ESQ_EINVAL, "tableau needs %d rows, context has %d", s + 1,
+                    c->n_rows);
+    for (int i = 0; i < s; ++i) {
+        int nz = 0;
+        for (int j = 0; j < s; ++j) {
+            if (j >= i && A[i * s + j] != 0.0)
+                return fail(c, ESQ_EINVAL, "A must be strictly lower triangular");
+            nz += A[i * s + j] != 0.0;
+        }
+        if (nz > kMaxTerms)
+            return fail(c, ESQ_EINVAL, "row %d of A has %d > %d nonzeros", i, nz, kMaxTerms);
+    }
+    {
+        // the solution / error kernels read the union of the supports of B and E
+        int nz = 0;
+        for (int j = 0; j < s; ++j) nz += (B[j] != 0.0 || E[j] != 0.0);
+        if (nz + (E[s] != 0.0) > kMaxTerms)
+            return fail(c, ESQ_EINVAL, "B and E together have %d > %d nonzero weights",
+                        nz + (E[s] != 0.0), kMaxTerms);
+    }
+    c->s = s;
+    c->fsal = fsal ? 1 : 0;
+    c->A.assign(A, A + (size_t)s * s);
+    c->B.assign(B, B + s);
+    c->C.assign(C, C + s);
+    c->E.assign(E, E + s + 1);
+    c->have_tab = true;
+    // ---- blocked accumulation plan (up to 3 column boundaries, exhaustive)
+    c->blocks.clear();
+    c->stage_init.assign(s, -1);
+    c->stage_from.assign(s, 0);
+    if (env_uint("ESQ_BLOCK_ACC", 1) != 0 && s >= 4) {
+        std::vector<int> best;
+        int best_words = plan_words(c->A, s, best, nullptr);
+        // fewest boundaries first: a plan with more boundaries must be strictly
+        // better (every boundary is one more launch)
+        for (int b1 = 2; b1 < s; ++b1) {
+            const int w = plan_words(c->A, s, {b1}, nullptr);
+            if (w >= 0 && w < best_words) { best_words = w; best = {b1}; }
+        }
+        for (int b1 = 2; b1 < s; ++b1)
+            for (int b2 = b1 + 1; b2 < s; ++b2) {
+                const int w = plan_words(c->A, s, {b1, b2}, nullptr);
+                if (w >= 0 && w < best_words) { best_words = w; best = {b1, b2}; }
+            }
+        for (int b1 = 2; b1 < s; ++b1)
+            for (int b2 = b1 + 1; b2 < s; ++b2)
+                for (int b3 = b2 + 1; b3 < s; ++b3) {
+                    const int w = plan_words(c->A, s, {b1, b2, b3}, nullptr);
+                    if (w >= 0 && w < best_words) { best_words = w; best = {b1, b2, b3}; }
+                }
+        // ESQ_BLOCK_BOUNDS="6,10": override the boundaries (tuning experiments)
+        if (const char *ov = getenv("ESQ_BLOCK_BOUNDS")) {
+            std::vector<int> forced;
+            for (const char *q = ov; *q;) {
+                char *end = nullptr;
+                const long v = strtol(q, &end, 10);
+                if (end == q) break;
+                if (v >= 2 && v < s) forced.push_back((int)v);
+                q = *end ? end + 1 : end;
+            }
+            if (plan_words(c->A, s, forced, nullptr) >= 0) best = forced;
+        }
+        if (!best.empty()) {
+            std::vector<esq_ctx::Block> blocks;
+            plan_words(c->A, s, best, &blocks);
+            int count = 0;
+            for (auto &bl : blocks) count += (int)bl.stages.size();
+            // partial-sum rows: those of an earlier plan on this context are
+            // reused (a second esq_rk_set_tableau must not leak a slab)
+            int first = c->block_rows_first;
+            if (count > c->block_rows_count) {
+                int r = esq_aux_rows(c, count, &first);
+                if (r) return r;
+                c->block_rows_first = first;
+                c->block_rows_count = count;
+            }
+            std::vector<int> cur(s, -1);
+            for (auto &bl : blocks) {
+                for (int i : bl.stages) {
+                    bl.in_vec.push_back(cur[i]);
+                    bl.out_vec.push_back(first);
+                    cur[i] = first++;
+                }
+            }
+            c->blocks = blocks;
+            for (int i = 1; i < s; ++i) {
+                int last = 0;
+                for (int J : best)
+                    if (J <= i) last = J;
+                c->stage_from[i] = cur[i] >= 0 ? last : 0;
+                c->stage_init[i] = cur[i] >= 0 && last > 0 ? cur[i] : -1;
+                if (c->stage_init[i] < 0) c->stage_from[i] = 0;
+            }
+        }
+    }
+    // what each stage kernel still has to add: the non-zero columns at or beyond
+    // its blocked-accumulation boundary (built once; the step allocates nothing)
+    c->stage_terms.assign(s, {});
+    c->stage_nnz.assign(s, 0);
+    for (int i = 1; i < s; ++i)
+        for (int j = 0; j < i; ++j) {
+            const double a = c->A[(size_t)i * s + j];
+            if (a == 0.0) continue;
+            ++c->stage_nnz[i];
+            if (j >= c->stage_from[i]) c->stage_terms[i].push_back(Term{j, a});
+        }
+    return 0;
+}
+
+int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    if (i < 1 || i >= c->s) return fail(c, ESQ_EINVAL, "stage %d out of range", i);
+    for (const auto &b : c->blocks)
+        if (b.J == i) {
+            bool made = false;
+            const int r = run_block(c, b, h, &made);
+            if (r) return r;
+            if (made) return 0;        // YSTAGE already holds this stage's argument
+        }
+    // columns [stage_from, i): the chain resumes from the stored partial sum
+    const double *init = nullptr;
+    Terms tm;
+    int nnz_all = 0;
+    const int nt = stage_terms(c, i, -1, tm, &init, &nnz_all, nullptr);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    Prof p(c, ESQ_PROF_STAGE, "k_lincomb", nt, 8.0 * (nnz_all + 2) * (double)c->len,
+           false, 8.0 * (nt + 2 + (init ? 1 : 0)) * (double)c->len);
+    return launch_lincomb(c, c->ystage, c->y, tm, nt, h, &p, init);
+}
+
+int esq_rk_block_plan(esq_ctx *c, int *boundaries, int max_boundaries,
+                      int *words_plain, int *words_blocked) {
+    if (!c || !c->have_tab) return ESQ_EINVAL;
+    std::vector<int> b;
+    for (const auto &bl : c->blocks) b.push_back(bl.J);
+    if (words_plain) *words_plain = plan_words(c->A, c->s, {}, nullptr);
+    if (words_blocked) *words_blocked = plan_words(c->A, c->s, b, nullptr);
+    for (int k = 0; k < (int)b.size() && k < max_boundaries; ++k)
+        if (boundaries) boundaries[k] = b[k];
+    return (int)b.size();
+}
+
+int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    double *dst = slot_ptr(c, ESQ_SLOT_K, dst_row);
+    double *src = slot_ptr(c, src_slot, src_row);
+    if (!dst || !src) return fail(c, ESQ_EINVAL, "bad row/slot");
+    return call_rhs(c, t, src, dst);
+}
+
+int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
+    if (!c) return ESQ_EINVAL;
+    // YSTAGE may already hold the first stage's argument (esq_rk_accept)
+    bool ready = i_from == 1 && c->pre_valid && c->pre_h == h;
+    ENTER(c);
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    if (i_from < 1 || i_to > c->s || i_from > i_to)
+        return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
+    c->ynew_ready = false;
+    c->solerr_ready = false;
+    bool block_done = false;   // the block at boundary i already ran in a sweep
+    for (int i = i_from; i < i_to; ++i) {
+        if (i == 1 && !ready && i + 1 < i_to && may_use_src(c)) {
+            // the first sweep forms its own input from y and K[0]: no stage-1
+            // kernel, no stage argument in memory
+            bool boundary = false;
+            for (const auto &b : c->blocks) boundary |= (b.J == 2);
+            if (!boundary) {
+                const int r = sweep_next_stage(c, 1, t, h, /*from_state=*/true);
+                if (r == 0) { ready = true; continue; }
+                if (r == ESQ_ENOTSUP) c->src_declined = true;   // the plugin declined
+                else if (r != kNotApplicable) return r;
+            }
+        }
+        if (!ready) {
+            if (block_done) {
+                // partial sums are in place; only the stage kernel is left
+                const double *init = nullptr;
+                Terms tm;
+                int nnz_all = 0;
+                const int nt = stage_terms(c, i, -1, tm, &init, &nnz_all, nullptr);
+                if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+                Prof p(c, ESQ_PROF_STAGE, "k_lincomb", nt,
+                       8.0 * (nnz_all + 2) * (double)c->len, false,
+                       8.0 * (nt + 2 + (init ? 1 : 0)) * (double)c->len);
+                const int r = launch_lincomb(c, c->ystage, c->y, tm, nt, h, &p, init);
+                if (r) return r;
+            } else {
+                const int r = esq_rk_stage_accumulate(c, i, h);
+                if (r) return r;
+            }
+        }
+        ready = false;
+        block_done = false;
+        const esq_ctx::Block *bnext = nullptr;
+        for (const auto &b : c->blocks)
+            if (b.J == i + 1) bnext = &b;
+        if (i + 1 < i_to && !bnext && may_fuse(c, ESQ_EPI_STAGE)) {
+            // this stage's RHS sweep also forms the NEXT stage's argument
+            const int r = sweep_next_stage(c, i, t, h);
+            if (r == 0) { ready = true; continue; }
+            if (r != ESQ_ENOTSUP) return r;
+        }
+        if (i + 1 < i_to && bnext && may_fuse(c, ESQ_EPI_BLOCK)) {
+            // ... or runs the blocked accumulation at the column boundary
+            bool made = false;
+            const int r = sweep_block(c, *bnext, i, t, h, &made);
+            if (r == 0) { ready = made; block_done = !made; continue; }
+            if (r != ESQ_ENOTSUP) return r;
+        }
+        if (i == c->s - 1 && i_to == c->s) {
+            if (c->fsal && may_fuse(c, ESQ_EPI_STAGE)) {
+                // FSAL pairs: the LAST stage's sweep also forms y_new
+                const int r = sweep_ynew(c, i, t, h);
+                if (r == 0) { c->ynew_ready = true; continue; }
+                if (r != ESQ_ENOTSUP) return r;
+            }
+            if (!c->fsal && !c->cplx && may_fuse(c, ESQ_EPI_SOLERR)) {
+                // others: ... y_new and the error partial sums
+                const int r = sweep_solerr(c, i, t, h);
+                if (r == 0) { c->ynew_ready = c->solerr_ready = true; continue; }
+                if (r != ESQ_ENOTSUP) return r;
+            }
+        }
+        const int r = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
+        if (r) return r;
+    }
+    return 0;
+}
+
+int esq_rk_solution(esq_ctx *c, double h) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    Terms tm;
+    const int nt = build_row_terms(c, c->B.data(), c->s, tm, c->kmap);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    Prof p(c, ESQ_PROF_SOLERR, "k_lincomb", nt, 8.0 * (nt + 2) * (double)c->len);
+    return launch_lincomb(c, c->ynew, c->y, tm, nt, h, &p);
+}
+
+int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    Terms tm;
+    const int nt = build_row_terms(c, c->E.data(), c->s + c->fsal, tm, c->kmap);
+    if (nt < 1) return fail(c, ESQ_EINVAL, "error weights are all zero");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, "k_error_norm", nt,
+               8.0 * (nt + 2) * (double)c->len);
+        const int r = launch_errnorm(c, tm, nt, h, p);
+        if (r) return r;
+    }
+    return finish_reduction(c, sumsq_out);
+}
+
+int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    const bool ynew_ready = c->ynew_ready, solerr_ready = c->solerr_ready;
+    ENTER(c);
+    c->ynew_ready = c->solerr_ready = false;
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    if (c->fsal) {
+        int r = 0;
+        if (!ynew_ready) r = esq_rk_solution(c, h);
+        if (r) return r;
+        if (!c->cplx && may_fuse(c, ESQ_EPI_ERRNORM)) {
+            // K[s] = f(t + h, y_new) and the error norm in ONE sweep
+            esq_epilogue e;
+            epi_common(c, e, ESQ_EPI_ERRNORM);
+            int nt = 0;
+            bool ok = true;
+            for (int j = 0; j < c->s; ++j) {
+                if (c->E[j] == 0.0) continue;
+                if (nt >= ESQ_EPI_MAX_ROWS) { ok = false; break; }
+                e.rows[nt] = c->krow[c->kmap[j]];
+                e.e[nt] = c->E[j];
+                ++nt;
+            }
+            if (ok) {
+                e.nt = nt;
+                e.e_self = c->E[c->s];
+                e.y = c->y;
+                e.h = h;
+                e.f_store_nt = (c->epi_nt >> 4) & 1;   // K[s] is the next step's K[0]
+                // booked: RHS 16 B + error pass (rows incl. K[s], y, y_new);
+                // moved: y_new, rows, y in; K[s] out
+                Prof p(c, ESQ_PROF_SOLERR, "rhs+errnorm", nt,
+                       8.0 * (nt + 1 + 2 + 2) * (double)c->len, false,
+                       8.0 * (nt + 3) * (double)c->len);
+                r = run_fused(c, t + h, c->ynew, c->krow[c->kmap[c->s]], e, p);
+                if (r == 0) return finish_reduction(c, sumsq_out, false, c->partials,
+                                                    c->red_count);
+                if (r != ESQ_ENOTSUP) return r;
+            }
+        }
+        r = call_rhs(c, t + h, c->ynew, c->krow[c->kmap[c->s]]);
+        if (r) return r;
+        return esq_rk_error_norm(c, h, sumsq_out);
+    }
+    if (solerr_ready)
+        return finish_reduction(c, sumsq_out, false, c->partials, c->red_count);
+    Terms2 tm;
+    const int nt = build_row_terms2(c, c->B.data(), c->s, c->E.data(), c->s, tm, c->kmap);
+    if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, "k_solution_error", nt,
+               8.0 * (nt + 2) * (double)c->len);
+        const int r = launch_solerr(c, tm, nt, h, p);
+        if (r) return r;
+    }
+    return finish_reduction(c, sumsq_out);
+}
+
+int esq_rk_pre_error(esq_ctx *c, double h, const double *e_pre,
+                     const double *b_scale_pre, int rows, double *sumsq_out) {
+    if (!c || !e_pre || !b_scale_pre || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
+    if (rows < 1 || rows > c->n_rows) return fail(c, ESQ_EINVAL, "bad rows %d", rows);
+    Terms2 tm;
+    const int nt = build_row_terms2(c, b_scale_pre, rows, e_pre, rows, tm, c->kmap);
+    if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, "k_pre_error", nt,
+               8.0 * (nt + 1) * (double)c->len);
+        const int r = launch_preerr(c, tm, nt, h, p);
+        if (r) return r;
+    }
+    return finish_reduction(c, sumsq_out);
+}
+
+int esq_rk_custom_sol_err(esq_ctx *c, double h, const double *b, const double *e,
+                          int rows, int store_ynew, double *sumsq_out) {
+    if (!store_ynew) return esq_rk_pre_error(c, h, e, b, rows, sumsq_out);
+    if (!c || !b || !e || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
+    if (rows < 1 || rows > c->n_rows) return fail(c, ESQ_EINVAL, "bad rows %d", rows);
+    Terms2 tm;
+    const int nt = build_row_terms2(c, b, rows, e, rows, tm, c->kmap);
+    if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, "k_solution_error", nt,
+               8.0 * (nt + 2) * (double)c->len);
+        const int r = launch_solerr(c, tm, nt, h, p);
+        if (r) return r;
+    }
+    return finish_reduction(c, sumsq_out);
+}
+
+int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    // the next step's first stage argument can be formed now: stage 1 reads
+    // nothing but y and K[0]
+    const bool want_pre = h_next != 0.0 && c->s >= 2 && c->rhs != nullptr &&
+                          !(may_use_src(c) && c->s >= 3);
+    bool pre_done = false;
+    if (!c->fsal && with_end_eval) {
+        int r = ESQ_ENOTSUP;
+        if (want_pre && may_fuse(c, ESQ_EPI_STAGE)) {
+            // K[s] = f(t_new, y_new) and YSTAGE = y_new + h_next*a_10*K[s] in
+            // ONE sweep (K[s] becomes K[0], y_new becomes y below)
+            esq_epilogue e;
+            epi_common(c, e, ESQ_EPI_STAGE);
+            e.nt = 0;
+            e.c_self = c->A[(size_t)c->s];          // A[1][0]
+            e.y = nullptr;                          // base = the sweep's input
+            e.h = h_next;
+            e.out = c->ystage;
+            e.f_store_nt = (c->epi_nt >> 3) & 1;    // K[0] of the next step
+            const int nnz = e.c_self != 0.0 ? 1 : 0;
+            Prof p(c, ESQ_PROF_STAGE, "rhs+stage", 0, 8.0 * (nnz + 4) * (double)c->len,
+                   false, 8.0 * 3 * (double)c->len);
+            r = run_fused(c, t_new, c->ynew, c->krow[c->kmap[c->s]], e, p);
+            if (r == 0) pre_done = true;
+            else if (r != ESQ_ENOTSUP) return r;
+        }
+        if (r == ESQ_ENOTSUP) {
+            r = call_rhs(c, t_new, c->ynew, c->krow[c->kmap[c->s]]);
+            if (r) return r;
+        }
+    }
+    c->kmap_last = c->kmap;
+    std::swap(c->kmap[0], c->kmap[c->s]);
+    std::swap(c->y, c->ynew);
+    if (want_pre && !pre_done) {
+        // stage 1's accumulate, launched now: it runs while the host controller
+        // is between steps
+        const int r = esq_rk_stage_accumulate(c, 1, h_next);
+        if (r) return r;
+        pre_done = true;
+    }
+    c->pre_valid = pre_done;
+    c->pre_h = h_next;
+    return 0;
+}
+
+int esq_rk_error_vector(esq_ctx *c, double h, int last_step) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    Terms tm;
+    const int nt = build_row_terms(c, c->E.data(), c->s + c->fsal, tm,
+                                   last_step ? c->kmap_last : c->kmap);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    return launch_lincomb(c, c->work, nullptr, tm, nt, h);
+}
+
+int esq_rk_row_id(esq_ctx *c, int logical_row, int last_step) {
+    if (!c || logical_row < 0 || logical_row >= c->n_rows) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    return last_step ? c->kmap_last[logical_row] : c->kmap[logical_row];
+}
+int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
+    return d2h(c, host, c->krow[c->kmap_last[row]], c->len * sizeof(double), c->idle);
+}
+
+int esq_rk_dense_stage(esq_ctx *c, int row, const double *a, int count, double h) {
+    if (!c || !a) return ESQ_EINVAL;
+    ENTER(c);
+    if (row < 1 || row >= c->n_rows || count < 0 || count > row)
+        return fail(c, ESQ_EINVAL, "bad row/count %d/%d", row, count);
+    Terms tm;
+    const int nt = build_row_terms(c, a, count, tm, c->kmap_last);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    // after esq_rk_accept the pre-step state is in the YNEW slot
+    return launch_lincomb(c, c->ystage, c->ynew, tm, nt, h);
+}
+int esq_rk_dense_eval(esq_ctx *c, int row, double t) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
+    return call_rhs(c, t, c->ystage, c->krow[c->kmap_last[row]]);
+}
+int esq_rk_upload_last_K(esq_ctx *c, int row, const double *host) {
+    if (!c || !host) return ESQ_EINVAL;
+    const bool was_idle = c->idle;
+    ENTER(c);
+    if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
+    return h2d(c, c->krow[c->kmap_last[row]], host, c->len * sizeof(double), was_idle);
+}
+
+}  // extern "C"

@@ -211,11 +211,13 @@ class ControlGroup:
         self.allreduce([0.0])
 
     def exchange(self, make_id, n_local):
-        """the `exchange` hook of `init_lockstep`: ncclUniqueId from rank 0 and
-        the summed shard size"""
+        """the `exchange` hook of `init_lockstep`: ncclUniqueId from rank 0, the
+        summed shard size and this shard's offset in the concatenated state"""
         ident = self.broadcast(make_id() if self.rank == 0 else None)
-        total = self.allreduce([float(n_local)], "sum")[0]
-        return ident, int(round(total))
+        sizes = [0.0] * self.world
+        sizes[self.rank] = float(n_local)
+        sizes = [int(round(v)) for v in self.allreduce(sizes, "sum")]
+        return ident, sum(sizes), sum(sizes[:self.rank])
 
     def close(self):
         for c in self._peers:
@@ -240,8 +242,12 @@ def init_lockstep(rank, world_size, device, n_local, addr=None, port=None,
     one-shot TCP rendezvous (bench.py passes `ControlGroup.exchange`, which rides
     on its persistent control connections)."""
     lib = _lib.load()
+    offset = None
     if exchange is not None:
-        ident, n_total = exchange(_rccl_unique_id, n_local)
+        got = exchange(_rccl_unique_id, n_local)
+        ident, n_total = got[0], got[1]
+        if len(got) > 2:
+            offset = got[2]
     else:
         ident, n_total = rendezvous(rank, world_size, n_local, _rccl_unique_id,
                                     addr, port)
@@ -249,7 +255,7 @@ def init_lockstep(rank, world_size, device, n_local, addr=None, port=None,
     buf = C.create_string_buffer(ident, _ID_BYTES)
     _lib.check(lib.esq_comm_init_rank(C.byref(comm), world_size, buf, rank,
                                       device), None, "esq_comm_init_rank")
-    return LockstepGroup(comm, n_total)
+    return LockstepGroup(comm, n_total, offset=offset)
 
 
 def comm_size(group):
@@ -263,12 +269,12 @@ def comm_size(group):
 def abort_lockstep(group):
     """ncclCommAbort: called by a rank that fails outside a collective so that
     its peers' pending all-reduce errors out instead of blocking"""
-    if group is not None and group.comm:
+    if group is not None and not group.sync_aborted():
         _lib.load().esq_comm_abort(group.comm)
         group.comm = None
 
 
 def destroy_lockstep(group):
-    if group is not None and group.comm:
+    if group is not None and not group.sync_aborted():
         _lib.load().esq_comm_destroy(group.comm)
         group.comm = None

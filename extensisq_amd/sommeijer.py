@@ -126,6 +126,7 @@ class SSV2stab(OdeSolver):
         if lockstep is not None:
             self._dev._chk(self._lib.esq_set_comm(self._ctx, lockstep.comm),
                            "esq_set_comm")
+            lockstep.attach(self._dev)
             self._n_norm = lockstep.n_total
         self._dev.upload(SLOT_K, self._r["yn"], y_host)
         if self._device_rhs is not None:
@@ -143,7 +144,21 @@ class SSV2stab(OdeSolver):
 
     # --------------------------------------------------------------- helpers
     def _chk(self, code, what):
-        self._dev._chk(code, what)
+        try:
+            self._dev._chk(code, what)
+        except Exception:
+            if getattr(self, "_lockstep", None) is not None:
+                self._lockstep.sync_aborted()
+            raise
+
+    def _group_reduce(self, values, op="sum"):
+        """shard-local scalars from the library -> scalars of the whole batch
+        (identity outside a lock-step group and on the RCCL path, where the
+        library has all-reduced them already)"""
+        grp = getattr(self, "_lockstep", None)
+        if grp is None:
+            return list(values)
+        return grp.host_reduce(self._dev, values, op)
 
     @property
     def y(self):
@@ -174,7 +189,8 @@ class SSV2stab(OdeSolver):
         out = C.c_double()
         self._chk(self._lib.esq_vec_sumsq(self._ctx, x, y, C.byref(out)),
                   "esq_vec_sumsq")
-        return out.value
+        # the power iteration's 2-norms are norms of the WHOLE batch
+        return self._group_reduce([out.value], "sum")[0]
 
     def _axpbmc(self, dst, a, alpha, b, c=-1):
         self._chk(self._lib.esq_vec_axpbmc(self._ctx, dst, a, float(alpha), b, c),
@@ -183,9 +199,7 @@ class SSV2stab(OdeSolver):
     def _rms(self, sumsq):
         # an RCCL communicator has summed over the ranks inside the library; a
         # host reducer (several solvers of one process in lock-step) sums here
-        grp = getattr(self, "_lockstep", None)
-        if grp is not None and not grp.comm and grp._reduce is not None:
-            sumsq = grp.allreduce(self._dev, [sumsq], "sum")[0]
+        sumsq = self._group_reduce([sumsq], "sum")[0]
         return (sumsq / self._n_norm) ** 0.5 if self._n_norm else np.nan
 
     # ------------------------------------------------------------ first step
@@ -280,10 +294,19 @@ class SSV2stab(OdeSolver):
             if dfnrm != 0.0:
                 self._axpbmc(v, yn, dynrm / dfnrm, fv, fn)
             else:
-                vec = self._dev.download(SLOT_K, v)
-                idx = it % self.n
-                vec[idx] = -vec[idx]
-                self._dev.upload(SLOT_K, v, vec)
+                # the reference flips ONE element of the whole state
+                # (sommeijer.py:386-388); in a lock-step batch only the rank
+                # that owns it does (shard offset known), else every shard
+                # flips its own -- either way all ranks take the same branch
+                grp = self._lockstep
+                if grp is not None and grp.offset is not None:
+                    idx = it % self._n_norm - grp.offset
+                else:
+                    idx = it % self.n
+                if 0 <= idx < self.n:
+                    vec = self._dev.download(SLOT_K, v)
+                    vec[idx] = -vec[idx]
+                    self._dev.upload(SLOT_K, v, vec)
         return None
 
     def _spectral_radius(self, t):
@@ -293,7 +316,9 @@ class SSV2stab(OdeSolver):
         differs from rank to rank; the batch uses the LARGEST one (the spectral
         radius of the block-diagonal Jacobian of the concatenated system) --
         otherwise the ranks would choose different m and h.  The power
-        iteration needs no exchange: its norms are all-reduced sums already."""
+        iteration's norms are sums over the whole batch (`_sumsq`: all-reduced
+        inside the library over RCCL, through the group's host reducer
+        otherwise), so every rank iterates on the same scalars."""
         if self.rho_jac is None:
             return self._rho(t)
         sprad = self.rho_jac(t, self.y)

@@ -72,7 +72,8 @@ class _Workspace:
         self.s._chk(self.lib.esq_vec_wdot(self.ctx, a, b, VEC_Y, VEC_YNEW,
                                           self.floor, ctypes.byref(out)),
                     "esq_vec_wdot")
-        return out.value
+        # weighted inner products of the WHOLE batch in a lock-step group
+        return self.s._group_reduce([out.value], "sum")[0]
 
     def axpbmc(self, dst, a, alpha, b, c=VEC_NONE):
         self.s._chk(self.lib.esq_vec_axpbmc(self.ctx, dst, a, float(alpha), b, c),

@@ -392,6 +392,10 @@ int  esq_comm_count(void *comm, int *nranks_out);
  * not complete within ESQ_COMM_TIMEOUT_S (default 120 s) and returns
  * ESQ_ETIMEOUT. */
 int  esq_comm_abort(void *comm);
+/* 1 if the library itself aborted the context's communicator (a lock-step
+ * collective returned ESQ_ETIMEOUT): the handle passed to esq_set_comm is then
+ * gone and must be neither aborted nor destroyed again by the host. */
+int  esq_comm_is_aborted(const esq_ctx *ctx);
 /* all-reduce `count` (<= 4) host doubles in place over the context's
  * communicator; a no-op without one.  Used for the rank-local scalars that feed
  * the step size or the stage count (SSV2stab's spectral radius,

@@ -1252,3 +1252,71 @@ def test_host_slab_mode_is_faster_for_small_host_rhs(monkeypatch, capsys):
               f"device slab {1e6 * t_dev:.0f} us/step, NumPy oracle "
               f"{1e6 * t_ora:.0f} us/step")
     assert t_host < 1.1 * t_dev
+
+
+def test_lockstep_host_reducer_estimates_the_first_step_on_the_whole_batch():
+    """host-reducer lock-step with `first_step=None`: Watts' starting-step
+    procedure (common.py:519-763) runs on norms, log-tolerance sums and minima of
+    the WHOLE batch, so every shard starts with the step the oracle chooses on
+    the concatenated state and the batch stays in lock-step from there."""
+    import threading
+    N, world = 16, 2
+    n = N * N
+    y0s = [(1.0 + 0.5 * r) * pb.heat2d_y0(N, seed=7 + r) for r in range(world)]
+    slots = [0.0] * world
+    barrier = threading.Barrier(world)
+    local = threading.local()
+
+    def reducer(values, op):
+        out = []
+        for v in values:
+            slots[local.rank] = v
+            barrier.wait()
+            out.append(sum(slots) if op == "sum" else max(slots) if op == "max"
+                       else min(slots))
+            barrier.wait()
+        return out
+
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            local.rank = rank
+            grp = esq.LockstepGroup(None, world * n, reduce_scalars=reducer)
+            grp.debug = True
+            s = esq.Pr7(esq.Heat2D(N), 0.0, y0s[rank], 2e-3, rtol=1e-5, atol=1e-8,
+                        nfev_stiff_detect=0, lockstep=grp)
+            h0 = s.h_abs
+            ts = []
+            while s.status == "running":
+                assert s.step() is None
+                ts.append(s.t)
+            results[rank] = (h0, ts, s.y, s.nfev)
+        except BaseException as exc:       # noqa: BLE001
+            errors.append(exc)
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
+    assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
+    f1 = pb.heat2d_rhs(N)
+
+    def fun(t, y):
+        return np.concatenate([f1(t, y[k * n:(k + 1) * n]) for k in range(world)])
+
+    ref = rk_oracle.Pr7(fun, 0.0, np.concatenate(y0s), 2e-3, rtol=1e-5, atol=1e-8,
+                        nfev_stiff_detect=0)
+    assert_allclose(results[0][0], ref.h_abs, rtol=1e-9)
+    ts = []
+    while ref.status == "running":
+        assert ref.step() is None
+        ts.append(ref.t)
+    assert len(ts) == len(results[0][1])
+    assert_allclose(results[0][1], ts, rtol=1e-7)
+    assert_allclose(np.concatenate([r[2] for r in results]), ref.y, rtol=1e-7,
+                    atol=1e-11)
+    assert results[0][3] == ref.nfev

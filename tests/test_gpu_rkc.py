@@ -274,3 +274,89 @@ def test_lockstep_two_shards_with_y_dependent_spectral_radius():
     assert_allclose(np.concatenate([r[1] for r in results]), ref.y, rtol=1e-8,
                     atol=1e-12)
     assert results[0][2] == ref.nfev
+
+
+def _run_lockstep_threads(world, make_solver):
+    """`world` solvers of this process (one context + stream + thread each) in
+    lock-step through a host reducer standing in for RCCL; returns
+    [(ts, y, nfev, extra)] per rank"""
+    import threading
+    slots = [0.0] * world
+    barrier = threading.Barrier(world)
+    local = threading.local()
+
+    def reducer(values, op):
+        out = []
+        for v in values:
+            slots[local.rank] = v
+            barrier.wait()
+            out.append(sum(slots) if op == "sum" else max(slots) if op == "max"
+                       else min(slots))
+            barrier.wait()
+        return out
+
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            local.rank = rank
+            s = make_solver(rank, reducer)
+            ts = []
+            while s.status == "running":
+                assert s.step() is None
+                ts.append(s.t)
+            results[rank] = (ts, s.y, s.nfev, s)
+        except BaseException as exc:       # noqa: BLE001
+            errors.append(exc)
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
+    return results
+
+
+def test_lockstep_two_shards_power_iteration_and_estimated_first_step():
+    """host-reducer lock-step with NOTHING handed to the solvers: `rho_jac=None`
+    (nonlinear power iteration, sommeijer.py:331-398) and `first_step=None`
+    (`_init_step_size`, :147-160).  Every norm of both procedures is a norm of
+    the WHOLE batch, so both shards must reproduce the oracle's run on the
+    concatenated state -- same steps, same nfev, same spectral-radius
+    evaluations -- instead of silently leaving lock-step with shard-local
+    norms divided by the total size."""
+    N, world = 12, 2
+    n = N * N
+    y0s = [(1.0 + r) * pb.heat2d_y0(N, seed=40 + r) for r in range(world)]
+    offsets = [0, n]
+
+    def make(rank, reducer):
+        grp = esq.LockstepGroup(None, world * n, reduce_scalars=reducer,
+                                offset=offsets[rank])
+        grp.debug = True                 # cross-check (t, h, m) every step
+        return esq.SSV2stab(esq.Heat2D(N), 0.0, y0s[rank], 2e-3, rtol=1e-4,
+                            atol=1e-7, lockstep=grp)
+
+    results = _run_lockstep_threads(world, make)
+    nfesig_dev = int(dev_rkc.nfesig[()])
+    assert results[0][0] == results[1][0]                  # bitwise lock-step
+    f1 = pb.heat2d_rhs(N)
+
+    def fun(t, y):
+        return np.concatenate([f1(t, y[k * n:(k + 1) * n]) for k in range(world)])
+
+    ref = rkc_oracle.SSV2stab(fun, 0.0, np.concatenate(y0s), 2e-3, rtol=1e-4,
+                              atol=1e-7)
+    ts = []
+    while ref.status == "running":
+        assert ref.step() is None
+        ts.append(ref.t)
+    assert len(results[0][0]) == len(ts)
+    assert_allclose(results[0][0], ts, rtol=1e-7)
+    assert_allclose(np.concatenate([r[1] for r in results]), ref.y, rtol=1e-6,
+                    atol=1e-10)
+    assert results[0][2] == ref.nfev and results[1][2] == ref.nfev
+    # both threads count into the module-level counter
+    assert nfesig_dev == world * int(rkc_oracle.nfesig[()])

@@ -54,7 +54,8 @@ def _control_group_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     from extensisq_amd import lockstep
     ctl = lockstep.ControlGroup(rank, world, "127.0.0.1", port, timeout=60)
-    ident, total = ctl.exchange(lambda: bytes(range(128)), 1000 + rank)
+    ident, total, offset = ctl.exchange(lambda: bytes(range(128)), 1000 + rank)
+    assert offset == sum(1000 + r for r in range(rank))
     ctl.barrier()
     mx = ctl.allreduce([float(rank), -float(rank)], "max")
     sm = ctl.allreduce([1.5], "sum")
