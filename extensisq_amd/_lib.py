@@ -97,12 +97,15 @@ SIGNATURES = {
     "esq_comm_is_aborted": (C.c_int, [_vp]),
     "esq_allreduce_scalars": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "esq_rhs_diag_create": (C.c_int, [_vpp, C.c_int, _vp, C.c_size_t, C.c_double]),
+    "esq_rhs_cdiag_create": (C.c_int, [_vpp, C.c_int, _vp, C.c_size_t, C.c_double,
+                                       C.c_double]),
     "esq_rhs_heat2d_create": (C.c_int, [_vpp, C.c_int]),
     "esq_rhs_bruss2d_create": (C.c_int, [_vpp, C.c_int, C.c_double, C.c_double,
                                          C.c_double]),
     "esq_rhs_diff3d_create": (C.c_int, [_vpp, C.c_int]),
     "esq_rhs_free": (C.c_int, [_vp]),
     "esq_rhs_diag": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
+    "esq_rhs_cdiag": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
     "esq_rhs_heat2d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
     "esq_rhs_bruss2d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
     "esq_rhs_diff3d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
@@ -111,6 +114,7 @@ SIGNATURES = {
     "esq_rhs_bruss2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_heat2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_diag_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_cdiag_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_profile_enable": (C.c_int, [_vp, C.c_int]),
     "esq_profile_sampling": (C.c_int, [_vp, C.c_int]),
     "esq_profile_read": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_long), _dp]),

@@ -225,7 +225,9 @@ struct EpiBlock {
 
 // y_new = y + h*(sum b_j K_j + b_self*fresh); err = h*(sum e_j K_j + e_self*fresh);
 // partial sum of |err / (atol + rtol*max(|y|, |y_new|))|^2
-template <int NT>
+// CPLX: one double2 is one complex element; the sums act on (re, im) separately
+// (real weights), the scale uses the complex modulus (common.py:57-66)
+template <int NT, bool CPLX = false>
 struct EpiSolErr {
     static constexpr bool kReduce = true;
     Terms2 tm;
@@ -268,14 +270,14 @@ struct EpiSolErr {
         er.x = __dmul_rn(h, se.x);
         er.y = __dmul_rn(h, se.y);
         st2(ynew, i2, yn);
-        local += ratio_sq<false>(er, in.yb, yn, red.atol_vec, red.atol_s, red.rtol,
-                                 i2, red.n_valid);
+        local += ratio_sq<CPLX>(er, in.yb, yn, red.atol_vec, red.atol_s, red.rtol,
+                                i2, red.n_valid);
     }
 };
 
 // FSAL: the sweep's input IS y_new, fresh = K_s;
 // err = h*(sum e_j K_j + e_self*fresh), scale from y (memory) and y_new (centre)
-template <int NT>
+template <int NT, bool CPLX = false>
 struct EpiErrNorm {
     static constexpr bool kReduce = true;
     Terms tm;
@@ -309,8 +311,8 @@ struct EpiErrNorm {
         double2 er;
         er.x = __dmul_rn(h, se.x);
         er.y = __dmul_rn(h, se.y);
-        local += ratio_sq<false>(er, in.yb, centre, red.atol_vec, red.atol_s,
-                                 red.rtol, i2, red.n_valid);
+        local += ratio_sq<CPLX>(er, in.yb, centre, red.atol_vec, red.atol_s,
+                                red.rtol, i2, red.n_valid);
     }
 };
 

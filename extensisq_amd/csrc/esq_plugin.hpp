@@ -76,9 +76,9 @@ EpiBlock<NT> make_block(const esq_epilogue *e) {
     s.red = red_of(e);
     return s;
 }
-template <int NT>
-EpiSolErr<NT> make_solerr(const esq_epilogue *e) {
-    EpiSolErr<NT> s;
+template <int NT, bool CPLX = false>
+EpiSolErr<NT, CPLX> make_solerr(const esq_epilogue *e) {
+    EpiSolErr<NT, CPLX> s;
     for (int j = 0; j < kMaxTerms; ++j) {
         s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
         s.tm.b[j] = j < e->nt ? e->c[j] : 0.0;
@@ -89,9 +89,9 @@ EpiSolErr<NT> make_solerr(const esq_epilogue *e) {
     s.red = red_of(e);
     return s;
 }
-template <int NT>
-EpiErrNorm<NT> make_errnorm(const esq_epilogue *e) {
-    EpiErrNorm<NT> s;
+template <int NT, bool CPLX = false>
+EpiErrNorm<NT, CPLX> make_errnorm(const esq_epilogue *e) {
+    EpiErrNorm<NT, CPLX> s;
     for (int j = 0; j < kMaxTerms; ++j) {
         s.tm.p[j] = j < e->nt ? e->rows[j] : nullptr;
         s.tm.c[j] = j < e->nt ? e->e[j] : 0.0;
@@ -115,9 +115,38 @@ EpiErrNorm<NT> make_errnorm(const esq_epilogue *e) {
 #define ESQ_EPI_CASES_13_16_(MAKE)                                               \
     ESQ_EPI_CASE_(MAKE, 13) ESQ_EPI_CASE_(MAKE, 14) ESQ_EPI_CASE_(MAKE, 15)      \
     ESQ_EPI_CASE_(MAKE, 16)
-template <class Launch>
+template <int NT> EpiSolErr<NT, true> make_solerr_c(const esq_epilogue *e) {
+    return make_solerr<NT, true>(e);
+}
+template <int NT> EpiErrNorm<NT, true> make_errnorm_c(const esq_epilogue *e) {
+    return make_errnorm<NT, true>(e);
+}
+// CPLX_OK: the plugin's state may be complex (interleaved re, im): the reducing
+// epilogues are then instantiated for complex weights too.  Real-only plugins
+// (the default) answer ESQ_ENOTSUP to a complex reduction and the library falls
+// back to its stand-alone kernels.
+template <bool CPLX_OK = false, class Launch>
 int dispatch_epilogue(const esq_epilogue *epi, Launch &&launch) {
     if (!epi || epi->nt < 0) return ESQ_EINVAL;
+    if (epi->is_complex && epilogue_reduces(epi)) {
+        if constexpr (CPLX_OK) {
+            if (!epi->y || !epi->partials) return ESQ_EINVAL;
+            if (epi->kind == ESQ_EPI_SOLERR) {
+                if (!epi->out) return ESQ_EINVAL;
+                switch (epi->nt) {
+                    ESQ_EPI_CASES_0_8_(make_solerr_c) ESQ_EPI_CASES_9_12_(make_solerr_c)
+                    ESQ_EPI_CASES_13_16_(make_solerr_c)
+                    default: return ESQ_ENOTSUP;
+                }
+            }
+            switch (epi->nt) {
+                ESQ_EPI_CASES_0_8_(make_errnorm_c) ESQ_EPI_CASES_9_12_(make_errnorm_c)
+                default: return ESQ_ENOTSUP;
+            }
+        } else {
+            return ESQ_ENOTSUP;
+        }
+    }
     switch (epi->kind) {
         case ESQ_EPI_STAGE:
             if (!epi->out) return ESQ_EINVAL;

@@ -1,0 +1,134 @@
+// esq_rhs_diff3d.hip -- 3-D diffusion, 7-point Laplacian, Dirichlet 0
+// (BASELINE.json configs[3], the SSV2stab workload).
+#include "esq_rhs_common.hpp"
+
+using namespace esq_rhs;
+
+namespace {
+
+// 3-D diffusion, Dirichlet 0, 7-point
+__global__ __launch_bounds__(kBlock) void k_diff3d(const double *__restrict__ u,
+                                                   double *__restrict__ f, int N,
+                                                   double c, unsigned nblocks,
+                                                   unsigned bpr) {
+    const unsigned lb = band_block(blockIdx.x, nblocks);
+    const unsigned row = lb / bpr;   // row = i*N + j
+    const unsigned l = (lb % bpr) * kBlock + threadIdx.x;
+    if (row >= (unsigned)N * N || l >= (unsigned)N) return;
+    const unsigned i = row / N, j = row % N;
+    const size_t NN = (size_t)N * N;
+    const size_t k = (size_t)row * N + l;
+    const double uc = u[k];
+    const double a0 = i > 0 ? u[k - NN] : 0.0;
+    const double a1 = i + 1 < (unsigned)N ? u[k + NN] : 0.0;
+    const double b0 = j > 0 ? u[k - N] : 0.0;
+    const double b1 = j + 1 < (unsigned)N ? u[k + N] : 0.0;
+    const double c0 = l > 0 ? u[k - 1] : 0.0;
+    const double c1 = l + 1 < (unsigned)N ? u[k + 1] : 0.0;
+    f[k] = c * ((((a0 + a1) + (b0 + b1)) + (c0 + c1)) - 6.0 * uc);
+}
+
+// 3-D diffusion, marching version: a thread owns one (j, l) column of the grid
+// (flattened plane index p) and walks R planes along i with a rolling
+// (below, centre, above) window; the l-neighbours come from adjacent lanes,
+// the j-neighbours are two coalesced loads of the centre plane.  3 loads per
+// output instead of 7; arithmetic order identical to k_diff3d.
+template <int R, bool RKC>
+__global__ __launch_bounds__(kBlock) void k_diff3d_v2(
+    const double *__restrict__ u, double *__restrict__ f, int N, double c,
+    unsigned nblocks, unsigned bpp, RkcEpi epi) {
+    const unsigned lb = band_block(blockIdx.x, nblocks);
+    const int i0 = (int)(lb / bpp) * R;
+    const unsigned p = (lb % bpp) * kBlock + threadIdx.x;     // plane index
+    const unsigned NN = (unsigned)N * (unsigned)N;
+    if (i0 >= N) return;
+    const bool live = p < NN;
+    const unsigned j = live ? p / N : 0, l = live ? p % N : 0;
+    const int lane = threadIdx.x & 63;
+    auto at = [&](int i) -> double {
+        return (live && i >= 0 && i < N) ? u[(size_t)i * NN + p] : 0.0;
+    };
+    double below = at(i0 - 1), centre = at(i0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = i0 + r;
+        if (i >= N) break;
+        const double above = at(i + 1);
+        double c0 = __shfl_up(centre, 1, 64), c1 = __shfl_down(centre, 1, 64);
+        if (live) {
+            const double *pl = u + (size_t)i * NN;
+            if (l == 0) c0 = 0.0; else if (lane == 0) c0 = pl[p - 1];
+            if (l + 1 == (unsigned)N) c1 = 0.0;
+            else if (lane == 63 || p + 1 >= NN) c1 = pl[p + 1];
+            const double b0 = j > 0 ? pl[p - N] : 0.0;
+            const double b1 = j + 1 < (unsigned)N ? pl[p + N] : 0.0;
+            const double fy =
+                c * ((((below + above) + (b0 + b1)) + (c0 + c1)) - 6.0 * centre);
+            const size_t k = (size_t)i * NN + p;
+            if (RKC)
+                epi.out[k] = epi.one(centre, epi.yjm2[k], epi.yn[k], epi.fn[k], fy);
+            else
+                f[k] = fy;
+        }
+        below = centre;
+        centre = above;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int esq_rhs_diff3d_create(void **user_out, int N) {
+    if (N < 1) return ESQ_EINVAL;
+    Rhs r{};
+    r.kind = DIFF3D; r.N = N; r.n = (size_t)N * N * N;
+    return make(user_out, r);
+}
+
+int esq_rhs_diff3d_rkc(void *user, double t, const double *yjm1, const double *yjm2,
+                       const double *yn, const double *fn, double mu, double nu,
+                       double omn, double hmus, double ajm1, double *y_out,
+                       size_t n, void *stream, void *start_event, void *stop_event) {
+    (void)t;
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != DIFF3D || n != r->n) return ESQ_EINVAL;
+    if (r->N < 2) return ESQ_ENOTSUP;
+    constexpr int R = 8;
+    const unsigned NN = (unsigned)r->N * (unsigned)r->N;
+    const unsigned bpp = (NN + kBlock - 1) / kBlock;
+    const unsigned nb = bpp * (unsigned)((r->N + R - 1) / R);
+    const unsigned grid = ((nb + kXcd - 1) / kXcd) * kXcd;
+    const double c = (double)(r->N + 1) * (double)(r->N + 1);
+    hipExtLaunchKernelGGL((k_diff3d_v2<R, true>), dim3(grid), dim3(kBlock), 0,
+                          (hipStream_t)stream, (hipEvent_t)start_event,
+                          (hipEvent_t)stop_event, 0, yjm1, (double *)nullptr, r->N,
+                          c, grid, bpp,
+                          make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out));
+    return (int)hipGetLastError();
+}
+int esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
+                   void *stream) {
+    (void)t;
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != DIFF3D || n != r->n) return ESQ_EINVAL;
+    const double c = (double)(r->N + 1) * (double)(r->N + 1);
+    if (rhs_variant() != 1 && r->N >= 2) {
+        constexpr int R = 8;
+        const unsigned NN = (unsigned)r->N * (unsigned)r->N;
+        const unsigned bpp = (NN + kBlock - 1) / kBlock;        // blocks per plane
+        const unsigned nb = bpp * (unsigned)((r->N + R - 1) / R);
+        const unsigned grid = ((nb + kXcd - 1) / kXcd) * kXcd;
+        hipLaunchKernelGGL((k_diff3d_v2<R, false>), dim3(grid), dim3(kBlock), 0,
+                           (hipStream_t)stream, y, f, r->N, c, grid, bpp, RkcEpi{});
+        return (int)hipGetLastError();
+    }
+    const unsigned bpr = (r->N + kBlock - 1) / kBlock;
+    unsigned nblocks = bpr * (unsigned)r->N * (unsigned)r->N;
+    const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
+    hipLaunchKernelGGL(k_diff3d, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                       y, f, r->N, c, grid, bpr);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

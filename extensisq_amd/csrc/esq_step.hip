@@ -127,6 +127,7 @@ void epi_common(esq_ctx *c, esq_epilogue &e, int kind) {
     e.partials = c->partials;
     e.partials_cap = kPartialsCap;
     e.partials_used = &c->red_count;
+    e.is_complex = c->cplx ? 1 : 0;
 }
 
 // one fused sweep; returns 0, ESQ_ENOTSUP (caller falls back) or an error
@@ -520,7 +521,7 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 if (r == 0) { c->ynew_ready = true; continue; }
                 if (r != ESQ_ENOTSUP) return r;
             }
-            if (!c->fsal && !c->cplx && may_fuse(c, ESQ_EPI_SOLERR)) {
+            if (!c->fsal && may_fuse(c, ESQ_EPI_SOLERR)) {
                 // others: ... y_new and the error partial sums
                 const int r = sweep_solerr(c, i, t, h);
                 if (r == 0) { c->ynew_ready = c->solerr_ready = true; continue; }
@@ -570,7 +571,7 @@ int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
         int r = 0;
         if (!ynew_ready) r = esq_rk_solution(c, h);
         if (r) return r;
-        if (!c->cplx && may_fuse(c, ESQ_EPI_ERRNORM)) {
+        if (may_fuse(c, ESQ_EPI_ERRNORM)) {
             // K[s] = f(t + h, y_new) and the error norm in ONE sweep
             esq_epilogue e;
             epi_common(c, e, ESQ_EPI_ERRNORM);

@@ -397,22 +397,32 @@ class _Builtin(DeviceRHS):
 
 
 class DiagonalLinear(_Builtin):
-    """f = lam * y + amp * sin(t)   (lam: vector of n reals)"""
-    _symbol = "esq_rhs_diag"
-    _symbol_fused = "esq_rhs_diag_fused"
+    """f = lam * y + amp * sin(t)   (lam: vector of n reals, or of n complex
+    numbers -- the state is then complex128, as the reference's `RungeKutta`
+    accepts it, common.py:187-190)"""
     _fuse_default = True
 
     def __init__(self, lam, forcing_amp=0.0):
         super().__init__()
-        self.lam = np.ascontiguousarray(lam, dtype=np.float64)
-        self.amp = float(forcing_amp)
+        self.is_complex = bool(np.iscomplexobj(lam) or np.iscomplexobj(forcing_amp))
+        dt = np.complex128 if self.is_complex else np.float64
+        self.lam = np.ascontiguousarray(lam, dtype=dt)
+        self.amp = complex(forcing_amp) if self.is_complex else float(forcing_amp)
         self.n = self.lam.size
+        kind = "cdiag" if self.is_complex else "diag"
+        self._symbol = f"esq_rhs_{kind}"
+        self._symbol_fused = f"esq_rhs_{kind}_fused"
 
     def _make_user(self, lib, device):
         user = C.c_void_p()
-        check(lib.esq_rhs_diag_create(C.byref(user), device, as_ptr(self.lam),
-                                      self.n, self.amp), None,
-              "esq_rhs_diag_create")
+        if self.is_complex:
+            check(lib.esq_rhs_cdiag_create(C.byref(user), device, as_ptr(self.lam),
+                                           self.n, self.amp.real, self.amp.imag),
+                  None, "esq_rhs_cdiag_create")
+        else:
+            check(lib.esq_rhs_diag_create(C.byref(user), device, as_ptr(self.lam),
+                                          self.n, self.amp), None,
+                  "esq_rhs_diag_create")
         return user
 
 

@@ -138,6 +138,10 @@ typedef struct esq_epilogue {
      * argument is then never written to nor read from memory. */
     const double *in_base, *in_row;
     double in_c, in_h;
+    /* the state is complex: one (re, im) pair per element.  Only the reducing
+     * kinds differ (|.| is the complex modulus, n_valid counts complex
+     * elements); a plugin for real states returns ESQ_ENOTSUP for them. */
+    int is_complex;
 } esq_epilogue;
 typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
                                 double *f_dev, const esq_epilogue *epi, size_t n,
@@ -410,6 +414,12 @@ int  esq_allreduce_scalars(esq_ctx *ctx, double *inout, int count, int op);
  * esq_rhs_* function to esq_set_rhs; free with esq_rhs_free. */
 int  esq_rhs_diag_create(void **user_out, int device, const double *lam_host,
                          size_t n, double forcing_amp);  /* f = lam*y + amp*sin(t) */
+/* complex twin: lam_host holds n_complex (re, im) pairs, the state is complex
+ * (context created with is_complex = 1); f = lam*y + (amp_re + i amp_im)*sin(t).
+ * Carries the reference's complex-state support (common.py:64-66, 187-190) onto
+ * the device-RHS path, fused reducing epilogues included. */
+int  esq_rhs_cdiag_create(void **user_out, int device, const double *lam_host,
+                          size_t n_complex, double amp_re, double amp_im);
 int  esq_rhs_heat2d_create(void **user_out, int N);       /* n = N*N            */
 int  esq_rhs_bruss2d_create(void **user_out, int N, double alpha, double a,
                             double b);                    /* n = 2*N*N          */
@@ -417,6 +427,8 @@ int  esq_rhs_diff3d_create(void **user_out, int N);       /* n = N*N*N          
 int  esq_rhs_free(void *user);
 int  esq_rhs_diag(void *user, double t, const double *y, double *f, size_t n,
                   void *stream);
+int  esq_rhs_cdiag(void *user, double t, const double *y, double *f, size_t n,
+                   void *stream);
 int  esq_rhs_heat2d(void *user, double t, const double *y, double *f, size_t n,
                     void *stream);
 int  esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
@@ -444,6 +456,9 @@ int  esq_rhs_heat2d_fused(void *user, double t, const double *y_in, double *f,
 int  esq_rhs_diag_fused(void *user, double t, const double *y_in, double *f,
                         const esq_epilogue *epi, size_t n, void *stream,
                         void *start_event, void *stop_event);
+int  esq_rhs_cdiag_fused(void *user, double t, const double *y_in, double *f,
+                         const esq_epilogue *epi, size_t n, void *stream,
+                         void *start_event, void *stop_event);
 
 /* ---- measurement (bench.py `roofline`) ------------------------------------ */
 /* class_mask bit k = 1: every launch of kernel class k carries a start/stop HIP

@@ -62,6 +62,14 @@ REQUIRED = {
     "test_gpu_rkc.py::test_published_table": 6,
     "test_gpu_rkc.py::test_published_combustion_table": 4,
     "test_gpu_rkc.py::test_power_iteration_golden": 1,
+    "test_gpu_parity.py::test_lockstep_host_reducer_estimates_the_first_step_on_the_whole_batch": 1,
+    "test_gpu_rkc.py::test_lockstep_two_shards_power_iteration_and_estimated_first_step": 1,
+    # complex states with a device RHS
+    "test_gpu_parity.py::test_complex_device_rhs_step": 32,
+    "test_gpu_parity.py::test_complex_fused_equals_unfused": 8,
+    "test_gpu_parity.py::test_complex_device_rhs_trajectory_golden": 8,
+    "test_gpu_parity.py::test_error_estimation_complex_device_rhs": 8,
+    "test_gpu_parity.py::test_user_plugin_complex_state": 1,
     # next rows
     "test_gpu_parity.py::test_device_dense_output_large_n": 8,
     "test_gpu_parity.py::test_device_h_start": 18,

@@ -1320,3 +1320,141 @@ def test_lockstep_host_reducer_estimates_the_first_step_on_the_whole_batch():
     assert_allclose(np.concatenate([r[2] for r in results]), ref.y, rtol=1e-7,
                     atol=1e-11)
     assert results[0][3] == ref.nfev
+
+
+# ------------------------------------------ complex states on the device path
+# The reference's RungeKutta accepts complex128 states (common.py:187-190,
+# norm = real(x @ conj(x)), :64-66; tests/test_rk.py:92-98,
+# tests/test_ivp.py:216-259).  Here they run with a DEVICE right-hand side: the
+# state never leaves HBM, the reducing epilogues use the complex modulus.
+def _complex_problem(n, seed=5):
+    rng = np.random.default_rng(seed)
+    lam = -rng.random(n) * 2.0 + 1j * (rng.random(n) * 6.0 - 3.0)
+    y0 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    amp = 0.7 - 0.4j
+    return lam, y0, amp
+
+
+@pytest.mark.parametrize("name", ERK)
+@pytest.mark.parametrize("n", [1, 37, 256, 4099])
+def test_complex_device_rhs_step(name, n):
+    """one step of every ERK class on a complex state with the complex
+    DiagonalLinear plugin: K, y_new, the error norm and the next step size
+    against the oracle from identical (t, y, f, h)"""
+    lam, y0, amp = _complex_problem(n)
+    kw = dict(first_step=0.05, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+    rhs = esq.DiagonalLinear(lam, amp)
+    assert rhs.is_complex
+    d, o = _pair(name, rhs, lambda t, y: lam * y + amp * np.sin(t), 0.3, y0, 5.0,
+                 **kw)
+    assert d.y.dtype == np.complex128
+    assert d.step() is None and o.step() is None
+    assert d.t == o.t
+    check_step(d, o.K, o.y, o.error_norm_old, o.h_abs, y0, o.h_previous, 1e-6,
+               1e-9, k_rtol=4e-13)
+    assert d.nfev == o.nfev
+    assert np.isrealobj(d.error_norm_old)
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_complex_fused_equals_unfused(name, monkeypatch):
+    """the complex reducing epilogues (solution + error norm inside the last
+    stage's sweep, FSAL error norm inside the end-point sweep) against the
+    one-kernel-per-operation sequence: K rows and the state bit-identical, the
+    error norm to rounding"""
+    lam, y0, amp = _complex_problem(3001)
+    kw = dict(first_step=0.04, rtol=1e-7, atol=1e-10, nfev_stiff_detect=0)
+    out = {}
+    for chain in ("0", "1"):
+        monkeypatch.setenv("ESQ_CHAIN", chain)
+        s = DEV[name](esq.DiagonalLinear(lam, amp), 0.1, y0, 3.0, **kw)
+        for _ in range(3):
+            assert s.step() is None
+        out[chain] = (s.t, s.y.copy(), s.K.copy(), s.error_norm_old, s.nfev)
+    a, b = out["0"], out["1"]
+    assert a[0] == b[0] and a[4] == b[4]
+    assert_equal(a[1], b[1])
+    assert_equal(a[2], b[2])
+    assert_allclose(a[3], b[3], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_complex_device_rhs_trajectory_golden(traces, name):
+    """the reference's complex decay trace (y' = -y, y0 = 0.5 + 1j, [0, 1];
+    tests/test_ivp.py:216-259) with the state resident on the device"""
+    res = solve_ivp(esq.DiagonalLinear(np.array([-1.0 + 0.0j])), [0, 1],
+                    [0.5 + 1j], method=DEV[name], rtol=1e-3, atol=1e-6)
+    compare_trajectory(res, int(esq.NFS[()]), traces[name]["complex"], 1e-3,
+                       t_rtol=1e-7)
+    assert np.iscomplexobj(res.y)
+
+
+@pytest.mark.parametrize("name", ERK)
+def test_error_estimation_complex_device_rhs(name):
+    """tests/test_rk.py:92-98 with a device RHS: the error norm of a complex
+    state is real"""
+    h = 0.2
+    s = DEV[name](esq.DiagonalLinear(np.array([1j])), 0, [1j], 1, first_step=h)
+    assert s.step() is None
+    err_norm = s._estimate_error_norm(s.K, h, scale=[1])
+    assert np.isrealobj(err_norm)
+    assert np.isrealobj(s.error_norm_old) and s.error_norm_old >= 0
+
+
+CPLX_PLUGIN_SRC = r'''
+#include <hip/hip_runtime.h>
+// complex state, f_k = (a + i b) * y_k: n counts DOUBLES (two per element,
+// interleaved re, im) -- include/extensisq_amd.h, esq_rhs_fn
+__global__ void k_rot(const double2* y, double2* f, size_t n_cplx, double a, double b) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_cplx) {
+        const double2 v = y[k];
+        f[k] = make_double2(a * v.x - b * v.y, a * v.y + b * v.x);
+    }
+}
+extern "C" int user_rhs_c(void* user, double t, const double* y, double* f, size_t n,
+                          void* stream) {
+    const double* ab = (const double*)user;
+    const size_t nc = n / 2;
+    hipLaunchKernelGGL(k_rot, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const double2*)y, (double2*)f, nc, ab[0],
+                       ab[1]);
+    return (int)hipGetLastError();
+}
+'''
+
+
+def test_user_plugin_complex_state(tmp_path):
+    """`CFunctionRHS(..., is_complex=True)`: a user's plain `esq_rhs_fn` on a
+    complex state -- the stand-alone complex kernels (stage accumulate,
+    solution + error norm with the complex modulus) against the oracle"""
+    import ctypes
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = tmp_path / "user_rhs_c.hip"
+    so = tmp_path / "libuser_rhs_c.so"
+    src.write_text(CPLX_PLUGIN_SRC)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-fPIC", "-shared",
+                    "-ffp-contract=off", str(src), "-o", str(so)], check=True)
+    lib = ctypes.CDLL(str(so))
+    ab = (ctypes.c_double * 2)(-0.3, 2.0)
+    n = 1501
+    rhs = esq.CFunctionRHS(ctypes.cast(lib.user_rhs_c, ctypes.c_void_p).value,
+                           ctypes.addressof(ab), n, is_complex=True)
+    rng = np.random.default_rng(11)
+    y0 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    lam = -0.3 + 2.0j
+    cpu = lambda t, y: lam * y  # noqa: E731
+    assert_allclose(rhs(0.0, y0), cpu(0.0, y0), rtol=1e-15)
+    for name in ("Ts5", "Pr8"):
+        kw = dict(first_step=0.05, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+        d, o = _pair(name, rhs, cpu, 0.0, y0, 2.0, **kw)
+        assert d.step() is None and o.step() is None
+        check_step(d, o.K, o.y, o.error_norm_old, o.h_abs, y0, o.h_previous, 1e-6,
+                   1e-9, k_rtol=4e-13)
+    got = solve_ivp(rhs, (0.0, 1.0), y0, method=esq.Pr7, rtol=1e-7, atol=1e-10)
+    ref = solve_ivp(cpu, (0.0, 1.0), y0, method=rk_oracle.Pr7, rtol=1e-7, atol=1e-10)
+    assert got.nfev == ref.nfev
+    assert_allclose(got.t, ref.t, rtol=1e-6)
+    assert_allclose(got.y[:, -1], ref.y[:, -1], rtol=1e-7, atol=1e-11)
