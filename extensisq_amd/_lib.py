@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libextensisq_amd.so")
 ABI_VERSION = 2
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
-FUSE_ALL = 0x1e
+EPI_RKCERR = 6
+FUSE_ALL = 0x5e
 FUSE_SRC = 0x20
 CREATE_HOST_SLAB = 1
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
@@ -74,6 +75,8 @@ SIGNATURES = {
     "esq_rkc_stages": (C.c_int, [_vp] + [C.c_int] * 5 + [C.c_double, C.c_int, _vp,
                                                          C.POINTER(C.c_int)]),
     "esq_rkc_error_norm": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, _dp]),
+    "esq_rkc_end_error": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, C.c_double,
+                                                            _dp]),
     "esq_rkc_eval_rhs": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),
     "esq_vec_sumsq": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "esq_vec_axpbmc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]),
@@ -113,6 +116,7 @@ SIGNATURES = {
     "esq_rhs_diff3d_rkc": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp] + [C.c_double] * 5 + [_vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_bruss2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_heat2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_diff3d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_diag_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_cdiag_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_profile_enable": (C.c_int, [_vp, C.c_int]),

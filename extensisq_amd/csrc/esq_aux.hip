@@ -187,6 +187,7 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
             const double omn = (1.0 - sc[0]) - sc[1];
             Prof p(c, ESQ_PROF_RKC, "rhs_rkc", -1, 64.0 * (double)c->len, false,
                    40.0 * (double)c->len);
+            c->self_valid = false;
             r = c->rhs_rkc(c->rhs_user, sc[4], a, b, y0, g, sc[0], sc[1], omn,
                            sc[2], sc[3], d, c->len, (void *)c->stream,
                            (void *)p.start(), (void *)p.stop());
@@ -233,6 +234,45 @@ int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
         HIPCHK(c, hipGetLastError());
     }
     return finish_reduction(c, sumsq_out);
+}
+int esq_rkc_end_error(esq_ctx *c, int y, int yn, int fn, int fy, double t_end,
+                      double h, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER(c);
+    double *a = ROW(c, y), *b = ROW(c, yn), *f = ROW(c, fn), *g = ROW(c, fy);
+    if (!a || !b || !f || !g) return fail(c, ESQ_EINVAL, "bad row");
+    if (c->cplx) return fail(c, ESQ_EINVAL, "RKC is real-only (sommeijer.py:98)");
+    if (c->rhs_fused && ((c->fuse_mask >> ESQ_EPI_RKCERR) & 1)) {
+        // fy = f(t_end, y) and the error partial sums in ONE sweep
+        esq_epilogue e;
+        memset(&e, 0, sizeof(e));
+        e.kind = ESQ_EPI_RKCERR;
+        e.rows[0] = b;
+        e.rows[1] = f;
+        e.h = h;
+        e.atol_vec = c->atol_is_vec ? c->atolv : nullptr;
+        e.atol_s = c->atol_s;
+        e.rtol = c->rtol;
+        e.n_valid = c->n;
+        e.partials = c->partials;
+        e.partials_cap = kPartialsCap;
+        e.partials_used = &c->red_count;
+        // booked: RHS 16 B + the error pass (y, yn, fn, fy); moved: y, yn, fn in,
+        // fy out
+        Prof p(c, ESQ_PROF_SOLERR, "rhs+rkcerr", -1, 48.0 * (double)c->len, false,
+               32.0 * (double)c->len);
+        c->self_valid = false;
+        const int r = c->rhs_fused(c->rhs_user, t_end, a, g, &e, c->len,
+                                   (void *)c->stream, (void *)p.start(),
+                                   (void *)p.stop());
+        if (r == 0) return finish_reduction(c, sumsq_out, false, c->partials,
+                                            c->red_count);
+        p.cancel();
+        if (r != ESQ_ENOTSUP) return fail(c, ESQ_ERHS, "fused RHS entry returned %d", r);
+    }
+    int r = call_rhs(c, t_end, a, g);
+    if (r) return r;
+    return esq_rkc_error_norm(c, y, yn, fn, fy, h, sumsq_out);
 }
 int esq_vec_sumsq(esq_ctx *c, int x, int y, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;

@@ -347,4 +347,38 @@ struct EpiRkc {
     }
 };
 
+// End of a Chebyshev step (sommeijer.py:214-220): the sweep's input is the new
+// state y, fresh = f(t + h, y) (stored: it is the next step's f_n);
+//   est = 0.8*(yn - y) + 0.4*h*(fn + f);  wt = atol + rtol*max(|y|, |yn|)
+// partial sums of |est / wt|^2, same operation order as k_rkc_error
+struct EpiRkcErr {
+    static constexpr bool kReduce = true;
+    const double *yn, *fn;
+    double h04;
+    int f_nt;
+    RedArgs red;
+    struct In {
+        double2 b, g;
+    };
+    __device__ __forceinline__ void load(In &in, size_t i2) const {
+        in.b = ld2(yn, i2);
+        in.g = ld2(fn, i2);
+    }
+    __device__ __forceinline__ void store_f(double *f, size_t i2, double2 v) const {
+        if (f_nt) st2_nt(f, i2, v); else st2(f, i2, v);
+    }
+    __device__ __forceinline__ double one(double y, double b, double g, double fy) const {
+        return __dadd_rn(__dmul_rn(0.8, __dsub_rn(b, y)),
+                         __dmul_rn(h04, __dadd_rn(g, fy)));
+    }
+    __device__ __forceinline__ void finish(const In &in, double2 fresh,
+                                           double2 centre, size_t i2,
+                                           double &local) const {
+        const double2 er = make_double2(one(centre.x, in.b.x, in.g.x, fresh.x),
+                                        one(centre.y, in.b.y, in.g.y, fresh.y));
+        local += ratio_sq<false>(er, centre, in.b, red.atol_vec, red.atol_s,
+                                 red.rtol, i2, red.n_valid);
+    }
+};
+
 }  // namespace esq

@@ -36,7 +36,8 @@
 namespace esq {
 
 inline bool epilogue_reduces(const esq_epilogue *epi) {
-    return epi->kind == ESQ_EPI_SOLERR || epi->kind == ESQ_EPI_ERRNORM;
+    return epi->kind == ESQ_EPI_SOLERR || epi->kind == ESQ_EPI_ERRNORM ||
+           epi->kind == ESQ_EPI_RKCERR;
 }
 inline RedArgs red_of(const esq_epilogue *e) {
     RedArgs r;
@@ -115,6 +116,14 @@ EpiErrNorm<NT, CPLX> make_errnorm(const esq_epilogue *e) {
 #define ESQ_EPI_CASES_13_16_(MAKE)                                               \
     ESQ_EPI_CASE_(MAKE, 13) ESQ_EPI_CASE_(MAKE, 14) ESQ_EPI_CASE_(MAKE, 15)      \
     ESQ_EPI_CASE_(MAKE, 16)
+inline EpiRkcErr make_rkcerr(const esq_epilogue *e) {
+    EpiRkcErr s;
+    s.yn = e->rows[0]; s.fn = e->rows[1];
+    s.h04 = 0.4 * e->h;
+    s.f_nt = e->f_store_nt;
+    s.red = red_of(e);
+    return s;
+}
 template <int NT> EpiSolErr<NT, true> make_solerr_c(const esq_epilogue *e) {
     return make_solerr<NT, true>(e);
 }
@@ -128,6 +137,12 @@ template <int NT> EpiErrNorm<NT, true> make_errnorm_c(const esq_epilogue *e) {
 template <bool CPLX_OK = false, class Launch>
 int dispatch_epilogue(const esq_epilogue *epi, Launch &&launch) {
     if (!epi || epi->nt < 0) return ESQ_EINVAL;
+    if (epi->kind == ESQ_EPI_RKCERR) {
+        if (epi->is_complex || !epi->rows[0] || !epi->rows[1] || !epi->partials)
+            return ESQ_EINVAL;
+        launch(make_rkcerr(epi));
+        return 0;
+    }
     if (epi->is_complex && epilogue_reduces(epi)) {
         if constexpr (CPLX_OK) {
             if (!epi->y || !epi->partials) return ESQ_EINVAL;

@@ -33,15 +33,22 @@ __global__ __launch_bounds__(kBlock) void k_diff3d(const double *__restrict__ u,
 // (below, centre, above) window; the l-neighbours come from adjacent lanes,
 // the j-neighbours are two coalesced loads of the centre plane.  3 loads per
 // output instead of 7; arithmetic order identical to k_diff3d.
-template <int R, bool RKC>
+// MODE 0: f = rhs(u);  1: Chebyshev recursion (EpiRkc, f not stored);
+// 2: end of a Chebyshev step (EpiRkcErr): f stored + error partial sums
+constexpr int kPlain = 0, kRkc = 1, kRkcErr = 2;
+template <int R, int MODE>
 __global__ __launch_bounds__(kBlock) void k_diff3d_v2(
     const double *__restrict__ u, double *__restrict__ f, int N, double c,
-    unsigned nblocks, unsigned bpp, RkcEpi epi) {
+    unsigned nblocks, unsigned bpp, RkcEpi epi, esq::EpiRkcErr err) {
     const unsigned lb = band_block(blockIdx.x, nblocks);
     const int i0 = (int)(lb / bpp) * R;
     const unsigned p = (lb % bpp) * kBlock + threadIdx.x;     // plane index
     const unsigned NN = (unsigned)N * (unsigned)N;
-    if (i0 >= N) return;
+    double local = 0.0;
+    if (i0 >= N) {                                            // block-uniform
+        if (MODE == kRkcErr) esq::block_partial(local, err.red.partials);
+        return;
+    }
     const bool live = p < NN;
     const unsigned j = live ? p / N : 0, l = live ? p % N : 0;
     const int lane = threadIdx.x & 63;
@@ -65,14 +72,26 @@ __global__ __launch_bounds__(kBlock) void k_diff3d_v2(
             const double fy =
                 c * ((((below + above) + (b0 + b1)) + (c0 + c1)) - 6.0 * centre);
             const size_t k = (size_t)i * NN + p;
-            if (RKC)
+            if (MODE == kRkc) {
                 epi.out[k] = epi.one(centre, epi.yjm2[k], epi.yn[k], epi.fn[k], fy);
-            else
+            } else {
                 f[k] = fy;
+                if (MODE == kRkcErr) {
+                    const double b = err.yn[k];
+                    const double er = err.one(centre, b, err.fn[k], fy);
+                    const double at = err.red.atol_vec ? err.red.atol_vec[k]
+                                                       : err.red.atol_s;
+                    const double sc =
+                        at + err.red.rtol * esq::pmax(fabs(centre), fabs(b));
+                    const double q = er / sc;
+                    local += q * q;
+                }
+            }
         }
         below = centre;
         centre = above;
     }
+    if (MODE == kRkcErr) esq::block_partial(local, err.red.partials);
 }
 
 }  // namespace
@@ -100,11 +119,36 @@ int esq_rhs_diff3d_rkc(void *user, double t, const double *yjm1, const double *y
     const unsigned nb = bpp * (unsigned)((r->N + R - 1) / R);
     const unsigned grid = ((nb + kXcd - 1) / kXcd) * kXcd;
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
-    hipExtLaunchKernelGGL((k_diff3d_v2<R, true>), dim3(grid), dim3(kBlock), 0,
+    hipExtLaunchKernelGGL((k_diff3d_v2<R, kRkc>), dim3(grid), dim3(kBlock), 0,
                           (hipStream_t)stream, (hipEvent_t)start_event,
                           (hipEvent_t)stop_event, 0, yjm1, (double *)nullptr, r->N,
                           c, grid, bpp,
-                          make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out));
+                          make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out),
+                          esq::EpiRkcErr{});
+    return (int)hipGetLastError();
+}
+// fused entry: only the end of a Chebyshev step (ESQ_EPI_RKCERR) is fused here
+int esq_rhs_diff3d_fused(void *user, double t, const double *y_in, double *f,
+                         const esq_epilogue *epi, size_t n, void *stream,
+                         void *start_event, void *stop_event) {
+    (void)t;
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != DIFF3D || n != r->n || !epi) return ESQ_EINVAL;
+    if (epi->kind != ESQ_EPI_RKCERR || r->N < 2 || epi->in_row) return ESQ_ENOTSUP;
+    if (epi->is_complex || !epi->rows[0] || !epi->rows[1] || !epi->partials)
+        return ESQ_EINVAL;
+    constexpr int R = 8;
+    const unsigned NN = (unsigned)r->N * (unsigned)r->N;
+    const unsigned bpp = (NN + kBlock - 1) / kBlock;
+    const unsigned nb = bpp * (unsigned)((r->N + R - 1) / R);
+    const unsigned grid = ((nb + kXcd - 1) / kXcd) * kXcd;
+    if ((int)grid > epi->partials_cap) return ESQ_ENOTSUP;
+    if (epi->partials_used) *epi->partials_used = (int)grid;
+    const double c = (double)(r->N + 1) * (double)(r->N + 1);
+    hipExtLaunchKernelGGL((k_diff3d_v2<R, kRkcErr>), dim3(grid), dim3(kBlock), 0,
+                          (hipStream_t)stream, (hipEvent_t)start_event,
+                          (hipEvent_t)stop_event, 0, y_in, f, r->N, c, grid, bpp,
+                          RkcEpi{}, esq::make_rkcerr(epi));
     return (int)hipGetLastError();
 }
 int esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
@@ -119,8 +163,9 @@ int esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
         const unsigned bpp = (NN + kBlock - 1) / kBlock;        // blocks per plane
         const unsigned nb = bpp * (unsigned)((r->N + R - 1) / R);
         const unsigned grid = ((nb + kXcd - 1) / kXcd) * kXcd;
-        hipLaunchKernelGGL((k_diff3d_v2<R, false>), dim3(grid), dim3(kBlock), 0,
-                           (hipStream_t)stream, y, f, r->N, c, grid, bpp, RkcEpi{});
+        hipLaunchKernelGGL((k_diff3d_v2<R, kPlain>), dim3(grid), dim3(kBlock), 0,
+                           (hipStream_t)stream, y, f, r->N, c, grid, bpp, RkcEpi{},
+                           esq::EpiRkcErr{});
         return (int)hipGetLastError();
     }
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;

@@ -216,17 +216,19 @@ class DeviceContext:
         if fused is not None and use:
             kinds = {"stage": 1 << _lib.EPI_STAGE, "block": 1 << _lib.EPI_BLOCK,
                      "solerr": 1 << _lib.EPI_SOLERR,
-                     "errnorm": 1 << _lib.EPI_ERRNORM, "src": _lib.FUSE_SRC}
+                     "errnorm": 1 << _lib.EPI_ERRNORM,
+                     "rkcerr": 1 << _lib.EPI_RKCERR, "src": _lib.FUSE_SRC}
             sel = os.environ.get("ESQ_FUSE", "")
-            mask = _lib.FUSE_ALL | (_lib.FUSE_SRC if rhs._fuse_src else 0)
+            mask = _lib.FUSE_ALL if rhs._fuse_mask is None else rhs._fuse_mask
+            mask |= _lib.FUSE_SRC if rhs._fuse_src else 0
+            supported = mask
             if sel:
                 mask = 0
                 for name in sel.split(","):
                     if name.strip() not in kinds:
                         raise ValueError(f"ESQ_FUSE: unknown epilogue {name!r}")
                     mask |= kinds[name.strip()]
-                if not rhs._fuse_src:
-                    mask &= ~_lib.FUSE_SRC
+                mask &= supported
             self._chk(self.lib.esq_set_rhs_fused(self.handle,
                                                  C.cast(fused, C.c_void_p), mask),
                       "esq_set_rhs_fused")
@@ -314,6 +316,7 @@ class DeviceRHS:
     is_complex = False
     _fuse_default = False      # use the fused entry unless ESQ_CHAIN says otherwise
     _fuse_src = False          # the fused entry accepts the on-the-fly first-stage input
+    _fuse_mask = None          # epilogue kinds the fused entry implements (None: all)
 
     def __init__(self):
         self._bound = {}       # device -> (fn, user)
@@ -477,7 +480,11 @@ class Diffusion3D(_Builtin):
     """7-point diffusion on an N^3 interior grid, Dirichlet 0
     (BASELINE.json configs[3])."""
     _symbol = "esq_rhs_diff3d"
+    _symbol_fused = "esq_rhs_diff3d_fused"      # end of a Chebyshev step only
     _symbol_rkc = "esq_rhs_diff3d_rkc"
+    _fuse_default = True
+    _fuse_src = False
+    _fuse_mask = 1 << _lib.EPI_RKCERR
 
     def __init__(self, N):
         super().__init__()

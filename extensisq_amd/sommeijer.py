@@ -360,11 +360,19 @@ class SSV2stab(OdeSolver):
                 self._lockstep.check_identical(self._dev, "(t, h, m)", (t, h, m))
             yrow = self._stages(t, h, m)
             fyrow = next(w for w in r["w"] if w != yrow)
-            self._eval_rhs(fyrow, t + h, yrow)
             out = C.c_double()
-            self._chk(self._lib.esq_rkc_error_norm(
-                self._ctx, yrow, r["yn"], r["fn"], fyrow, h, C.byref(out)),
-                "esq_rkc_error_norm")
+            if self._device_rhs is not None:
+                # f(t + h, y) and the error estimate (ref sommeijer.py:214-220)
+                # in one call: one sweep + final sum with a fused plugin entry
+                self._chk(self._lib.esq_rkc_end_error(
+                    self._ctx, yrow, r["yn"], r["fn"], fyrow, float(t + h), h,
+                    C.byref(out)), "esq_rkc_end_error")
+                self.nfev += 1
+            else:
+                self._eval_rhs(fyrow, t + h, yrow)
+                self._chk(self._lib.esq_rkc_error_norm(
+                    self._ctx, yrow, r["yn"], r["fn"], fyrow, h, C.byref(out)),
+                    "esq_rkc_error_norm")
             err = self._rms(out.value)
             if err < 1.0:
                 break

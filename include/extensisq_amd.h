@@ -91,6 +91,13 @@ typedef int (*esq_rhs_fn)(void *user, double t, const double *y_dev,
  *                    err = h*(sum e[j]*rows[j] + e_self*f), scale from y and
  *                    y_in, partial sums as above      (common.py:348-351)
  *
+ *   ESQ_EPI_RKCERR   end of a Runge-Kutta-Chebyshev step (sommeijer.py:214-220):
+ *                    y_in is the new state y, f = fun(t+h, y) is stored in f_dev
+ *                    (it is the next step's f_n); rows[0] = y_n, rows[1] = f_n;
+ *                    est = 0.8*(y_n - y) + 0.4*h*(f_n + f), partial sums of
+ *                    |est/(atol + rtol*max(|y|,|y_n|))|^2 as above.  One sweep
+ *                    instead of RHS + error kernel (3 words per element less).
+ *
  * The FMA chains run over j ascending and take f last; products with h and the
  * final add are rounded separately: bit-identical to the stand-alone kernels.
  * Reducing kinds write ONE partial per workgroup to partials[blockIdx.x] and
@@ -104,6 +111,7 @@ typedef int (*esq_rhs_fn)(void *user, double t, const double *y_dev,
 #define ESQ_EPI_BLOCK    2
 #define ESQ_EPI_SOLERR   3
 #define ESQ_EPI_ERRNORM  4
+#define ESQ_EPI_RKCERR   6   /* (bit 5 of the fuse mask is ESQ_FUSE_SRC) */
 #define ESQ_EPI_MAX_ROWS 20
 #define ESQ_EPI_MAX_OUT  12
 typedef struct esq_epilogue {
@@ -213,7 +221,7 @@ int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
  * fuse_mask selects the epilogue kinds the library may request (bit k =
  * ESQ_EPI_* value k; ESQ_FUSE_ALL for all) -- each one is bit-identical to the
  * unfused sequence and can be switched off for A/B tests. */
-#define ESQ_FUSE_ALL 0x1e
+#define ESQ_FUSE_ALL 0x5e
 #define ESQ_FUSE_SRC 0x20    /* the entry also accepts the on-the-fly input    */
 int  esq_set_rhs_fused(esq_ctx *ctx, esq_rhs_fused_fn fn, int fuse_mask);
 /* register (or clear) the optional RKC entry: esq_rkc_stages then issues ONE
@@ -340,6 +348,12 @@ int  esq_rkc_stages(esq_ctx *ctx, int yn, int fn, int w0, int w1, int w2,
  *                                                   sommeijer.py:218-220      */
 int  esq_rkc_error_norm(esq_ctx *ctx, int y, int yn, int fn, int fy, double h,
                         double *sumsq_out);
+/* the tail of a Chebyshev step in one call (sommeijer.py:214-220):
+ *   fy = rhs(t_end, y);  then the error sum of squares as esq_rkc_error_norm.
+ * With a plugin whose fused entry takes ESQ_EPI_RKCERR this is ONE sweep + the
+ * final sum (instead of RHS, error kernel, final sum).  Synchronises. */
+int  esq_rkc_end_error(esq_ctx *ctx, int y, int yn, int fn, int fy, double t_end,
+                       double h, double *sumsq_out);
 /* generic K[dst] = rhs(t, K[src]) on physical rows   sommeijer.py:214, 311    */
 int  esq_rkc_eval_rhs(esq_ctx *ctx, int dst, double t, int src);
 /* sum x^2 and sum (x - y)^2 (np.linalg.norm pieces of sommeijer.py:350-374;
@@ -451,6 +465,9 @@ int  esq_rhs_bruss2d_fused(void *user, double t, const double *y_in, double *f,
                            const esq_epilogue *epi, size_t n, void *stream,
                            void *start_event, void *stop_event);
 int  esq_rhs_heat2d_fused(void *user, double t, const double *y_in, double *f,
+                          const esq_epilogue *epi, size_t n, void *stream,
+                          void *start_event, void *stop_event);
+int  esq_rhs_diff3d_fused(void *user, double t, const double *y_in, double *f,
                           const esq_epilogue *epi, size_t n, void *stream,
                           void *start_event, void *stop_event);
 int  esq_rhs_diag_fused(void *user, double t, const double *y_in, double *f,

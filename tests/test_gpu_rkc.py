@@ -360,3 +360,34 @@ def test_lockstep_two_shards_power_iteration_and_estimated_first_step():
     assert results[0][2] == ref.nfev and results[1][2] == ref.nfev
     # both threads count into the module-level counter
     assert nfesig_dev == world * int(rkc_oracle.nfesig[()])
+
+
+@pytest.mark.parametrize("plugin,N", [("heat", 6), ("heat", 130), ("diff3d", 5),
+                                      ("diff3d", 24), ("diff3d", 41)])
+def test_rkc_fused_tail_matches_unfused(monkeypatch, plugin, N):
+    """the end of a Chebyshev step in ONE sweep (ESQ_EPI_RKCERR: f(t+h, y), the
+    estimate 0.8(yn - y) + 0.4h(fn + f) and its weighted partial sums,
+    sommeijer.py:214-220) against RHS launch + error kernel: states and
+    derivatives bit-identical, the error norm to rounding (its partial sums are
+    grouped by the sweep's workgroups)"""
+    if plugin == "heat":
+        mk, y0 = (lambda: esq.Heat2D(N)), pb.heat2d_y0(N)
+    else:
+        mk, y0 = (lambda: esq.Diffusion3D(N)), pb.diff3d_y0(N)
+    rho = mk().spectral_radius()
+    h = 100.0 / rho                       # m ~ 13: the tail is ~10 % of a step
+    kw = dict(rtol=1e-2, atol=1e-2, const_jac=True, rho_jac=lambda t, y: rho,
+              first_step=h, max_step=h)
+    a = esq.SSV2stab(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_FUSE", "stage,block,solerr,errnorm")     # no rkcerr
+    b = esq.SSV2stab(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_FUSE")
+    for _ in range(4):
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t
+        np.testing.assert_array_equal(a.y, b.y)
+        fa = a._dev.download(SLOT_K, a._r["fn"])
+        fb = b._dev.download(SLOT_K, b._r["fn"])
+        np.testing.assert_array_equal(fa, fb)
+        assert_allclose(a.errold, b.errold, rtol=1e-12)
+    assert a.nfev == b.nfev
