@@ -448,6 +448,7 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     c->comm_timeout_s = (double)env_uint("ESQ_COMM_TIMEOUT_S", 120);
     c->epi_nt = env_uint("ESQ_EPI_NT", 0x3);
     c->skip_dead = env_uint("ESQ_DEAD_STORE", 1) != 0;
+    c->pair_mode = (int)env_uint("ESQ_PAIR", 2);
     // launch geometry: grid-stride kernels, a few resident blocks per CU
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
@@ -557,6 +558,13 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     c->rhs_fused = nullptr;
     c->fuse_mask = 0;
     c->rhs_rkc = nullptr;
+    c->rhs_pair = nullptr;
+    return 0;
+}
+int esq_set_rhs_pair(esq_ctx *c, esq_rhs_pair_fn fn) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    c->rhs_pair = fn;
     return 0;
 }
 int esq_set_rhs_rkc(esq_ctx *c, esq_rhs_rkc_fn fn) {

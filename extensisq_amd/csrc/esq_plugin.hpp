@@ -30,8 +30,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/extensisq_amd.h"
 #include "esq_epilogue.hpp"
+#include "esq_pair.hpp"
 
 namespace esq {
 
@@ -192,6 +195,54 @@ int dispatch_epilogue(const esq_epilogue *epi, Launch &&launch) {
         default: return ESQ_ENOTSUP;
     }
 }
+
+// ---- pair entry (esq_rhs_pair_fn): esq_pair -> PairArgs<NU>
+template <int NU>
+PairArgs<NU> make_pair_args(const esq_pair *e) {
+    PairArgs<NU> a;
+    a.b_mask = 0;
+    for (int j = 0; j < (NU > 0 ? NU : 1); ++j) {
+        const bool on = j < NU && j < e->nu;
+        a.rows[j] = on ? e->rows[j] : nullptr;
+        a.ca[j] = on ? e->ca[j] : 0.0;
+        a.cb[j] = on ? e->cb[j] : 0.0;
+        a.eb[j] = on ? e->eb[j] : 0.0;
+        if (on && (e->cb[j] != 0.0 ||
+                   (e->kind_b == ESQ_EPI_SOLERR && e->eb[j] != 0.0)))
+            a.b_mask |= 1u << j;
+    }
+    a.prev_in_b = e->prev_in_b;
+    a.init_a = e->init_a; a.init_b = e->init_b; a.y = e->y;
+    a.ca_self = e->ca_self; a.cb_prev = e->cb_prev; a.cb_self = e->cb_self;
+    a.eb_prev = e->eb_prev; a.eb_self = e->eb_self; a.h = e->h;
+    a.out = e->out;
+    a.store_fa = e->store_fa; a.f_nt = e->f_store_nt;
+    a.red.atol_vec = e->atol_vec; a.red.atol_s = e->atol_s; a.red.rtol = e->rtol;
+    a.red.n_valid = e->n_valid; a.red.partials = e->partials;
+    return a;
+}
+// (kind_b, nu) -> launch(PairArgs<NU>, integral_constant<kind_b>)
+template <class Launch>
+int dispatch_pair(const esq_pair *e, Launch &&launch) {
+    if (!e || e->nu < 0 || !e->y || !e->out) return ESQ_EINVAL;
+    if (e->kind_b == ESQ_EPI_SOLERR && !e->partials) return ESQ_EINVAL;
+    if (e->kind_b != ESQ_EPI_STAGE && e->kind_b != ESQ_EPI_SOLERR) return ESQ_ENOTSUP;
+#define ESQ_PAIR_CASE_(K)                                                          \
+    case K:                                                                        \
+        if (e->kind_b == ESQ_EPI_STAGE)                                            \
+            launch(make_pair_args<K>(e), std::integral_constant<int, ESQ_EPI_STAGE>{}); \
+        else                                                                       \
+            launch(make_pair_args<K>(e), std::integral_constant<int, ESQ_EPI_SOLERR>{}); \
+        return 0;
+    switch (e->nu) {
+        ESQ_PAIR_CASE_(0) ESQ_PAIR_CASE_(1) ESQ_PAIR_CASE_(2) ESQ_PAIR_CASE_(3)
+        ESQ_PAIR_CASE_(4) ESQ_PAIR_CASE_(5) ESQ_PAIR_CASE_(6) ESQ_PAIR_CASE_(7)
+        ESQ_PAIR_CASE_(8)
+        default: return ESQ_ENOTSUP;
+    }
+#undef ESQ_PAIR_CASE_
+}
+
 #undef ESQ_EPI_CASE_
 #undef ESQ_EPI_CASES_0_8_
 #undef ESQ_EPI_CASES_9_12_

@@ -96,6 +96,20 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d_sweep(
     if (Epi::kReduce) esq::block_partial(local, epi.red.partials);
 }
 
+// pointwise part of the Brusselator for the two-stage marching sweep: centres
+// and five-point Laplacians of (u, v) -> (du, dv), same operation order as above
+struct BrussFn {
+    double d, A, B;
+    __device__ __forceinline__ void eval(const double2 (&c)[2], const double2 (&lap)[2],
+                                         double2 (&f)[2]) const {
+        const double uuvx = c[0].x * c[0].x * c[1].x, uuvy = c[0].y * c[0].y * c[1].y;
+        f[0].x = ((A + uuvx) - (B + 1.0) * c[0].x) + d * lap[0].x;
+        f[0].y = ((A + uuvy) - (B + 1.0) * c[0].y) + d * lap[0].y;
+        f[1].x = (B * c[0].x - uuvx) + d * lap[1].x;
+        f[1].y = (B * c[0].y - uuvy) + d * lap[1].y;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -167,6 +181,30 @@ int esq_rhs_bruss2d_fused(void *user, double t, const double *y_in, double *f,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
                               SrcPlain{y_in}, f, ep, r->N, d, r->a, r->b, g.grid,
                               g.wpr);
+    });
+    return rc ? rc : (int)hipGetLastError();
+}
+
+int esq_rhs_bruss2d_pair(void *user, double t_a, double t_b, const double *y_in,
+                         double *fa, double *fb, const esq_pair *pair, size_t n,
+                         void *stream, void *start_event, void *stop_event) {
+    (void)t_a; (void)t_b;
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != BRUSS2D || n != r->n || !pair) return ESQ_EINVAL;
+    if (r->N % 2 != 0 || r->N < 8) return ESQ_ENOTSUP;
+    const GeoPair g = geo_pair(r->N);
+    if (pair->kind_b == ESQ_EPI_SOLERR) {
+        if ((int)g.grid > pair->partials_cap) return ESQ_ENOTSUP;
+        if (pair->partials_used) *pair->partials_used = (int)g.grid;
+    }
+    const BrussFn fn{r->alpha * ((double)r->N * (double)r->N), r->a, r->b};
+    const int rc = esq::dispatch_pair(pair, [&](auto pa, auto kind) {
+        using PA = decltype(pa);
+        hipExtLaunchKernelGGL((esq::k_pair2d<2, true, PA::kNU, decltype(kind)::value, BrussFn>),
+                              dim3(g.grid), dim3(kBlock), 0, (hipStream_t)stream,
+                              (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in,
+                              fa, fb, pa, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
+                              (unsigned)kXcd);
     });
     return rc ? rc : (int)hipGetLastError();
 }

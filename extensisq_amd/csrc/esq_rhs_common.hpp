@@ -166,6 +166,32 @@ inline Geo2d geo2d(int N) {
     return g;
 }
 
+// ---- launch geometry of the two-stage marching sweeps (esq_pair.hpp): one wave
+// per tile of R rows x 62 column pairs; R balances the halo rows (2 per tile)
+// against the number of waves the chip needs in flight
+struct GeoPair {
+    int R;
+    unsigned tpr, ntiles, nblocks, grid;
+};
+inline GeoPair geo_pair(int N) {
+    GeoPair g;
+    g.tpr = ((unsigned)N / 2 + esq::kPairCols - 1) / esq::kPairCols;
+    const char *env = getenv("ESQ_PAIR_ROWS");          // tuning / tests
+    const int forced = env ? atoi(env) : 0;
+    int R = forced;
+    if (R <= 0) {
+        // about 8 waves per CU in one round: rows per tile = wave-rows / 2048
+        R = (int)(((size_t)N * g.tpr + 2047) / 2048);
+        if (R < 8) R = 8;
+        if (R > 64) R = 64;
+    }
+    g.R = R;
+    g.ntiles = g.tpr * (unsigned)((N + R - 1) / R);
+    g.nblocks = (g.ntiles + kBlock / 64 - 1) / (kBlock / 64);
+    g.grid = ((g.nblocks + kXcd - 1) / kXcd) * kXcd;
+    return g;
+}
+
 inline RkcEpi make_epi(const double *yjm2, const double *yn, const double *fn,
                        double mu, double nu, double omn, double hmus, double ajm1,
                        double *out) {

@@ -56,6 +56,16 @@ __global__ __launch_bounds__(kBlock) void k_heat2d_sweep(
     if (Epi::kReduce) esq::block_partial(local, epi.red.partials);
 }
 
+// pointwise part for the two-stage marching sweep: f = c * laplacian
+struct HeatFn {
+    double c;
+    __device__ __forceinline__ void eval(const double2 (&)[1], const double2 (&lap)[1],
+                                         double2 (&f)[1]) const {
+        f[0].x = c * lap[0].x;
+        f[0].y = c * lap[0].y;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -135,6 +145,30 @@ int esq_rhs_heat2d_rkc(void *user, double t, const double *yjm1, const double *y
                           make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out),
                           r->N, c, g.grid, g.wpr);
     return (int)hipGetLastError();
+}
+
+int esq_rhs_heat2d_pair(void *user, double t_a, double t_b, const double *y_in,
+                        double *fa, double *fb, const esq_pair *pair, size_t n,
+                        void *stream, void *start_event, void *stop_event) {
+    (void)t_a; (void)t_b;
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != HEAT2D || n != r->n || !pair) return ESQ_EINVAL;
+    if (r->N % 2 != 0 || r->N < 8) return ESQ_ENOTSUP;
+    const GeoPair g = geo_pair(r->N);
+    if (pair->kind_b == ESQ_EPI_SOLERR) {
+        if ((int)g.grid > pair->partials_cap) return ESQ_ENOTSUP;
+        if (pair->partials_used) *pair->partials_used = (int)g.grid;
+    }
+    const HeatFn fn{(double)(r->N + 1) * (double)(r->N + 1)};
+    const int rc = esq::dispatch_pair(pair, [&](auto pa, auto kind) {
+        using PA = decltype(pa);
+        hipExtLaunchKernelGGL((esq::k_pair2d<1, false, PA::kNU, decltype(kind)::value, HeatFn>),
+                              dim3(g.grid), dim3(kBlock), 0, (hipStream_t)stream,
+                              (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in,
+                              fa, fb, pa, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
+                              (unsigned)kXcd);
+    });
+    return rc ? rc : (int)hipGetLastError();
 }
 
 }  // extern "C"

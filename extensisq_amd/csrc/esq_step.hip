@@ -188,6 +188,91 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = fa
     if (r == 0) std::swap(c->ystage, c->work);   // double buffer
     return r;
 }
+// TWO stages in one marching sweep (esq_rhs_pair_fn, esq_pair.hpp): the RHS
+// sweeps of stages i and i + 1; the argument of stage i + 1 stays in registers.
+// what_b: 0 = B forms the argument of stage i + 2, 1 = y_new of an FSAL pair
+// (weights B), 2 = y_new + error partial sums (non-FSAL: weights B and E).
+// Returns 0, kNotApplicable / ESQ_ENOTSUP (caller goes on with single sweeps)
+// or an error.
+int sweep_pair(esq_ctx *c, int i, double t, double h, int what_b) {
+    const int s = c->s, nx = i + 1;
+    esq_pair e;
+    memset(&e, 0, sizeof(e));
+    e.kind_b = what_b == 2 ? ESQ_EPI_SOLERR : ESQ_EPI_STAGE;
+    // stage A's sum: the argument of stage i + 1
+    double ca[kMaxTerms + 2] = {0}, cb[kMaxTerms + 2] = {0}, eb[kMaxTerms + 2] = {0};
+    bool use[kMaxTerms + 2] = {false};
+    if (s > kMaxTerms + 2) return kNotApplicable;
+    int nnz_a = c->stage_nnz[nx], nnz_b = 0;
+    for (const Term &term : c->stage_terms[nx]) {
+        if (term.col == i) { e.ca_self = term.c; continue; }
+        ca[term.col] = term.c;
+        use[term.col] = true;
+    }
+    e.init_a = c->stage_init[nx] >= 0 ? c->krow[c->stage_init[nx]] : nullptr;
+    // stage B's sum(s)
+    if (what_b == 0) {
+        nnz_b = c->stage_nnz[nx + 1];
+        for (const Term &term : c->stage_terms[nx + 1]) {
+            if (term.col == nx) { e.cb_self = term.c; continue; }
+            if (term.col == i) { e.cb_prev = term.c; e.prev_in_b = 1; continue; }
+            cb[term.col] = term.c;
+            use[term.col] = true;
+        }
+        e.init_b = c->stage_init[nx + 1] >= 0 ? c->krow[c->stage_init[nx + 1]] : nullptr;
+    } else {
+        for (int j = 0; j < s; ++j) {
+            const double bj = c->B[j], ej = what_b == 2 ? c->E[j] : 0.0;
+            if (bj == 0.0 && ej == 0.0 && !(what_b == 2 && j == nx)) continue;
+            ++nnz_b;
+            if (j == nx) { e.cb_self = bj; e.eb_self = ej; continue; }
+            if (j == i) { e.cb_prev = bj; e.eb_prev = ej; e.prev_in_b = 1; continue; }
+            cb[j] = bj;
+            eb[j] = ej;
+            use[j] = true;
+        }
+    }
+    int nu = 0;
+    for (int j = 0; j < s; ++j) {
+        if (!use[j]) continue;
+        if (nu >= ESQ_PAIR_MAX_ROWS) return kNotApplicable;
+        e.rows[nu] = c->krow[c->kmap[j]];
+        e.ca[nu] = ca[j];
+        e.cb[nu] = cb[j];
+        e.eb[nu] = eb[j];
+        ++nu;
+    }
+    e.nu = nu;
+    e.y = c->y;
+    e.h = h;
+    e.out = what_b == 0 ? c->work : c->ynew;
+    e.store_fa = 1;
+    e.f_store_nt = c->epi_nt & 1;
+    e.atol_vec = c->atol_is_vec ? c->atolv : nullptr;
+    e.atol_s = c->atol_s;
+    e.rtol = c->rtol;
+    e.n_valid = c->n;
+    e.partials = c->partials;
+    e.partials_cap = kPartialsCap;
+    e.partials_used = &c->red_count;
+    // booked: what the two one-stage sweeps book; moved: ys, rows, y, inits in;
+    // K_i, K_{i+1}, out out
+    const double alg = what_b == 2
+        ? 8.0 * (nnz_a + 4) * (double)c->len + 8.0 * (nnz_b + 4) * (double)c->len
+        : 8.0 * (nnz_a + 4 + nnz_b + 4) * (double)c->len;
+    const double moved = 8.0 * (2 + nu + (e.init_a ? 1 : 0) + (e.init_b ? 1 : 0) + 3) *
+                         (double)c->len;
+    Prof p(c, ESQ_PROF_STAGE, what_b == 2 ? "pair+solerr" : "pair", nu, alg, false, moved);
+    c->self_valid = false;
+    const int r = c->rhs_pair(c->rhs_user, t + c->C[i] * h, t + c->C[nx] * h, c->ystage,
+                              c->krow[c->kmap[i]], c->krow[c->kmap[nx]], &e, c->len,
+                              (void *)c->stream, (void *)p.start(), (void *)p.stop());
+    if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
+    if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "pair RHS entry returned %d", r); }
+    if (what_b == 0) std::swap(c->ystage, c->work);
+    return 0;
+}
+
 bool may_use_src(const esq_ctx *c) {
     return c->src_pays && may_fuse(c, ESQ_EPI_STAGE) && (c->fuse_mask & ESQ_FUSE_SRC) &&
            !c->src_declined;
@@ -465,6 +550,11 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     c->ynew_ready = false;
     c->solerr_ready = false;
     bool block_done = false;   // the block at boundary i already ran in a sweep
+    // two-stage marching sweeps: ESQ_PAIR=0|1 (default: where the working set
+    // is beyond the Infinity Cache -- the halo rows cost more than the saved
+    // stage argument on small grids)
+    const bool pairs = c->rhs_pair && c->rhs_fused && !c->cplx &&
+                       (c->pair_mode == 1 || (c->pair_mode == 2 && !c->src_pays));
     for (int i = i_from; i < i_to; ++i) {
         if (i == 1 && !ready && i + 1 < i_to && may_use_src(c)) {
             // the first sweep forms its own input from y and K[0]: no stage-1
@@ -501,6 +591,29 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
         const esq_ctx::Block *bnext = nullptr;
         for (const auto &b : c->blocks)
             if (b.J == i + 1) bnext = &b;
+        if (pairs && i + 1 < i_to && !bnext) {
+            // stages i and i + 1 in ONE marching sweep: stage i + 1's argument
+            // stays in registers
+            bool b2 = false;
+            for (const auto &b : c->blocks) b2 |= (b.J == i + 2);
+            int what = -1;
+            if (i + 1 == c->s - 1 && i_to == c->s)
+                what = c->fsal ? (may_fuse(c, ESQ_EPI_STAGE) ? 1 : -1)
+                               : (may_fuse(c, ESQ_EPI_SOLERR) && !c->cplx ? 2 : -1);
+            else if (i + 2 < i_to && !b2 && may_fuse(c, ESQ_EPI_STAGE))
+                what = 0;
+            if (what >= 0) {
+                const int r = sweep_pair(c, i, t, h, what);
+                if (r == 0) {
+                    ++i;                               // stage i + 1 is done too
+                    ready = what == 0;
+                    if (what >= 1) c->ynew_ready = true;
+                    if (what == 2) c->solerr_ready = true;
+                    continue;
+                }
+                if (r != ESQ_ENOTSUP && r != kNotApplicable) return r;
+            }
+        }
         if (i + 1 < i_to && !bnext && may_fuse(c, ESQ_EPI_STAGE)) {
             // this stage's RHS sweep also forms the NEXT stage's argument
             const int r = sweep_next_stage(c, i, t, h);
