@@ -47,7 +47,7 @@ SIGNATURES = {
     "esq_set_rhs": (C.c_int, [_vp, _vp, _vp]),
     "esq_set_rhs_fused": (C.c_int, [_vp, _vp, C.c_int]),
     "esq_set_rhs_rkc": (C.c_int, [_vp, _vp]),
-    "esq_set_rhs_pair": (C.c_int, [_vp, _vp]),
+    "esq_set_rhs_chain": (C.c_int, [_vp, _vp]),
     "esq_rk_stage_accumulate": (C.c_int, [_vp, C.c_int, C.c_double]),
     "esq_rk_block_plan": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -117,8 +117,8 @@ SIGNATURES = {
     "esq_rhs_diff3d_rkc": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp] + [C.c_double] * 5 + [_vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_bruss2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_heat2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
-    "esq_rhs_bruss2d_pair": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
-    "esq_rhs_heat2d_pair": (C.c_int, [_vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_bruss2d_chain": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_heat2d_chain": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_diff3d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_diag_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_cdiag_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),

@@ -448,7 +448,8 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     c->comm_timeout_s = (double)env_uint("ESQ_COMM_TIMEOUT_S", 120);
     c->epi_nt = env_uint("ESQ_EPI_NT", 0x3);
     c->skip_dead = env_uint("ESQ_DEAD_STORE", 1) != 0;
-    c->pair_mode = (int)env_uint("ESQ_PAIR", 2);
+    c->chain_depth = (int)env_uint("ESQ_CHAIN_DEPTH", 4);
+    if (c->chain_depth > ESQ_CHAIN_MAX_DEPTH) c->chain_depth = ESQ_CHAIN_MAX_DEPTH;
     // launch geometry: grid-stride kernels, a few resident blocks per CU
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
@@ -558,14 +559,15 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     c->rhs_fused = nullptr;
     c->fuse_mask = 0;
     c->rhs_rkc = nullptr;
-    c->rhs_pair = nullptr;
+    c->rhs_chain = nullptr;
     return 0;
 }
-int esq_set_rhs_pair(esq_ctx *c, esq_rhs_pair_fn fn) {
+int esq_set_rhs_chain(esq_ctx *c, esq_rhs_chain_fn fn) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
-    c->rhs_pair = fn;
-    return 0;
+    c->rhs_chain = fn;
+    // the blocked-accumulation plan depends on how the plugin sweeps
+    return c->have_tab ? esq_replan(c) : 0;
 }
 int esq_set_rhs_rkc(esq_ctx *c, esq_rhs_rkc_fn fn) {
     if (!c) return ESQ_EINVAL;

@@ -108,8 +108,8 @@ struct esq_ctx {
     bool src_declined = false;              // the PLUGIN returned ENOTSUP for ESQ_FUSE_SRC
     bool src_pays = false;                  // working set inside the Infinity Cache
     esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
-    esq_rhs_pair_fn rhs_pair = nullptr;     // optional two-stage marching sweep
-    int pair_mode = 2;                      // ESQ_PAIR: 0 off, 1 on, 2 by working-set size
+    esq_rhs_chain_fn rhs_chain = nullptr;   // optional multi-stage marching sweep
+    int chain_depth = 4;                    // ESQ_CHAIN_DEPTH: 1 off, up to 4 stages per sweep
     bool ynew_ready = false;     // YNEW already formed by the last stage's sweep
     bool solerr_ready = false;   // ... and the error partial sums too
     int red_count = 0;           // partials written by the last reducing sweep
@@ -265,3 +265,6 @@ constexpr int kNcclMin = 3;       // ncclMin
 void abort_comm(esq_ctx *c);
 
 }  // namespace esqi
+
+// internal (not in the public header): rebuild the blocked-accumulation plan
+extern "C" int esq_replan(esq_ctx *c);

@@ -34,7 +34,7 @@
 
 #include "../../include/extensisq_amd.h"
 #include "esq_epilogue.hpp"
-#include "esq_pair.hpp"
+#include "esq_chain.hpp"
 
 namespace esq {
 
@@ -196,51 +196,72 @@ int dispatch_epilogue(const esq_epilogue *epi, Launch &&launch) {
     }
 }
 
-// ---- pair entry (esq_rhs_pair_fn): esq_pair -> PairArgs<NU>
-template <int NU>
-PairArgs<NU> make_pair_args(const esq_pair *e) {
-    PairArgs<NU> a;
-    a.b_mask = 0;
-    for (int j = 0; j < (NU > 0 ? NU : 1); ++j) {
-        const bool on = j < NU && j < e->nu;
-        a.rows[j] = on ? e->rows[j] : nullptr;
-        a.ca[j] = on ? e->ca[j] : 0.0;
-        a.cb[j] = on ? e->cb[j] : 0.0;
-        a.eb[j] = on ? e->eb[j] : 0.0;
-        if (on && (e->cb[j] != 0.0 ||
-                   (e->kind_b == ESQ_EPI_SOLERR && e->eb[j] != 0.0)))
-            a.b_mask |= 1u << j;
+// ---- chain entry (esq_rhs_chain_fn): esq_chain -> ChainArgs<D, NU>
+template <int D, int NU>
+ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
+    ChainArgs<D, NU> a;
+    for (int j = 0; j < ChainArgs<D, NU>::NUa; ++j) {
+        const bool on = j < NU && j < c->nu;
+        a.rows[j] = on ? c->rows[j] : nullptr;
+        a.eu[j] = on ? c->eu[j] : 0.0;
+        for (int e = 0; e < D; ++e) a.cu[e][j] = on ? c->cu[e][j] : 0.0;
     }
-    a.prev_in_b = e->prev_in_b;
-    a.init_a = e->init_a; a.init_b = e->init_b; a.y = e->y;
-    a.ca_self = e->ca_self; a.cb_prev = e->cb_prev; a.cb_self = e->cb_self;
-    a.eb_prev = e->eb_prev; a.eb_self = e->eb_self; a.h = e->h;
-    a.out = e->out;
-    a.store_fa = e->store_fa; a.f_nt = e->f_store_nt;
-    a.red.atol_vec = e->atol_vec; a.red.atol_s = e->atol_s; a.red.rtol = e->rtol;
-    a.red.n_valid = e->n_valid; a.red.partials = e->partials;
+    for (int e = 0; e < D; ++e) {
+        a.umask[e] = c->umask[e];
+        a.kmask[e] = c->kmask[e];
+        a.ek[e] = c->ek[e];
+        a.init[e] = c->init[e];
+        a.fk[e] = c->f_out[e];
+        for (int k = 0; k < D; ++k) a.ck[e][k] = c->ck[e][k];
+    }
+    a.y = c->y; a.h = c->h; a.out = c->out; a.f_nt = c->f_store_nt;
+    a.red.atol_vec = c->atol_vec; a.red.atol_s = c->atol_s; a.red.rtol = c->rtol;
+    a.red.n_valid = c->n_valid; a.red.partials = c->partials;
     return a;
 }
-// (kind_b, nu) -> launch(PairArgs<NU>, integral_constant<kind_b>)
+// (depth, kind_last, nu) -> launch(ChainArgs<D, NU>, integral_constant<kind_last>).
+// Instantiated: depth 2 and 3 with up to 9 memory rows, depth 4 with up to 6.
 template <class Launch>
-int dispatch_pair(const esq_pair *e, Launch &&launch) {
-    if (!e || e->nu < 0 || !e->y || !e->out) return ESQ_EINVAL;
-    if (e->kind_b == ESQ_EPI_SOLERR && !e->partials) return ESQ_EINVAL;
-    if (e->kind_b != ESQ_EPI_STAGE && e->kind_b != ESQ_EPI_SOLERR) return ESQ_ENOTSUP;
-#define ESQ_PAIR_CASE_(K)                                                          \
+int dispatch_chain(const esq_chain *c, Launch &&launch) {
+    if (!c || c->nu < 0 || !c->out) return ESQ_EINVAL;
+    if (c->kind_last == ESQ_EPI_SOLERR && (!c->partials || !c->y)) return ESQ_EINVAL;
+    if (c->kind_last != ESQ_EPI_STAGE && c->kind_last != ESQ_EPI_SOLERR)
+        return ESQ_ENOTSUP;
+#define ESQ_CHAIN_CASE_(DD, K)                                                     \
     case K:                                                                        \
-        if (e->kind_b == ESQ_EPI_STAGE)                                            \
-            launch(make_pair_args<K>(e), std::integral_constant<int, ESQ_EPI_STAGE>{}); \
+        if (c->kind_last == ESQ_EPI_STAGE)                                         \
+            launch(make_chain_args<DD, K>(c),                                      \
+                   std::integral_constant<int, ESQ_EPI_STAGE>{});                  \
         else                                                                       \
-            launch(make_pair_args<K>(e), std::integral_constant<int, ESQ_EPI_SOLERR>{}); \
+            launch(make_chain_args<DD, K>(c),                                      \
+                   std::integral_constant<int, ESQ_EPI_SOLERR>{});                 \
         return 0;
-    switch (e->nu) {
-        ESQ_PAIR_CASE_(0) ESQ_PAIR_CASE_(1) ESQ_PAIR_CASE_(2) ESQ_PAIR_CASE_(3)
-        ESQ_PAIR_CASE_(4) ESQ_PAIR_CASE_(5) ESQ_PAIR_CASE_(6) ESQ_PAIR_CASE_(7)
-        ESQ_PAIR_CASE_(8)
+#define ESQ_CHAIN_CASES_0_6_(DD)                                                   \
+    ESQ_CHAIN_CASE_(DD, 0) ESQ_CHAIN_CASE_(DD, 1) ESQ_CHAIN_CASE_(DD, 2)           \
+    ESQ_CHAIN_CASE_(DD, 3) ESQ_CHAIN_CASE_(DD, 4) ESQ_CHAIN_CASE_(DD, 5)           \
+    ESQ_CHAIN_CASE_(DD, 6)
+    switch (c->depth) {
+        case 2:
+            switch (c->nu) {
+                ESQ_CHAIN_CASES_0_6_(2) ESQ_CHAIN_CASE_(2, 7) ESQ_CHAIN_CASE_(2, 8)
+                ESQ_CHAIN_CASE_(2, 9)
+                default: return ESQ_ENOTSUP;
+            }
+        case 3:
+            switch (c->nu) {
+                ESQ_CHAIN_CASES_0_6_(3) ESQ_CHAIN_CASE_(3, 7) ESQ_CHAIN_CASE_(3, 8)
+                ESQ_CHAIN_CASE_(3, 9)
+                default: return ESQ_ENOTSUP;
+            }
+        case 4:
+            switch (c->nu) {
+                ESQ_CHAIN_CASES_0_6_(4)
+                default: return ESQ_ENOTSUP;
+            }
         default: return ESQ_ENOTSUP;
     }
-#undef ESQ_PAIR_CASE_
+#undef ESQ_CHAIN_CASE_
+#undef ESQ_CHAIN_CASES_0_6_
 }
 
 #undef ESQ_EPI_CASE_

@@ -166,25 +166,55 @@ inline Geo2d geo2d(int N) {
     return g;
 }
 
-// ---- launch geometry of the two-stage marching sweeps (esq_pair.hpp): one wave
-// per tile of R rows x 62 column pairs; R balances the halo rows (2 per tile)
-// against the number of waves the chip needs in flight
-struct GeoPair {
+// ---- launch geometry of the marching chain sweeps (esq_chain.hpp): one wave per
+// tile of R rows x (64 - 2(D-1)) column pairs.  R balances the halo rows
+// (2(D-1) per tile) against keeping every wave slot of the chip busy: the tile
+// count is made a multiple of the resident waves (256 CUs x waves per CU from
+// the occupancy query), so that the launch runs as whole rounds.
+struct GeoChain {
     int R;
     unsigned tpr, ntiles, nblocks, grid;
 };
-inline GeoPair geo_pair(int N) {
-    GeoPair g;
-    g.tpr = ((unsigned)N / 2 + esq::kPairCols - 1) / esq::kPairCols;
-    const char *env = getenv("ESQ_PAIR_ROWS");          // tuning / tests
-    const int forced = env ? atoi(env) : 0;
-    int R = forced;
+template <class Kernel>
+inline int chain_waves_per_cu(Kernel kern) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, kBlock, 0) != hipSuccess ||
+        blocks < 1)
+        blocks = 2;
+    if (blocks > 8) blocks = 8;
+    return blocks * (kBlock / 64);
+}
+// a chain of depth D carries 2(D-1) halo rows per tile: it pays only where the
+// grid gives every wave slot a tile of at least ~8(D-1) rows (measured: Ts5 at
+// N = 1000 gains with depth 2 and loses with depth 4); ESQ_CHAIN_ROWS (tests)
+// lifts the rule
+inline bool chain_fits_grid(int N, int depth) {
+    if (getenv("ESQ_CHAIN_ROWS")) return true;
+    const int W = 64 - 2 * (depth - 1);
+    const size_t tpr = ((size_t)N / 2 + W - 1) / W;
+    return (size_t)N * tpr >= (size_t)8192 * (depth - 1);
+}
+inline GeoChain geo_chain(int N, int depth, int waves_per_cu) {
+    GeoChain g;
+    const int W = 64 - 2 * (depth - 1);
+    g.tpr = ((unsigned)N / 2 + W - 1) / W;
+    const char *env = getenv("ESQ_CHAIN_ROWS");           // tuning / tests
+    int R = env ? atoi(env) : 0;
     if (R <= 0) {
-        // about 8 waves per CU in one round: rows per tile = wave-rows / 2048
-        R = (int)(((size_t)N * g.tpr + 2047) / 2048);
-        if (R < 8) R = 8;
-        if (R > 64) R = 64;
+        // rounds of resident waves: pick the fewest rounds whose tiles are at
+        // least 8 * depth rows high (halo overhead <= 25 %), then the tile height
+        // that fills those rounds
+        const size_t slots = (size_t)256 * (size_t)waves_per_cu;
+        const size_t wave_rows = (size_t)N * g.tpr;
+        size_t rounds = 1;
+        R = (int)((wave_rows + slots * rounds - 1) / (slots * rounds));
+        while (R > 48) {
+            ++rounds;
+            R = (int)((wave_rows + slots * rounds - 1) / (slots * rounds));
+        }
+        if (R < 4 * depth) R = 4 * depth;
     }
+    if (R > N) R = N;
     g.R = R;
     g.ntiles = g.tpr * (unsigned)((N + R - 1) / R);
     g.nblocks = (g.ntiles + kBlock / 64 - 1) / (kBlock / 64);

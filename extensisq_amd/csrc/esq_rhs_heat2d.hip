@@ -147,28 +147,31 @@ int esq_rhs_heat2d_rkc(void *user, double t, const double *yjm1, const double *y
     return (int)hipGetLastError();
 }
 
-int esq_rhs_heat2d_pair(void *user, double t_a, double t_b, const double *y_in,
-                        double *fa, double *fb, const esq_pair *pair, size_t n,
-                        void *stream, void *start_event, void *stop_event) {
-    (void)t_a; (void)t_b;
+int esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
+                          size_t n, void *stream, void *start_event,
+                          void *stop_event) {
     Rhs *r = (Rhs *)user;
-    if (!r || r->kind != HEAT2D || n != r->n || !pair) return ESQ_EINVAL;
-    if (r->N % 2 != 0 || r->N < 8) return ESQ_ENOTSUP;
-    const GeoPair g = geo_pair(r->N);
-    if (pair->kind_b == ESQ_EPI_SOLERR) {
-        if ((int)g.grid > pair->partials_cap) return ESQ_ENOTSUP;
-        if (pair->partials_used) *pair->partials_used = (int)g.grid;
-    }
+    if (!r || r->kind != HEAT2D || n != r->n || !chain) return ESQ_EINVAL;
+    if (r->N % 2 != 0 || r->N < 16) return ESQ_ENOTSUP;
+    if (!chain_fits_grid(r->N, chain->depth)) return ESQ_ENOTSUP;
     const HeatFn fn{(double)(r->N + 1) * (double)(r->N + 1)};
-    const int rc = esq::dispatch_pair(pair, [&](auto pa, auto kind) {
-        using PA = decltype(pa);
-        hipExtLaunchKernelGGL((esq::k_pair2d<1, false, PA::kNU, decltype(kind)::value, HeatFn>),
-                              dim3(g.grid), dim3(kBlock), 0, (hipStream_t)stream,
+    int rc_launch = 0;
+    const int rc = esq::dispatch_chain(chain, [&](auto ca, auto kind) {
+        using CA = decltype(ca);
+        auto kern = esq::k_chain2d<1, false, CA::kD, CA::kNU, decltype(kind)::value, HeatFn>;
+        static const int wpc = chain_waves_per_cu(kern);    // per instantiation
+        const GeoChain g = geo_chain(r->N, CA::kD, wpc);
+        if (decltype(kind)::value == ESQ_EPI_SOLERR) {
+            if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
+            if (chain->partials_used) *chain->partials_used = (int)g.grid;
+        }
+        hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(kBlock), 0, (hipStream_t)stream,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in,
-                              fa, fb, pa, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
+                              ca, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
                               (unsigned)kXcd);
     });
-    return rc ? rc : (int)hipGetLastError();
+    if (rc) return rc;
+    return rc_launch ? rc_launch : (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -188,65 +188,86 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = fa
     if (r == 0) std::swap(c->ystage, c->work);   // double buffer
     return r;
 }
-// TWO stages in one marching sweep (esq_rhs_pair_fn, esq_pair.hpp): the RHS
-// sweeps of stages i and i + 1; the argument of stage i + 1 stays in registers.
-// what_b: 0 = B forms the argument of stage i + 2, 1 = y_new of an FSAL pair
-// (weights B), 2 = y_new + error partial sums (non-FSAL: weights B and E).
-// Returns 0, kNotApplicable / ESQ_ENOTSUP (caller goes on with single sweeps)
-// or an error.
-int sweep_pair(esq_ctx *c, int i, double t, double h, int what_b) {
-    const int s = c->s, nx = i + 1;
-    esq_pair e;
+// `depth` stages in one marching sweep (esq_rhs_chain_fn, esq_chain.hpp): the RHS
+// sweeps of stages i .. i + depth - 1; the arguments of the later stages stay in
+// registers.  what_last: 0 = the last target is the argument of stage i + depth,
+// 1 = y_new of an FSAL pair (weights B), 2 = y_new + error partial sums
+// (non-FSAL: weights B and E).  Returns 0, kNotApplicable / ESQ_ENOTSUP (the
+// caller tries a shorter chain or single sweeps) or an error.
+int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last) {
+    const int s = c->s;
+    if (depth < 2 || depth > ESQ_CHAIN_MAX_DEPTH || s > 62) return kNotApplicable;
+    esq_chain e;
     memset(&e, 0, sizeof(e));
-    e.kind_b = what_b == 2 ? ESQ_EPI_SOLERR : ESQ_EPI_STAGE;
-    // stage A's sum: the argument of stage i + 1
-    double ca[kMaxTerms + 2] = {0}, cb[kMaxTerms + 2] = {0}, eb[kMaxTerms + 2] = {0};
-    bool use[kMaxTerms + 2] = {false};
-    if (s > kMaxTerms + 2) return kNotApplicable;
-    int nnz_a = c->stage_nnz[nx], nnz_b = 0;
-    for (const Term &term : c->stage_terms[nx]) {
-        if (term.col == i) { e.ca_self = term.c; continue; }
-        ca[term.col] = term.c;
-        use[term.col] = true;
+    e.depth = depth;
+    e.kind_last = what_last == 2 ? ESQ_EPI_SOLERR : ESQ_EPI_STAGE;
+    // per target: weights by COLUMN first (memory rows and chain members alike)
+    double cw[ESQ_CHAIN_MAX_DEPTH][64] = {{0}}, ew[64] = {0};
+    bool part[ESQ_CHAIN_MAX_DEPTH][64] = {{false}};
+    bool use[64] = {false};
+    double alg = 0.0;
+    int n_init = 0;
+    for (int q = 0; q < depth; ++q) {            // target q + 1
+        const int stage = i + q + 1;             // the stage this target feeds
+        if (q + 1 < depth || what_last == 0) {
+            for (const Term &term : c->stage_terms[stage]) {
+                cw[q][term.col] = term.c;
+                part[q][term.col] = true;
+            }
+            if (c->stage_init[stage] >= 0) {
+                e.init[q] = c->krow[c->stage_init[stage]];
+                ++n_init;
+            }
+            alg += 8.0 * (c->stage_nnz[stage] + 4) * (double)c->len;
+        } else {
+            int nz = 0;
+            for (int j = 0; j < s; ++j) {
+                const double bj = c->B[j], ej = what_last == 2 ? c->E[j] : 0.0;
+                // the fresh last row is always part of the solution/error sums
+                // (a zero weight contributes fma(0, v, s), as in EpiSolErr)
+                const bool self = what_last == 2 && j == s - 1;
+                if (bj == 0.0 && ej == 0.0 && !self) continue;
+                cw[q][j] = bj;
+                ew[j] = ej;
+                part[q][j] = true;
+                ++nz;
+            }
+            alg += 8.0 * (nz + 4) * (double)c->len;
+        }
     }
-    e.init_a = c->stage_init[nx] >= 0 ? c->krow[c->stage_init[nx]] : nullptr;
-    // stage B's sum(s)
-    if (what_b == 0) {
-        nnz_b = c->stage_nnz[nx + 1];
-        for (const Term &term : c->stage_terms[nx + 1]) {
-            if (term.col == nx) { e.cb_self = term.c; continue; }
-            if (term.col == i) { e.cb_prev = term.c; e.prev_in_b = 1; continue; }
-            cb[term.col] = term.c;
-            use[term.col] = true;
+    // columns i .. i + depth - 1 are the chain's own derivatives
+    for (int q = 0; q < depth; ++q) {
+        for (int k = 0; k < depth; ++k) {
+            const int col = i + k;
+            if (!part[q][col]) continue;
+            if (k > q) return kNotApplicable;    // cannot happen for an explicit method
+            e.ck[q][k] = cw[q][col];
+            e.kmask[q] |= 1u << k;
+            if (q == depth - 1) e.ek[k] = ew[col];
         }
-        e.init_b = c->stage_init[nx + 1] >= 0 ? c->krow[c->stage_init[nx + 1]] : nullptr;
-    } else {
-        for (int j = 0; j < s; ++j) {
-            const double bj = c->B[j], ej = what_b == 2 ? c->E[j] : 0.0;
-            if (bj == 0.0 && ej == 0.0 && !(what_b == 2 && j == nx)) continue;
-            ++nnz_b;
-            if (j == nx) { e.cb_self = bj; e.eb_self = ej; continue; }
-            if (j == i) { e.cb_prev = bj; e.eb_prev = ej; e.prev_in_b = 1; continue; }
-            cb[j] = bj;
-            eb[j] = ej;
-            use[j] = true;
-        }
+        for (int j = 0; j < s; ++j)
+            if (part[q][j] && (j < i || j >= i + depth)) use[j] = true;
     }
     int nu = 0;
     for (int j = 0; j < s; ++j) {
         if (!use[j]) continue;
-        if (nu >= ESQ_PAIR_MAX_ROWS) return kNotApplicable;
+        if (nu >= ESQ_CHAIN_MAX_ROWS) return kNotApplicable;
         e.rows[nu] = c->krow[c->kmap[j]];
-        e.ca[nu] = ca[j];
-        e.cb[nu] = cb[j];
-        e.eb[nu] = eb[j];
+        for (int q = 0; q < depth; ++q) {
+            e.cu[q][nu] = cw[q][j];
+            if (part[q][j]) e.umask[q] |= 1u << nu;
+        }
+        e.eu[nu] = ew[j];
         ++nu;
     }
     e.nu = nu;
     e.y = c->y;
     e.h = h;
-    e.out = what_b == 0 ? c->work : c->ynew;
-    e.store_fa = 1;
+    for (int k = 0; k < depth; ++k) {
+        e.t[k] = t + c->C[i + k] * h;
+        e.f_out[k] = c->krow[c->kmap[i + k]];
+    }
+    e.out = what_last == 0 ? c->work : c->ynew;
     e.f_store_nt = c->epi_nt & 1;
     e.atol_vec = c->atol_is_vec ? c->atolv : nullptr;
     e.atol_s = c->atol_s;
@@ -255,21 +276,18 @@ int sweep_pair(esq_ctx *c, int i, double t, double h, int what_b) {
     e.partials = c->partials;
     e.partials_cap = kPartialsCap;
     e.partials_used = &c->red_count;
-    // booked: what the two one-stage sweeps book; moved: ys, rows, y, inits in;
-    // K_i, K_{i+1}, out out
-    const double alg = what_b == 2
-        ? 8.0 * (nnz_a + 4) * (double)c->len + 8.0 * (nnz_b + 4) * (double)c->len
-        : 8.0 * (nnz_a + 4 + nnz_b + 4) * (double)c->len;
-    const double moved = 8.0 * (2 + nu + (e.init_a ? 1 : 0) + (e.init_b ? 1 : 0) + 3) *
-                         (double)c->len;
-    Prof p(c, ESQ_PROF_STAGE, what_b == 2 ? "pair+solerr" : "pair", nu, alg, false, moved);
+    // booked: what the one-stage sweeps book; moved: input, y, rows, inits in;
+    // the chain's K rows and the last target out
+    const double moved = 8.0 * (2 + nu + n_init + depth + 1) * (double)c->len;
+    char label[24];
+    snprintf(label, sizeof(label), "chain%d%s", depth, what_last == 2 ? "+solerr" : "");
+    Prof p(c, ESQ_PROF_STAGE, label, nu, alg, false, moved);
     c->self_valid = false;
-    const int r = c->rhs_pair(c->rhs_user, t + c->C[i] * h, t + c->C[nx] * h, c->ystage,
-                              c->krow[c->kmap[i]], c->krow[c->kmap[nx]], &e, c->len,
-                              (void *)c->stream, (void *)p.start(), (void *)p.stop());
+    const int r = c->rhs_chain(c->rhs_user, c->ystage, &e, c->len, (void *)c->stream,
+                               (void *)p.start(), (void *)p.stop());
     if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
-    if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "pair RHS entry returned %d", r); }
-    if (what_b == 0) std::swap(c->ystage, c->work);
+    if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "chain RHS entry returned %d", r); }
+    if (what_last == 0) std::swap(c->ystage, c->work);
     return 0;
 }
 
@@ -376,66 +394,149 @@ int sweep_solerr(esq_ctx *c, int i, double t, double h) {
     return run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
 }
 
+// ---- cost of a plan in memory-side request units (one read word = 1, one
+// written word = 2: profiles/r02_experiments.md) when the RHS plugin runs
+// marching chain sweeps (esq_chain.hpp).  Mirrors the decomposition
+// esq_rk_stages makes: the longest chain that crosses no boundary, else the
+// block / stage / solution-error sweep.  Read words of a chain carry its halo
+// factor; wide chains (many memory rows) run below the request-rate ceiling.
+double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
+    const int s = c->s, depth = c->chain_depth;
+    const std::vector<double> &A = c->A;
+    auto nz = [&](int i, int j) { return A[(size_t)i * s + j] != 0.0; };
+    static const double kHalo[5] = {1.0, 1.0, 1.10, 1.20, 1.31};
+    std::vector<int> from(s, 0);
+    std::vector<char> has_init(s, 0), cur(s, 0);
+    struct Blk { int J, nt, no, ninit; std::vector<int> cols; };
+    std::vector<Blk> blocks;
+    int prev = 0;
+    for (int J : bounds) {
+        Blk b{J, 0, 0, 0, {}};
+        std::vector<char> col(s, 0);
+        for (int i = J; i < s; ++i) {
+            bool any = false;
+            for (int j = prev; j < J; ++j)
+                if (nz(i, j)) { any = true; col[j] = 1; }
+            if (any) { ++b.no; b.ninit += cur[i]; cur[i] = 1; }
+        }
+        for (int j = prev; j < J; ++j)
+            if (col[j]) b.cols.push_back(j);
+        // more than 8 rows besides the fresh column: the block epilogue is not
+        // instantiated, the boundary would cost an unfused RHS + block kernel
+        if (b.no == 0 || b.no > kMaxOut || (int)b.cols.size() > 9) return -1.0;
+        blocks.push_back(b);
+        prev = J;
+    }
+    for (int i = 1; i < s; ++i) {
+        int last = 0;
+        for (int J : bounds)
+            if (J <= i) last = J;
+        if (cur[i] && last > 0) { from[i] = last; has_init[i] = 1; }
+    }
+    auto rows_of = [&](int stage, int below, std::vector<char> &u) {
+        for (int j = from[stage]; j < stage && j < below; ++j)
+            if (nz(stage, j)) u[j] = 1;
+    };
+    double total = c->fsal ? 0.0 : 5.0;           // end-point sweep: 1 read, 2 writes
+    int i = 1;
+    while (i < s) {
+        const Blk *bnext = nullptr;
+        for (const auto &b : blocks)
+            if (b.J == i + 1) bnext = &b;
+        bool done = false;
+        if (!bnext) {
+            for (int D = depth; D >= 2 && !done; --D) {
+                if (i + D > s) continue;
+                bool crosses = false;
+                for (const auto &b : blocks) crosses |= (b.J > i && b.J <= i + D);
+                if (crosses) continue;
+                const bool last_sol = i + D == s;
+                std::vector<char> u(s, 0);
+                int ninit = 0;
+                for (int q = 0; q < D; ++q) {
+                    const int st = i + q + 1;
+                    if (q + 1 < D || !last_sol) {
+                        rows_of(st, i, u);
+                        ninit += has_init[st];
+                    } else {
+                        for (int j = 0; j < i; ++j)
+                            if (c->B[j] != 0.0 || (!c->fsal && c->E[j] != 0.0)) u[j] = 1;
+                    }
+                }
+                int nu = 0;
+                for (int j = 0; j < s; ++j) nu += u[j];
+                // what the built-in two-field plugin accepts (register budget)
+                if (nu > 9 || (D == 3 && last_sol && nu > 5) ||
+                    (D == 4 && (last_sol || nu > 2)))
+                    continue;
+                double units = (2 + nu + ninit) * kHalo[D] + 2.0 * (D + 1);
+                if (nu > 6) units *= 1.12;
+                total += units;
+                i += D;
+                done = true;
+            }
+        }
+        if (done) continue;
+        if (bnext) {
+            int nt = 0;
+            for (int col : bnext->cols) nt += col != i;
+            total += (2 + nt + bnext->ninit) + 2.0 * (1 + bnext->no);
+        } else if (i == s - 1) {
+            int nu = 0;
+            for (int j = 0; j < s; ++j)
+                nu += j != i && (c->B[j] != 0.0 || (!c->fsal && c->E[j] != 0.0));
+            total += 2 + nu + 4;
+        } else {
+            int nu = 0;
+            for (int j = from[i + 1]; j < i; ++j) nu += nz(i + 1, j);
+            total += 2 + nu + has_init[i + 1] + 4;
+        }
+        ++i;
+    }
+    return total;
+}
+
 }  // namespace
 
 extern "C" {
 
-int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
-                       const double *C, const double *E, int fsal) {
-    if (!c || !A || !B || !C || !E || s < 1) return ESQ_EINVAL;
-    ENTER(c);
-    if (s + 1 > c->n_rows)
-        return fail(c, ESQ_EINVAL, "tableau needs %d rows, context has %d", s + 1,
-                    c->n_rows);
-    for (int i = 0; i < s; ++i) {
-        int nz = 0;
-        for (int j = 0; j < s; ++j) {
-            if (j >= i && A[i * s + j] != 0.0)
-                return fail(c, ESQ_EINVAL, "A must be strictly lower triangular");
-            nz += A[i * s + j] != 0.0;
-        }
-        if (nz > kMaxTerms)
-            return fail(c, ESQ_EINVAL, "row %d of A has %d > %d nonzeros", i, nz, kMaxTerms);
-    }
-    {
-        // the solution / error kernels read the union of the supports of B and E
-        int nz = 0;
-        for (int j = 0; j < s; ++j) nz += (B[j] != 0.0 || E[j] != 0.0);
-        if (nz + (E[s] != 0.0) > kMaxTerms)
-            return fail(c, ESQ_EINVAL, "B and E together have %d > %d nonzero weights",
-                        nz + (E[s] != 0.0), kMaxTerms);
-    }
-    c->s = s;
-    c->fsal = fsal ? 1 : 0;
-    c->A.assign(A, A + (size_t)s * s);
-    c->B.assign(B, B + s);
-    c->C.assign(C, C + s);
-    c->E.assign(E, E + s + 1);
-    c->have_tab = true;
+// (re)build the blocked-accumulation plan and the per-stage term lists for the
+// current tableau: called by esq_rk_set_tableau and again when a chain entry is
+// registered (the cost model depends on how the plugin sweeps)
+int esq_replan(esq_ctx *c) {
+    if (!c || !c->have_tab) return ESQ_EINVAL;
+    const int s = c->s;
+    const bool chained = c->rhs_chain && c->chain_depth >= 2 &&
+                         env_uint("ESQ_PLAN_CHAINED", 1) != 0;
+    auto cost = [&](const std::vector<int> &bounds) -> double {
+        if (chained) return plan_units_chained(c, bounds);
+        return (double)plan_words(c->A, s, bounds, nullptr);
+    };
     // ---- blocked accumulation plan (up to 3 column boundaries, exhaustive)
     c->blocks.clear();
     c->stage_init.assign(s, -1);
     c->stage_from.assign(s, 0);
     if (env_uint("ESQ_BLOCK_ACC", 1) != 0 && s >= 4) {
         std::vector<int> best;
-        int best_words = plan_words(c->A, s, best, nullptr);
+        double best_words = cost(best);
         // fewest boundaries first: a plan with more boundaries must be strictly
         // better (every boundary is one more launch)
         for (int b1 = 2; b1 < s; ++b1) {
-            const int w = plan_words(c->A, s, {b1}, nullptr);
+            const double w = cost({b1});
             if (w >= 0 && w < best_words) { best_words = w; best = {b1}; }
         }
         for (int b1 = 2; b1 < s; ++b1)
             for (int b2 = b1 + 1; b2 < s; ++b2) {
-                const int w = plan_words(c->A, s, {b1, b2}, nullptr);
+                const double w = cost({b1, b2});
                 if (w >= 0 && w < best_words) { best_words = w; best = {b1, b2}; }
             }
-        for (int b1 = 2; b1 < s; ++b1)
-            for (int b2 = b1 + 1; b2 < s; ++b2)
-                for (int b3 = b2 + 1; b3 < s; ++b3) {
-                    const int w = plan_words(c->A, s, {b1, b2, b3}, nullptr);
-                    if (w >= 0 && w < best_words) { best_words = w; best = {b1, b2, b3}; }
-                }
+        if (!chained)
+            for (int b1 = 2; b1 < s; ++b1)
+                for (int b2 = b1 + 1; b2 < s; ++b2)
+                    for (int b3 = b2 + 1; b3 < s; ++b3) {
+                        const double w = cost({b1, b2, b3});
+                        if (w >= 0 && w < best_words) { best_words = w; best = {b1, b2, b3}; }
+                    }
         // ESQ_BLOCK_BOUNDS="6,10": override the boundaries (tuning experiments)
         if (const char *ov = getenv("ESQ_BLOCK_BOUNDS")) {
             std::vector<int> forced;
@@ -495,6 +596,41 @@ int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
     return 0;
 }
 
+int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
+                       const double *C, const double *E, int fsal) {
+    if (!c || !A || !B || !C || !E || s < 1) return ESQ_EINVAL;
+    ENTER(c);
+    if (s + 1 > c->n_rows)
+        return fail(c, ESQ_EINVAL, "tableau needs %d rows, context has %d", s + 1,
+                    c->n_rows);
+    for (int i = 0; i < s; ++i) {
+        int nz = 0;
+        for (int j = 0; j < s; ++j) {
+            if (j >= i && A[i * s + j] != 0.0)
+                return fail(c, ESQ_EINVAL, "A must be strictly lower triangular");
+            nz += A[i * s + j] != 0.0;
+        }
+        if (nz > kMaxTerms)
+            return fail(c, ESQ_EINVAL, "row %d of A has %d > %d nonzeros", i, nz, kMaxTerms);
+    }
+    {
+        // the solution / error kernels read the union of the supports of B and E
+        int nz = 0;
+        for (int j = 0; j < s; ++j) nz += (B[j] != 0.0 || E[j] != 0.0);
+        if (nz + (E[s] != 0.0) > kMaxTerms)
+            return fail(c, ESQ_EINVAL, "B and E together have %d > %d nonzero weights",
+                        nz + (E[s] != 0.0), kMaxTerms);
+    }
+    c->s = s;
+    c->fsal = fsal ? 1 : 0;
+    c->A.assign(A, A + (size_t)s * s);
+    c->B.assign(B, B + s);
+    c->C.assign(C, C + s);
+    c->E.assign(E, E + s + 1);
+    c->have_tab = true;
+    return esq_replan(c);
+}
+
 int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
@@ -550,11 +686,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     c->ynew_ready = false;
     c->solerr_ready = false;
     bool block_done = false;   // the block at boundary i already ran in a sweep
-    // two-stage marching sweeps: ESQ_PAIR=0|1 (default: where the working set
-    // is beyond the Infinity Cache -- the halo rows cost more than the saved
-    // stage argument on small grids)
-    const bool pairs = c->rhs_pair && c->rhs_fused && !c->cplx &&
-                       (c->pair_mode == 1 || (c->pair_mode == 2 && !c->src_pays));
+    // marching chain sweeps: ESQ_CHAIN_DEPTH = 1 (off), 2, 3 (default), 4
+    const bool chains = c->rhs_chain && c->rhs_fused && !c->cplx && c->chain_depth >= 2;
     for (int i = i_from; i < i_to; ++i) {
         if (i == 1 && !ready && i + 1 < i_to && may_use_src(c)) {
             // the first sweep forms its own input from y and K[0]: no stage-1
@@ -591,28 +724,35 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
         const esq_ctx::Block *bnext = nullptr;
         for (const auto &b : c->blocks)
             if (b.J == i + 1) bnext = &b;
-        if (pairs && i + 1 < i_to && !bnext) {
-            // stages i and i + 1 in ONE marching sweep: stage i + 1's argument
-            // stays in registers
-            bool b2 = false;
-            for (const auto &b : c->blocks) b2 |= (b.J == i + 2);
-            int what = -1;
-            if (i + 1 == c->s - 1 && i_to == c->s)
-                what = c->fsal ? (may_fuse(c, ESQ_EPI_STAGE) ? 1 : -1)
-                               : (may_fuse(c, ESQ_EPI_SOLERR) && !c->cplx ? 2 : -1);
-            else if (i + 2 < i_to && !b2 && may_fuse(c, ESQ_EPI_STAGE))
-                what = 0;
-            if (what >= 0) {
-                const int r = sweep_pair(c, i, t, h, what);
+        if (chains && i + 1 < i_to && !bnext) {
+            // stages i .. i + D - 1 in ONE marching sweep: the arguments of the
+            // later stages stay in registers.  The longest chain that crosses no
+            // blocked-accumulation boundary and fits the plugin is taken.
+            bool done = false;
+            for (int D = c->chain_depth; D >= 2 && !done; --D) {
+                if (i + D > i_to) continue;
+                bool crosses = false;
+                for (const auto &b : c->blocks) crosses |= (b.J > i && b.J <= i + D);
+                if (crosses) continue;
+                int what = -1;
+                if (i + D == c->s && i_to == c->s)
+                    what = c->fsal ? (may_fuse(c, ESQ_EPI_STAGE) ? 1 : -1)
+                                   : (may_fuse(c, ESQ_EPI_SOLERR) ? 2 : -1);
+                else if (i + D < i_to && may_fuse(c, ESQ_EPI_STAGE))
+                    what = 0;
+                if (what < 0) continue;
+                const int r = sweep_chain(c, i, D, t, h, what);
                 if (r == 0) {
-                    ++i;                               // stage i + 1 is done too
+                    i += D - 1;                        // those stages are done too
                     ready = what == 0;
                     if (what >= 1) c->ynew_ready = true;
                     if (what == 2) c->solerr_ready = true;
-                    continue;
+                    done = true;
+                } else if (r != ESQ_ENOTSUP && r != kNotApplicable) {
+                    return r;
                 }
-                if (r != ESQ_ENOTSUP && r != kNotApplicable) return r;
             }
+            if (done) continue;
         }
         if (i + 1 < i_to && !bnext && may_fuse(c, ESQ_EPI_STAGE)) {
             // this stage's RHS sweep also forms the NEXT stage's argument

@@ -232,13 +232,13 @@ class DeviceContext:
             self._chk(self.lib.esq_set_rhs_fused(self.handle,
                                                  C.cast(fused, C.c_void_p), mask),
                       "esq_set_rhs_fused")
-        # pair entry: two stages per marching sweep (needs the fused entry for the
-        # remaining single stages); ESQ_PAIR=0|1 decides per step in the library
-        pair = rhs._pair_entry(self.lib)
-        if pair is not None and fused is not None and use:
-            self._chk(self.lib.esq_set_rhs_pair(self.handle,
-                                                C.cast(pair, C.c_void_p)),
-                      "esq_set_rhs_pair")
+        # chain entry: several stages per marching sweep (needs the fused entry
+        # for the remaining single stages); ESQ_CHAIN_DEPTH=1 switches it off
+        chain = rhs._chain_entry(self.lib)
+        if chain is not None and fused is not None and use:
+            self._chk(self.lib.esq_set_rhs_chain(self.handle,
+                                                 C.cast(chain, C.c_void_p)),
+                      "esq_set_rhs_chain")
         # RKC entry: derivative + Chebyshev recursion in one sweep
         rkc = rhs._rkc_entry(self.lib)
         if rkc is not None and os.environ.get("ESQ_RKC_CHAIN", "1") != "0":
@@ -341,8 +341,8 @@ class DeviceRHS:
         """optional `esq_rhs_rkc_fn` of this plugin"""
         return None
 
-    def _pair_entry(self, lib):
-        """optional `esq_rhs_pair_fn` of this plugin"""
+    def _chain_entry(self, lib):
+        """optional `esq_rhs_chain_fn` of this plugin"""
         return None
 
     def _bind(self, ctx):
@@ -393,13 +393,13 @@ class _Builtin(DeviceRHS):
     _symbol = None
     _symbol_fused = None
     _symbol_rkc = None
-    _symbol_pair = None
+    _symbol_chain = None
 
     def _rkc_entry(self, lib):
         return getattr(lib, self._symbol_rkc) if self._symbol_rkc else None
 
-    def _pair_entry(self, lib):
-        return getattr(lib, self._symbol_pair) if self._symbol_pair else None
+    def _chain_entry(self, lib):
+        return getattr(lib, self._symbol_chain) if self._symbol_chain else None
 
 
     def _fused_entry(self, lib):
@@ -450,7 +450,7 @@ class Heat2D(_Builtin):
     _symbol = "esq_rhs_heat2d"
     _symbol_fused = "esq_rhs_heat2d_fused"
     _symbol_rkc = "esq_rhs_heat2d_rkc"
-    _symbol_pair = "esq_rhs_heat2d_pair"
+    _symbol_chain = "esq_rhs_heat2d_chain"
     _fuse_default = True
 
     def __init__(self, N):
@@ -473,7 +473,7 @@ class Brusselator2D(_Builtin):
     (BASELINE.json configs[2], the north-star workload)."""
     _symbol = "esq_rhs_bruss2d"
     _symbol_fused = "esq_rhs_bruss2d_fused"
-    _symbol_pair = "esq_rhs_bruss2d_pair"
+    _symbol_chain = "esq_rhs_bruss2d_chain"
     _fuse_default = True
 
     def __init__(self, N, alpha=0.1, a=1.0, b=3.4):

@@ -157,43 +157,48 @@ typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
                                 void *stop_event);
 
 /*
- * OPTIONAL pair entry of a plugin: TWO consecutive stages in ONE marching sweep
- *     K_i     = fun(t_a, y_in)                               -> fa_dev
- *     ys      = y + h*(init_a + sum_u ca[u]*rows[u] + ca_self*K_i)   (registers)
- *     K_{i+1} = fun(t_b, ys)                                 -> fb_dev
- * followed by stage i+1's pointwise epilogue on K_{i+1}:
- *   kind_b == ESQ_EPI_STAGE   out = y + h*(init_b + sum_u cb[u]*rows[u]
- *                                          + cb_prev*K_i + cb_self*K_{i+1})
- *   kind_b == ESQ_EPI_SOLERR  out = y_new as above (cb = solution weights),
- *                             err = h*(sum_u eb[u]*rows[u] + eb_prev*K_i
- *                                      + eb_self*K_{i+1}), partial sums of
- *                             |err/(atol + rtol*max(|y|,|y_new|))|^2
- * The argument of stage i+1 never touches memory, and y and the K rows both
- * sums share are read once (common.py:353-356 twice, or :353-356 + :341-351).
- * rows[] is the union of the K rows either sum reads from memory, in ascending
- * column order; a zero ca[u] / cb[u] means "not part of that sum" (skipped, not
- * multiplied); for SOLERR the rows with cb[u] != 0 or eb[u] != 0 take part in
- * both chains, like ESQ_EPI_SOLERR.  The FMA chains run over ascending column
- * index -- rows, then K_i, then K_{i+1} -- so K rows and states are
- * bit-identical to two one-stage sweeps.  How a stencil plugin does it (stage
- * i+1 marches one grid row behind stage i): csrc/esq_pair.hpp.
- * Return ESQ_ENOTSUP for any case the plugin does not pair.
+ * OPTIONAL chain entry of a plugin: `depth` consecutive stages in ONE marching
+ * sweep.  With T_0 = y_in (the argument of the chain's first stage i):
+ *     K_{i+k} = fun(t[k], T_k)                          -> f_out[k]   (k < depth)
+ *     T_{e+1} = y + h*(init[e] + sum_u cu[e][u]*rows[u] + sum_{k<=e} ck[e][k]*K_{i+k})
+ * T_1 .. T_{depth-1} (the arguments of the chain's later stages) live in
+ * registers only; the last target T_depth goes to `out`:
+ *   kind_last == ESQ_EPI_STAGE   the argument of stage i+depth, or y_new of an
+ *                                FSAL pair (common.py:355, 343)
+ *   kind_last == ESQ_EPI_SOLERR  y_new with the solution weights, and
+ *       err = h*(sum_u eu[u]*rows[u] + sum_k ek[k]*K_{i+k}), partial sums of
+ *       |err/(atol + rtol*max(|y|,|y_new|))|^2            (common.py:341-351)
+ * The intermediate arguments never touch memory; y and the K rows the sums share
+ * are read once for the whole chain.  rows[] is the union of the K rows any
+ * target reads from memory, in ascending column order; bit u of umask[e] (bit k
+ * of kmask[e]) says whether rows[u] (K_{i+k}) takes part in target e+1's sum --
+ * a row that does not is skipped, not multiplied by zero.  Every sum runs over
+ * ascending column index (init, rows, then the chain's own K in order), each
+ * product with h and the final add rounded separately: K rows and states are
+ * bit-identical to `depth` one-stage sweeps.  y == NULL: the base is y_in itself
+ * (a chain that starts with the end-point evaluation of the previous step).
+ * How a stencil plugin does it (stage k marches k grid rows behind stage 0):
+ * csrc/esq_chain.hpp.  Return ESQ_ENOTSUP for any case the plugin does not chain.
  */
-#define ESQ_PAIR_MAX_ROWS 10
-typedef struct esq_pair {
-    int kind_b;                              /* ESQ_EPI_STAGE or ESQ_EPI_SOLERR */
+#define ESQ_CHAIN_MAX_DEPTH 4
+#define ESQ_CHAIN_MAX_ROWS 10
+typedef struct esq_chain {
+    int depth;                               /* 2 .. ESQ_CHAIN_MAX_DEPTH        */
+    int kind_last;                           /* ESQ_EPI_STAGE or ESQ_EPI_SOLERR */
     int nu;                                  /* K rows read from memory         */
-    const double *rows[ESQ_PAIR_MAX_ROWS];
-    double ca[ESQ_PAIR_MAX_ROWS], cb[ESQ_PAIR_MAX_ROWS], eb[ESQ_PAIR_MAX_ROWS];
-    const double *init_a, *init_b;           /* leading partial sums or NULL    */
-    double ca_self;                          /* weight of K_i in ys             */
-    double cb_prev, cb_self;                 /* weights of K_i, K_{i+1} in out  */
-    double eb_prev, eb_self;
-    int prev_in_b;                           /* K_i takes part in B's chain(s)  */
+    const double *rows[ESQ_CHAIN_MAX_ROWS];
+    double cu[ESQ_CHAIN_MAX_DEPTH][ESQ_CHAIN_MAX_ROWS];
+    double eu[ESQ_CHAIN_MAX_ROWS];
+    unsigned umask[ESQ_CHAIN_MAX_DEPTH];
+    double ck[ESQ_CHAIN_MAX_DEPTH][ESQ_CHAIN_MAX_DEPTH];
+    double ek[ESQ_CHAIN_MAX_DEPTH];
+    unsigned kmask[ESQ_CHAIN_MAX_DEPTH];
+    const double *init[ESQ_CHAIN_MAX_DEPTH]; /* leading partial sums or NULL    */
     const double *y;
     double h;
+    double t[ESQ_CHAIN_MAX_DEPTH];
+    double *f_out[ESQ_CHAIN_MAX_DEPTH];      /* NULL: K_{i+k} is never read again */
     double *out;
-    int store_fa;                            /* 0: K_i is never read again      */
     int f_store_nt;
     const double *atol_vec;                  /* SOLERR, as in esq_epilogue      */
     double atol_s, rtol;
@@ -201,11 +206,10 @@ typedef struct esq_pair {
     double *partials;
     int partials_cap;
     int *partials_used;
-} esq_pair;
-typedef int (*esq_rhs_pair_fn)(void *user, double t_a, double t_b,
-                               const double *y_in, double *fa_dev, double *fb_dev,
-                               const esq_pair *pair, size_t n, void *hip_stream,
-                               void *start_event, void *stop_event);
+} esq_chain;
+typedef int (*esq_rhs_chain_fn)(void *user, const double *y_in,
+                                const esq_chain *chain, size_t n, void *hip_stream,
+                                void *start_event, void *stop_event);
 
 /*
  * OPTIONAL RKC entry of a plugin: enqueue ONE sweep that evaluates
@@ -275,11 +279,11 @@ int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
 #define ESQ_FUSE_ALL 0x5e
 #define ESQ_FUSE_SRC 0x20    /* the entry also accepts the on-the-fly input    */
 int  esq_set_rhs_fused(esq_ctx *ctx, esq_rhs_fused_fn fn, int fuse_mask);
-/* register (or clear) the optional pair entry: esq_rk_stages then runs two
- * stages per launch wherever two plain stage sweeps (or the last stage sweep and
+/* register (or clear) the optional chain entry: esq_rk_stages then runs up to
+ * ESQ_CHAIN_DEPTH (default 4) stages per launch wherever plain stage sweeps (and
  * the solution/error sweep) follow each other.  Needs the fused entry too (the
  * remaining single stages). */
-int  esq_set_rhs_pair(esq_ctx *ctx, esq_rhs_pair_fn fn);
+int  esq_set_rhs_chain(esq_ctx *ctx, esq_rhs_chain_fn fn);
 /* register (or clear) the optional RKC entry: esq_rkc_stages then issues ONE
  * kernel per Chebyshev stage (RHS + recursion) instead of two */
 int  esq_set_rhs_rkc(esq_ctx *ctx, esq_rhs_rkc_fn fn);
@@ -523,13 +527,13 @@ int  esq_rhs_bruss2d_fused(void *user, double t, const double *y_in, double *f,
 int  esq_rhs_heat2d_fused(void *user, double t, const double *y_in, double *f,
                           const esq_epilogue *epi, size_t n, void *stream,
                           void *start_event, void *stop_event);
-/* pair entries (esq_rhs_pair_fn) */
-int  esq_rhs_bruss2d_pair(void *user, double t_a, double t_b, const double *y_in,
-                          double *fa, double *fb, const esq_pair *pair, size_t n,
-                          void *stream, void *start_event, void *stop_event);
-int  esq_rhs_heat2d_pair(void *user, double t_a, double t_b, const double *y_in,
-                         double *fa, double *fb, const esq_pair *pair, size_t n,
-                         void *stream, void *start_event, void *stop_event);
+/* chain entries (esq_rhs_chain_fn) */
+int  esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chain,
+                           size_t n, void *stream, void *start_event,
+                           void *stop_event);
+int  esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
+                          size_t n, void *stream, void *start_event,
+                          void *stop_event);
 int  esq_rhs_diff3d_fused(void *user, double t, const double *y_in, double *f,
                           const esq_epilogue *epi, size_t n, void *stream,
                           void *start_event, void *stop_event);

@@ -1460,40 +1460,45 @@ def test_user_plugin_complex_state(tmp_path):
     assert_allclose(got.y[:, -1], ref.y[:, -1], rtol=1e-7, atol=1e-11)
 
 
-# ------------------------------------------- two stages per marching sweep
+# --------------------------------------- several stages per marching sweep
 @pytest.mark.parametrize("name,plugin,N", [
-    ("Pr8", "bruss", 8), ("Pr8", "bruss", 50), ("Pr8", "bruss", 124),
-    ("Pr8", "bruss", 126), ("Pr8", "bruss", 258), ("Pr9", "heat", 130),
-    ("Pr9", "heat", 250), ("Pr7", "heat", 36), ("Pr7", "bruss", 130),
-    ("Ts5", "heat", 258), ("Ts5", "bruss", 48), ("BS5", "heat", 130),
-    ("CK5", "bruss", 64), ("Me4", "heat", 100), ("CFMR7osc", "bruss", 36)])
-@pytest.mark.parametrize("rows", [0, 5, 64])
-def test_paired_stage_sweeps_are_bit_identical(monkeypatch, name, plugin, N, rows):
-    """ESQ_PAIR: two consecutive stages in ONE marching sweep (stage i + 1 one
-    grid row behind stage i, its argument never in memory; csrc/esq_pair.hpp),
-    also the last stage + solution/error sweep -- K rows and states must equal
-    the one-sweep-per-stage path bit for bit, at tile heights that put the halo
-    rows everywhere (ESQ_PAIR_ROWS), on periodic and Dirichlet grids whose width
-    is and is not a multiple of the 62-pair tile"""
+    ("Pr8", "bruss", 16), ("Pr8", "bruss", 50), ("Pr8", "bruss", 116),
+    ("Pr8", "bruss", 120), ("Pr8", "bruss", 124), ("Pr8", "bruss", 258),
+    ("Pr9", "heat", 130), ("Pr9", "heat", 250), ("Pr7", "heat", 36),
+    ("Pr7", "bruss", 130), ("Ts5", "heat", 258), ("Ts5", "bruss", 48),
+    ("BS5", "heat", 130), ("CK5", "bruss", 64), ("Me4", "heat", 100),
+    ("CFMR7osc", "bruss", 36)])
+@pytest.mark.parametrize("depth,rows", [(2, 0), (2, 5), (3, 0), (3, 7), (3, 64),
+                                        (4, 0), (4, 9)])
+def test_chained_stage_sweeps_are_bit_identical(monkeypatch, name, plugin, N, depth,
+                                                rows):
+    """ESQ_CHAIN_DEPTH: up to `depth` consecutive stages in ONE marching sweep
+    (stage k runs k grid rows behind stage 0, the arguments in between never in
+    memory; csrc/esq_chain.hpp), the solution/error sweep included -- K rows and
+    states must equal the one-sweep-per-stage path bit for bit, at tile heights
+    that put the halo rows everywhere (ESQ_CHAIN_ROWS), on periodic and
+    Dirichlet grids whose width is and is not a multiple of the tile width"""
     mk, y0, rho = _plugin(plugin, N)
     h = 0.4 / rho
     kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
     cls = getattr(esq, name)
     if rows:
-        monkeypatch.setenv("ESQ_PAIR_ROWS", str(rows))
-    monkeypatch.setenv("ESQ_PAIR", "1")
-    paired = cls(mk(), 0.0, y0, 1.0, **kw)
-    monkeypatch.setenv("ESQ_PAIR", "0")
+        monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    monkeypatch.setenv("ESQ_CHAIN_DEPTH", str(depth))
+    chained = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_CHAIN_DEPTH", "1")
     single = cls(mk(), 0.0, y0, 1.0, **kw)
-    monkeypatch.delenv("ESQ_PAIR")
-    paired._dev.profile_enable([0, 1, 2])
+    monkeypatch.delenv("ESQ_CHAIN_DEPTH")
+    chained._dev.profile_enable([0, 1, 2])
     for _ in range(3):
-        assert paired.step() is None and single.step() is None
-        assert paired.t == single.t
-        assert_allclose(paired.error_norm_old, single.error_norm_old, rtol=1e-12)
-        assert_equal(paired.K, single.K)
-        assert_equal(paired.y, single.y)
-    assert paired.nfev == single.nfev
-    labels = [row[0] for row in paired._dev.profile_kernels()]
-    if name in ("Pr7", "Pr8", "Pr9", "Ts5"):     # tableaux with pairable stages
-        assert any(lab.startswith("pair") for lab in labels), labels
+        assert chained.step() is None and single.step() is None
+        assert chained.t == single.t
+        assert_allclose(chained.error_norm_old, single.error_norm_old, rtol=1e-12)
+        assert_equal(chained.K, single.K)
+        assert_equal(chained.y, single.y)
+    assert chained.nfev == single.nfev
+    labels = [row[0] for row in chained._dev.profile_kernels()]
+    if name in ("Pr7", "Pr8", "Pr9", "Ts5"):     # tableaux with chainable stages
+        assert any(lab.startswith("chain") for lab in labels), labels
+    if name == "Pr8" and depth >= 3:
+        assert any(lab.startswith(("chain3", "chain4")) for lab in labels), labels
