@@ -1468,8 +1468,8 @@ def test_user_plugin_complex_state(tmp_path):
     ("Pr7", "bruss", 130), ("Ts5", "heat", 258), ("Ts5", "bruss", 48),
     ("BS5", "heat", 130), ("CK5", "bruss", 64), ("Me4", "heat", 100),
     ("CFMR7osc", "bruss", 36)])
-@pytest.mark.parametrize("depth,rows", [(2, 0), (2, 5), (3, 0), (3, 7), (3, 64),
-                                        (4, 0), (4, 9)])
+@pytest.mark.parametrize("depth,rows", [(2, 5), (2, 32), (3, 7), (3, 64), (4, 9),
+                                        (4, 30), (4, 200)])
 def test_chained_stage_sweeps_are_bit_identical(monkeypatch, name, plugin, N, depth,
                                                 rows):
     """ESQ_CHAIN_DEPTH: up to `depth` consecutive stages in ONE marching sweep
@@ -1482,8 +1482,8 @@ def test_chained_stage_sweeps_are_bit_identical(monkeypatch, name, plugin, N, de
     h = 0.4 / rho
     kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
     cls = getattr(esq, name)
-    if rows:
-        monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    # a forced tile height also lifts the "grid too small for this depth" rule
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
     monkeypatch.setenv("ESQ_CHAIN_DEPTH", str(depth))
     chained = cls(mk(), 0.0, y0, 1.0, **kw)
     monkeypatch.setenv("ESQ_CHAIN_DEPTH", "1")
