@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-solve-ivp", action="store_true",
                     help="skip the plain solve_ivp(...) figure (PCIe-inclusive)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the sustained / generic-plugin / adaptive figures")
+    ap.add_argument("--sustained-steps", type=int, default=2000)
     ap.add_argument("--force-lockstep", action="store_true",
                     help="create the RCCL communicator even for one rank")
     ap.add_argument("--replicas", action="store_true",
@@ -89,7 +92,10 @@ def spawn_ranks(args):
     """start `args.gpus` fresh rank processes of this script, relay rank 0's
     stdout, return non-zero if any rank fails or the time limit passes"""
     world = args.gpus
-    port, ctl_port = free_port(), free_port()
+    port = free_port()
+    ctl_port = free_port()
+    while ctl_port in range(port, port + 2):      # MASTER_PORT(+1) belong to the launcher
+        ctl_port = free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ)
@@ -100,6 +106,17 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen(
             [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
             stdout=subprocess.PIPE if rank == 0 else sys.stderr, cwd=ROOT))
+    # rank 0's stdout is drained while the ranks run: a full pipe (a large kernel
+    # table, a library banner) must not block it in write()
+    import threading
+    chunks = []
+
+    def drain():
+        for block in iter(lambda: procs[0].stdout.read(65536), b""):
+            chunks.append(block)
+
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
     deadline = time.time() + args.timeout
     rc = 0
     live = set(range(world))
@@ -125,7 +142,8 @@ def spawn_ranks(args):
                     procs[r].kill()
             break
         time.sleep(0.05)
-    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    reader.join(timeout=30)
+    out = b"".join(chunks).decode()
     if rc == 0:
         sys.stdout.write(out)
         sys.stdout.flush()
@@ -135,7 +153,11 @@ def spawn_ranks(args):
 
 
 def dry_run(args, rank, world, ctl):
-    """control-plane rehearsal without a GPU (tests/test_bench_cpu.py)"""
+    """control-plane rehearsal without a GPU (tests/test_bench_cpu.py): spawn,
+    rendezvous, id exchange, barrier, min/max-over-ranks timing -- and the SAME
+    JSON line the real run prints (`assemble`), filled with placeholder kernel
+    rows, so that the shape of the N = 8 line is checked before an 8-GPU node
+    ever sees it"""
     n = 1000 + rank
     ident, n_total, offset = ctl.exchange(lambda: bytes(range(128)), n)
     assert len(ident) == 128 and n_total == sum(1000 + r for r in range(world))
@@ -143,24 +165,63 @@ def dry_run(args, rank, world, ctl):
     ctl.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
-    elapsed = ctl.allreduce([time.perf_counter() - t0], "max")[0]
+    mine = time.perf_counter() - t0
+    elapsed = ctl.allreduce([mine], "max")[0]
+    fastest = ctl.allreduce([mine], "min")[0]
     ctl.barrier()
     if os.environ.get("ESQ_BENCH_DRY_FAIL_RANK") == str(rank):
         sys.exit(3)                       # a failing rank must fail the whole run
     if rank == 0:
-        print(json.dumps({"metric": "dry-run", "value": n_total / elapsed,
-                          "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "max_elapsed": elapsed}),
-              flush=True)
+        meta = workload_meta(args.config, args.grid)
+        table = {"dry-run": {"class": meta["klass"], "launches": args.steps,
+                             "total_ms": 1e3 * elapsed, "moved_bytes": 8.0 * n,
+                             "algorithmic_bytes": 8.0 * n}}
+        timing = dict(elapsed=elapsed, elapsed_min=fastest, elapsed_prof=elapsed,
+                      rejected=0, nfev_timed=0)
+        lock = world > 1 and not args.replicas
+        out = assemble(args, meta, world, 1000, timing, table,
+                       lockstep_on=lock, rccl_nranks=world if lock else None,
+                       preflight="dry-run" if lock else None,
+                       replicas={"value": 1.0, "ms_per_step": 1.0} if lock else None)
+        out["metric"] = "dry-run"
+        out["value"] = n_total / elapsed
+        out["max_elapsed"] = elapsed
+        print(json.dumps(out), flush=True)
     ctl.close()
 
 
 # ---------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------
-STAGE_KERNEL = ("stage-accumulate class: k_lincomb / rhs_chain (RHS sweep of the "
-                "previous stage with this stage's accumulate chained in) / "
-                "k_block_acc")
+STAGE_KERNEL = ("stage class: marching chain sweeps (up to 4 RHS evaluations + their "
+                "stage arithmetic per launch) / one-stage RHS sweeps with the next "
+                "stage's accumulate or the blocked accumulation as epilogue")
+
+
+def workload_meta(name, N):
+    """what the JSON says about a config (no arrays, no GPU)"""
+    PROF_STAGE, PROF_RKC = 0, 3               # extensisq_amd._lib.PROF_*
+    if name == "pr8":
+        N = N or 2236
+        return dict(label=f"Pr8 (13 stages) on 2-D Brusselator reaction-diffusion N={N}",
+                    metric="accepted RK steps/s x state-dim (fp64), Pr8 n=1e7",
+                    bytes_per_elt_step=1040.0, klass=PROF_STAGE, kernel=STAGE_KERNEL)
+    if name == "ts5":
+        N = N or 1000
+        return dict(label=f"Ts5 (6 stages, FSAL) on 2-D heat equation N={N}",
+                    metric="accepted RK steps/s x state-dim (fp64), Ts5 n=1e6",
+                    bytes_per_elt_step=432.0, klass=PROF_STAGE, kernel=STAGE_KERNEL)
+    if name == "pr9":
+        N = N or 2236
+        return dict(label=f"Pr9 (17 stages) on 2-D heat equation N={N}",
+                    metric="accepted RK steps/s x state-dim (fp64), Pr9 n=5e6 per GPU",
+                    bytes_per_elt_step=1624.0, klass=PROF_STAGE, kernel=STAGE_KERNEL)
+    N = N or 159
+    return dict(label=f"SSV2stab (RKC, m~100 stages/step) on 3-D diffusion N={N}",
+                metric="accepted RKC steps/s x state-dim (fp64), SSV2stab n=4e6",
+                bytes_per_elt_step=None, klass=PROF_RKC,
+                kernel="RKC stage class: rhs_rkc (stencil sweep + three-term Chebyshev "
+                       "recursion in one kernel) / k_rkc_first")
 
 
 def make_workload(name, N, rank):
@@ -272,18 +333,93 @@ def pmc_traffic(config):
         return None, None
 
 
-def kernel_table(dev):
-    """per-kernel rows of the profiled replay"""
+def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
+             preflight, replicas):
+    """the ONE JSON line (rank 0).  `table`: per-kernel totals of the profiled
+    replay {label: {class, launches, total_ms, moved_bytes, algorithmic_bytes}}"""
+    elapsed = timing["elapsed"]
     rows = {}
-    for name, klass, launches, ms, alg, moved in dev.profile_kernels():
+    for name, r in table.items():
+        launches, ms = r["launches"], r["total_ms"]
         rows[name] = {
-            "class": klass, "launches": launches,
+            "class": r["class"], "launches": launches,
             "avg_us": 1e3 * ms / launches if launches else None,
-            "moved_bytes_per_launch": moved / launches if launches else None,
-            "algorithmic_bytes_per_launch": alg / launches if launches else None,
-            "gbs": moved / (ms * 1e-3) / 1e9 if ms > 0 else None,
-            "total_ms": ms, "moved_bytes": moved, "algorithmic_bytes": alg}
-    return rows
+            "moved_bytes_per_launch": r["moved_bytes"] / launches if launches else None,
+            "algorithmic_bytes_per_launch":
+                r["algorithmic_bytes"] / launches if launches else None,
+            "gbs": r["moved_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else None}
+    dom = [r for r in table.values() if r["class"] == meta["klass"]]
+    ms = sum(r["total_ms"] for r in dom)
+    cnt = sum(r["launches"] for r in dom)
+    moved = sum(r["moved_bytes"] for r in dom)
+    alg = sum(r["algorithmic_bytes"] for r in dom)
+    achieved = moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(args.config)
+    all_moved = sum(r["moved_bytes"] for r in table.values())
+    all_ms = sum(r["total_ms"] for r in table.values())
+    return {
+        "metric": meta["metric"],
+        "value": world * n * args.steps / elapsed,
+        "unit": "state-dim*steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{meta['label']}, n={n} per GPU, device RHS, state "
+                        f"resident in HBM, steps driven by solver.step()",
+            "n_per_gpu": n, "global_state_dim": world * n,
+            "parallelism": (f"lockstep x{world}: independent IVP per GPU, "
+                            "1 fp64 RCCL all-reduce per step")
+            if lockstep_on else
+            (f"replicas x{world}: independent solvers, no collective"
+             if world > 1 else "single GPU"),
+            "rccl_nranks": rccl_nranks,
+            "rccl_preflight": preflight,
+            "replicas_no_collective": replicas,
+            # skew between the ranks: the timed region of the slowest / fastest
+            "ms_per_step_rank_max": 1e3 * elapsed / args.steps,
+            "ms_per_step_rank_min": 1e3 * timing["elapsed_min"] / args.steps,
+            "rejected_steps_in_timed_region": timing["rejected"],
+            "rhs_evaluations_in_timed_region": timing["nfev_timed"],
+            "ms_per_step_profiled_replay": 1e3 * timing["elapsed_prof"] / args.steps,
+            # N = 1 only (rank 0 measures them after the timed region)
+            "solve_ivp": None, "sustained": None, "generic_plugin": None,
+            "adaptive": None,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": meta["kernel"],
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "definition": "bytes the class is designed to move (halo re-reads of "
+                          "the marching sweeps NOT counted) / its device time (HIP "
+                          "events on every launch of a K-step replay right after "
+                          "the timed region)",
+            "traffic": traffic, "traffic_source": traffic_src,
+            "launches_timed": cnt,
+            "avg_launch_us": 1e3 * ms / cnt if cnt else None,
+            "moved_bytes_per_launch": moved / cnt if cnt else None,
+            "algorithmic_bytes_per_launch": alg / cnt if cnt else None,
+            "algorithmic_gbs": alg / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            "device_busy_frac_replay":
+                all_ms * 1e-3 / timing["elapsed_prof"] if timing["elapsed_prof"] else None,
+            # every kernel of the step: moved bytes / wall time of the
+            # TIMED region (launch gaps and the host controller included)
+            "whole_step_gbs": all_moved / elapsed / 1e9,
+            "whole_step_algorithmic_gbs": (
+                meta["bytes_per_elt_step"] * n * args.steps / elapsed / 1e9)
+            if meta["bytes_per_elt_step"] else None,
+            "kernels": rows,
+        },
+        "cpu_baseline": None,
+    }
+
+
+def raw_table(dev):
+    """per-kernel totals of the profiled replay"""
+    return {name: {"class": klass, "launches": launches, "total_ms": ms,
+                   "moved_bytes": moved, "algorithmic_bytes": alg}
+            for name, klass, launches, ms, alg, moved in dev.profile_kernels()}
 
 
 def main():
@@ -312,10 +448,12 @@ def main():
         # the launcher restricted this rank's visibility (one GPU per rank)
         local = local % visible
 
+    meta = workload_meta(args.config, args.grid)
     w = make_workload(args.config, args.grid, rank)
     n = w["y0"].size
     group = None
     rccl_nranks = None
+    preflight = None
     try:
         if (world > 1 and not args.replicas) or args.force_lockstep:
             group = lockstep.init_lockstep(rank, world, local, n,
@@ -323,6 +461,9 @@ def main():
             rccl_nranks = lockstep.comm_size(group)
             if rccl_nranks != world:
                 raise RuntimeError(f"RCCL sees {rccl_nranks} ranks, expected {world}")
+            # before anything is timed: the collectives the run depends on,
+            # checked against values every rank can compute for itself
+            preflight = lockstep.preflight(group, rank, world, local, ctl)
 
         def timed(lock_group):
             solver = w["cls"](w["rhs"], 0.0, w["y0"], 1.0e9, device=local,
@@ -346,13 +487,14 @@ def main():
             t0 = time.perf_counter()
             run(args.steps)
             barrier()
-            elapsed = time.perf_counter() - t0
+            mine = time.perf_counter() - t0
             rejected = int(esq.NFS[()]) - nfs0
             nfev_timed = solver.nfev - nfev0
-            elapsed, rejected = ctl.allreduce([elapsed, rejected], "max")
-            return solver, run, barrier, elapsed, int(rejected), nfev_timed
+            elapsed, rejected = ctl.allreduce([mine, rejected], "max")
+            fastest = ctl.allreduce([mine], "min")[0]
+            return solver, run, barrier, elapsed, fastest, int(rejected), nfev_timed
 
-        solver, run, barrier, elapsed, rejected, nfev_timed = timed(group)
+        solver, run, barrier, elapsed, fastest, rejected, nfev_timed = timed(group)
         dev = solver._dev
         # ---- profiled replay: the same K steps with an event pair on EVERY
         # launch (all ranks step -- the lock-step collective needs them all)
@@ -364,12 +506,12 @@ def main():
         barrier()
         elapsed_prof = time.perf_counter() - t1
         dev.profile_enable(None)
-        table = kernel_table(dev)
+        table = raw_table(dev)
 
         replicas = None
         if world > 1 and group is not None:
             # the no-collective upper bound, same run
-            _s2, _r2, _b2, el2, _rj2, _nf2 = timed(None)
+            _s2, _r2, _b2, el2, _f2, _rj2, _nf2 = timed(None)
             replicas = {"value": world * n * args.steps / el2,
                         "ms_per_step": 1e3 * el2 / args.steps}
             del _s2, _r2, _b2
@@ -379,71 +521,25 @@ def main():
         raise
 
     if rank == 0:
-        klass = w["klass"]
-        dom = [r for r in table.values() if r["class"] == klass]
-        ms = sum(r["total_ms"] for r in dom)
-        cnt = sum(r["launches"] for r in dom)
-        moved = sum(r["moved_bytes"] for r in dom)
-        alg = sum(r["algorithmic_bytes"] for r in dom)
-        achieved = moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(args.config)
-        all_moved = sum(r["moved_bytes"] for r in table.values())
-        all_ms = sum(r["total_ms"] for r in table.values())
-        for r in table.values():
-            for key in ("total_ms", "moved_bytes", "algorithmic_bytes"):
-                r.pop(key)
-        out = {
-            "metric": w["metric"],
-            "value": world * n * args.steps / elapsed,
-            "unit": "state-dim*steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": f"{w['label']}, n={n} per GPU, device RHS, state "
-                            f"resident in HBM, steps driven by solver.step()",
-                "n_per_gpu": n, "global_state_dim": world * n,
-                "parallelism": (f"lockstep x{world}: independent IVP per GPU, "
-                                "1 fp64 RCCL all-reduce per step")
-                if group is not None else
-                (f"replicas x{world}: independent solvers, no collective"
-                 if world > 1 else "single GPU"),
-                "rccl_nranks": rccl_nranks,
-                "replicas_no_collective": replicas,
-                "rejected_steps_in_timed_region": rejected,
-                "rhs_evaluations_in_timed_region": nfev_timed,
-                "ms_per_step_profiled_replay": 1e3 * elapsed_prof / args.steps,
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": w["kernel"],
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "definition": "bytes the class is designed to move / its device "
-                              "time (HIP events on every launch of a K-step "
-                              "replay right after the timed region)",
-                "traffic": traffic, "traffic_source": traffic_src,
-                "launches_timed": cnt,
-                "avg_launch_us": 1e3 * ms / cnt if cnt else None,
-                "moved_bytes_per_launch": moved / cnt if cnt else None,
-                "algorithmic_bytes_per_launch": alg / cnt if cnt else None,
-                "algorithmic_gbs": alg / (ms * 1e-3) / 1e9 if ms > 0 else None,
-                "device_busy_frac_replay": all_ms * 1e-3 / elapsed_prof,
-                # every kernel of the step: moved bytes / wall time of the
-                # TIMED region (launch gaps and the host controller included)
-                "whole_step_gbs": all_moved / elapsed / 1e9,
-                "whole_step_algorithmic_gbs": (
-                    w["bytes_per_elt_step"] * n * args.steps / elapsed / 1e9)
-                if w["bytes_per_elt_step"] else None,
-                "kernels": table,
-            },
-        }
-        if world == 1 and not args.no_solve_ivp:
-            out["config"]["solve_ivp"] = solve_ivp_figure(w, local)
+        timing = dict(elapsed=elapsed, elapsed_min=fastest, elapsed_prof=elapsed_prof,
+                      rejected=rejected, nfev_timed=nfev_timed)
+        out = assemble(args, meta, world, n, timing, table,
+                       lockstep_on=group is not None, rccl_nranks=rccl_nranks,
+                       preflight=preflight, replicas=replicas)
+        if world == 1:
+            # further driver-visible figures of the same workload -- none of them
+            # the headline
+            out["config"]["solve_ivp"] = (None if args.no_solve_ivp
+                                          else solve_ivp_figure(w, local))
+            out["config"]["sustained"] = (None if args.no_extras
+                                          else sustained_figure(solver, run, barrier,
+                                                                args.sustained_steps))
+            out["config"]["generic_plugin"] = (None if args.no_extras
+                                               else generic_plugin_figure(w, local, args))
+            out["config"]["adaptive"] = (None if args.no_extras
+                                         else adaptive_figure(w, local, esq))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps)
-        else:
-            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
     if group is not None:
@@ -452,6 +548,83 @@ def main():
         lockstep.destroy_lockstep(group)
     ctl.barrier()
     ctl.close()
+
+
+def sustained_figure(solver, run, barrier, steps):
+    """the same solver, `steps` more accepted steps in one go (seconds, not
+    milliseconds, of GPU work: clocks and caches in their steady state)"""
+    barrier()
+    t0 = time.perf_counter()
+    run(steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    return {"steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "value": solver.n * steps / dt}
+
+
+def generic_plugin_figure(w, device, args):
+    """what a plugin that exports ONLY `esq_rhs_fn` gets (first
+    example): the same workload with the fused / chain entries switched off
+    (ESQ_CHAIN=0), i.e. one RHS launch + one stage kernel per stage"""
+    from extensisq_amd._lib import PROF_RHS, PROF_RKC, PROF_SOLERR, PROF_STAGE
+    old = os.environ.get("ESQ_CHAIN")
+    os.environ["ESQ_CHAIN"] = "0"
+    try:
+        s = w["cls"](w["rhs"], 0.0, w["y0"], 1.0e9, device=device, **w["kw"])
+    finally:
+        if old is None:
+            del os.environ["ESQ_CHAIN"]
+        else:
+            os.environ["ESQ_CHAIN"] = old
+    dev = s._dev
+    for _ in range(args.warmup):
+        assert s.step() is None
+    dev.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        assert s.step() is None
+    dev.synchronize()
+    dt = time.perf_counter() - t0
+    dev.profile_reset()
+    dev.profile_enable([PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC], every=1)
+    for _ in range(args.steps):
+        assert s.step() is None
+    dev.profile_enable(None)
+    tab = raw_table(dev)
+    launches = sum(r["launches"] for r in tab.values())
+    ms = sum(r["total_ms"] for r in tab.values())
+    moved = sum(r["moved_bytes"] for r in tab.values())
+    return {"ms_per_step": 1e3 * dt / args.steps, "value": s.n * args.steps / dt,
+            "launches_per_step": launches / args.steps + 1,     # + the final sum
+            "all_kernels_gbs": moved / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            "note": "ESQ_CHAIN=0: RHS plugin launch + stand-alone stage / block / "
+                    "solution-error kernels, as for a user plugin without fused entry"}
+
+
+def adaptive_figure(w, device, esq, span_steps=40):
+    """free-running step-size controller (no max_step clamp) at the bench
+    tolerances over a fixed t-span of `span_steps` stability-sized steps"""
+    kw = dict(w["kw"])
+    h = kw.pop("max_step")
+    kw["first_step"] = 0.25 * h
+    if "rho_jac" in kw:
+        return None                       # SSV2stab config: m is pinned by max_step
+    s = w["cls"](w["rhs"], 0.0, w["y0"], span_steps * h, device=device, **kw)
+    s._dev.synchronize()
+    t0 = time.perf_counter()
+    accepted = 0
+    while s.status == "running":
+        msg = s.step()
+        if msg is not None and s.status != "finished":
+            return {"failed": msg}
+        accepted += 1
+    s._dev.synchronize()
+    dt = time.perf_counter() - t0
+    return {"t_span_in_stability_steps": span_steps, "accepted": accepted,
+            "rejected": int(esq.NFS[()]), "rhs_evaluations": s.nfev,
+            "ms_per_accepted_step": 1e3 * dt / accepted if accepted else None,
+            "note": "first_step = h_stab/4, controller free (max_step = inf): the "
+                    "step grows to the stability limit, where rejections appear"}
 
 
 def solve_ivp_figure(w, device, steps=24):

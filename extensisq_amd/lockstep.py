@@ -258,6 +258,44 @@ def init_lockstep(rank, world_size, device, n_local, addr=None, port=None,
     return LockstepGroup(comm, n_total, offset=offset)
 
 
+def preflight(group, rank, world, device, ctl=None):
+    """Check the lock-step collectives before anything depends on them: every
+    rank all-reduces `rank + 1` through `esq_allreduce_scalars` (sum, max, min ->
+    N(N+1)/2, N, 1) and one weighted-norm reduction through the error-norm path
+    (`finish_reduction`: k_final_sum -> ncclAllReduce -> pinned slot), which is
+    compared with the sum the TCP control plane computes from the per-rank
+    values.  Raises on any mismatch; returns "ok"."""
+    import numpy as np
+    from ._lib import SLOT_Y, VEC_NONE, VEC_Y
+    from .device import DeviceContext
+    dev = DeviceContext(1024, 2, False, device)
+    try:
+        dev._chk(dev.lib.esq_set_comm(dev.handle, group.comm), "esq_set_comm")
+        group.attach(dev)
+        want = {"sum": world * (world + 1) / 2.0, "max": float(world), "min": 1.0}
+        for op, expect in want.items():
+            got = group.allreduce(dev, [rank + 1.0, 2.0 * (rank + 1.0)], op)
+            if got != [expect, 2.0 * expect]:
+                raise RuntimeError(f"lock-step pre-flight: all-reduce({op}) of rank+1 "
+                                   f"over {world} ranks gave {got}, expected "
+                                   f"{[expect, 2.0 * expect]}")
+        dev.upload(SLOT_Y, 0, np.full(1024, rank + 1.0))
+        out = C.c_double()
+        dev._chk(dev.lib.esq_vec_sumsq(dev.handle, VEC_Y, VEC_NONE, C.byref(out)),
+                 "esq_vec_sumsq")
+        local = 1024.0 * (rank + 1.0) ** 2
+        expect = ctl.allreduce([local], "sum")[0] if ctl is not None else \
+            1024.0 * sum((r + 1.0) ** 2 for r in range(world))
+        if out.value != expect:
+            raise RuntimeError(f"lock-step pre-flight: all-reduced sum of squares "
+                               f"{out.value} != {expect} (control plane)")
+    finally:
+        group._contexts = [d for d in group._contexts if d is not dev]
+        dev._chk(dev.lib.esq_set_comm(dev.handle, None), "esq_set_comm")
+        dev.close()
+    return "ok"
+
+
 def comm_size(group):
     """number of ranks RCCL reports for the group's communicator"""
     out = C.c_int(0)

@@ -74,3 +74,54 @@ def test_bench_does_not_import_torch():
     for name in os.listdir(pkg):
         if name.endswith(".py"):
             assert "import torch" not in open(os.path.join(pkg, name)).read(), name
+
+
+def _shape(obj, path=""):
+    """the set of key paths of a JSON value (kernel labels excluded: they depend
+    on the method, not on the number of ranks)"""
+    out = set()
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if path.endswith("roofline/kernels"):
+                out.add(path + "/<label>")
+                out |= {p.replace(f"/{k}/", "/<label>/") for p in
+                        _shape(v, path + "/" + k)}
+            else:
+                out.add(path + "/" + k)
+                out |= _shape(v, path + "/" + k)
+    return out
+
+
+def test_json_line_has_the_same_shape_for_one_and_eight_ranks():
+    """the N = 1 line of `--gpus 1`, of a self-launched 1-rank world and the
+    N = 8 line are built by the same function (`assemble`) and carry the same
+    fields -- so the first contact with an 8-GPU node cannot fail on a missing
+    key of the line the driver parses"""
+    def run(world, env):
+        res = subprocess.run([sys.executable, BENCH, "--gpus", str(world), "--steps",
+                              "3", "--warmup", "1", "--dry-run"],
+                             capture_output=True, text=True, timeout=300, cwd=ROOT,
+                             env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        (line,) = [ln for ln in res.stdout.splitlines() if ln.strip()]
+        return json.loads(line)
+
+    one = run(1, clean_env())
+    one_world = run(1, clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                                 MASTER_ADDR="127.0.0.1",
+                                 MASTER_PORT=str(free_port())))
+    eight = run(8, clean_env())
+    # replicas_no_collective is measured only where there is a collective to drop
+    extra = {"/config/replicas_no_collective/value",
+             "/config/replicas_no_collective/ms_per_step"}
+    assert _shape(one) == _shape(one_world) == _shape(eight) - extra
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in eight
+    assert eight["n_gpus"] == 8 and one["n_gpus"] == 1
+    assert eight["config"]["rccl_nranks"] == 8
+    assert eight["config"]["rccl_preflight"] is not None
+    assert eight["config"]["ms_per_step_rank_min"] <= eight["config"]["ms_per_step_rank_max"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in eight["roofline"]
