@@ -391,10 +391,10 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
             "bound": "hbm", "kernel": meta["kernel"],
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "definition": "bytes the class is designed to move (halo re-reads of "
-                          "the marching sweeps NOT counted) / its device time (HIP "
-                          "events on every launch of a K-step replay right after "
-                          "the timed region)",
+            "definition": "bytes the class is designed to move (the halo rows and "
+                          "columns the marching sweeps read twice included) / its "
+                          "device time (HIP events on every launch of a K-step "
+                          "replay right after the timed region)",
             "traffic": traffic, "traffic_source": traffic_src,
             "launches_timed": cnt,
             "avg_launch_us": 1e3 * ms / cnt if cnt else None,

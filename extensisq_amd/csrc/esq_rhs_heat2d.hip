@@ -161,6 +161,9 @@ int esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
         auto kern = esq::k_chain2d<1, false, CA::kD, CA::kNU, decltype(kind)::value, HeatFn>;
         static const int wpc = chain_waves_per_cu(kern);    // per instantiation
         const GeoChain g = geo_chain(r->N, CA::kD, wpc);
+        if (chain->read_amplification)
+            *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1)) / g.R * 64.0 /
+                                         (64 - 2 * (CA::kD - 1));
         if (decltype(kind)::value == ESQ_EPI_SOLERR) {
             if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
             if (chain->partials_used) *chain->partials_used = (int)g.grid;

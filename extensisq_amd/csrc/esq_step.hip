@@ -276,15 +276,20 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last)
     e.partials = c->partials;
     e.partials_cap = kPartialsCap;
     e.partials_used = &c->red_count;
-    // booked: what the one-stage sweeps book; moved: input, y, rows, inits in;
-    // the chain's K rows and the last target out
-    const double moved = 8.0 * (2 + nu + n_init + depth + 1) * (double)c->len;
+    // booked: what the one-stage sweeps book; moved: input, y, rows, inits in
+    // (times the tile geometry's read amplification); the chain's K rows and the
+    // last target out
+    const double reads = 2 + nu + n_init, writes = depth + 1;
+    double amp = 1.0;
+    e.read_amplification = &amp;
     char label[24];
     snprintf(label, sizeof(label), "chain%d%s", depth, what_last == 2 ? "+solerr" : "");
-    Prof p(c, ESQ_PROF_STAGE, label, nu, alg, false, moved);
+    Prof p(c, ESQ_PROF_STAGE, label, nu, alg, false, 8.0 * (reads + writes) * (double)c->len);
     c->self_valid = false;
     const int r = c->rhs_chain(c->rhs_user, c->ystage, &e, c->len, (void *)c->stream,
                                (void *)p.start(), (void *)p.stop());
+    // designed traffic incl. the halo rows / columns the plugin's tiles re-read
+    if (p.on) p.ev.moved = 8.0 * (reads * amp + writes) * (double)c->len;
     if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
     if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "chain RHS entry returned %d", r); }
     if (what_last == 0) std::swap(c->ystage, c->work);

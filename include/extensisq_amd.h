@@ -206,6 +206,10 @@ typedef struct esq_chain {
     double *partials;
     int partials_cap;
     int *partials_used;
+    /* out (may be NULL): the factor by which the plugin's tile geometry
+     * multiplies the bytes READ (halo rows and columns are loaded by two tiles);
+     * the library books it in the launch's designed traffic (esq_profile_*) */
+    double *read_amplification;
 } esq_chain;
 typedef int (*esq_rhs_chain_fn)(void *user, const double *y_in,
                                 const esq_chain *chain, size_t n, void *hip_stream,

@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
 P = os.path.join(ROOT, "profiles")
-TAG = "r02"
+TAG = "r03"
 
 
 @pytest.mark.parametrize("config", ["pr8", "ts5", "pr9", "rkc"])

@@ -5,10 +5,10 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 CFG=${1:-pr8}; shift
-python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp > /dev/null 2>&1
+python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras > /dev/null 2>&1
 for round in 1 2 3; do
   for D in "$@"; do
-    ESQ_CHAIN_DEPTH=$D python3 $ROOT/bench.py --config $CFG --steps 60 --warmup 10 --no-cpu-baseline --no-solve-ivp \
+    ESQ_CHAIN_DEPTH=$D python3 $ROOT/bench.py --config $CFG --steps 60 --warmup 10 --no-cpu-baseline --no-solve-ivp --no-extras \
       > $OUT/ab_chain_${CFG}_${D}_${round}.json 2>> $OUT/ab_chain.err
     python3 - <<PY
 import json

@@ -13,7 +13,7 @@ for grp in "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
   k=$((k+1))
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_probe_${CFG}_$k -o p -- \
-      python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp > $OUT/pmc_probe_${CFG}_$k.log 2>&1
+      python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp --no-extras > $OUT/pmc_probe_${CFG}_$k.log 2>&1
 done
 python3 - <<PY
 import csv, collections, glob, re

@@ -13,18 +13,18 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 # a fresh box runs its first seconds of GPU work measurably slower: warm it up
-python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp > /dev/null 2>&1
+python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras > /dev/null 2>&1
 for CFG in "${@:-pr8}"; do
-    python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-solve-ivp \
+    python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras \
         > $OUT/prof_${CFG}_bench.json 2> $OUT/prof_${CFG}_bench.err
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${CFG}_stats -o bench -- \
-        python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-solve-ivp \
+        python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras \
         > $OUT/prof_${CFG}_stats.log 2>&1
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${CFG}_fetch -o bench -- \
-        python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp \
+        python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp --no-extras \
         > $OUT/prof_${CFG}_fetch.log 2>&1
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${CFG}_write -o bench -- \
-        python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp \
+        python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp --no-extras \
         > $OUT/prof_${CFG}_write.log 2>&1
 done
 ls $OUT | grep prof_ | head -40

@@ -28,19 +28,30 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 PEAK = 8.0e12
 
-STAGE = ("k_lincomb", "k_block_acc", "rhs+stage", "rhs1+stage", "rhs+block")
+STAGE = ("k_lincomb", "k_block_acc", "rhs+stage", "rhs1+stage", "rhs+block",
+         "chain2", "chain3", "chain4", "chain2+solerr", "chain3+solerr",
+         "chain4+solerr")
 RKC = ("rhs_rkc", "k_rkc_first", "k_rkc_stage")
 
 
 def label(name):
     """rocprof kernel name -> bench.py kernel label"""
+    # marching chain sweeps (round 3): k_chain2d<NF, PERIODIC, D, NU, KINDLAST, Fn>
+    m = re.search(r"k_chain2d<\d+, (?:true|false), (\d+), (\d+), (\d+)", name)
+    if m:
+        sol = "+solerr" if m.group(3) == "3" else ""
+        return f"chain{m.group(1)}{sol}<{m.group(2)}>"
+    if re.search(r"_sweep<.*EpiRkcErr", name):
+        return "rhs+rkcerr"
+    if re.search(r"_sweep<.*EpiRkc\b", name):
+        return "rhs_rkc"
     m = re.search(r"k_(bruss2d|heat2d|diff3d|diag)_sweep<.*Epi(\w+)<(\d+)", name)
     if m:                                   # fused sweeps (round 2)
         first = "1" if "SrcAxpy" in name else ""
         return f"rhs{first}+{m.group(2).lower()}<{m.group(3)}>"
-    m = re.search(r"k_(heat2d|diff3d)_v2<\d+, (true|false)>", name)
+    m = re.search(r"k_diff3d_v2<\d+, (\d+)>", name)
     if m:
-        return "rhs_rkc" if m.group(2) == "true" else "rhs_plugin"
+        return {"0": "rhs_plugin", "1": "rhs_rkc", "2": "rhs+rkcerr"}[m.group(1)]
     if re.search(r"k_(bruss2d|heat2d|diff3d|diag)", name):
         return "rhs_plugin"
     m = re.search(r"(k_[a-z0-9_]+)<(\d+)", name)
@@ -132,7 +143,7 @@ def one(tag, cfg):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     os.makedirs(P, exist_ok=True)
     for cfg in (sys.argv[2:] or ["pr8"]):
         one(tag, cfg)
