@@ -15,8 +15,9 @@
 //       T_{k+1}[rho_k] is complete now: it enters stage k+1's window (registers)
 //                      or, for the last stage, is stored (next argument / y_new)
 //
-// Target e's sum for a row starts when stage 0 visits the row (leading partial
-// sum `init`, the K rows read from memory -- ONCE for all D targets) and takes
+// Target e's sum for a row starts when stage 0 visits the row (the K rows read
+// from memory -- ONCE for all D targets; a leading partial sum of the blocked
+// accumulation is simply the first such row, with weight 1) and takes
 // the chain's own derivatives as they appear, one per iteration, in ascending
 // column order: the same FMA chain as every other kernel here, so K rows and
 // states are bit-identical to D one-stage sweeps.  The intermediate arguments
@@ -29,12 +30,42 @@
 // rows and 2(D-1)/64 lanes of loads and stage evaluations.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/extensisq_amd.h"
 #include "esq_epilogue.hpp"
 #include "esq_terms.hpp"
 
 namespace esq {
+
+// Register budget of the two-field (Brusselator) instantiations, from
+// `hipcc -Rpass-analysis=kernel-resource-usage`: the largest number of memory
+// rows per (depth, last kind) that still leaves two waves per SIMD.  Wider
+// chains drop to one wave per SIMD and lose more than they save (measured:
+// chain3+solerr<6> at one wave per SIMD took 590 us where a two-wave chain2 +
+// a single sweep take 360).  The block planner (esq_step.hip) uses the same
+// table.  ESQ_CHAIN_CAPS="s2,e2,s3,e3,s4,e4" overrides it (tuning).
+struct ChainCaps {
+    int stage[5], solerr[5];
+};
+inline ChainCaps chain_caps() {
+    ChainCaps c = {{0, 0, 8, 5, 1}, {0, 0, 7, 2, -1}};
+    if (const char *env = getenv("ESQ_CHAIN_CAPS")) {
+        int v[6];
+        if (sscanf(env, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
+            c.stage[2] = v[0]; c.solerr[2] = v[1];
+            c.stage[3] = v[2]; c.solerr[3] = v[3];
+            c.stage[4] = v[4]; c.solerr[4] = v[5];
+        }
+    }
+    return c;
+}
+inline bool chain_within_caps(int depth, bool solerr, int nu) {
+    if (depth < 2 || depth > 4) return false;
+    const ChainCaps c = chain_caps();
+    return nu <= (solerr ? c.solerr[depth] : c.stage[depth]);
+}
 
 // device-side description of a chain (built from `esq_chain` by make_chain_args)
 template <int D, int NU>
@@ -48,7 +79,6 @@ struct ChainArgs {
     double ck[D][D];                 // ck[e][k]: weight of K_k in target e + 1 (k <= e)
     double ek[D];                    // SOLERR: error weight of K_k
     unsigned kmask[D];               // stages whose K takes part in target e + 1
-    const double *init[D];           // leading partial sum of target e + 1 or nullptr
     const double *y;                 // base state; nullptr: the chain's own input
     double h;
     double *fk[D];                   // where K_k goes (nullptr: not stored)
@@ -61,7 +91,11 @@ struct ChainArgs {
 // Fn::eval(centres, laplacians) -> derivatives, all per column pair.
 // KINDLAST: ESQ_EPI_STAGE (the last target is a stage argument / y_new of an
 // FSAL pair) or ESQ_EPI_SOLERR (y_new and the error partial sums).
-template <int NF, bool PERIODIC, int D, int NU, int KINDLAST, class Fn>
+#ifndef ESQ_CHAIN_PREFETCH
+#define ESQ_CHAIN_PREFETCH true
+#endif
+template <int NF, bool PERIODIC, int D, int NU, int KINDLAST, class Fn,
+          bool PREFETCH = ESQ_CHAIN_PREFETCH>
 __global__ __launch_bounds__(kBlock) void k_chain2d(
     const double *__restrict__ ys, ChainArgs<D, NU> ca, Fn fn, int N, int R,
     unsigned tpr, unsigned ntiles, unsigned nblocks, unsigned xcd) {
@@ -113,37 +147,53 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             wc[0][f] = ld_ys(r0 - H, f);
         }
         const int iters = Re + 2 * H;
+        // operands of stage 0's row: loaded ONE ITERATION AHEAD, so that a wave
+        // always has a whole row set in flight behind the row it computes on
+        // (the sweeps are latency-bound: few waves per SIMD at this register use)
+        double2 u[ChainArgs<D, NU>::NUa][NF], yrow[NF], ysn[NF];
+#define ESQ_CHAIN_LOAD_ROW(IT)                                                     \
+    {                                                                              \
+        const int rho_ = r0 - H + (IT);                                            \
+        const bool act_ = live && row_ok(rho_);                                    \
+        const size_t base_ = (size_t)wrap(rho_) * npairs + pw;                     \
+        _Pragma("unroll") for (int f = 0; f < NF; ++f) {                           \
+            ysn[f] = ld_ys(rho_ + 1, f);                                           \
+            const size_t k2_ = (size_t)f * fstride + base_;                        \
+            _Pragma("unroll") for (int j = 0; j < NU; ++j)                         \
+                u[j][f] = act_ ? ld2_nt(ca.rows[j], k2_) : zero;                   \
+            yrow[f] = (ca.y && act_) ? ld2(ca.y, k2_) : zero;                      \
+        }                                                                          \
+    }
+        ESQ_CHAIN_LOAD_ROW(0)
         for (int it = 0; it < iters; ++it) {
             const int rho0 = r0 - H + it;                  // stage 0's row
-            const bool act0 = live && row_ok(rho0);
-            const size_t base0 = (size_t)wrap(rho0) * npairs + pw;
-            // ---- every load of the iteration before the first use
-            double2 u[ChainArgs<D, NU>::NUa][NF], in[D][NF];
+            // ---- take over the row loaded one iteration ago ...
+            double2 uc[ChainArgs<D, NU>::NUa][NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                wp[0][f] = ld_ys(rho0 + 1, f);
-                const size_t k2 = (size_t)f * fstride + base0;
+                wp[0][f] = ysn[f];
+                yf[0][f] = ca.y ? yrow[f] : wc[0][f];
 #pragma unroll
-                for (int j = 0; j < NU; ++j) u[j][f] = act0 ? ld2_nt(ca.rows[j], k2) : zero;
-                yf[0][f] = ca.y ? (act0 ? ld2(ca.y, k2) : zero) : wc[0][f];
-#pragma unroll
-                for (int e = 0; e < D; ++e)
-                    in[e][f] = (act0 && ca.init[e]) ? ld2_nt(ca.init[e], k2) : zero;
+                for (int j = 0; j < NU; ++j) uc[j][f] = u[j][f];
+            }
+            // ---- ... and request the next one before any arithmetic
+            if (PREFETCH) {
+                if (it + 1 < iters) ESQ_CHAIN_LOAD_ROW(it + 1)
             }
             // ---- the D targets' sums for row rho0: leading partial + memory rows
 #pragma unroll
             for (int e = 0; e < D; ++e)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
-                    double2 s = in[e][f], se = zero;
+                    double2 s = zero, se = zero;
 #pragma unroll
                     for (int j = 0; j < NU; ++j) {
                         if ((ca.umask[e] >> j) & 1u) {             // uniform
-                            s.x = fma(ca.cu[e][j], u[j][f].x, s.x);
-                            s.y = fma(ca.cu[e][j], u[j][f].y, s.y);
+                            s.x = fma(ca.cu[e][j], uc[j][f].x, s.x);
+                            s.y = fma(ca.cu[e][j], uc[j][f].y, s.y);
                             if (SOLERR && e == D - 1) {
-                                se.x = fma(ca.eu[j], u[j][f].x, se.x);
-                                se.y = fma(ca.eu[j], u[j][f].y, se.y);
+                                se.x = fma(ca.eu[j], uc[j][f].x, se.x);
+                                se.y = fma(ca.eu[j], uc[j][f].y, se.y);
                             }
                         }
                     }
@@ -209,6 +259,9 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                     }
                 }
             }
+            if (!PREFETCH) {
+                if (it + 1 < iters) ESQ_CHAIN_LOAD_ROW(it + 1)
+            }
             // ---- every row moves one stage on
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
@@ -229,5 +282,6 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
     }
     if (SOLERR) block_partial(local, ca.red.partials);
 }
+#undef ESQ_CHAIN_LOAD_ROW
 
 }  // namespace esq

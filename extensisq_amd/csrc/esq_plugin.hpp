@@ -210,7 +210,6 @@ ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
         a.umask[e] = c->umask[e];
         a.kmask[e] = c->kmask[e];
         a.ek[e] = c->ek[e];
-        a.init[e] = c->init[e];
         a.fk[e] = c->f_out[e];
         for (int k = 0; k < D; ++k) a.ck[e][k] = c->ck[e][k];
     }

@@ -192,10 +192,9 @@ int esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chain
     if (!r || r->kind != BRUSS2D || n != r->n || !chain) return ESQ_EINVAL;
     if (r->N % 2 != 0 || r->N < 16) return ESQ_ENOTSUP;
     if (!chain_fits_grid(r->N, chain->depth)) return ESQ_ENOTSUP;
-    // register budget of the two-field kernel (hipcc -Rpass-analysis): deeper or
-    // wider instantiations drop to one wave per SIMD and lose more than they save
-    if ((chain->depth == 3 && chain->kind_last == ESQ_EPI_SOLERR && chain->nu > 5) ||
-        (chain->depth == 4 && (chain->kind_last == ESQ_EPI_SOLERR || chain->nu > 2)))
+    // register budget of the two-field kernel (esq_chain.hpp, ChainCaps)
+    if (!esq::chain_within_caps(chain->depth, chain->kind_last == ESQ_EPI_SOLERR,
+                                chain->nu))
         return ESQ_ENOTSUP;
     const BrussFn fn{r->alpha * ((double)r->N * (double)r->N), r->a, r->b};
     int rc_launch = 0;

@@ -201,16 +201,28 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu) {
     const char *env = getenv("ESQ_CHAIN_ROWS");           // tuning / tests
     int R = env ? atoi(env) : 0;
     if (R <= 0) {
-        // rounds of resident waves: pick the fewest rounds whose tiles are at
-        // least 8 * depth rows high (halo overhead <= 25 %), then the tile height
-        // that fills those rounds
-        const size_t slots = (size_t)256 * (size_t)waves_per_cu;
-        const size_t wave_rows = (size_t)N * g.tpr;
-        size_t rounds = 1;
-        R = (int)((wave_rows + slots * rounds - 1) / (slots * rounds));
-        while (R > 48) {
-            ++rounds;
-            R = (int)((wave_rows + slots * rounds - 1) / (slots * rounds));
+        // ONE round of resident waves, as few per CU as keeps the tiles at most
+        // 48 rows high (measured, profiles/r03_experiments.md: whole rounds
+        // matter, and with the next row's operands prefetched one wave per SIMD
+        // runs as fast as two -- so prefer tall tiles, whose halo rows cost less);
+        // grids too large for one round at full occupancy take several
+        // tiles = tpr * ceil(N / R) must not exceed the wave slots of the round
+        auto rows_for = [&](size_t slots) -> int {
+            const size_t max_row_tiles = slots / g.tpr;
+            if (max_row_tiles == 0) return N + 1;
+            return (int)(((size_t)N + max_row_tiles - 1) / max_row_tiles);
+        };
+        for (int wpc = 4; wpc <= waves_per_cu && R <= 0; wpc += 4) {
+            const int cand = rows_for((size_t)256 * (size_t)wpc);
+            if (cand <= 48) R = cand;
+        }
+        if (R <= 0) {
+            size_t rounds = 1;
+            R = rows_for((size_t)256 * (size_t)waves_per_cu * rounds);
+            while (R > 48) {
+                ++rounds;
+                R = rows_for((size_t)256 * (size_t)waves_per_cu * rounds);
+            }
         }
         if (R < 4 * depth) R = 4 * depth;
     }

@@ -3,6 +3,7 @@
 // error norm, accept (extensisq/common.py:222-356).  Host orchestration only;
 // the kernels are in esq_kernels.hpp / esq_epilogue.hpp / the RHS plugins.
 #include "esq_internal.hpp"
+#include "esq_chain.hpp"
 
 using namespace esqi;
 
@@ -205,6 +206,7 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last)
     double cw[ESQ_CHAIN_MAX_DEPTH][64] = {{0}}, ew[64] = {0};
     bool part[ESQ_CHAIN_MAX_DEPTH][64] = {{false}};
     bool use[64] = {false};
+    const double *init[ESQ_CHAIN_MAX_DEPTH] = {nullptr};
     double alg = 0.0;
     int n_init = 0;
     for (int q = 0; q < depth; ++q) {            // target q + 1
@@ -215,7 +217,7 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last)
                 part[q][term.col] = true;
             }
             if (c->stage_init[stage] >= 0) {
-                e.init[q] = c->krow[c->stage_init[stage]];
+                init[q] = c->krow[c->stage_init[stage]];
                 ++n_init;
             }
             alg += 8.0 * (c->stage_nnz[stage] + 4) * (double)c->len;
@@ -248,7 +250,17 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last)
         for (int j = 0; j < s; ++j)
             if (part[q][j] && (j < i || j >= i + depth)) use[j] = true;
     }
+    // memory rows: the leading partial sums first (each the start of its target's
+    // chain: weight 1, fma(1, p, 0) == p), then the K rows by ascending column
     int nu = 0;
+    for (int q = 0; q < depth; ++q) {
+        if (!init[q]) continue;
+        if (nu >= ESQ_CHAIN_MAX_ROWS) return kNotApplicable;
+        e.rows[nu] = init[q];
+        e.cu[q][nu] = 1.0;
+        e.umask[q] |= 1u << nu;
+        ++nu;
+    }
     for (int j = 0; j < s; ++j) {
         if (!use[j]) continue;
         if (nu >= ESQ_CHAIN_MAX_ROWS) return kNotApplicable;
@@ -279,7 +291,8 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last)
     // booked: what the one-stage sweeps book; moved: input, y, rows, inits in
     // (times the tile geometry's read amplification); the chain's K rows and the
     // last target out
-    const double reads = 2 + nu + n_init, writes = depth + 1;
+    const double reads = 2 + nu, writes = depth + 1;     // nu counts the partial sums too
+    (void)n_init;
     double amp = 1.0;
     e.read_amplification = &amp;
     char label[24];
@@ -470,9 +483,10 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
                 }
                 int nu = 0;
                 for (int j = 0; j < s; ++j) nu += u[j];
-                // what the built-in two-field plugin accepts (register budget)
-                if (nu > 9 || (D == 3 && last_sol && nu > 5) ||
-                    (D == 4 && (last_sol || nu > 2)))
+                // what the built-in two-field plugin accepts (register budget);
+                // the leading partial sums are memory rows of the chain too
+                if (nu + ninit > ESQ_CHAIN_MAX_ROWS - 1 ||
+                    !chain_within_caps(D, last_sol, nu + ninit))
                     continue;
                 double units = (2 + nu + ninit) * kHalo[D] + 2.0 * (D + 1);
                 if (nu > 6) units *= 1.12;

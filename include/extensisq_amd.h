@@ -160,7 +160,7 @@ typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
  * OPTIONAL chain entry of a plugin: `depth` consecutive stages in ONE marching
  * sweep.  With T_0 = y_in (the argument of the chain's first stage i):
  *     K_{i+k} = fun(t[k], T_k)                          -> f_out[k]   (k < depth)
- *     T_{e+1} = y + h*(init[e] + sum_u cu[e][u]*rows[u] + sum_{k<=e} ck[e][k]*K_{i+k})
+ *     T_{e+1} = y + h*(sum_u cu[e][u]*rows[u] + sum_{k<=e} ck[e][k]*K_{i+k})
  * T_1 .. T_{depth-1} (the arguments of the chain's later stages) live in
  * registers only; the last target T_depth goes to `out`:
  *   kind_last == ESQ_EPI_STAGE   the argument of stage i+depth, or y_new of an
@@ -172,8 +172,10 @@ typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
  * are read once for the whole chain.  rows[] is the union of the K rows any
  * target reads from memory, in ascending column order; bit u of umask[e] (bit k
  * of kmask[e]) says whether rows[u] (K_{i+k}) takes part in target e+1's sum --
- * a row that does not is skipped, not multiplied by zero.  Every sum runs over
- * ascending column index (init, rows, then the chain's own K in order), each
+ * a row that does not is skipped, not multiplied by zero.  A leading partial
+ * sum of the blocked accumulation is passed as the FIRST row of its target with
+ * weight 1 (fma(1, p, 0) == p).  Every sum runs over ascending column index
+ * (rows, then the chain's own K in order), each
  * product with h and the final add rounded separately: K rows and states are
  * bit-identical to `depth` one-stage sweeps.  y == NULL: the base is y_in itself
  * (a chain that starts with the end-point evaluation of the previous step).
@@ -193,7 +195,6 @@ typedef struct esq_chain {
     double ck[ESQ_CHAIN_MAX_DEPTH][ESQ_CHAIN_MAX_DEPTH];
     double ek[ESQ_CHAIN_MAX_DEPTH];
     unsigned kmask[ESQ_CHAIN_MAX_DEPTH];
-    const double *init[ESQ_CHAIN_MAX_DEPTH]; /* leading partial sums or NULL    */
     const double *y;
     double h;
     double t[ESQ_CHAIN_MAX_DEPTH];
