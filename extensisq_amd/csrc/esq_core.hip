@@ -6,6 +6,7 @@
 // by value in their kernel arguments.
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 
 #include "esq_internal.hpp"
@@ -581,6 +582,7 @@ int esq_set_rhs_fused(esq_ctx *c, esq_rhs_fused_fn fn, int fuse_mask) {
     c->rhs_fused = fn;
     c->fuse_mask = fn ? fuse_mask : 0;
     c->src_declined = false;
+    std::fill(c->chain_refused.begin(), c->chain_refused.end(), 0);
     return 0;
 }
 

@@ -110,6 +110,9 @@ struct esq_ctx {
     esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
     esq_rhs_chain_fn rhs_chain = nullptr;   // optional multi-stage marching sweep
     int chain_depth = 4;                    // ESQ_CHAIN_DEPTH: 1 off, up to 4 stages per sweep
+    // chains the plugin (or the library) has refused for this tableau / grid:
+    // refused[i * 8 + D] -- not asked again every step (esq_replan clears it)
+    std::vector<char> chain_refused;
     bool ynew_ready = false;     // YNEW already formed by the last stage's sweep
     bool solerr_ready = false;   // ... and the error partial sums too
     int red_count = 0;           // partials written by the last reducing sweep

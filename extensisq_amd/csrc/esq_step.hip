@@ -525,6 +525,7 @@ extern "C" {
 int esq_replan(esq_ctx *c) {
     if (!c || !c->have_tab) return ESQ_EINVAL;
     const int s = c->s;
+    c->chain_refused.assign((size_t)(s + 1) * 8, 0);
     const bool chained = c->rhs_chain && c->chain_depth >= 2 &&
                          env_uint("ESQ_PLAN_CHAINED", 1) != 0;
     auto cost = [&](const std::vector<int> &bounds) -> double {
@@ -760,7 +761,14 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 else if (i + D < i_to && may_fuse(c, ESQ_EPI_STAGE))
                     what = 0;
                 if (what < 0) continue;
+                const size_t slot = (size_t)i * 8 + (size_t)D;
+                if (slot < c->chain_refused.size() && c->chain_refused[slot]) continue;
                 const int r = sweep_chain(c, i, D, t, h, what);
+                if (r == ESQ_ENOTSUP || r == kNotApplicable) {
+                    // a property of the tableau and the grid, not of this step
+                    if (slot < c->chain_refused.size()) c->chain_refused[slot] = 1;
+                    continue;
+                }
                 if (r == 0) {
                     i += D - 1;                        // those stages are done too
                     ready = what == 0;

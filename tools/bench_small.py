@@ -30,9 +30,28 @@ def per_step(make, budget_s=1.0, min_steps=10, max_steps=400):
     return (time.perf_counter() - t0) / k
 
 
+def device_time(make, steps=50):
+    """summed kernel device time per step and launches per step (HIP events on
+    every launch) -- what a launch-free replay of the same kernels would cost at
+    the very least, before the ~1.5 us dependent-kernel boundaries"""
+    s = make()
+    for _ in range(5):
+        assert s.step() is None
+    dev = s._dev
+    dev.profile_reset()
+    dev.profile_enable([0, 1, 2, 3], every=1)
+    for _ in range(steps):
+        assert s.step() is None
+    dev.profile_enable(None)
+    rows = dev.profile_kernels()
+    launches = sum(r[2] for r in rows)
+    ms = sum(r[3] for r in rows)
+    return 1e3 * ms / steps, launches / steps + 1        # + the final sum
+
+
 def main():
     rows = []
-    for N in (10, 14, 32, 64, 100, 316, 1000):
+    for N in (10, 14, 32, 64, 100, 316, 1000, 2236):
         n = 2 * N * N
         y0 = pb.bruss2d_y0(N)
         h = 1.0 / pb.bruss2d_rho(N)
@@ -45,13 +64,16 @@ def main():
                    lambda: esq.Pr8(cpu_rhs, 0.0, y0, 1e9, **kw)),
                "oracle_us": 1e6 * per_step(
                    lambda: rk_oracle.Pr8(cpu_rhs, 0.0, y0, 1e9, **kw))}
+        row["device_kernels_us"], row["launches"] = device_time(
+            lambda: esq.Pr8(esq.Brusselator2D(N), 0.0, y0, 1e9, **kw))
         rows.append(row)
         print(json.dumps(row), flush=True)
-    print("\n| n | device RHS (us/step) | Python RHS on the device classes | NumPy oracle |")
-    print("|---|---|---|---|")
+    print("\n| n | device RHS (us/step) | launches | summed kernel time (us) | Python RHS on "
+          "the device classes | NumPy oracle |")
+    print("|---|---|---|---|---|---|")
     for r in rows:
-        print(f"| {r['n']} | {r['device_rhs_us']:.0f} | {r['host_rhs_us']:.0f} | "
-              f"{r['oracle_us']:.0f} |")
+        print(f"| {r['n']} | {r['device_rhs_us']:.0f} | {r['launches']:.0f} | "
+              f"{r['device_kernels_us']:.0f} | {r['host_rhs_us']:.0f} | {r['oracle_us']:.0f} |")
 
 
 if __name__ == "__main__":
