@@ -49,8 +49,11 @@ namespace esq {
 struct ChainCaps {
     int stage[5], solerr[5];
 };
-inline ChainCaps chain_caps() {
-    ChainCaps c = {{0, 0, 8, 5, 1}, {0, 0, 7, 2, -1}};
+// split = one field per wave (k_chain2d<..., SPLIT = true>): the budget of a
+// one-field kernel, every instantiated width keeps two waves per SIMD
+inline ChainCaps chain_caps(bool split = true) {
+    ChainCaps c = split ? ChainCaps{{0, 0, 9, 9, 9}, {0, 0, 9, 9, 9}}
+                        : ChainCaps{{0, 0, 8, 5, 1}, {0, 0, 7, 2, -1}};
     if (const char *env = getenv("ESQ_CHAIN_CAPS")) {
         int v[6];
         if (sscanf(env, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
@@ -61,9 +64,9 @@ inline ChainCaps chain_caps() {
     }
     return c;
 }
-inline bool chain_within_caps(int depth, bool solerr, int nu) {
+inline bool chain_within_caps(int depth, bool solerr, int nu, bool split = true) {
     if (depth < 2 || depth > 4) return false;
-    const ChainCaps c = chain_caps();
+    const ChainCaps c = chain_caps(split);
     return nu <= (solerr ? c.solerr[depth] : c.stage[depth]);
 }
 
@@ -94,18 +97,30 @@ struct ChainArgs {
 #ifndef ESQ_CHAIN_PREFETCH
 #define ESQ_CHAIN_PREFETCH true
 #endif
-template <int NF, bool PERIODIC, int D, int NU, int KINDLAST, class Fn,
-          bool PREFETCH = ESQ_CHAIN_PREFETCH>
+// SPLIT (fields coupled only pointwise, e.g. the Brusselator's u and v): a tile is
+// worked by NFT waves, ONE FIELD EACH (workgroup = 64 * NFT threads = one tile);
+// the centre values a stage's pointwise function needs from the other fields go
+// through LDS (1 KiB per field and stage, one workgroup barrier per stage
+// evaluation).  Per-wave register use is that of a one-field kernel, so depth-4
+// chains with 8-9 memory rows keep two waves per SIMD -- the whole Pr8 step
+// becomes E + three chains.  Same arithmetic, bit-identical.
+template <int NFT, bool PERIODIC, int D, int NU, int KINDLAST, class Fn,
+          bool SPLIT = false, bool PREFETCH = ESQ_CHAIN_PREFETCH>
 __global__ __launch_bounds__(kBlock) void k_chain2d(
     const double *__restrict__ ys, ChainArgs<D, NU> ca, Fn fn, int N, int R,
     unsigned tpr, unsigned ntiles, unsigned nblocks, unsigned xcd) {
+    constexpr int NF = SPLIT ? 1 : NFT;            // fields per wave
     constexpr int H = D - 1;                       // halo rows / lanes per side
     constexpr int W = 64 - 2 * H;                  // last-stage pairs per tile
     constexpr bool SOLERR = KINDLAST == ESQ_EPI_SOLERR;
+    constexpr int WAVES = SPLIT ? NFT : kBlock / 64;    // waves per workgroup
+    __shared__ double2 xch[SPLIT ? D : 1][SPLIT ? NFT : 1][SPLIT ? 64 : 1];
     // XCD band remap as in the one-stage sweeps: XCD x takes a contiguous band
     const unsigned per = (nblocks + xcd - 1) / xcd;
     const unsigned lb = (blockIdx.x % xcd) * per + blockIdx.x / xcd;
-    const unsigned tile = lb * (kBlock / 64) + (threadIdx.x >> 6);
+    const unsigned wave = threadIdx.x >> 6;
+    const unsigned tile = SPLIT ? lb : lb * (kBlock / 64) + wave;
+    const int fbase = SPLIT ? (int)wave : 0;       // first field of this wave
     double local = 0.0;
     if (lb < nblocks && tile < ntiles) {                        // wave-uniform
         const int npairs = N / 2;
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         };
         auto ld_ys = [&](int r, int f) -> double2 {
             if (!live || !row_ok(r)) return make_double2(0.0, 0.0);
-            return ld2(ys, (size_t)f * fstride + (size_t)wrap(r) * npairs + pw);
+            return ld2(ys, (size_t)(fbase + f) * fstride + (size_t)wrap(r) * npairs + pw);
         };
         const double2 zero = make_double2(0.0, 0.0);
         // windows of the D stages: rows rho_k - 1, rho_k, rho_k + 1 of T_k
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         const size_t base_ = (size_t)wrap(rho_) * npairs + pw;                     \
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                           \
             ysn[f] = ld_ys(rho_ + 1, f);                                           \
-            const size_t k2_ = (size_t)f * fstride + base_;                        \
+            const size_t k2_ = (size_t)(fbase + f) * fstride + base_;              \
             _Pragma("unroll") for (int j = 0; j < NU; ++j)                         \
                 u[j][f] = act_ ? ld2_nt(ca.rows[j], k2_) : zero;                   \
             yrow[f] = (ca.y && act_) ? ld2(ca.y, k2_) : zero;                      \
@@ -219,10 +234,20 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                         lap[f].y = ((wm[k][f].y + wp[k][f].y) + (wc[k][f].x + rt)) -
                                    4.0 * wc[k][f].y;
                     }
-                    fn.eval(cc, lap, fK);
+                    if constexpr (SPLIT) {
+                        // the other fields' centre values of this row, through LDS
+                        xch[k][wave][lane] = cc[0];
+                        __syncthreads();
+                        double2 call[NFT];
+#pragma unroll
+                        for (int g = 0; g < NFT; ++g) call[g] = xch[k][g][lane];
+                        fK[0] = fn.eval_one(fbase, call, lap[0]);
+                    } else {
+                        fn.eval(cc, lap, fK);
+                    }
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
-                        const size_t k2 = (size_t)f * fstride + basek;
+                        const size_t k2 = (size_t)(fbase + f) * fstride + basek;
                         if (ca.fk[k] && own && store_ok) {
                             if (ca.f_nt) st2_nt(ca.fk[k], k2, fK[f]);
                             else st2(ca.fk[k], k2, fK[f]);
@@ -280,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             }
         }
     }
-    if (SOLERR) block_partial(local, ca.red.partials);
+    if (SOLERR) block_partial_w<WAVES>(local, ca.red.partials);
 }
 #undef ESQ_CHAIN_LOAD_ROW
 

@@ -447,7 +447,13 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
                             hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->h_slot, 0, sizeof(HostSlot));
     c->comm_timeout_s = (double)env_uint("ESQ_COMM_TIMEOUT_S", 120);
-    c->epi_nt = env_uint("ESQ_EPI_NT", 0x3);
+    // K_i of the stage / block sweeps is streamed out (nobody re-reads it soon).
+    // The last stage's and the end-point sweep's derivative is read again by the
+    // next launches: kept cacheable while three vectors fit the Infinity Cache
+    // (Pr9 at n = 5e6: plain 74 us vs streamed 80 us for the following chain),
+    // streamed beyond (Pr8 at n = 1e7: end-point sweep 58 -> 48 us, step -2.5 %)
+    const bool three_fit = 3 * c->len_pad * sizeof(double) <= ((size_t)160 << 20);
+    c->epi_nt = env_uint("ESQ_EPI_NT", three_fit ? 0x3 : 0xf);
     c->skip_dead = env_uint("ESQ_DEAD_STORE", 1) != 0;
     c->chain_depth = (int)env_uint("ESQ_CHAIN_DEPTH", 4);
     if (c->chain_depth > ESQ_CHAIN_MAX_DEPTH) c->chain_depth = ESQ_CHAIN_MAX_DEPTH;

@@ -65,6 +65,22 @@ __device__ __forceinline__ void block_partial(double v, double *partials) {
     }
 }
 
+// the same for a workgroup of NW waves (the split chain sweeps)
+template <int NW>
+__device__ __forceinline__ void block_partial_w(double v, double *partials) {
+    __shared__ double lds[NW];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = lds[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += lds[w];
+        partials[blockIdx.x] = s;
+    }
+}
+
 // np.maximum propagates NaN, fmax drops it: keep NumPy's semantics
 __device__ __forceinline__ double pmax(double a, double b) {
     double m = fmax(a, b);

@@ -219,7 +219,7 @@ ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
     return a;
 }
 // (depth, kind_last, nu) -> launch(ChainArgs<D, NU>, integral_constant<kind_last>).
-// Instantiated: depth 2 and 3 with up to 9 memory rows, depth 4 with up to 6.
+// Instantiated: depth 2, 3 and 4 with up to 9 memory rows.
 template <class Launch>
 int dispatch_chain(const esq_chain *c, Launch &&launch) {
     if (!c || c->nu < 0 || !c->out) return ESQ_EINVAL;
@@ -254,7 +254,8 @@ int dispatch_chain(const esq_chain *c, Launch &&launch) {
             }
         case 4:
             switch (c->nu) {
-                ESQ_CHAIN_CASES_0_6_(4)
+                ESQ_CHAIN_CASES_0_6_(4) ESQ_CHAIN_CASE_(4, 7) ESQ_CHAIN_CASE_(4, 8)
+                ESQ_CHAIN_CASE_(4, 9)
                 default: return ESQ_ENOTSUP;
             }
         default: return ESQ_ENOTSUP;

@@ -108,6 +108,15 @@ struct BrussFn {
         f[1].x = (B * c[0].x - uuvx) + d * lap[1].x;
         f[1].y = (B * c[0].y - uuvy) + d * lap[1].y;
     }
+    // one field only (split chain sweeps: a wave per field), same operations
+    __device__ __forceinline__ double2 eval_one(int field, const double2 (&c)[2],
+                                                double2 lap) const {
+        const double uuvx = c[0].x * c[0].x * c[1].x, uuvy = c[0].y * c[0].y * c[1].y;
+        if (field == 0)
+            return make_double2(((A + uuvx) - (B + 1.0) * c[0].x) + d * lap.x,
+                                ((A + uuvy) - (B + 1.0) * c[0].y) + d * lap.y);
+        return make_double2((B * c[0].x - uuvx) + d * lap.x, (B * c[0].y - uuvy) + d * lap.y);
+    }
 };
 
 }  // namespace
@@ -192,28 +201,38 @@ int esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chain
     if (!r || r->kind != BRUSS2D || n != r->n || !chain) return ESQ_EINVAL;
     if (r->N % 2 != 0 || r->N < 16) return ESQ_ENOTSUP;
     if (!chain_fits_grid(r->N, chain->depth)) return ESQ_ENOTSUP;
-    // register budget of the two-field kernel (esq_chain.hpp, ChainCaps)
+    // register budget (esq_chain.hpp, ChainCaps): one field per wave keeps two
+    // waves per SIMD up to depth 4 with 9 memory rows; ESQ_CHAIN_SPLIT=0 runs
+    // both fields in one wave (the first version; narrower caps)
+    static const bool split = !getenv("ESQ_CHAIN_SPLIT") || atoi(getenv("ESQ_CHAIN_SPLIT")) != 0;
     if (!esq::chain_within_caps(chain->depth, chain->kind_last == ESQ_EPI_SOLERR,
-                                chain->nu))
+                                chain->nu, split))
         return ESQ_ENOTSUP;
     const BrussFn fn{r->alpha * ((double)r->N * (double)r->N), r->a, r->b};
     int rc_launch = 0;
     const int rc = esq::dispatch_chain(chain, [&](auto ca, auto kind) {
         using CA = decltype(ca);
-        auto kern = esq::k_chain2d<2, true, CA::kD, CA::kNU, decltype(kind)::value, BrussFn>;
-        static const int wpc = chain_waves_per_cu(kern);    // per instantiation
-        const GeoChain g = geo_chain(r->N, CA::kD, wpc);
-        if (chain->read_amplification)
-            *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1)) / g.R * 64.0 /
-                                         (64 - 2 * (CA::kD - 1));
-        if (decltype(kind)::value == ESQ_EPI_SOLERR) {
-            if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
-            if (chain->partials_used) *chain->partials_used = (int)g.grid;
-        }
-        hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(kBlock), 0, (hipStream_t)stream,
-                              (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in,
-                              ca, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
-                              (unsigned)kXcd);
+        auto launch = [&](auto kern, unsigned block, int tiles_per_block, int waves_per_tile) {
+            static const int wpc = chain_waves_per_cu(kern, block);   // per instantiation
+            const GeoChain g = geo_chain(r->N, CA::kD, wpc, tiles_per_block, waves_per_tile);
+            if (decltype(kind)::value == ESQ_EPI_SOLERR) {
+                if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
+                if (chain->partials_used) *chain->partials_used = (int)g.grid;
+            }
+            if (chain->read_amplification)
+                *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1)) / g.R * 64.0 /
+                                             (64 - 2 * (CA::kD - 1));
+            hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(block), 0, (hipStream_t)stream,
+                                  (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in,
+                                  ca, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
+                                  (unsigned)kXcd);
+        };
+        if (split)
+            launch(esq::k_chain2d<2, true, CA::kD, CA::kNU, decltype(kind)::value, BrussFn, true>,
+                   128u, 1, 2);
+        else
+            launch(esq::k_chain2d<2, true, CA::kD, CA::kNU, decltype(kind)::value, BrussFn, false>,
+                   (unsigned)kBlock, kBlock / 64, 1);
     });
     if (rc) return rc;
     return rc_launch ? rc_launch : (int)hipGetLastError();

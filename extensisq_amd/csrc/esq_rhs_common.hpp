@@ -176,13 +176,14 @@ struct GeoChain {
     unsigned tpr, ntiles, nblocks, grid;
 };
 template <class Kernel>
-inline int chain_waves_per_cu(Kernel kern) {
+inline int chain_waves_per_cu(Kernel kern, unsigned block) {
     int blocks = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, kBlock, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, (int)block, 0) != hipSuccess ||
         blocks < 1)
         blocks = 2;
-    if (blocks > 8) blocks = 8;
-    return blocks * (kBlock / 64);
+    int waves = blocks * (int)(block / 64);
+    if (waves > 32) waves = 32;
+    return waves;
 }
 // a chain of depth D carries 2(D-1) halo rows per tile: it pays only where the
 // grid gives every wave slot a tile of at least ~8(D-1) rows (measured: Ts5 at
@@ -194,7 +195,10 @@ inline bool chain_fits_grid(int N, int depth) {
     const size_t tpr = ((size_t)N / 2 + W - 1) / W;
     return (size_t)N * tpr >= (size_t)8192 * (depth - 1);
 }
-inline GeoChain geo_chain(int N, int depth, int waves_per_cu) {
+// tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
+// share one tile (the split sweeps: one per field)
+inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_block,
+                          int waves_per_tile) {
     GeoChain g;
     const int W = 64 - 2 * (depth - 1);
     g.tpr = ((unsigned)N / 2 + W - 1) / W;
@@ -208,7 +212,7 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu) {
         // grids too large for one round at full occupancy take several
         // tiles = tpr * ceil(N / R) must not exceed the wave slots of the round
         auto rows_for = [&](size_t slots) -> int {
-            const size_t max_row_tiles = slots / g.tpr;
+            const size_t max_row_tiles = slots / (size_t)waves_per_tile / g.tpr;
             if (max_row_tiles == 0) return N + 1;
             return (int)(((size_t)N + max_row_tiles - 1) / max_row_tiles);
         };
@@ -229,7 +233,7 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu) {
     if (R > N) R = N;
     g.R = R;
     g.ntiles = g.tpr * (unsigned)((N + R - 1) / R);
-    g.nblocks = (g.ntiles + kBlock / 64 - 1) / (kBlock / 64);
+    g.nblocks = (g.ntiles + tiles_per_block - 1) / tiles_per_block;
     g.grid = ((g.nblocks + kXcd - 1) / kXcd) * kXcd;
     return g;
 }

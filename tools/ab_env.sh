@@ -1,24 +1,17 @@
 #!/bin/bash
-# A/B of one environment knob on ONE box, interleaved rounds.
-#   tools/ab_env.sh <config> <VAR> "<v1> <v2> ..." [rounds] [steps]
-# prints per value: wall ms/step of every round, and the summed device time of
-# all kernels per step (less sensitive to host jitter than the wall clock)
-CFG=$1; VAR=$2; VALS=$3; ROUNDS=${4:-2}; STEPS=${5:-100}
+# same-box interleaved A/B of environment settings on a bench config:
+#   tools/ab_env.sh <config> "VAR=a VAR2=b" "VAR=c" ...     ("" = defaults)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/ab_${VAR}_$CFG.jsonl
-: > $OUT
-for r in $(seq 1 $ROUNDS); do
-  for v in $VALS; do
-    env $VAR=$v python3 $ROOT/bench.py --config $CFG --steps $STEPS --warmup 10 \
-        --no-cpu-baseline --no-solve-ivp 2>/dev/null | \
-        python3 -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']; print(json.dumps({'v':'$v','ms':d['ms_per_step'],'frac':d['roofline']['frac'],'dev_ms':sum(x['avg_us']*x['launches'] for x in k.values())/d['steps']/1e3,'k':{n:round(x['avg_us'],1) for n,x in k.items()}}))" >> $OUT
+CFG=${1:-pr8}; shift
+python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras > /dev/null 2>&1
+for round in 1 2 3; do
+  for SET in "$@"; do
+    env $SET python3 $ROOT/bench.py --config $CFG --steps 60 --warmup 10 --no-cpu-baseline --no-solve-ivp --no-extras > /tmp/ab_env.json 2>/dev/null
+    python3 - <<PY
+import json
+d=json.load(open("/tmp/ab_env.json"))
+ks=d["roofline"]["kernels"]
+print("$CFG [%s] round=$round ms/step=%.4f sum=%.4f  "%("$SET", d["ms_per_step"], sum(v["avg_us"]*v["launches"] for v in ks.values())/d["steps"]/1e3) + " ".join("%s=%.0f"%(k,v["avg_us"]) for k,v in sorted(ks.items())))
+PY
   done
 done
-python3 - <<PY
-import json,collections
-agg=collections.defaultdict(list)
-for l in open("$OUT"):
-    d=json.loads(l); agg[d['v']].append(d)
-for k,v in agg.items():
-    print('$CFG $VAR=%-9s wall %s | kernels %s | mean %.4f'%(k,' '.join('%.4f'%x['ms'] for x in v),' '.join('%.4f'%x['dev_ms'] for x in v), sum(x['dev_ms'] for x in v)/len(v)))
-PY
