@@ -47,25 +47,25 @@ namespace esq {
 // a single sweep take 360).  The block planner (esq_step.hip) uses the same
 // table.  ESQ_CHAIN_CAPS="s2,e2,s3,e3,s4,e4" overrides it (tuning).
 struct ChainCaps {
-    int stage[5], solerr[5];
+    int stage[7], solerr[7];
 };
 // split = one field per wave (k_chain2d<..., SPLIT = true>): the budget of a
-// one-field kernel, every instantiated width keeps two waves per SIMD
+// one-field kernel.  Depth 5 and 6 are instantiated with up to 6 memory rows.
 inline ChainCaps chain_caps(bool split = true) {
-    ChainCaps c = split ? ChainCaps{{0, 0, 9, 9, 9}, {0, 0, 9, 9, 9}}
-                        : ChainCaps{{0, 0, 8, 5, 1}, {0, 0, 7, 2, -1}};
+    ChainCaps c = split ? ChainCaps{{0, 0, 9, 9, 9, 6, 6}, {0, 0, 9, 9, 9, 6, 6}}
+                        : ChainCaps{{0, 0, 8, 5, 1, -1, -1}, {0, 0, 7, 2, -1, -1, -1}};
     if (const char *env = getenv("ESQ_CHAIN_CAPS")) {
-        int v[6];
-        if (sscanf(env, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
-            c.stage[2] = v[0]; c.solerr[2] = v[1];
-            c.stage[3] = v[2]; c.solerr[3] = v[3];
-            c.stage[4] = v[4]; c.solerr[4] = v[5];
+        int v[10];
+        const int got = sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3],
+                               &v[4], &v[5], &v[6], &v[7], &v[8], &v[9]);
+        for (int d = 2; d <= 6; ++d) {
+            if (got >= 2 * (d - 1)) { c.stage[d] = v[2 * (d - 2)]; c.solerr[d] = v[2 * (d - 2) + 1]; }
         }
     }
     return c;
 }
 inline bool chain_within_caps(int depth, bool solerr, int nu, bool split = true) {
-    if (depth < 2 || depth > 4) return false;
+    if (depth < 2 || depth > 6) return false;
     const ChainCaps c = chain_caps(split);
     return nu <= (solerr ? c.solerr[depth] : c.stage[depth]);
 }

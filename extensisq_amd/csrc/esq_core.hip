@@ -455,7 +455,7 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     const bool three_fit = 3 * c->len_pad * sizeof(double) <= ((size_t)160 << 20);
     c->epi_nt = env_uint("ESQ_EPI_NT", three_fit ? 0x3 : 0xf);
     c->skip_dead = env_uint("ESQ_DEAD_STORE", 1) != 0;
-    c->chain_depth = (int)env_uint("ESQ_CHAIN_DEPTH", 4);
+    c->chain_depth = (int)env_uint("ESQ_CHAIN_DEPTH", 4);     // 5 and 6 exist too
     if (c->chain_depth > ESQ_CHAIN_MAX_DEPTH) c->chain_depth = ESQ_CHAIN_MAX_DEPTH;
     // launch geometry: grid-stride kernels, a few resident blocks per CU
     hipDeviceProp_t prop;
@@ -566,8 +566,10 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     c->rhs_fused = nullptr;
     c->fuse_mask = 0;
     c->rhs_rkc = nullptr;
+    const bool had_chain = c->rhs_chain != nullptr;
     c->rhs_chain = nullptr;
-    return 0;
+    // the block plan was made for a chaining plugin: make it again for this one
+    return (had_chain && c->have_tab) ? esq_replan(c) : 0;
 }
 int esq_set_rhs_chain(esq_ctx *c, esq_rhs_chain_fn fn) {
     if (!c) return ESQ_EINVAL;

@@ -219,8 +219,10 @@ ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
     return a;
 }
 // (depth, kind_last, nu) -> launch(ChainArgs<D, NU>, integral_constant<kind_last>).
-// Instantiated: depth 2, 3 and 4 with up to 9 memory rows.
-template <class Launch>
+// Instantiated: depth 2, 3 and 4 with up to 9 memory rows, 5 and 6 with up to 6.
+// MAXD: deepest chain the caller's kernel is instantiated for (compile time grows
+// with every depth)
+template <int MAXD = 4, class Launch>
 int dispatch_chain(const esq_chain *c, Launch &&launch) {
     if (!c || c->nu < 0 || !c->out) return ESQ_EINVAL;
     if (c->kind_last == ESQ_EPI_SOLERR && (!c->partials || !c->y)) return ESQ_EINVAL;
@@ -258,6 +260,22 @@ int dispatch_chain(const esq_chain *c, Launch &&launch) {
                 ESQ_CHAIN_CASE_(4, 9)
                 default: return ESQ_ENOTSUP;
             }
+        case 5:
+            if constexpr (MAXD >= 5) {
+                switch (c->nu) {
+                    ESQ_CHAIN_CASES_0_6_(5)
+                    default: return ESQ_ENOTSUP;
+                }
+            }
+            return ESQ_ENOTSUP;
+        case 6:
+            if constexpr (MAXD >= 6) {
+                switch (c->nu) {
+                    ESQ_CHAIN_CASES_0_6_(6)
+                    default: return ESQ_ENOTSUP;
+                }
+            }
+            return ESQ_ENOTSUP;
         default: return ESQ_ENOTSUP;
     }
 #undef ESQ_CHAIN_CASE_

@@ -422,7 +422,7 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
     const int s = c->s, depth = c->chain_depth;
     const std::vector<double> &A = c->A;
     auto nz = [&](int i, int j) { return A[(size_t)i * s + j] != 0.0; };
-    static const double kHalo[5] = {1.0, 1.0, 1.10, 1.20, 1.31};
+    static const double kHalo[7] = {1.0, 1.0, 1.10, 1.20, 1.31, 1.38, 1.46};
     std::vector<int> from(s, 0);
     std::vector<char> has_init(s, 0), cur(s, 0);
     struct Blk { int J, nt, no, ninit; std::vector<int> cols; };

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ESQ_ABI_VERSION 2
+#define ESQ_ABI_VERSION 3
 
 /* error codes (negative = misuse) */
 #define ESQ_EINVAL   (-1)   /* bad argument (row/slot out of range, NULL, ...) */
@@ -182,7 +182,7 @@ typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
  * How a stencil plugin does it (stage k marches k grid rows behind stage 0):
  * csrc/esq_chain.hpp.  Return ESQ_ENOTSUP for any case the plugin does not chain.
  */
-#define ESQ_CHAIN_MAX_DEPTH 4
+#define ESQ_CHAIN_MAX_DEPTH 6
 #define ESQ_CHAIN_MAX_ROWS 10
 typedef struct esq_chain {
     int depth;                               /* 2 .. ESQ_CHAIN_MAX_DEPTH        */

@@ -51,7 +51,7 @@ REQUIRED = {
     "test_gpu_parity.py::test_each_epilogue_kind_is_bit_identical": 40,
     "test_gpu_parity.py::test_prelaunched_first_stage_is_used_only_when_valid": 4,
     "test_gpu_rkc.py::test_rkc_chained_stage_is_bit_identical": 1,
-    "test_gpu_parity.py::test_chained_stage_sweeps_are_bit_identical": 112,
+    "test_gpu_parity.py::test_chained_stage_sweeps_are_bit_identical": 160,
     "test_gpu_rkc.py::test_rkc_fused_tail_matches_unfused": 5,
     "test_gpu_parity.py::test_host_slab_mode_is_bit_identical": 10,
     "test_gpu_parity.py::test_host_slab_mode_is_faster_for_small_host_rhs": 1,
