@@ -385,7 +385,7 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
             "ms_per_step_profiled_replay": 1e3 * timing["elapsed_prof"] / args.steps,
             # N = 1 only (rank 0 measures them after the timed region)
             "solve_ivp": None, "sustained": None, "generic_plugin": None,
-            "adaptive": None,
+            "adaptive": None, "rows_kept": None,
         },
         "roofline": {
             "bound": "hbm", "kernel": meta["kernel"],
@@ -538,6 +538,8 @@ def main():
                                                else generic_plugin_figure(w, local, args))
             out["config"]["adaptive"] = (None if args.no_extras
                                          else adaptive_figure(w, local, esq))
+            out["config"]["rows_kept"] = (None if args.no_extras
+                                          else rows_kept_figure(w, local, args))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_steps)
         print(json.dumps(out), flush=True)
@@ -599,6 +601,37 @@ def generic_plugin_figure(w, device, args):
             "all_kernels_gbs": moved / (ms * 1e-3) / 1e9 if ms > 0 else None,
             "note": "ESQ_CHAIN=0: RHS plugin launch + stand-alone stage / block / "
                     "solution-error kernels, as for a user plugin without fused entry"}
+
+
+def rows_kept_figure(w, device, args):
+    """the same workload on a context that writes EVERY row of K in every step
+    (ESQ_LAZY_ROWS=0).  By default the rows of a step's last chain sweep -- read by
+    nothing but that sweep's own solution / error sums -- are written only for a
+    caller that reads them (dense output, `solver.K`, stiffness detection): the
+    first such read re-evaluates them, a second within four steps makes the
+    context keep them.  This is what such a caller's steps cost."""
+    if "rho_jac" in w["kw"]:
+        return None                       # SSV2stab config: no K rows
+    old = os.environ.get("ESQ_LAZY_ROWS")
+    os.environ["ESQ_LAZY_ROWS"] = "0"
+    try:
+        s = w["cls"](w["rhs"], 0.0, w["y0"], 1.0e9, device=device, **w["kw"])
+    finally:
+        if old is None:
+            del os.environ["ESQ_LAZY_ROWS"]
+        else:
+            os.environ["ESQ_LAZY_ROWS"] = old
+    dev = s._dev
+    for _ in range(args.warmup):
+        assert s.step() is None
+    dev.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        assert s.step() is None
+    dev.synchronize()
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": 1e3 * dt / args.steps, "value": s.n * args.steps / dt,
+            "note": "ESQ_LAZY_ROWS=0: the last chain sweep also writes its K rows"}
 
 
 def adaptive_figure(w, device, esq, span_steps=40):

@@ -25,6 +25,7 @@ int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
                      int from_end, esq_dense **out) {
     if (!c || !P || !out) return ESQ_EINVAL;
     ENTER_KEEP(c);
+    ENSURE_ROWS(c);
     if (rows < 1 || rows > c->n_rows || p < 1 || p > kMaxCols)
         return fail(c, ESQ_EINVAL, "bad interpolant shape (%d, %d)", rows, p);
     esq_dense *d = new (std::nothrow) esq_dense();

@@ -100,8 +100,8 @@ struct ChainArgs {
 // SPLIT (fields coupled only pointwise, e.g. the Brusselator's u and v): a tile is
 // worked by NFT waves, ONE FIELD EACH (workgroup = 64 * NFT threads = one tile);
 // the centre values a stage's pointwise function needs from the other fields go
-// through LDS (1 KiB per field and stage, one workgroup barrier per stage
-// evaluation).  Per-wave register use is that of a one-field kernel, so depth-4
+// through LDS (2 x 1 KiB per field and stage, one workgroup barrier per grid
+// row).  Per-wave register use is that of a one-field kernel, so depth-4
 // chains with 8-9 memory rows keep two waves per SIMD -- the whole Pr8 step
 // becomes E + three chains.  Same arithmetic, bit-identical.
 template <int NFT, bool PERIODIC, int D, int NU, int KINDLAST, class Fn,
@@ -114,11 +114,14 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
     constexpr int W = 64 - 2 * H;                  // last-stage pairs per tile
     constexpr bool SOLERR = KINDLAST == ESQ_EPI_SOLERR;
     constexpr int WAVES = SPLIT ? NFT : kBlock / 64;    // waves per workgroup
-    __shared__ double2 xch[SPLIT ? D : 1][SPLIT ? NFT : 1][SPLIT ? 64 : 1];
+    // SPLIT: the centre rows of all D stages, double-buffered by iteration parity
+    __shared__ double2 xch[SPLIT ? 2 : 1][SPLIT ? D : 1][SPLIT ? NFT : 1][SPLIT ? 64 : 1];
     // XCD band remap as in the one-stage sweeps: XCD x takes a contiguous band
     const unsigned per = (nblocks + xcd - 1) / xcd;
     const unsigned lb = (blockIdx.x % xcd) * per + blockIdx.x / xcd;
-    const unsigned wave = threadIdx.x >> 6;
+    // wave-uniform by construction; said so, the tile, its row range and every
+    // branch on them are scalar for the compiler too
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned tile = SPLIT ? lb : lb * (kBlock / 64) + wave;
     const int fbase = SPLIT ? (int)wave : 0;       // first field of this wave
     double local = 0.0;
@@ -138,11 +141,37 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         auto wrap = [&](int r) {
             return PERIODIC ? (r < 0 ? r + N : (r >= N ? r - N : r)) : r;
         };
+        // periodic grids: every row exists, and a lane beyond the halo columns
+        // (its results reach no stored lane) simply reads column pair 0 -- no load
+        // sits under a lane mask.  Dirichlet grids: outside is zero.
+        const int pwl = PERIODIC ? (live ? pw : 0) : pw;
         auto ld_ys = [&](int r, int f) -> double2 {
-            if (!live || !row_ok(r)) return make_double2(0.0, 0.0);
-            return ld2(ys, (size_t)(fbase + f) * fstride + (size_t)wrap(r) * npairs + pw);
+            if (!PERIODIC && (!live || !row_ok(r))) return make_double2(0.0, 0.0);
+            return ld2(ys, (size_t)(fbase + f) * fstride + (size_t)wrap(r) * npairs + pwl);
         };
         const double2 zero = make_double2(0.0, 0.0);
+        // every weight as a scalar of its own: taken straight from the argument
+        // struct, the compiler keeps whole 16-register load tuples alive and, out
+        // of scalar registers, re-reads a TUPLE for every use (706 v_readlane per
+        // row in chain4+solerr<8>, half of its vector instructions)
+        double w_cu[D][ChainArgs<D, NU>::NUa], w_eu[ChainArgs<D, NU>::NUa], w_ck[D][D],
+            w_ek[D];
+#pragma unroll
+        for (int e = 0; e < D; ++e) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                asm("s_mov_b64 %0, %1" : "=s"(w_cu[e][j]) : "s"(ca.cu[e][j]));
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                asm("s_mov_b64 %0, %1" : "=s"(w_ck[e][k]) : "s"(ca.ck[e][k]));
+            }
+            asm("s_mov_b64 %0, %1" : "=s"(w_ek[e]) : "s"(ca.ek[e]));
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            asm("s_mov_b64 %0, %1" : "=s"(w_eu[j]) : "s"(ca.eu[j]));
+        }
         // windows of the D stages: rows rho_k - 1, rho_k, rho_k + 1 of T_k
         double2 wm[D][NF], wc[D][NF], wp[D][NF];
         // acc[e][k]: target e + 1's sum for the row stage k is at (k <= e)
@@ -169,14 +198,15 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
 #define ESQ_CHAIN_LOAD_ROW(IT)                                                     \
     {                                                                              \
         const int rho_ = r0 - H + (IT);                                            \
-        const bool act_ = live && row_ok(rho_);                                    \
-        const size_t base_ = (size_t)wrap(rho_) * npairs + pw;                     \
+        const bool act_ = PERIODIC || (live && row_ok(rho_));                      \
+        const size_t base_ = (size_t)wrap(rho_) * npairs + pwl;                    \
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                           \
             ysn[f] = ld_ys(rho_ + 1, f);                                           \
             const size_t k2_ = (size_t)(fbase + f) * fstride + base_;              \
             _Pragma("unroll") for (int j = 0; j < NU; ++j)                         \
                 u[j][f] = act_ ? ld2_nt(ca.rows[j], k2_) : zero;                   \
-            yrow[f] = (ca.y && act_) ? ld2(ca.y, k2_) : zero;                      \
+            yrow[f] = zero;                                                        \
+            if (ca.y) yrow[f] = act_ ? ld2(ca.y, k2_) : zero;                      \
         }                                                                          \
     }
         ESQ_CHAIN_LOAD_ROW(0)
@@ -195,6 +225,26 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             if (PREFETCH) {
                 if (it + 1 < iters) ESQ_CHAIN_LOAD_ROW(it + 1)
             }
+            // the participation masks, opaque per row: tested where they are used
+            // (one scalar bit test) instead of 2 x 90 hoisted lane masks that live
+            // in spilled scalar registers
+            unsigned um[D], km[D];
+#pragma unroll
+            for (int e = 0; e < D; ++e) {
+                um[e] = ca.umask[e];
+                km[e] = ca.kmask[e];
+                asm volatile("" : "+s"(um[e]), "+s"(km[e]));
+            }
+            if constexpr (SPLIT) {
+                // the other fields' centre values, for ALL stages at once: a stage's
+                // centre row was completed an iteration ago, so the exchange (LDS
+                // write, ONE workgroup barrier, LDS read) is off the stage-to-stage
+                // dependency chain.  Two buffers: a wave that runs ahead writes
+                // iteration it + 1's values while its partner still reads it's.
+#pragma unroll
+                for (int k = 0; k < D; ++k) xch[it & 1][k][wave][lane] = wc[k][0];
+                __syncthreads();
+            }
             // ---- the D targets' sums for row rho0: leading partial + memory rows
 #pragma unroll
             for (int e = 0; e < D; ++e)
@@ -203,12 +253,13 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                     double2 s = zero, se = zero;
 #pragma unroll
                     for (int j = 0; j < NU; ++j) {
-                        if ((ca.umask[e] >> j) & 1u) {             // uniform
-                            s.x = fma(ca.cu[e][j], uc[j][f].x, s.x);
-                            s.y = fma(ca.cu[e][j], uc[j][f].y, s.y);
+                        if ((um[e] >> j) & 1u) {                   // uniform
+                            asm volatile("");    // a real branch, not 2 selects per fma
+                            s.x = fma(w_cu[e][j], uc[j][f].x, s.x);
+                            s.y = fma(w_cu[e][j], uc[j][f].y, s.y);
                             if (SOLERR && e == D - 1) {
-                                se.x = fma(ca.eu[j], uc[j][f].x, se.x);
-                                se.y = fma(ca.eu[j], uc[j][f].y, se.y);
+                                se.x = fma(w_eu[j], uc[j][f].x, se.x);
+                                se.y = fma(w_eu[j], uc[j][f].y, se.y);
                             }
                         }
                     }
@@ -235,12 +286,9 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                                    4.0 * wc[k][f].y;
                     }
                     if constexpr (SPLIT) {
-                        // the other fields' centre values of this row, through LDS
-                        xch[k][wave][lane] = cc[0];
-                        __syncthreads();
                         double2 call[NFT];
 #pragma unroll
-                        for (int g = 0; g < NFT; ++g) call[g] = xch[k][g][lane];
+                        for (int g = 0; g < NFT; ++g) call[g] = xch[it & 1][k][g][lane];
                         fK[0] = fn.eval_one(fbase, call, lap[0]);
                     } else {
                         fn.eval(cc, lap, fK);
@@ -255,12 +303,13 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                         // K_k enters the sums of the later targets
 #pragma unroll
                         for (int e = k; e < D; ++e) {
-                            if ((ca.kmask[e] >> k) & 1u) {         // uniform
-                                acc[e][k][f].x = fma(ca.ck[e][k], fK[f].x, acc[e][k][f].x);
-                                acc[e][k][f].y = fma(ca.ck[e][k], fK[f].y, acc[e][k][f].y);
+                            if ((km[e] >> k) & 1u) {               // uniform
+                                asm volatile("");
+                                acc[e][k][f].x = fma(w_ck[e][k], fK[f].x, acc[e][k][f].x);
+                                acc[e][k][f].y = fma(w_ck[e][k], fK[f].y, acc[e][k][f].y);
                                 if (SOLERR && e == D - 1) {
-                                    acce[k][f].x = fma(ca.ek[k], fK[f].x, acce[k][f].x);
-                                    acce[k][f].y = fma(ca.ek[k], fK[f].y, acce[k][f].y);
+                                    acce[k][f].x = fma(w_ek[k], fK[f].x, acce[k][f].x);
+                                    acce[k][f].y = fma(w_ek[k], fK[f].y, acce[k][f].y);
                                 }
                             }
                         }
@@ -276,9 +325,16 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                             if (SOLERR) {
                                 const double2 er = make_double2(__dmul_rn(ca.h, acce[k][f].x),
                                                                 __dmul_rn(ca.h, acce[k][f].y));
-                                local += ratio_sq<false>(er, yf[k][f], t, ca.red.atol_vec,
-                                                         ca.red.atol_s, ca.red.rtol, k2,
-                                                         ca.red.n_valid);
+                                // two copies: with a scalar atol no load (and no wait
+                                // for the prefetched row behind it) is here
+                                if (ca.red.atol_vec)
+                                    local += ratio_sq<false>(er, yf[k][f], t, ca.red.atol_vec,
+                                                             ca.red.atol_s, ca.red.rtol, k2,
+                                                             ca.red.n_valid);
+                                else
+                                    local += ratio_sq<false>(er, yf[k][f], t, nullptr,
+                                                             ca.red.atol_s, ca.red.rtol, k2,
+                                                             ca.red.n_valid);
                             }
                         }
                     }

@@ -454,7 +454,7 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     // streamed beyond (Pr8 at n = 1e7: end-point sweep 58 -> 48 us, step -2.5 %)
     const bool three_fit = 3 * c->len_pad * sizeof(double) <= ((size_t)160 << 20);
     c->epi_nt = env_uint("ESQ_EPI_NT", three_fit ? 0x3 : 0xf);
-    c->skip_dead = env_uint("ESQ_DEAD_STORE", 1) != 0;
+    c->lazy_rows = env_uint("ESQ_LAZY_ROWS", 1) != 0;
     c->chain_depth = (int)env_uint("ESQ_CHAIN_DEPTH", 4);     // 5 and 6 exist too
     if (c->chain_depth > ESQ_CHAIN_MAX_DEPTH) c->chain_depth = ESQ_CHAIN_MAX_DEPTH;
     // launch geometry: grid-stride kernels, a few resident blocks per CU
@@ -519,6 +519,7 @@ size_t esq_vector_len(const esq_ctx *c) { return c ? c->len : 0; }
 
 int esq_upload(esq_ctx *c, int slot, int row, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    if (slot == ESQ_SLOT_K) ENSURE_ROWS(c);   // a later restore must not undo the upload
     const bool was_idle = c->idle;
     ENTER(c);
     double *d = slot_ptr(c, slot, row);
@@ -529,6 +530,7 @@ int esq_upload(esq_ctx *c, int slot, int row, const double *host) {
 int esq_download(esq_ctx *c, int slot, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
     ENTER_KEEP(c);
+    if (slot == ESQ_SLOT_K) ENSURE_ROWS(c);
     double *d = slot_ptr(c, slot, row);
     if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
     const size_t cnt = (slot == ESQ_SLOT_ATOL) ? c->n : c->len;
@@ -537,6 +539,7 @@ int esq_download(esq_ctx *c, int slot, int row, double *host) {
 int esq_copy(esq_ctx *c, int dst_slot, int dst_row, int src_slot, int src_row) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
+    if (dst_slot == ESQ_SLOT_K || src_slot == ESQ_SLOT_K) ENSURE_ROWS(c);
     double *d = slot_ptr(c, dst_slot, dst_row), *s = slot_ptr(c, src_slot, src_row);
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad slot/row");
     HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),

@@ -138,11 +138,16 @@ struct esq_ctx {
     // (what a stage kernel still has to add), and the row's total non-zero count
     std::vector<std::vector<esqi::Term>> stage_terms;
     std::vector<int> stage_nnz;
-    // K rows nothing reads after their own sweep (dead stores, esq_rk_set_tableau)
-    std::vector<char> row_dead;
-    bool skip_dead = true;                // ESQ_DEAD_STORE=0 stores every row
-    std::vector<char> row_stale;          // logical rows of the step in flight /
-    std::vector<char> row_stale_last;     // ... just accepted that were not stored
+    // rows of K that only the solution/error epilogue of their own (last) chain
+    // sweep reads are not written by a step (ESQ_LAZY_ROWS=0: always written);
+    // every other reader restores them first (esqi::restore_rows)
+    bool lazy_rows = true;
+    bool keep_rows = false;               // sticky: a reader asked twice in a row
+    bool tail_missing = false;            // rows [tail_i0, tail_i0 + tail_depth) of
+    bool tail_accepted = false;           // ... the step in flight / just accepted
+    int tail_i0 = 0, tail_depth = 0;
+    double tail_t = 0.0, tail_h = 0.0;
+    long accepted_steps = 0, last_restore_at = -100, restores = 0;
     // launch geometry
     unsigned grid_stream = 0;         // grid for streaming kernels
     unsigned grid_reduce = 0;
@@ -186,6 +191,14 @@ double *slot_ptr(esq_ctx *c, int slot, int row, bool logical = true);
 // YSTAGE until the next esq_rk_stages: any entry point that may write a vector
 // drops it (ENTER); the read-only ones keep it (ENTER_KEEP).
 #define ENTER_KEEP(c) (void)hipSetDevice((c)->device)
+// before anything but the step itself reads rows of K
+#define ENSURE_ROWS(c)                                   \
+    do {                                                 \
+        if ((c)->tail_missing) {                         \
+            const int rr_ = esqi::restore_rows(c);       \
+            if (rr_) return rr_;                         \
+        }                                                \
+    } while (0)
 #define ENTER(c)                             \
     do {                                     \
         (void)hipSetDevice((c)->device);     \
@@ -226,6 +239,10 @@ int build_row_terms(esq_ctx *c, const double *coef, int count, Terms &tm,
                     const std::vector<int> &map);
 int build_row_terms2(esq_ctx *c, const double *b, int nb, const double *e, int ne,
                      Terms2 &tm, const std::vector<int> &map);
+// ---- esq_step.hip --------------------------------------------------------------
+// re-evaluate the rows of K the last chain sweep did not write (lazy_rows)
+int restore_rows(esq_ctx *c);
+// ---- esq_core.hip ------------------------------------------------------------
 // sink of the next reduction / completion signal (bumps red_seq)
 ResultSink next_sink(esq_ctx *c, bool to_host_value);
 // lock-step: scalars in h_slot->vals -> device, and back behind a sequence number

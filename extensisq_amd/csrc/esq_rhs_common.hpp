@@ -216,6 +216,14 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
             if (max_row_tiles == 0) return N + 1;
             return (int)(((size_t)N + max_row_tiles - 1) / max_row_tiles);
         };
+        // as many waves per CU as the kernel can hold while the tiles stay
+        // between 24 and 48 rows (Pr8, n = 1e7: chain4<1> at three waves per SIMD
+        // and R = 30 takes 124 us, at two and R = 44 140 us) ...
+        for (int wpc = waves_per_cu - waves_per_cu % 4; wpc >= 4 && R <= 0; wpc -= 4) {
+            const int cand = rows_for((size_t)256 * (size_t)wpc);
+            if (cand >= 24 && cand <= 48) R = cand;
+        }
+        // ... else as few as keep them at most 48 rows high
         for (int wpc = 4; wpc <= waves_per_cu && R <= 0; wpc += 4) {
             const int cand = rows_for((size_t)256 * (size_t)wpc);
             if (cand <= 48) R = cand;

@@ -195,7 +195,8 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = fa
 // 1 = y_new of an FSAL pair (weights B), 2 = y_new + error partial sums
 // (non-FSAL: weights B and E).  Returns 0, kNotApplicable / ESQ_ENOTSUP (the
 // caller tries a shorter chain or single sweeps) or an error.
-int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last) {
+int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
+                bool keep_rows = true) {
     const int s = c->s;
     if (depth < 2 || depth > ESQ_CHAIN_MAX_DEPTH || s > 62) return kNotApplicable;
     esq_chain e;
@@ -277,7 +278,8 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last)
     e.h = h;
     for (int k = 0; k < depth; ++k) {
         e.t[k] = t + c->C[i + k] * h;
-        e.f_out[k] = c->krow[c->kmap[i + k]];
+        // !keep_rows: nothing but this sweep's solution/error sums reads them
+        e.f_out[k] = keep_rows ? c->krow[c->kmap[i + k]] : nullptr;
     }
     e.out = what_last == 0 ? c->work : c->ynew;
     e.f_store_nt = c->epi_nt & 1;
@@ -291,12 +293,14 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last)
     // booked: what the one-stage sweeps book; moved: input, y, rows, inits in
     // (times the tile geometry's read amplification); the chain's K rows and the
     // last target out
-    const double reads = 2 + nu, writes = depth + 1;     // nu counts the partial sums too
+    // nu counts the partial sums too
+    const double reads = 2 + nu, writes = (keep_rows ? depth : 0) + 1;
     (void)n_init;
     double amp = 1.0;
     e.read_amplification = &amp;
     char label[24];
-    snprintf(label, sizeof(label), "chain%d%s", depth, what_last == 2 ? "+solerr" : "");
+    snprintf(label, sizeof(label), "chain%d%s%s", depth, what_last == 2 ? "+solerr" : "",
+             keep_rows ? "" : "-K");
     Prof p(c, ESQ_PROF_STAGE, label, nu, alg, false, 8.0 * (reads + writes) * (double)c->len);
     c->self_valid = false;
     const int r = c->rhs_chain(c->rhs_user, c->ystage, &e, c->len, (void *)c->stream,
@@ -423,6 +427,10 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
     const std::vector<double> &A = c->A;
     auto nz = [&](int i, int j) { return A[(size_t)i * s + j] != 0.0; };
     static const double kHalo[7] = {1.0, 1.0, 1.10, 1.20, 1.31, 1.38, 1.46};
+    // cost of a written word in read words (tuning: ESQ_PLAN_WRITE_COST=1.5)
+    const char *wenv = getenv("ESQ_PLAN_WRITE_COST");
+    const double kW = wenv ? atof(wenv) : 2.0;
+    const double kWide = getenv("ESQ_PLAN_WIDE") ? atof(getenv("ESQ_PLAN_WIDE")) : 1.12;
     std::vector<int> from(s, 0);
     std::vector<char> has_init(s, 0), cur(s, 0);
     struct Blk { int J, nt, no, ninit; std::vector<int> cols; };
@@ -455,7 +463,7 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
         for (int j = from[stage]; j < stage && j < below; ++j)
             if (nz(stage, j)) u[j] = 1;
     };
-    double total = c->fsal ? 0.0 : 5.0;           // end-point sweep: 1 read, 2 writes
+    double total = c->fsal ? 0.0 : 1.0 + 2.0 * kW;   // end-point sweep: 1 read, 2 writes
     int i = 1;
     while (i < s) {
         const Blk *bnext = nullptr;
@@ -488,8 +496,8 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
                 if (nu + ninit > ESQ_CHAIN_MAX_ROWS - 1 ||
                     !chain_within_caps(D, last_sol, nu + ninit))
                     continue;
-                double units = (2 + nu + ninit) * kHalo[D] + 2.0 * (D + 1);
-                if (nu > 6) units *= 1.12;
+                double units = (2 + nu + ninit) * kHalo[D] + kW * (D + 1);
+                if (nu > 6) units *= kWide;
                 total += units;
                 i += D;
                 done = true;
@@ -499,16 +507,16 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
         if (bnext) {
             int nt = 0;
             for (int col : bnext->cols) nt += col != i;
-            total += (2 + nt + bnext->ninit) + 2.0 * (1 + bnext->no);
+            total += (2 + nt + bnext->ninit) + kW * (1 + bnext->no);
         } else if (i == s - 1) {
             int nu = 0;
             for (int j = 0; j < s; ++j)
                 nu += j != i && (c->B[j] != 0.0 || (!c->fsal && c->E[j] != 0.0));
-            total += 2 + nu + 4;
+            total += 2 + nu + 2.0 * kW;
         } else {
             int nu = 0;
             for (int j = from[i + 1]; j < i; ++j) nu += nz(i + 1, j);
-            total += 2 + nu + has_init[i + 1] + 4;
+            total += 2 + nu + has_init[i + 1] + 2.0 * kW;
         }
         ++i;
     }
@@ -516,6 +524,36 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
 }
 
 }  // namespace
+
+// The rows [tail_i0, tail_i0 + tail_depth) of the step in flight (or of the step
+// just accepted) exist only as terms of y_new and the error sums.  Re-evaluate
+// them the plain way, stage by stage: a_i. K in ascending column order from the
+// rows in memory (what k_lincomb does when no partial sum is stored: the same FMA
+// chain as the blocked / chained sweeps), then the RHS.  A context that is asked
+// again within a few steps (dense output on every step) keeps its rows from then on.
+int esqi::restore_rows(esq_ctx *c) {
+    if (!c->tail_missing) return 0;
+    c->tail_missing = false;
+    (void)hipSetDevice(c->device);
+    c->idle = false;
+    c->self_valid = false;
+    const std::vector<int> &map = c->tail_accepted ? c->kmap_last : c->kmap;
+    // after esq_rk_accept the pre-step state is in the YNEW slot
+    const double *base = c->tail_accepted ? c->ynew : c->y;
+    for (int st = c->tail_i0; st < c->tail_i0 + c->tail_depth; ++st) {
+        Terms tm;
+        const int nt = build_row_terms(c, &c->A[(size_t)st * c->s], st, tm, map);
+        if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+        int r = launch_lincomb(c, c->work, base, tm, nt, c->tail_h);
+        if (r) return r;
+        r = call_rhs(c, c->tail_t + c->C[st] * c->tail_h, c->work, c->krow[map[st]]);
+        if (r) return r;
+    }
+    ++c->restores;
+    if (c->accepted_steps - c->last_restore_at <= 4) c->keep_rows = true;
+    c->last_restore_at = c->accepted_steps;
+    return 0;
+}
 
 extern "C" {
 
@@ -656,6 +694,7 @@ int esq_rk_stage_accumulate(esq_ctx *c, int i, double h) {
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (i < 1 || i >= c->s) return fail(c, ESQ_EINVAL, "stage %d out of range", i);
+    if (i > 1) ENSURE_ROWS(c);
     for (const auto &b : c->blocks)
         if (b.J == i) {
             bool made = false;
@@ -689,6 +728,7 @@ int esq_rk_block_plan(esq_ctx *c, int *boundaries, int max_boundaries,
 int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
+    if (src_slot == ESQ_SLOT_K || dst_row != 0) ENSURE_ROWS(c);
     double *dst = slot_ptr(c, ESQ_SLOT_K, dst_row);
     double *src = slot_ptr(c, src_slot, src_row);
     if (!dst || !src) return fail(c, ESQ_EINVAL, "bad row/slot");
@@ -703,6 +743,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (i_from < 1 || i_to > c->s || i_from > i_to)
         return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
+    if (i_from > 1) ENSURE_ROWS(c);
+    c->tail_missing = false;       // whatever was missing is overwritten from here on
     c->ynew_ready = false;
     c->solerr_ready = false;
     bool block_done = false;   // the block at boundary i already ran in a sweep
@@ -763,7 +805,19 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 if (what < 0) continue;
                 const size_t slot = (size_t)i * 8 + (size_t)D;
                 if (slot < c->chain_refused.size() && c->chain_refused[slot]) continue;
-                const int r = sweep_chain(c, i, D, t, h, what);
+                // the rows of a chain that ends in the solution/error sums are read
+                // by nothing else in a step: written only for a context whose
+                // caller keeps asking for them (restore_rows)
+                const bool lazy = what == 2 && c->lazy_rows && !c->keep_rows && c->rhs;
+                const int r = sweep_chain(c, i, D, t, h, what, !lazy);
+                if (r == 0 && lazy) {
+                    c->tail_missing = true;
+                    c->tail_accepted = false;
+                    c->tail_i0 = i;
+                    c->tail_depth = D;
+                    c->tail_t = t;
+                    c->tail_h = h;
+                }
                 if (r == ESQ_ENOTSUP || r == kNotApplicable) {
                     // a property of the tableau and the grid, not of this step
                     if (slot < c->chain_refused.size()) c->chain_refused[slot] = 1;
@@ -818,6 +872,7 @@ int esq_rk_solution(esq_ctx *c, double h) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    ENSURE_ROWS(c);
     Terms tm;
     const int nt = build_row_terms(c, c->B.data(), c->s, tm, c->kmap);
     if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
@@ -829,6 +884,7 @@ int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    ENSURE_ROWS(c);
     Terms tm;
     const int nt = build_row_terms(c, c->E.data(), c->s + c->fsal, tm, c->kmap);
     if (nt < 1) return fail(c, ESQ_EINVAL, "error weights are all zero");
@@ -887,6 +943,7 @@ int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
     }
     if (solerr_ready)
         return finish_reduction(c, sumsq_out, false, c->partials, c->red_count);
+    ENSURE_ROWS(c);
     Terms2 tm;
     const int nt = build_row_terms2(c, c->B.data(), c->s, c->E.data(), c->s, tm, c->kmap);
     if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
@@ -904,6 +961,7 @@ int esq_rk_pre_error(esq_ctx *c, double h, const double *e_pre,
     if (!c || !e_pre || !b_scale_pre || !sumsq_out) return ESQ_EINVAL;
     ENTER(c);
     if (rows < 1 || rows > c->n_rows) return fail(c, ESQ_EINVAL, "bad rows %d", rows);
+    ENSURE_ROWS(c);
     Terms2 tm;
     const int nt = build_row_terms2(c, b_scale_pre, rows, e_pre, rows, tm, c->kmap);
     if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
@@ -922,6 +980,7 @@ int esq_rk_custom_sol_err(esq_ctx *c, double h, const double *b, const double *e
     if (!c || !b || !e || !sumsq_out) return ESQ_EINVAL;
     ENTER(c);
     if (rows < 1 || rows > c->n_rows) return fail(c, ESQ_EINVAL, "bad rows %d", rows);
+    ENSURE_ROWS(c);
     Terms2 tm;
     const int nt = build_row_terms2(c, b, rows, e, rows, tm, c->kmap);
     if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
@@ -969,6 +1028,8 @@ int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
         }
     }
     c->kmap_last = c->kmap;
+    c->tail_accepted = true;       // a restore now works from kmap_last and YNEW
+    ++c->accepted_steps;
     std::swap(c->kmap[0], c->kmap[c->s]);
     std::swap(c->y, c->ynew);
     if (want_pre && !pre_done) {
@@ -987,6 +1048,7 @@ int esq_rk_error_vector(esq_ctx *c, double h, int last_step) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    ENSURE_ROWS(c);
     Terms tm;
     const int nt = build_row_terms(c, c->E.data(), c->s + c->fsal, tm,
                                    last_step ? c->kmap_last : c->kmap);
@@ -997,13 +1059,23 @@ int esq_rk_error_vector(esq_ctx *c, double h, int last_step) {
 int esq_rk_row_id(esq_ctx *c, int logical_row, int last_step) {
     if (!c || logical_row < 0 || logical_row >= c->n_rows) return ESQ_EINVAL;
     ENTER_KEEP(c);
+    ENSURE_ROWS(c);                // the caller is about to read that row
     return last_step ? c->kmap_last[logical_row] : c->kmap[logical_row];
 }
 int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
     if (!c || !host) return ESQ_EINVAL;
     ENTER_KEEP(c);
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);
+    ENSURE_ROWS(c);
     return d2h(c, host, c->krow[c->kmap_last[row]], c->len * sizeof(double), c->idle);
+}
+
+int esq_rk_lazy_rows(esq_ctx *c, int *missing_out, int *keeps_out, long *restores_out) {
+    if (!c) return ESQ_EINVAL;
+    if (missing_out) *missing_out = c->tail_missing ? c->tail_depth : 0;
+    if (keeps_out) *keeps_out = (c->keep_rows || !c->lazy_rows) ? 1 : 0;
+    if (restores_out) *restores_out = c->restores;
+    return 0;
 }
 
 int esq_rk_dense_stage(esq_ctx *c, int row, const double *a, int count, double h) {
@@ -1011,6 +1083,7 @@ int esq_rk_dense_stage(esq_ctx *c, int row, const double *a, int count, double h
     ENTER(c);
     if (row < 1 || row >= c->n_rows || count < 0 || count > row)
         return fail(c, ESQ_EINVAL, "bad row/count %d/%d", row, count);
+    ENSURE_ROWS(c);
     Terms tm;
     const int nt = build_row_terms(c, a, count, tm, c->kmap_last);
     if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
@@ -1025,6 +1098,7 @@ int esq_rk_dense_eval(esq_ctx *c, int row, double t) {
 }
 int esq_rk_upload_last_K(esq_ctx *c, int row, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    ENSURE_ROWS(c);
     const bool was_idle = c->idle;
     ENTER(c);
     if (row < 0 || row >= c->n_rows) return fail(c, ESQ_EINVAL, "bad row %d", row);

@@ -362,6 +362,18 @@ int  esq_rk_error_vector(esq_ctx *ctx, double h, int last_step);
 int  esq_rk_row_id(esq_ctx *ctx, int logical_row, int last_step);
 /* logical->physical row of K for the step just accepted (for solver.K) */
 int  esq_rk_download_last_K(esq_ctx *ctx, int row, double *host);
+/* Rows of K that only the solution / error sums of their own sweep read (the
+ * stages of a step's last chain sweep, non-FSAL pairs: `self.K[s] = f` of
+ * common.py:355 for rows nothing in `_step_impl` reads again) are NOT written
+ * by esq_rk_stages.  Every entry point that reads rows of K (this block, the
+ * dense output, esq_download / esq_copy on ESQ_SLOT_K, esq_rk_row_id ...)
+ * first re-evaluates them, bit-identically, so callers never see the
+ * difference; a context asked twice within four accepted steps writes them in
+ * every step from then on.  ESQ_LAZY_ROWS=0 in the environment: always written.
+ * State for tests and tuning: rows currently not in memory, whether the context
+ * now keeps its rows, re-evaluations so far.  Any pointer may be NULL. */
+int  esq_rk_lazy_rows(esq_ctx *ctx, int *missing_out, int *keeps_out,
+                      long *restores_out);
 
 /* ---- dense output (common.py:358-368, 766-790) --------------------------- */
 /* Device-resident interpolant (ref HornerDenseOutput, common.py:766-790): an

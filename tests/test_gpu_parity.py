@@ -1503,3 +1503,97 @@ def test_chained_stage_sweeps_are_bit_identical(monkeypatch, name, plugin, N, de
     if name == "Pr8" and depth >= 3:
         assert any(lab.startswith(("chain3", "chain4", "chain5", "chain6"))
                    for lab in labels), labels
+
+
+# ------------------------- rows of K only their own sweep reads (lazy rows)
+def _lazy_state(solver):
+    import ctypes
+    missing, keeps, restores = ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
+    solver._chk(solver._lib.esq_rk_lazy_rows(solver._ctx, ctypes.byref(missing),
+                                             ctypes.byref(keeps),
+                                             ctypes.byref(restores)),
+                "esq_rk_lazy_rows")
+    return missing.value, bool(keeps.value), restores.value
+
+
+@pytest.mark.parametrize("name,plugin,N,rows", [
+    ("Pr8", "bruss", 50, 9), ("Pr8", "bruss", 124, 30), ("Pr7", "heat", 36, 8),
+    ("Pr8", "heat", 130, 30), ("Pr7", "bruss", 64, 16)])
+def test_rows_only_their_sweep_reads_are_restored_on_demand(monkeypatch, name, plugin,
+                                                            N, rows):
+    """The stages of a step's last chain sweep (non-FSAL pairs) are read by nothing
+    but that sweep's own solution / error sums; esq_rk_stages does not write them
+    (label `chain<D>+solerr-K`).  Whoever reads rows of K (`solver.K`, the dense
+    output, the error vector) gets them re-evaluated first, bit-identical to a
+    context that always writes them (ESQ_LAZY_ROWS=0); a second reader within four
+    steps makes the context keep its rows (ref: `self.K[s] = ...`,
+    common.py:353-356, where every row is always in memory)."""
+    mk, y0, rho = _plugin(plugin, N)
+    h = 0.4 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
+    cls = getattr(esq, name)
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    lazy = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_LAZY_ROWS", "0")
+    eager = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_LAZY_ROWS")
+    assert _lazy_state(eager)[1] and not _lazy_state(lazy)[1]
+    lazy._dev.profile_enable([0, 1, 2])
+    # steps nobody looks into: rows missing, states identical
+    for _ in range(3):
+        assert lazy.step() is None and eager.step() is None
+        assert lazy.t == eager.t
+        assert lazy.error_norm_old == eager.error_norm_old
+    missing, keeps, restores = _lazy_state(lazy)
+    assert missing >= 2 and not keeps and restores == 0
+    assert _lazy_state(eager) == (0, True, 0)
+    labels = [row[0] for row in lazy._dev.profile_kernels()]
+    assert any("+solerr-K<" in lab for lab in labels), labels
+    assert_equal(lazy.y, eager.y)                    # reading y restores nothing
+    assert _lazy_state(lazy)[0] == missing
+    # first reader: the dense output of the step just accepted
+    sl, se = lazy.dense_output(), eager.dense_output()
+    tc = np.linspace(eager.t_old, eager.t, 4)
+    assert_equal(sl(tc), se(tc))
+    assert _lazy_state(lazy) == (0, False, 1)
+    assert_equal(lazy.K, eager.K)
+    # five quiet steps, then one reader: still lazy
+    for _ in range(5):
+        assert lazy.step() is None and eager.step() is None
+    assert_equal(lazy.K, eager.K)
+    assert _lazy_state(lazy) == (0, False, 2)
+    # a reader on the very next step too: the context keeps its rows from now on
+    assert lazy.step() is None and eager.step() is None
+    assert _lazy_state(lazy)[0] >= 2
+    assert_equal(lazy.K, eager.K)
+    assert _lazy_state(lazy) == (0, True, 3)
+    for _ in range(2):
+        assert lazy.step() is None and eager.step() is None
+        assert _lazy_state(lazy) == (0, True, 3)
+        assert_equal(lazy.K, eager.K)
+        assert_equal(lazy.y, eager.y)
+    assert lazy.nfev == eager.nfev
+
+
+@pytest.mark.parametrize("name", ["Pr8", "Pr7"])
+def test_lazy_rows_solve_ivp_with_dense_output(monkeypatch, name):
+    """solve_ivp(dense_output=True, t_eval=...) reads every step's interpolant:
+    same result, bit for bit, whether the rows were restored or always written;
+    also across rejected steps (free controller)"""
+    from scipy.integrate import solve_ivp
+    N = 64
+    mk, y0, rho = _plugin("bruss", N)
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", "16")
+    t_end = 30.0 / rho
+    t_eval = np.linspace(0.0, t_end, 23)
+    kw = dict(method=getattr(esq, name), rtol=1e-5, atol=1e-8, t_eval=t_eval,
+              dense_output=True)
+    a = solve_ivp(mk(), (0.0, t_end), y0, **kw)
+    monkeypatch.setenv("ESQ_LAZY_ROWS", "0")
+    b = solve_ivp(mk(), (0.0, t_end), y0, **kw)
+    assert a.success and b.success
+    assert_equal(a.t, b.t)
+    assert_equal(a.y, b.y)
+    assert a.nfev == b.nfev
+    tc = np.linspace(0.0, t_end, 7)
+    assert_equal(a.sol(tc), b.sol(tc))
