@@ -63,7 +63,7 @@ SIGNATURES = {
     "esq_rk_error_vector": (C.c_int, [_vp, C.c_double, C.c_int]),
     "esq_rk_row_id": (C.c_int, [_vp, C.c_int, C.c_int]),
     "esq_rk_download_last_K": (C.c_int, [_vp, C.c_int, _vp]),
-    "esq_rk_lazy_rows": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "esq_rk_lazy_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "esq_dense_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int,
                                    _vpp]),
     "esq_dense_eval": (C.c_int, [_vp, C.c_double, _vp]),

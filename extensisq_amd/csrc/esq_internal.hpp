@@ -148,6 +148,15 @@ struct esq_ctx {
     int tail_i0 = 0, tail_depth = 0;
     double tail_t = 0.0, tail_h = 0.0;
     long accepted_steps = 0, last_restore_at = -100, restores = 0;
+    // non-FSAL pairs: f(t_new, y_new) of an accepted step is not evaluated by
+    // esq_rk_accept but as stage 0 of the NEXT step's first chain sweep
+    // (ESQ_LAZY_END=0: at accept time); whoever reads logical row 0 earlier has
+    // it evaluated first (esqi::restore_rows)
+    bool lazy_end = true;
+    bool k0_missing = false;
+    double k0_t = 0.0;
+    int end_fused_ok = -1;                // -1 not tried yet, 0 the plugin declined
+    long end_fused = 0, end_plain = 0;    // how the end-point evaluations ran
     // launch geometry
     unsigned grid_stream = 0;         // grid for streaming kernels
     unsigned grid_reduce = 0;
@@ -194,7 +203,7 @@ double *slot_ptr(esq_ctx *c, int slot, int row, bool logical = true);
 // before anything but the step itself reads rows of K
 #define ENSURE_ROWS(c)                                   \
     do {                                                 \
-        if ((c)->tail_missing) {                         \
+        if ((c)->tail_missing || (c)->k0_missing) {      \
             const int rr_ = esqi::restore_rows(c);       \
             if (rr_) return rr_;                         \
         }                                                \

@@ -274,7 +274,8 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
         ++nu;
     }
     e.nu = nu;
-    e.y = c->y;
+    // i == 0: the chain starts from the state itself (stage 0 = f(t, y))
+    e.y = i == 0 ? nullptr : c->y;
     e.h = h;
     for (int k = 0; k < depth; ++k) {
         e.t[k] = t + c->C[i + k] * h;
@@ -294,7 +295,7 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     // (times the tile geometry's read amplification); the chain's K rows and the
     // last target out
     // nu counts the partial sums too
-    const double reads = 2 + nu, writes = (keep_rows ? depth : 0) + 1;
+    const double reads = (i == 0 ? 1 : 2) + nu, writes = (keep_rows ? depth : 0) + 1;
     (void)n_init;
     double amp = 1.0;
     e.read_amplification = &amp;
@@ -303,8 +304,8 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
              keep_rows ? "" : "-K");
     Prof p(c, ESQ_PROF_STAGE, label, nu, alg, false, 8.0 * (reads + writes) * (double)c->len);
     c->self_valid = false;
-    const int r = c->rhs_chain(c->rhs_user, c->ystage, &e, c->len, (void *)c->stream,
-                               (void *)p.start(), (void *)p.stop());
+    const int r = c->rhs_chain(c->rhs_user, i == 0 ? c->y : c->ystage, &e, c->len,
+                               (void *)c->stream, (void *)p.start(), (void *)p.stop());
     // designed traffic incl. the halo rows / columns the plugin's tiles re-read
     if (p.on) p.ev.moved = 8.0 * (reads * amp + writes) * (double)c->len;
     if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
@@ -532,11 +533,19 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
 // chain as the blocked / chained sweeps), then the RHS.  A context that is asked
 // again within a few steps (dense output on every step) keeps its rows from then on.
 int esqi::restore_rows(esq_ctx *c) {
-    if (!c->tail_missing) return 0;
-    c->tail_missing = false;
+    if (!c->tail_missing && !c->k0_missing) return 0;
     (void)hipSetDevice(c->device);
     c->idle = false;
     c->self_valid = false;
+    if (c->k0_missing) {
+        // f(t, y) of the current state (= K[s] of the step just accepted)
+        c->k0_missing = false;
+        ++c->end_plain;
+        const int r = call_rhs(c, c->k0_t, c->y, c->krow[c->kmap[0]]);
+        if (r) return r;
+    }
+    if (!c->tail_missing) return 0;
+    c->tail_missing = false;
     const std::vector<int> &map = c->tail_accepted ? c->kmap_last : c->kmap;
     // after esq_rk_accept the pre-step state is in the YNEW slot
     const double *base = c->tail_accepted ? c->ynew : c->y;
@@ -564,6 +573,7 @@ int esq_replan(esq_ctx *c) {
     if (!c || !c->have_tab) return ESQ_EINVAL;
     const int s = c->s;
     c->chain_refused.assign((size_t)(s + 1) * 8, 0);
+    c->end_fused_ok = -1;
     const bool chained = c->rhs_chain && c->chain_depth >= 2 &&
                          env_uint("ESQ_PLAN_CHAINED", 1) != 0;
     auto cost = [&](const std::vector<int> &bounds) -> double {
@@ -728,6 +738,7 @@ int esq_rk_block_plan(esq_ctx *c, int *boundaries, int max_boundaries,
 int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
+    if (dst_row == 0 && src_slot != ESQ_SLOT_K) c->k0_missing = false;   // evaluated here
     if (src_slot == ESQ_SLOT_K || dst_row != 0) ENSURE_ROWS(c);
     double *dst = slot_ptr(c, ESQ_SLOT_K, dst_row);
     double *src = slot_ptr(c, src_slot, src_row);
@@ -748,9 +759,46 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     c->ynew_ready = false;
     c->solerr_ready = false;
     bool block_done = false;   // the block at boundary i already ran in a sweep
-    // marching chain sweeps: ESQ_CHAIN_DEPTH = 1 (off), 2, 3 (default), 4
+    // marching chain sweeps: ESQ_CHAIN_DEPTH = 1 (off), 2, 3, 4 (default) ...
     const bool chains = c->rhs_chain && c->rhs_fused && !c->cplx && c->chain_depth >= 2;
-    for (int i = i_from; i < i_to; ++i) {
+    int i_first = i_from;
+    if (c->k0_missing) {
+        // f(t, y) was left to this step (esq_rk_accept): one stage more in front
+        // of the chain the plan starts with -- stage 0 reads the state itself, its
+        // argument never existed, K[0] is written once and not read back
+        bool fused = false;
+        if (i_from == 1 && chains && c->end_fused_ok != 0 && may_fuse(c, ESQ_EPI_STAGE)) {
+            int d1 = 0;
+            for (int D = c->chain_depth; D >= 2 && !d1; --D) {
+                if (1 + D >= i_to) continue;
+                bool crosses = false;
+                for (const auto &b : c->blocks) crosses |= (b.J > 1 && b.J <= 1 + D);
+                const size_t slot = (size_t)8 + (size_t)D;
+                if (!crosses && !(slot < c->chain_refused.size() && c->chain_refused[slot]))
+                    d1 = D;
+            }
+            int r = kNotApplicable;
+            if (d1 && d1 + 1 <= ESQ_CHAIN_MAX_DEPTH) r = sweep_chain(c, 0, d1 + 1, t, h, 0);
+            if (r == 0) {
+                fused = true;
+                c->end_fused_ok = 1;
+                ++c->end_fused;
+                i_first = d1 + 1;
+                ready = true;
+            } else if (r == ESQ_ENOTSUP || r == kNotApplicable) {
+                c->end_fused_ok = 0;       // esq_rk_accept evaluates it from now on
+            } else {
+                return r;
+            }
+        }
+        c->k0_missing = false;
+        if (!fused) {
+            ++c->end_plain;
+            const int r = call_rhs(c, t, c->y, c->krow[c->kmap[0]]);
+            if (r) return r;
+        }
+    }
+    for (int i = i_first; i < i_to; ++i) {
         if (i == 1 && !ready && i + 1 < i_to && may_use_src(c)) {
             // the first sweep forms its own input from y and K[0]: no stage-1
             // kernel, no stage argument in memory
@@ -1002,7 +1050,14 @@ int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
     const bool want_pre = h_next != 0.0 && c->s >= 2 && c->rhs != nullptr &&
                           !(may_use_src(c) && c->s >= 3);
     bool pre_done = false;
-    if (!c->fsal && with_end_eval) {
+    // the end-point derivative can wait for the next step's first chain sweep
+    const bool defer = !c->fsal && with_end_eval && c->lazy_end && c->end_fused_ok != 0 &&
+                       c->rhs && c->rhs_chain && c->rhs_fused && !c->cplx &&
+                       c->chain_depth >= 2 && may_fuse(c, ESQ_EPI_STAGE);
+    if (defer) {
+        c->k0_missing = true;
+        c->k0_t = t_new;
+    } else if (!c->fsal && with_end_eval) {
         int r = ESQ_ENOTSUP;
         if (want_pre && may_fuse(c, ESQ_EPI_STAGE)) {
             // K[s] = f(t_new, y_new) and YSTAGE = y_new + h_next*a_10*K[s] in
@@ -1032,7 +1087,7 @@ int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
     ++c->accepted_steps;
     std::swap(c->kmap[0], c->kmap[c->s]);
     std::swap(c->y, c->ynew);
-    if (want_pre && !pre_done) {
+    if (want_pre && !pre_done && !defer) {
         // stage 1's accumulate, launched now: it runs while the host controller
         // is between steps
         const int r = esq_rk_stage_accumulate(c, 1, h_next);
@@ -1070,11 +1125,15 @@ int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
     return d2h(c, host, c->krow[c->kmap_last[row]], c->len * sizeof(double), c->idle);
 }
 
-int esq_rk_lazy_rows(esq_ctx *c, int *missing_out, int *keeps_out, long *restores_out) {
+int esq_rk_lazy_rows(esq_ctx *c, int *missing_out, int *keeps_out, long *restores_out,
+                     long *end_fused_out, long *end_plain_out) {
     if (!c) return ESQ_EINVAL;
-    if (missing_out) *missing_out = c->tail_missing ? c->tail_depth : 0;
+    if (missing_out)
+        *missing_out = (c->tail_missing ? c->tail_depth : 0) + (c->k0_missing ? 1 : 0);
     if (keeps_out) *keeps_out = (c->keep_rows || !c->lazy_rows) ? 1 : 0;
     if (restores_out) *restores_out = c->restores;
+    if (end_fused_out) *end_fused_out = c->end_fused;
+    if (end_plain_out) *end_plain_out = c->end_plain;
     return 0;
 }
 

@@ -370,10 +370,18 @@ int  esq_rk_download_last_K(esq_ctx *ctx, int row, double *host);
  * first re-evaluates them, bit-identically, so callers never see the
  * difference; a context asked twice within four accepted steps writes them in
  * every step from then on.  ESQ_LAZY_ROWS=0 in the environment: always written.
+ * Likewise the end-point derivative of a non-FSAL pair (`self.K[-1] = fun(t_new,
+ * y_new)`, common.py:300-301 -- the next step's K[0]): esq_rk_accept leaves it to
+ * the next esq_rk_stages, which evaluates it as one more stage in front of its
+ * first chain sweep (the stage reads the state itself: no end-point sweep, no
+ * first stage argument in memory); a reader of logical row 0 in between gets it
+ * evaluated first.  ESQ_LAZY_END=0: evaluated by esq_rk_accept.
  * State for tests and tuning: rows currently not in memory, whether the context
- * now keeps its rows, re-evaluations so far.  Any pointer may be NULL. */
+ * now keeps its rows, re-evaluations so far, end-point derivatives evaluated
+ * inside a chain sweep / by a sweep of their own (after the opt-out or a
+ * reader, or where no chain sweep fits).  Any pointer may be NULL. */
 int  esq_rk_lazy_rows(esq_ctx *ctx, int *missing_out, int *keeps_out,
-                      long *restores_out);
+                      long *restores_out, long *end_fused_out, long *end_plain_out);
 
 /* ---- dense output (common.py:358-368, 766-790) --------------------------- */
 /* Device-resident interpolant (ref HornerDenseOutput, common.py:766-790): an

@@ -1511,14 +1511,23 @@ def _lazy_state(solver):
     missing, keeps, restores = ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
     solver._chk(solver._lib.esq_rk_lazy_rows(solver._ctx, ctypes.byref(missing),
                                              ctypes.byref(keeps),
-                                             ctypes.byref(restores)),
+                                             ctypes.byref(restores), None, None),
                 "esq_rk_lazy_rows")
     return missing.value, bool(keeps.value), restores.value
 
 
+def _end_point_counts(solver):
+    import ctypes
+    fused, plain = ctypes.c_long(), ctypes.c_long()
+    solver._chk(solver._lib.esq_rk_lazy_rows(solver._ctx, None, None, None,
+                                             ctypes.byref(fused), ctypes.byref(plain)),
+                "esq_rk_lazy_rows")
+    return fused.value, plain.value
+
+
 @pytest.mark.parametrize("name,plugin,N,rows", [
     ("Pr8", "bruss", 50, 9), ("Pr8", "bruss", 124, 30), ("Pr7", "heat", 36, 8),
-    ("Pr8", "heat", 130, 30), ("Pr7", "bruss", 64, 16)])
+    ("Pr8", "heat", 130, 30), ("Pr8", "bruss", 258, 40)])
 def test_rows_only_their_sweep_reads_are_restored_on_demand(monkeypatch, name, plugin,
                                                             N, rows):
     """The stages of a step's last chain sweep (non-FSAL pairs) are read by nothing
@@ -1535,8 +1544,10 @@ def test_rows_only_their_sweep_reads_are_restored_on_demand(monkeypatch, name, p
     monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
     lazy = cls(mk(), 0.0, y0, 1.0, **kw)
     monkeypatch.setenv("ESQ_LAZY_ROWS", "0")
+    monkeypatch.setenv("ESQ_LAZY_END", "0")
     eager = cls(mk(), 0.0, y0, 1.0, **kw)
     monkeypatch.delenv("ESQ_LAZY_ROWS")
+    monkeypatch.delenv("ESQ_LAZY_END")
     assert _lazy_state(eager)[1] and not _lazy_state(lazy)[1]
     lazy._dev.profile_enable([0, 1, 2])
     # steps nobody looks into: rows missing, states identical
@@ -1569,8 +1580,11 @@ def test_rows_only_their_sweep_reads_are_restored_on_demand(monkeypatch, name, p
     assert _lazy_state(lazy) == (0, True, 3)
     for _ in range(2):
         assert lazy.step() is None and eager.step() is None
-        assert _lazy_state(lazy) == (0, True, 3)
+        # at most the end-point derivative (heat: no depth-5 kernels, evaluated
+        # at accept time)
+        assert _lazy_state(lazy) in ((1, True, 3), (0, True, 3))
         assert_equal(lazy.K, eager.K)
+        assert _lazy_state(lazy) == (0, True, 3)
         assert_equal(lazy.y, eager.y)
     assert lazy.nfev == eager.nfev
 
@@ -1590,6 +1604,7 @@ def test_lazy_rows_solve_ivp_with_dense_output(monkeypatch, name):
               dense_output=True)
     a = solve_ivp(mk(), (0.0, t_end), y0, **kw)
     monkeypatch.setenv("ESQ_LAZY_ROWS", "0")
+    monkeypatch.setenv("ESQ_LAZY_END", "0")
     b = solve_ivp(mk(), (0.0, t_end), y0, **kw)
     assert a.success and b.success
     assert_equal(a.t, b.t)
@@ -1597,3 +1612,67 @@ def test_lazy_rows_solve_ivp_with_dense_output(monkeypatch, name):
     assert a.nfev == b.nfev
     tc = np.linspace(0.0, t_end, 7)
     assert_equal(a.sol(tc), b.sol(tc))
+
+
+@pytest.mark.parametrize("name,plugin,N,rows,first", [
+    ("Pr8", "bruss", 50, 9, "chain5<0>"), ("Pr8", "bruss", 124, 30, "chain5<0>"),
+    ("Pr7", "bruss", 64, 16, "chain"), ("Pr9", "bruss", 64, 16, "chain5<0>"),
+    ("Pr8", "heat", 130, 30, ""), ("CK5", "bruss", 64, 16, ""), ("Me4", "heat", 100, 12, "")])
+def test_end_point_derivative_as_stage_zero_of_the_next_step(monkeypatch, name, plugin, N,
+                                                             rows, first):
+    """Non-FSAL pairs: `K[-1] = fun(t_new, y_new)` (ref common.py:300-301) is not
+    evaluated when the step is accepted but as one more stage in front of the next
+    step's first chain sweep (label `chain<D+1><0>`: the stage reads the state
+    itself).  States, K rows, `solver.f`, the dense output (its last row is that
+    derivative) and nfev equal a context that evaluates it at accept time
+    (ESQ_LAZY_END=0), bit for bit; a rejected step re-uses the K[0] it has."""
+    mk, y0, rho = _plugin(plugin, N)
+    h = 0.4 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
+    cls = getattr(esq, name)
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    lazy = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_LAZY_END", "0")
+    eager = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_LAZY_END")
+    lazy._dev.profile_enable([0, 1, 2])
+    for _ in range(4):
+        assert lazy.step() is None and eager.step() is None
+        assert lazy.t == eager.t
+        # (the partial sums are grouped by whichever sweep forms them)
+        assert_allclose(lazy.error_norm_old, eager.error_norm_old, rtol=1e-12)
+    fused, plain = _end_point_counts(lazy)
+    labels = [row[0] for row in lazy._dev.profile_kernels()]
+    if first:
+        assert fused == 3 and plain == 0, (fused, plain, labels)
+        assert any(lab.startswith(first) and lab.endswith("<0>") for lab in labels), labels
+    assert _end_point_counts(eager) == (0, 0)
+    # readers in between: the derivative is evaluated for them, once
+    assert_equal(lazy.f, eager.f)
+    assert _end_point_counts(lazy)[0] == fused
+    assert_equal(lazy.y, eager.y)
+    sl, se = lazy.dense_output(), eager.dense_output()
+    tc = np.linspace(eager.t_old, eager.t, 4)
+    assert_equal(sl(tc), se(tc))
+    assert_equal(lazy.K, eager.K)
+    n_plain = _end_point_counts(lazy)[1]
+    for _ in range(3):
+        assert lazy.step() is None and eager.step() is None
+    assert_equal(lazy.K, eager.K)
+    assert_equal(lazy.y, eager.y)
+    assert lazy.nfev == eager.nfev
+    if first:
+        assert _end_point_counts(lazy) == (fused + 2, n_plain + 1)
+    # a step that is rejected and retried: K[0] is in memory for the retry
+    kw2 = dict(first_step=40 * h, rtol=1e-6, atol=1e-9)
+    a = cls(mk(), 0.0, y0, 1.0, **kw2)
+    monkeypatch.setenv("ESQ_LAZY_END", "0")
+    b = cls(mk(), 0.0, y0, 1.0, **kw2)
+    monkeypatch.delenv("ESQ_LAZY_END")
+    nfs0 = int(esq.NFS[()])
+    for _ in range(6):
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t and a.h_abs == b.h_abs
+    assert_equal(a.y, b.y)
+    assert a.nfev == b.nfev
+    assert int(esq.NFS[()]) > nfs0
