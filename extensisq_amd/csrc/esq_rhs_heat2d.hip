@@ -156,7 +156,7 @@ int esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
     if (!chain_fits_grid(r->N, chain->depth)) return ESQ_ENOTSUP;
     const HeatFn fn{(double)(r->N + 1) * (double)(r->N + 1)};
     int rc_launch = 0;
-    const int rc = esq::dispatch_chain(chain, [&](auto ca, auto kind) {
+    const int rc = esq::dispatch_chain<6>(chain, [&](auto ca, auto kind) {
         using CA = decltype(ca);
         auto kern = esq::k_chain2d<1, false, CA::kD, CA::kNU, decltype(kind)::value, HeatFn>;
         static const int wpc = chain_waves_per_cu(kern, (unsigned)kBlock);   // per instantiation

@@ -1526,7 +1526,7 @@ def _end_point_counts(solver):
 
 
 @pytest.mark.parametrize("name,plugin,N,rows", [
-    ("Pr8", "bruss", 50, 9), ("Pr8", "bruss", 124, 30), ("Pr7", "heat", 36, 8),
+    ("Pr8", "bruss", 50, 9), ("Pr8", "bruss", 124, 30), ("Pr8", "heat", 36, 8),
     ("Pr8", "heat", 130, 30), ("Pr8", "bruss", 258, 40)])
 def test_rows_only_their_sweep_reads_are_restored_on_demand(monkeypatch, name, plugin,
                                                             N, rows):
@@ -1554,7 +1554,8 @@ def test_rows_only_their_sweep_reads_are_restored_on_demand(monkeypatch, name, p
     for _ in range(3):
         assert lazy.step() is None and eager.step() is None
         assert lazy.t == eager.t
-        assert lazy.error_norm_old == eager.error_norm_old
+        # (the partial sums are grouped by whichever sweep forms them)
+        assert_allclose(lazy.error_norm_old, eager.error_norm_old, rtol=1e-12)
     missing, keeps, restores = _lazy_state(lazy)
     assert missing >= 2 and not keeps and restores == 0
     assert _lazy_state(eager) == (0, True, 0)
