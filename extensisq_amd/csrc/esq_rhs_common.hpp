@@ -185,15 +185,16 @@ inline int chain_waves_per_cu(Kernel kern, unsigned block) {
     if (waves > 32) waves = 32;
     return waves;
 }
-// a chain of depth D carries 2(D-1) halo rows per tile: it pays only where the
-// grid gives every wave slot a tile of at least ~8(D-1) rows (measured: Ts5 at
-// N = 1000 gains with depth 2 and loses with depth 4); ESQ_CHAIN_ROWS (tests)
-// lifts the rule
+// a chain of depth D carries 2(D-1) halo rows per tile and marches row by row: on
+// grids below ~450 x 450 a step is bound by its launches and D single sweeps are
+// as fast or faster (tools/small_chain_sweep.py: Brusselator Pr8 at N = 316 78 us
+// unchained, 87 with depth-2 chains; at N = 500 100 against 87..98 chained; heat
+// Pr9 at N = 448 90 against 98); ESQ_CHAIN_ROWS (tests) lifts the rule
 inline bool chain_fits_grid(int N, int depth) {
     if (getenv("ESQ_CHAIN_ROWS")) return true;
     const int W = 64 - 2 * (depth - 1);
     const size_t tpr = ((size_t)N / 2 + W - 1) / W;
-    return (size_t)N * tpr >= (size_t)8192 * (depth - 1);
+    return (size_t)N * tpr >= 2048;
 }
 // tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
 // share one tile (the split sweeps: one per field)
@@ -205,38 +206,26 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
     const char *env = getenv("ESQ_CHAIN_ROWS");           // tuning / tests
     int R = env ? atoi(env) : 0;
     if (R <= 0) {
-        // ONE round of resident waves, as few per CU as keeps the tiles at most
-        // 48 rows high (measured, profiles/r03_experiments.md: whole rounds
-        // matter, and with the next row's operands prefetched one wave per SIMD
-        // runs as fast as two -- so prefer tall tiles, whose halo rows cost less);
-        // grids too large for one round at full occupancy take several
-        // tiles = tpr * ceil(N / R) must not exceed the wave slots of the round
+        // ONE round of resident waves at the kernel's own occupancy: the sweeps
+        // are latency-bound per wave (a row's loads are one iteration ahead, no
+        // more), so every wave slot should hold a tile, and a second, partial
+        // round costs a whole one.  Tiles of at most 48 rows (beyond, two rounds
+        // of shorter tiles), at least depth + 2 (the halo rows are recomputed).
+        // Measured (profiles/r03_experiments.md, tools/small_chain_sweep.py): Pr8
+        // at N = 1000: R = 9..12 160 us/step, R = 18 at one wave per SIMD 300;
+        // at N = 2236: R = 44 (two waves per SIMD) / 30 (three).
         auto rows_for = [&](size_t slots) -> int {
             const size_t max_row_tiles = slots / (size_t)waves_per_tile / g.tpr;
             if (max_row_tiles == 0) return N + 1;
             return (int)(((size_t)N + max_row_tiles - 1) / max_row_tiles);
         };
-        // as many waves per CU as the kernel can hold while the tiles stay
-        // between 24 and 48 rows (Pr8, n = 1e7: chain4<1> at three waves per SIMD
-        // and R = 30 takes 124 us, at two and R = 44 140 us) ...
-        for (int wpc = waves_per_cu - waves_per_cu % 4; wpc >= 4 && R <= 0; wpc -= 4) {
-            const int cand = rows_for((size_t)256 * (size_t)wpc);
-            if (cand >= 24 && cand <= 48) R = cand;
-        }
-        // ... else as few as keep them at most 48 rows high
-        for (int wpc = 4; wpc <= waves_per_cu && R <= 0; wpc += 4) {
-            const int cand = rows_for((size_t)256 * (size_t)wpc);
-            if (cand <= 48) R = cand;
-        }
-        if (R <= 0) {
-            size_t rounds = 1;
+        size_t rounds = 1;
+        R = rows_for((size_t)256 * (size_t)waves_per_cu);
+        while (R > 48) {
+            ++rounds;
             R = rows_for((size_t)256 * (size_t)waves_per_cu * rounds);
-            while (R > 48) {
-                ++rounds;
-                R = rows_for((size_t)256 * (size_t)waves_per_cu * rounds);
-            }
         }
-        if (R < 4 * depth) R = 4 * depth;
+        if (R < depth + 2) R = depth + 2;
     }
     if (R > N) R = N;
     g.R = R;
