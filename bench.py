@@ -604,23 +604,28 @@ def generic_plugin_figure(w, device, args):
 
 
 def rows_kept_figure(w, device, args):
-    """the same workload on a context that writes EVERY row of K in every step
-    (ESQ_LAZY_ROWS=0).  By default the rows of a step's last chain sweep -- read by
-    nothing but that sweep's own solution / error sums -- are written only for a
-    caller that reads them (dense output, `solver.K`, stiffness detection): the
-    first such read re-evaluates them, a second within four steps makes the
-    context keep them.  This is what such a caller's steps cost."""
+    """the same workload for a caller that reads K after every step (dense output
+    at every step, `solver.K`): every row of K is written by the step that forms
+    it and the end-point derivative is evaluated when the step is accepted
+    (ESQ_LAZY_ROWS=0 ESQ_LAZY_END=0 -- the state a context reaches by itself after
+    two such reads, esq_rk_lazy_rows).  By default the rows of a step's last chain
+    sweep (read by nothing but that sweep's own solution / error sums) are written
+    only on demand, and f(t_new, y_new) is evaluated as stage 0 of the next step's
+    first chain sweep."""
     if "rho_jac" in w["kw"]:
         return None                       # SSV2stab config: no K rows
-    old = os.environ.get("ESQ_LAZY_ROWS")
-    os.environ["ESQ_LAZY_ROWS"] = "0"
+    knobs = ("ESQ_LAZY_ROWS", "ESQ_LAZY_END")
+    old = {k: os.environ.get(k) for k in knobs}
+    for k in knobs:
+        os.environ[k] = "0"
     try:
         s = w["cls"](w["rhs"], 0.0, w["y0"], 1.0e9, device=device, **w["kw"])
     finally:
-        if old is None:
-            del os.environ["ESQ_LAZY_ROWS"]
-        else:
-            os.environ["ESQ_LAZY_ROWS"] = old
+        for k in knobs:
+            if old[k] is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = old[k]
     dev = s._dev
     for _ in range(args.warmup):
         assert s.step() is None
@@ -631,7 +636,8 @@ def rows_kept_figure(w, device, args):
     dev.synchronize()
     dt = time.perf_counter() - t0
     return {"ms_per_step": 1e3 * dt / args.steps, "value": s.n * args.steps / dt,
-            "note": "ESQ_LAZY_ROWS=0: the last chain sweep also writes its K rows"}
+            "note": "ESQ_LAZY_ROWS=0 ESQ_LAZY_END=0: every K row written by its step, "
+                    "end-point derivative evaluated at accept time"}
 
 
 def adaptive_figure(w, device, esq, span_steps=40):

@@ -199,7 +199,7 @@ inline bool chain_fits_grid(int N, int depth) {
 // tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
 // share one tile (the split sweeps: one per field)
 inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_block,
-                          int waves_per_tile) {
+                          int waves_per_tile, bool tall_if_one_round = false) {
     GeoChain g;
     const int W = 64 - 2 * (depth - 1);
     g.tpr = ((unsigned)N / 2 + W - 1) / W;
@@ -219,8 +219,16 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
             if (max_row_tiles == 0) return N + 1;
             return (int)(((size_t)N + max_row_tiles - 1) / max_row_tiles);
         };
+        // tall_if_one_round (one-field sweeps, light rows -- the heat plugin): where
+        // ONE wave per SIMD already gives tiles of 24..48 rows the launch is
+        // bandwidth-bound and the fewer halo rows win (heat Pr9 at N = 2236:
+        // R = 44 0.587 ms/step, R = 15 at three waves per SIMD 0.62)
+        if (tall_if_one_round) {
+            const int cand = rows_for((size_t)256 * 4);
+            if (cand >= 24 && cand <= 48) R = cand;
+        }
         size_t rounds = 1;
-        R = rows_for((size_t)256 * (size_t)waves_per_cu);
+        if (R <= 0) R = rows_for((size_t)256 * (size_t)waves_per_cu);
         while (R > 48) {
             ++rounds;
             R = rows_for((size_t)256 * (size_t)waves_per_cu * rounds);

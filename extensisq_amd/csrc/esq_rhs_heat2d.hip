@@ -160,7 +160,7 @@ int esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
         using CA = decltype(ca);
         auto kern = esq::k_chain2d<1, false, CA::kD, CA::kNU, decltype(kind)::value, HeatFn>;
         static const int wpc = chain_waves_per_cu(kern, (unsigned)kBlock);   // per instantiation
-        const GeoChain g = geo_chain(r->N, CA::kD, wpc, kBlock / 64, 1);
+        const GeoChain g = geo_chain(r->N, CA::kD, wpc, kBlock / 64, 1, /*tall_if_one_round=*/true);
         if (chain->read_amplification)
             *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1)) / g.R * 64.0 /
                                          (64 - 2 * (CA::kD - 1));

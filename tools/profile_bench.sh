@@ -15,6 +15,14 @@ cd /tmp && export TMPDIR=/tmp
 # a fresh box runs its first seconds of GPU work measurably slower: warm it up
 python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras > /dev/null 2>&1
 for CFG in "${@:-pr8}"; do
+    if [ "$CFG" = driver ]; then
+        # the driver's own command line (its flags), extras and CPU baseline included
+        python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 \
+            > $OUT/prof_driver_bench.json 2> $OUT/prof_driver_bench.err
+        rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_driver_stats -o bench -- \
+            python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/prof_driver_stats.log 2>&1
+        continue
+    fi
     python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras \
         > $OUT/prof_${CFG}_bench.json 2> $OUT/prof_${CFG}_bench.err
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${CFG}_stats -o bench -- \

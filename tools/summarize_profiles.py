@@ -28,9 +28,8 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 PEAK = 8.0e12
 
-STAGE = ("k_lincomb", "k_block_acc", "rhs+stage", "rhs1+stage", "rhs+block",
-         "chain2", "chain3", "chain4", "chain2+solerr", "chain3+solerr",
-         "chain4+solerr")
+STAGE = ("k_lincomb", "k_block_acc", "rhs+stage", "rhs1+stage", "rhs+block") + tuple(
+    f"chain{d}{suffix}" for d in range(2, 7) for suffix in ("", "+solerr"))
 RKC = ("rhs_rkc", "k_rkc_first", "k_rkc_stage")
 
 
@@ -100,7 +99,10 @@ def one(tag, cfg):
     dom = STAGE if cfg != "rkc" else RKC
     d_bytes = d_ns = d_calls = 0.0
     all_bytes = all_ns = 0.0
-    events = (bench or {}).get("roofline", {}).get("kernels", {})
+    # bench.py labels a chain sweep that does not write its K rows "...-K<n>"; it
+    # is the same kernel for rocprofv3
+    events = {k.replace("-K<", "<"): v
+              for k, v in (bench or {}).get("roofline", {}).get("kernels", {}).items()}
     for k in sorted(stats):
         calls, ns = stats[k]
         f_b = 2.0 * fetch.get(k, (0.0, 0))[0] * 1024.0
@@ -142,11 +144,27 @@ def one(tag, cfg):
         print(f"[{cfg}] bench.py roofline: {json.dumps(out['bench_roofline'])}")
 
 
+def driver(tag):
+    """the exact command the driver runs (tools/profile_bench.sh driver): kernel
+    stats + the JSON line, no counter passes"""
+    shutil.copy(os.path.join(G, "prof_driver_stats", "bench_kernel_stats.csv"),
+                os.path.join(P, f"{tag}_kernel_stats_driver_command.csv"))
+    with open(os.path.join(G, "prof_driver_bench.json")) as fh:
+        bench = json.loads(fh.read().strip().splitlines()[-1])
+    with open(os.path.join(P, f"{tag}_bench_driver_command.json"), "w") as fh:
+        json.dump(bench, fh, indent=1)
+    print(f"[driver] value {bench['value']:.4g}  ms/step {bench['ms_per_step']:.4f}  "
+          f"frac {bench['roofline']['frac']:.3f}")
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     os.makedirs(P, exist_ok=True)
     for cfg in (sys.argv[2:] or ["pr8"]):
-        one(tag, cfg)
+        if cfg == "driver":
+            driver(tag)
+        else:
+            one(tag, cfg)
 
 
 if __name__ == "__main__":
