@@ -537,15 +537,16 @@ int esqi::restore_rows(esq_ctx *c) {
     (void)hipSetDevice(c->device);
     c->idle = false;
     c->self_valid = false;
+    // (a flag is cleared only once its rows are in memory: after a failure the
+    // next reader tries again instead of reading what is not there)
     if (c->k0_missing) {
         // f(t, y) of the current state (= K[s] of the step just accepted)
-        c->k0_missing = false;
-        ++c->end_plain;
         const int r = call_rhs(c, c->k0_t, c->y, c->krow[c->kmap[0]]);
         if (r) return r;
+        c->k0_missing = false;
+        ++c->end_plain;
     }
     if (!c->tail_missing) return 0;
-    c->tail_missing = false;
     const std::vector<int> &map = c->tail_accepted ? c->kmap_last : c->kmap;
     // after esq_rk_accept the pre-step state is in the YNEW slot
     const double *base = c->tail_accepted ? c->ynew : c->y;
@@ -558,6 +559,7 @@ int esqi::restore_rows(esq_ctx *c) {
         r = call_rhs(c, c->tail_t + c->C[st] * c->tail_h, c->work, c->krow[map[st]]);
         if (r) return r;
     }
+    c->tail_missing = false;
     ++c->restores;
     if (c->accepted_steps - c->last_restore_at <= 4) c->keep_rows = true;
     c->last_restore_at = c->accepted_steps;
@@ -791,12 +793,12 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 return r;
             }
         }
-        c->k0_missing = false;
         if (!fused) {
-            ++c->end_plain;
             const int r = call_rhs(c, t, c->y, c->krow[c->kmap[0]]);
             if (r) return r;
+            ++c->end_plain;
         }
+        c->k0_missing = false;
     }
     for (int i = i_first; i < i_to; ++i) {
         if (i == 1 && !ready && i + 1 < i_to && may_use_src(c)) {
