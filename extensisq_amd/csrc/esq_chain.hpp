@@ -108,7 +108,7 @@ template <int NFT, bool PERIODIC, int D, int NU, int KINDLAST, class Fn,
           bool SPLIT = false, bool PREFETCH = ESQ_CHAIN_PREFETCH>
 __global__ __launch_bounds__(kBlock) void k_chain2d(
     const double *__restrict__ ys, ChainArgs<D, NU> ca, Fn fn, int N, int R,
-    unsigned tpr, unsigned ntiles, unsigned nblocks, unsigned xcd) {
+    unsigned tpr, unsigned ntiles, unsigned nblocks, unsigned xcd, unsigned serp) {
     constexpr int NF = SPLIT ? 1 : NFT;            // fields per wave
     constexpr int H = D - 1;                       // halo rows / lanes per side
     constexpr int W = 64 - 2 * H;                  // last-stage pairs per tile
@@ -136,6 +136,13 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         const bool store_ok = indom && lane >= H && lane < 64 - H;
         const int r0 = (int)(tile / tpr) * R;
         const int Re = (N - r0) < R ? (N - r0) : R;
+        // Even tile rows march DOWN the grid, odd ones UP: a tile and its vertical
+        // neighbour then read the halo rows they share at the same moment (both
+        // start at, or both arrive at, their common boundary), i.e. one of the two
+        // reads hits in the XCD's L2.  The arithmetic does not see the direction
+        // (the Laplacian adds the rows above and below in one commutative add).
+        const int dirn = (serp && ((tile / tpr) & 1u)) ? -1 : 1;
+        const int rbase = dirn > 0 ? r0 - H : r0 + Re - 1 + H;   // stage 0's first row
         const size_t fstride = (size_t)N * (size_t)npairs;     // pairs per field
         auto row_ok = [&](int r) { return PERIODIC || (r >= 0 && r < N); };
         auto wrap = [&](int r) {
@@ -187,8 +194,8 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             }
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            wm[0][f] = ld_ys(r0 - H - 1, f);
-            wc[0][f] = ld_ys(r0 - H, f);
+            wm[0][f] = ld_ys(rbase - dirn, f);
+            wc[0][f] = ld_ys(rbase, f);
         }
         const int iters = Re + 2 * H;
         // operands of stage 0's row: loaded ONE ITERATION AHEAD, so that a wave
@@ -197,11 +204,11 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         double2 u[ChainArgs<D, NU>::NUa][NF], yrow[NF], ysn[NF];
 #define ESQ_CHAIN_LOAD_ROW(IT)                                                     \
     {                                                                              \
-        const int rho_ = r0 - H + (IT);                                            \
+        const int rho_ = rbase + dirn * (IT);                                      \
         const bool act_ = PERIODIC || (live && row_ok(rho_));                      \
         const size_t base_ = (size_t)wrap(rho_) * npairs + pwl;                    \
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                           \
-            ysn[f] = ld_ys(rho_ + 1, f);                                           \
+            ysn[f] = ld_ys(rho_ + dirn, f);                                        \
             const size_t k2_ = (size_t)(fbase + f) * fstride + base_;              \
             _Pragma("unroll") for (int j = 0; j < NU; ++j)                         \
                 u[j][f] = act_ ? ld2_nt(ca.rows[j], k2_) : zero;                   \
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
     }
         ESQ_CHAIN_LOAD_ROW(0)
         for (int it = 0; it < iters; ++it) {
-            const int rho0 = r0 - H + it;                  // stage 0's row
+            const int rho0 = rbase + dirn * it;            // stage 0's row
             // ---- take over the row loaded one iteration ago ...
             double2 uc[ChainArgs<D, NU>::NUa][NF];
 #pragma unroll
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 if (it >= 2 * k) {                                 // wave-uniform
-                    const int rho = rho0 - k;
+                    const int rho = rho0 - dirn * k;
                     const bool actk = live && row_ok(rho);
                     const bool own = rho >= r0 && rho < r0 + Re;
                     const size_t basek = (size_t)wrap(rho) * npairs + pw;

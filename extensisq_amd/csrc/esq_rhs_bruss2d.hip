@@ -227,7 +227,7 @@ int esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chain
         hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(block), 0, (hipStream_t)stream,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in,
                               ca, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
-                              (unsigned)kXcd);
+                              (unsigned)kXcd, chain_serpentine());
     };
     const int rc = split
         ? esq::dispatch_chain<6>(chain, [&](auto ca, auto kind) { body(ca, kind, std::true_type{}); })

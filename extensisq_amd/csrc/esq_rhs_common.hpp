@@ -196,6 +196,12 @@ inline bool chain_fits_grid(int N, int depth) {
     const size_t tpr = ((size_t)N / 2 + W - 1) / W;
     return (size_t)N * tpr >= 2048;
 }
+// alternate tile rows march in opposite directions (esq_chain.hpp);
+// ESQ_CHAIN_SERPENTINE=0: all downwards
+inline unsigned chain_serpentine() {
+    const char *e = getenv("ESQ_CHAIN_SERPENTINE");
+    return (e && atoi(e) == 0) ? 0u : 1u;
+}
 // tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
 // share one tile (the split sweeps: one per field)
 inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_block,

@@ -171,7 +171,7 @@ int esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
         hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(kBlock), 0, (hipStream_t)stream,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in,
                               ca, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
-                              (unsigned)kXcd);
+                              (unsigned)kXcd, chain_serpentine());
     });
     if (rc) return rc;
     return rc_launch ? rc_launch : (int)hipGetLastError();
