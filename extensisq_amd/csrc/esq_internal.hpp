@@ -143,10 +143,10 @@ struct esq_ctx {
     // every other reader restores them first (esqi::restore_rows)
     bool lazy_rows = true;
     bool keep_rows = false;               // sticky: a reader asked twice in a row
-    bool tail_missing = false;            // rows [tail_i0, tail_i0 + tail_depth) of
-    bool tail_accepted = false;           // ... the step in flight / just accepted
-    int tail_i0 = 0, tail_depth = 0;
-    double tail_t = 0.0, tail_h = 0.0;
+    bool tail_missing = false;            // logical rows `missing_rows` (bit i: K_i)
+    bool tail_accepted = false;           // ... of the step in flight / just accepted
+    unsigned long long missing_rows = 0;
+    double tail_t = 0.0, tail_h = 0.0;    // that step's (t, h)
     long accepted_steps = 0, last_restore_at = -100, restores = 0;
     // non-FSAL pairs: f(t_new, y_new) of an accepted step is not evaluated by
     // esq_rk_accept but as stage 0 of the NEXT step's first chain sweep

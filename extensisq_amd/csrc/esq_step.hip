@@ -196,7 +196,7 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = fa
 // (non-FSAL: weights B and E).  Returns 0, kNotApplicable / ESQ_ENOTSUP (the
 // caller tries a shorter chain or single sweeps) or an error.
 int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
-                bool keep_rows = true) {
+                bool lazy_rows = false) {
     const int s = c->s;
     if (depth < 2 || depth > ESQ_CHAIN_MAX_DEPTH || s > 62) return kNotApplicable;
     esq_chain e;
@@ -277,10 +277,23 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     // i == 0: the chain starts from the state itself (stage 0 = f(t, y))
     e.y = i == 0 ? nullptr : c->y;
     e.h = h;
+    unsigned long long skipped = 0;
+    int n_stored = 0;
     for (int k = 0; k < depth; ++k) {
         e.t[k] = t + c->C[i + k] * h;
-        // !keep_rows: nothing but this sweep's solution/error sums reads them
-        e.f_out[k] = keep_rows ? c->krow[c->kmap[i + k]] : nullptr;
+        // lazy_rows: a derivative that nothing after this sweep reads -- no later
+        // stage's row of A (the stage right behind the chain gets its whole
+        // argument from the chain), no solution / error weight outside this sweep
+        // -- is not written (restore_rows re-evaluates it for whoever asks)
+        const int col = i + k;
+        bool needed = !lazy_rows;
+        for (int st = i + depth + (what_last == 0 ? 1 : 0); st < s && !needed; ++st)
+            needed = c->A[(size_t)st * s + col] != 0.0;
+        if (!needed && what_last != 2)
+            needed = c->B[col] != 0.0 || c->E[col] != 0.0;
+        e.f_out[k] = needed ? c->krow[c->kmap[col]] : nullptr;
+        if (!needed) skipped |= 1ull << col;
+        n_stored += needed;
     }
     e.out = what_last == 0 ? c->work : c->ynew;
     e.f_store_nt = c->epi_nt & 1;
@@ -295,13 +308,13 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     // (times the tile geometry's read amplification); the chain's K rows and the
     // last target out
     // nu counts the partial sums too
-    const double reads = (i == 0 ? 1 : 2) + nu, writes = (keep_rows ? depth : 0) + 1;
+    const double reads = (i == 0 ? 1 : 2) + nu, writes = n_stored + 1;
     (void)n_init;
     double amp = 1.0;
     e.read_amplification = &amp;
     char label[24];
     snprintf(label, sizeof(label), "chain%d%s%s", depth, what_last == 2 ? "+solerr" : "",
-             keep_rows ? "" : "-K");
+             n_stored == 0 ? "-K" : "");
     Prof p(c, ESQ_PROF_STAGE, label, nu, alg, false, 8.0 * (reads + writes) * (double)c->len);
     c->self_valid = false;
     const int r = c->rhs_chain(c->rhs_user, i == 0 ? c->y : c->ystage, &e, c->len,
@@ -311,6 +324,13 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
     if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "chain RHS entry returned %d", r); }
     if (what_last == 0) std::swap(c->ystage, c->work);
+    if (skipped) {
+        c->missing_rows |= skipped;
+        c->tail_missing = true;
+        c->tail_accepted = false;
+        c->tail_t = t;
+        c->tail_h = h;
+    }
     return 0;
 }
 
@@ -526,8 +546,8 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
 
 }  // namespace
 
-// The rows [tail_i0, tail_i0 + tail_depth) of the step in flight (or of the step
-// just accepted) exist only as terms of y_new and the error sums.  Re-evaluate
+// The rows `missing_rows` of the step in flight (or of the step just accepted) exist
+// only as terms of the sums their own sweep formed.  Re-evaluate
 // them the plain way, stage by stage: a_i. K in ascending column order from the
 // rows in memory (what k_lincomb does when no partial sum is stored: the same FMA
 // chain as the blocked / chained sweeps), then the RHS.  A context that is asked
@@ -550,7 +570,8 @@ int esqi::restore_rows(esq_ctx *c) {
     const std::vector<int> &map = c->tail_accepted ? c->kmap_last : c->kmap;
     // after esq_rk_accept the pre-step state is in the YNEW slot
     const double *base = c->tail_accepted ? c->ynew : c->y;
-    for (int st = c->tail_i0; st < c->tail_i0 + c->tail_depth; ++st) {
+    for (int st = 1; st < c->s; ++st) {             // ascending: a row may need an earlier one
+        if (!((c->missing_rows >> st) & 1ull)) continue;
         Terms tm;
         const int nt = build_row_terms(c, &c->A[(size_t)st * c->s], st, tm, map);
         if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
@@ -560,6 +581,7 @@ int esqi::restore_rows(esq_ctx *c) {
         if (r) return r;
     }
     c->tail_missing = false;
+    c->missing_rows = 0;
     ++c->restores;
     if (c->accepted_steps - c->last_restore_at <= 4) c->keep_rows = true;
     c->last_restore_at = c->accepted_steps;
@@ -758,6 +780,7 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
         return fail(c, ESQ_EINVAL, "bad stage range [%d, %d)", i_from, i_to);
     if (i_from > 1) ENSURE_ROWS(c);
     c->tail_missing = false;       // whatever was missing is overwritten from here on
+    c->missing_rows = 0;
     c->ynew_ready = false;
     c->solerr_ready = false;
     bool block_done = false;   // the block at boundary i already ran in a sweep
@@ -780,7 +803,9 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                     d1 = D;
             }
             int r = kNotApplicable;
-            if (d1 && d1 + 1 <= ESQ_CHAIN_MAX_DEPTH) r = sweep_chain(c, 0, d1 + 1, t, h, 0);
+            if (d1 && d1 + 1 <= ESQ_CHAIN_MAX_DEPTH)
+                r = sweep_chain(c, 0, d1 + 1, t, h, 0,
+                                c->lazy_rows && !c->keep_rows && i_to == c->s);
             if (r == 0) {
                 fused = true;
                 c->end_fused_ok = 1;
@@ -855,19 +880,13 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 if (what < 0) continue;
                 const size_t slot = (size_t)i * 8 + (size_t)D;
                 if (slot < c->chain_refused.size() && c->chain_refused[slot]) continue;
-                // the rows of a chain that ends in the solution/error sums are read
-                // by nothing else in a step: written only for a context whose
-                // caller keeps asking for them (restore_rows)
-                const bool lazy = what == 2 && c->lazy_rows && !c->keep_rows && c->rhs;
-                const int r = sweep_chain(c, i, D, t, h, what, !lazy);
-                if (r == 0 && lazy) {
-                    c->tail_missing = true;
-                    c->tail_accepted = false;
-                    c->tail_i0 = i;
-                    c->tail_depth = D;
-                    c->tail_t = t;
-                    c->tail_h = h;
-                }
+                // derivatives nothing after their chain reads (all rows of a chain that
+                // ends in the solution/error sums; K_1 of Pr7/8/9) are written only for
+                // a context whose caller keeps asking for them (restore_rows).  Whole
+                // steps only: a caller that runs the stages in pieces (BS5, CFMR7osc)
+                // reads rows with weights the tableau does not show
+                const bool lazy = c->lazy_rows && !c->keep_rows && c->rhs && i_to == c->s;
+                const int r = sweep_chain(c, i, D, t, h, what, lazy);
                 if (r == ESQ_ENOTSUP || r == kNotApplicable) {
                     // a property of the tableau and the grid, not of this step
                     if (slot < c->chain_refused.size()) c->chain_refused[slot] = 1;
@@ -1131,7 +1150,8 @@ int esq_rk_lazy_rows(esq_ctx *c, int *missing_out, int *keeps_out, long *restore
                      long *end_fused_out, long *end_plain_out) {
     if (!c) return ESQ_EINVAL;
     if (missing_out)
-        *missing_out = (c->tail_missing ? c->tail_depth : 0) + (c->k0_missing ? 1 : 0);
+        *missing_out = (c->tail_missing ? __builtin_popcountll(c->missing_rows) : 0) +
+                       (c->k0_missing ? 1 : 0);
     if (keeps_out) *keeps_out = (c->keep_rows || !c->lazy_rows) ? 1 : 0;
     if (restores_out) *restores_out = c->restores;
     if (end_fused_out) *end_fused_out = c->end_fused;
