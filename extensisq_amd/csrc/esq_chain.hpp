@@ -82,6 +82,8 @@ struct ChainArgs {
     double ck[D][D];                 // ck[e][k]: weight of K_k in target e + 1 (k <= e)
     double ek[D];                    // SOLERR: error weight of K_k
     unsigned kmask[D];               // stages whose K takes part in target e + 1
+    double c0[NUa];                  // FROMROWS: weights of rows[] in the chain's own
+    unsigned umask0;                 // input T_0 = y + h * sum_u c0[u] rows[u]
     const double *y;                 // base state; nullptr: the chain's own input
     double h;
     double *fk[D];                   // where K_k goes (nullptr: not stored)
@@ -104,8 +106,13 @@ struct ChainArgs {
 // row).  Per-wave register use is that of a one-field kernel, so depth-4
 // chains with 8-9 memory rows keep two waves per SIMD -- the whole Pr8 step
 // becomes E + three chains.  Same arithmetic, bit-identical.
+// FROMROWS: the chain's input T_0 (the argument of its first stage) is not read from
+// memory but formed from y and the memory rows the chain loads anyway
+// (ca.c0, ca.umask0) -- the previous sweep then need not write it.  The row sets
+// are requested one grid row further ahead (T_0's row must exist before stage 0's
+// window takes it) and the targets' sums over a row set wait one iteration.
 template <int NFT, bool PERIODIC, int D, int NU, int KINDLAST, class Fn,
-          bool SPLIT = false, bool PREFETCH = ESQ_CHAIN_PREFETCH>
+          bool SPLIT = false, bool FROMROWS = false, bool PREFETCH = ESQ_CHAIN_PREFETCH>
 __global__ __launch_bounds__(kBlock) void k_chain2d(
     const double *__restrict__ ys, ChainArgs<D, NU> ca, Fn fn, int N, int R,
     unsigned tpr, unsigned ntiles, unsigned nblocks, unsigned xcd, unsigned serp) {
@@ -179,6 +186,13 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         for (int j = 0; j < NU; ++j) {
             asm("s_mov_b64 %0, %1" : "=s"(w_eu[j]) : "s"(ca.eu[j]));
         }
+        double w_c0[ChainArgs<D, NU>::NUa];
+        if constexpr (FROMROWS) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                asm("s_mov_b64 %0, %1" : "=s"(w_c0[j]) : "s"(ca.c0[j]));
+            }
+        }
         // windows of the D stages: rows rho_k - 1, rho_k, rho_k + 1 of T_k
         double2 wm[D][NF], wc[D][NF], wp[D][NF];
         // acc[e][k]: target e + 1's sum for the row stage k is at (k <= e)
@@ -192,23 +206,26 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
 #pragma unroll
                 for (int e = 0; e < D; ++e) acc[e][k][f] = zero;
             }
+        if constexpr (!FROMROWS) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            wm[0][f] = ld_ys(rbase - dirn, f);
-            wc[0][f] = ld_ys(rbase, f);
+            for (int f = 0; f < NF; ++f) {
+                wm[0][f] = ld_ys(rbase - dirn, f);
+                wc[0][f] = ld_ys(rbase, f);
+            }
         }
         const int iters = Re + 2 * H;
         // operands of stage 0's row: loaded ONE ITERATION AHEAD, so that a wave
         // always has a whole row set in flight behind the row it computes on
-        // (the sweeps are latency-bound: few waves per SIMD at this register use)
+        // (the sweeps are latency-bound: few waves per SIMD at this register use).
+        // FROMROWS: the set of iteration IT is that of the row AFTER stage 0's.
         double2 u[ChainArgs<D, NU>::NUa][NF], yrow[NF], ysn[NF];
 #define ESQ_CHAIN_LOAD_ROW(IT)                                                     \
     {                                                                              \
-        const int rho_ = rbase + dirn * (IT);                                      \
+        const int rho_ = rbase + dirn * ((IT) + (FROMROWS ? 1 : 0));               \
         const bool act_ = PERIODIC || (live && row_ok(rho_));                      \
         const size_t base_ = (size_t)wrap(rho_) * npairs + pwl;                    \
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                           \
-            ysn[f] = ld_ys(rho_ + dirn, f);                                        \
+            if (!FROMROWS) ysn[f] = ld_ys(rho_ + dirn, f);                         \
             const size_t k2_ = (size_t)(fbase + f) * fstride + base_;              \
             _Pragma("unroll") for (int j = 0; j < NU; ++j)                         \
                 u[j][f] = act_ ? ld2_nt(ca.rows[j], k2_) : zero;                   \
@@ -216,21 +233,90 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             if (ca.y) yrow[f] = act_ ? ld2(ca.y, k2_) : zero;                      \
         }                                                                          \
     }
+        // FROMROWS: T_0 of the row a set belongs to (same ascending FMA chain, the
+        // same two roundings as the sweep that would have written it)
+#define ESQ_CHAIN_FORM_T0(IT, U_, Y_, DST)                                                 \
+    {                                                                              \
+        const int rho_ = rbase + dirn * ((IT) + 1);                                \
+        const bool act_ = live && row_ok(rho_);                                    \
+        _Pragma("unroll") for (int f = 0; f < NF; ++f) {                           \
+            double2 s0_ = zero;                                                    \
+            _Pragma("unroll") for (int j = 0; j < NU; ++j) {                       \
+                if ((um0 >> j) & 1u) {                                             \
+                    asm volatile("");                                              \
+                    s0_.x = fma(w_c0[j], U_[j][f].x, s0_.x);                       \
+                    s0_.y = fma(w_c0[j], U_[j][f].y, s0_.y);                       \
+                }                                                                  \
+            }                                                                      \
+            const double2 t0_ = make_double2(__dadd_rn(Y_[f].x, __dmul_rn(ca.h, s0_.x)), \
+                                             __dadd_rn(Y_[f].y, __dmul_rn(ca.h, s0_.y))); \
+            DST[f] = act_ ? t0_ : zero;                                            \
+        }                                                                          \
+    }
+        // the D targets' sums over a row set (leading partial + memory rows)
+#define ESQ_CHAIN_ROW_SUMS(S, SE)                                                  \
+    _Pragma("unroll") for (int e = 0; e < D; ++e)                                  \
+    _Pragma("unroll") for (int f = 0; f < NF; ++f) {                               \
+        double2 s_ = zero, se_ = zero;                                             \
+        _Pragma("unroll") for (int j = 0; j < NU; ++j) {                           \
+            if ((um[e] >> j) & 1u) {                   /* uniform */               \
+                asm volatile("");    /* a real branch, not 2 selects per fma */    \
+                s_.x = fma(w_cu[e][j], uc[j][f].x, s_.x);                          \
+                s_.y = fma(w_cu[e][j], uc[j][f].y, s_.y);                          \
+                if (SOLERR && e == D - 1) {                                        \
+                    se_.x = fma(w_eu[j], uc[j][f].x, se_.x);                       \
+                    se_.y = fma(w_eu[j], uc[j][f].y, se_.y);                       \
+                }                                                                  \
+            }                                                                      \
+        }                                                                          \
+        S[e][f] = s_;                                                              \
+        if (SOLERR && e == D - 1) SE[f] = se_;                                     \
+    }
+        // FROMROWS: sums and base row of the set that arrived one iteration ago
+        double2 sh[D][NF], seh[NF], yh[NF];
+        if constexpr (FROMROWS) {
+            unsigned um0 = ca.umask0, um[D];
+#pragma unroll
+            for (int e = 0; e < D; ++e) um[e] = ca.umask[e];
+            ESQ_CHAIN_LOAD_ROW(-2)                       // row rbase - dirn
+            ESQ_CHAIN_FORM_T0(-2, u, yrow, wm[0])
+            ESQ_CHAIN_LOAD_ROW(-1)                       // row rbase
+            ESQ_CHAIN_FORM_T0(-1, u, yrow, wc[0])
+            {
+                double2 uc[ChainArgs<D, NU>::NUa][NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    yh[f] = yrow[f];
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) uc[j][f] = u[j][f];
+                }
+                ESQ_CHAIN_ROW_SUMS(sh, seh)
+            }
+        }
         ESQ_CHAIN_LOAD_ROW(0)
         for (int it = 0; it < iters; ++it) {
             const int rho0 = rbase + dirn * it;            // stage 0's row
             // ---- take over the row loaded one iteration ago ...
-            double2 uc[ChainArgs<D, NU>::NUa][NF];
+            double2 uc[ChainArgs<D, NU>::NUa][NF], ycur[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                wp[0][f] = ysn[f];
-                yf[0][f] = ca.y ? yrow[f] : wc[0][f];
+                if constexpr (!FROMROWS) {
+                    wp[0][f] = ysn[f];
+                    yf[0][f] = ca.y ? yrow[f] : wc[0][f];
+                } else {
+                    ycur[f] = yrow[f];
+                }
 #pragma unroll
                 for (int j = 0; j < NU; ++j) uc[j][f] = u[j][f];
             }
             // ---- ... and request the next one before any arithmetic
             if (PREFETCH) {
                 if (it + 1 < iters) ESQ_CHAIN_LOAD_ROW(it + 1)
+            }
+            if constexpr (FROMROWS) {
+                unsigned um0 = ca.umask0;
+                asm volatile("" : "+s"(um0));
+                ESQ_CHAIN_FORM_T0(it, uc, ycur, wp[0])
             }
             // the participation masks, opaque per row: tested where they are used
             // (one scalar bit test) instead of 2 x 90 hoisted lane masks that live
@@ -252,27 +338,35 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                 for (int k = 0; k < D; ++k) xch[it & 1][k][wave][lane] = wc[k][0];
                 __syncthreads();
             }
-            // ---- the D targets' sums for row rho0: leading partial + memory rows
-#pragma unroll
-            for (int e = 0; e < D; ++e)
+            // ---- the D targets' sums: of row rho0 (this set), or -- FROMROWS -- of
+            // the row after it, held for one iteration
+            if constexpr (!FROMROWS) {
+                double2 s0[D][NF], se0[NF];
+                ESQ_CHAIN_ROW_SUMS(s0, se0)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
-                    double2 s = zero, se = zero;
 #pragma unroll
-                    for (int j = 0; j < NU; ++j) {
-                        if ((um[e] >> j) & 1u) {                   // uniform
-                            asm volatile("");    // a real branch, not 2 selects per fma
-                            s.x = fma(w_cu[e][j], uc[j][f].x, s.x);
-                            s.y = fma(w_cu[e][j], uc[j][f].y, s.y);
-                            if (SOLERR && e == D - 1) {
-                                se.x = fma(w_eu[j], uc[j][f].x, se.x);
-                                se.y = fma(w_eu[j], uc[j][f].y, se.y);
-                            }
-                        }
-                    }
-                    acc[e][0][f] = s;
-                    if (SOLERR && e == D - 1) acce[0][f] = se;
+                    for (int e = 0; e < D; ++e) acc[e][0][f] = s0[e][f];
+                    if (SOLERR) acce[0][f] = se0[f];
                 }
+            } else {
+                double2 s0[D][NF], se0[NF];
+                ESQ_CHAIN_ROW_SUMS(s0, se0)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                    for (int e = 0; e < D; ++e) {
+                        acc[e][0][f] = sh[e][f];
+                        sh[e][f] = s0[e][f];
+                    }
+                    if (SOLERR) {
+                        acce[0][f] = seh[f];
+                        seh[f] = se0[f];
+                    }
+                    yf[0][f] = yh[f];
+                    yh[f] = ycur[f];
+                }
+            }
             // ---- the stages, each one row behind its predecessor
 #pragma unroll
             for (int k = 0; k < D; ++k) {
@@ -328,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                         if (k + 1 < D) {
                             wp[k + 1 < D ? k + 1 : k][f] = actk ? t : zero;
                         } else if (own && store_ok) {
-                            st2(ca.out, k2, t);
+                            if (SOLERR || ca.out) st2(ca.out, k2, t);
                             if (SOLERR) {
                                 const double2 er = make_double2(__dmul_rn(ca.h, acce[k][f].x),
                                                                 __dmul_rn(ca.h, acce[k][f].y));
@@ -371,5 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
     if (SOLERR) block_partial_w<WAVES>(local, ca.red.partials);
 }
 #undef ESQ_CHAIN_LOAD_ROW
+#undef ESQ_CHAIN_FORM_T0
+#undef ESQ_CHAIN_ROW_SUMS
 
 }  // namespace esq

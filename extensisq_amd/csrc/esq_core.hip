@@ -456,6 +456,7 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     c->epi_nt = env_uint("ESQ_EPI_NT", three_fit ? 0x3 : 0xf);
     c->lazy_rows = env_uint("ESQ_LAZY_ROWS", 1) != 0;
     c->lazy_end = env_uint("ESQ_LAZY_END", 1) != 0;
+    c->chain_from_rows = env_uint("ESQ_CHAIN_FROM_ROWS", 1) != 0;
     c->chain_depth = (int)env_uint("ESQ_CHAIN_DEPTH", 4);     // 5 and 6 exist too
     if (c->chain_depth > ESQ_CHAIN_MAX_DEPTH) c->chain_depth = ESQ_CHAIN_MAX_DEPTH;
     // launch geometry: grid-stride kernels, a few resident blocks per CU

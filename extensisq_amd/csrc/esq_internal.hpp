@@ -113,6 +113,10 @@ struct esq_ctx {
     // chains the plugin (or the library) has refused for this tableau / grid:
     // refused[i * 8 + D] -- not asked again every step (esq_replan clears it)
     std::vector<char> chain_refused;
+    // from_rows[i * 8 + D]: the chain of depth D at stage i forms its own input from
+    // the rows it reads (esq_chain.from_rows): 0 not tried, 1 it does, 2 declined
+    std::vector<char> from_rows;
+    bool chain_from_rows = true;          // ESQ_CHAIN_FROM_ROWS=0: never
     bool ynew_ready = false;     // YNEW already formed by the last stage's sweep
     bool solerr_ready = false;   // ... and the error partial sums too
     int red_count = 0;           // partials written by the last reducing sweep

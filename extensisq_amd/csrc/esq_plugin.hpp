@@ -213,6 +213,9 @@ ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
         a.fk[e] = c->f_out[e];
         for (int k = 0; k < D; ++k) a.ck[e][k] = c->ck[e][k];
     }
+    for (int j = 0; j < ChainArgs<D, NU>::NUa; ++j)
+        a.c0[j] = (c->from_rows && j < NU && j < c->nu) ? c->c0[j] : 0.0;
+    a.umask0 = c->from_rows ? c->umask0 : 0u;
     a.y = c->y; a.h = c->h; a.out = c->out; a.f_nt = c->f_store_nt;
     a.red.atol_vec = c->atol_vec; a.red.atol_s = c->atol_s; a.red.rtol = c->rtol;
     a.red.n_valid = c->n_valid; a.red.partials = c->partials;
@@ -224,18 +227,30 @@ ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
 // with every depth)
 template <int MAXD = 4, class Launch>
 int dispatch_chain(const esq_chain *c, Launch &&launch) {
-    if (!c || c->nu < 0 || !c->out) return ESQ_EINVAL;
+    if (!c || c->nu < 0 || (!c->out && c->kind_last != ESQ_EPI_STAGE)) return ESQ_EINVAL;
+    if (c->from_rows && !c->y) return ESQ_EINVAL;
     if (c->kind_last == ESQ_EPI_SOLERR && (!c->partials || !c->y)) return ESQ_EINVAL;
     if (c->kind_last != ESQ_EPI_STAGE && c->kind_last != ESQ_EPI_SOLERR)
         return ESQ_ENOTSUP;
+    /* the from-rows form is instantiated for the solution/error kind, depth >= 3
+     * and 4+ memory rows (where a late stage's argument can be a subset of them) */ \
 #define ESQ_CHAIN_CASE_(DD, K)                                                     \
     case K:                                                                        \
+        if (c->from_rows) {                                                        \
+            if constexpr (DD >= 3 && K >= 4) {                                     \
+                if (c->kind_last != ESQ_EPI_SOLERR) return ESQ_ENOTSUP;            \
+                launch(make_chain_args<DD, K>(c),                                  \
+                       std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::true_type{}); \
+                return 0;                                                          \
+            }                                                                      \
+            return ESQ_ENOTSUP;                                                    \
+        }                                                                          \
         if (c->kind_last == ESQ_EPI_STAGE)                                         \
             launch(make_chain_args<DD, K>(c),                                      \
-                   std::integral_constant<int, ESQ_EPI_STAGE>{});                  \
+                   std::integral_constant<int, ESQ_EPI_STAGE>{}, std::false_type{}); \
         else                                                                       \
             launch(make_chain_args<DD, K>(c),                                      \
-                   std::integral_constant<int, ESQ_EPI_SOLERR>{});                 \
+                   std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::false_type{}); \
         return 0;
 #define ESQ_CHAIN_CASES_0_6_(DD)                                                   \
     ESQ_CHAIN_CASE_(DD, 0) ESQ_CHAIN_CASE_(DD, 1) ESQ_CHAIN_CASE_(DD, 2)           \

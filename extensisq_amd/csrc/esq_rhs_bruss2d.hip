@@ -210,10 +210,13 @@ int esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chain
         return ESQ_ENOTSUP;
     const BrussFn fn{r->alpha * ((double)r->N * (double)r->N), r->a, r->b};
     int rc_launch = 0;
-    auto body = [&](auto ca, auto kind, auto split_c) {
+    auto body = [&](auto ca, auto kind, auto split_c, auto from_c) {
         using CA = decltype(ca);
         constexpr bool kSplit = decltype(split_c)::value;
-        auto kern = esq::k_chain2d<2, true, CA::kD, CA::kNU, decltype(kind)::value, BrussFn, kSplit>;
+        constexpr bool kFrom = decltype(from_c)::value && kSplit;
+        if (decltype(from_c)::value && !kSplit) { rc_launch = ESQ_ENOTSUP; return; }
+        auto kern = esq::k_chain2d<2, true, CA::kD, CA::kNU, decltype(kind)::value, BrussFn, kSplit,
+                                   kFrom>;
         const unsigned block = kSplit ? 128u : (unsigned)kBlock;
         static const int wpc = chain_waves_per_cu(kern, block);       // per instantiation
         const GeoChain g = geo_chain(r->N, CA::kD, wpc, kSplit ? 1 : kBlock / 64, kSplit ? 2 : 1);
@@ -222,16 +225,18 @@ int esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chain
             if (chain->partials_used) *chain->partials_used = (int)g.grid;
         }
         if (chain->read_amplification)
-            *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1)) / g.R * 64.0 /
-                                         (64 - 2 * (CA::kD - 1));
+            *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1) + (kFrom ? 2 : 0)) /
+                                         g.R * 64.0 / (64 - 2 * (CA::kD - 1));
         hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(block), 0, (hipStream_t)stream,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in,
                               ca, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
                               (unsigned)kXcd, chain_serpentine());
     };
     const int rc = split
-        ? esq::dispatch_chain<6>(chain, [&](auto ca, auto kind) { body(ca, kind, std::true_type{}); })
-        : esq::dispatch_chain<4>(chain, [&](auto ca, auto kind) { body(ca, kind, std::false_type{}); });
+        ? esq::dispatch_chain<6>(chain, [&](auto ca, auto kind, auto from_c) {
+              body(ca, kind, std::true_type{}, from_c); })
+        : esq::dispatch_chain<4>(chain, [&](auto ca, auto kind, auto from_c) {
+              body(ca, kind, std::false_type{}, from_c); });
     if (rc) return rc;
     return rc_launch ? rc_launch : (int)hipGetLastError();
 }

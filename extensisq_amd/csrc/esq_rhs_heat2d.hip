@@ -156,14 +156,16 @@ int esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
     if (!chain_fits_grid(r->N, chain->depth)) return ESQ_ENOTSUP;
     const HeatFn fn{(double)(r->N + 1) * (double)(r->N + 1)};
     int rc_launch = 0;
-    const int rc = esq::dispatch_chain<6>(chain, [&](auto ca, auto kind) {
+    const int rc = esq::dispatch_chain<6>(chain, [&](auto ca, auto kind, auto from_c) {
         using CA = decltype(ca);
-        auto kern = esq::k_chain2d<1, false, CA::kD, CA::kNU, decltype(kind)::value, HeatFn>;
+        constexpr bool kFrom = decltype(from_c)::value;
+        auto kern = esq::k_chain2d<1, false, CA::kD, CA::kNU, decltype(kind)::value, HeatFn, false,
+                                   kFrom>;
         static const int wpc = chain_waves_per_cu(kern, (unsigned)kBlock);   // per instantiation
         const GeoChain g = geo_chain(r->N, CA::kD, wpc, kBlock / 64, 1, /*tall_if_one_round=*/true);
         if (chain->read_amplification)
-            *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1)) / g.R * 64.0 /
-                                         (64 - 2 * (CA::kD - 1));
+            *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1) + (kFrom ? 2 : 0)) /
+                                         g.R * 64.0 / (64 - 2 * (CA::kD - 1));
         if (decltype(kind)::value == ESQ_EPI_SOLERR) {
             if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
             if (chain->partials_used) *chain->partials_used = (int)g.grid;

@@ -196,7 +196,7 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = fa
 // (non-FSAL: weights B and E).  Returns 0, kNotApplicable / ESQ_ENOTSUP (the
 // caller tries a shorter chain or single sweeps) or an error.
 int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
-                bool lazy_rows = false) {
+                bool lazy_rows = false, bool from_rows = false, bool skip_out = false) {
     const int s = c->s;
     if (depth < 2 || depth > ESQ_CHAIN_MAX_DEPTH || s > 62) return kNotApplicable;
     esq_chain e;
@@ -274,6 +274,21 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
         ++nu;
     }
     e.nu = nu;
+    if (from_rows) {
+        // the argument of stage i from the rows this chain reads anyway: only where it
+        // needs no other row (no partial sum either) -- a pure saving
+        if (i < 2 || c->stage_init[i] >= 0 || c->stage_from[i] != 0) return kNotApplicable;
+        e.from_rows = 1;
+        for (const Term &term : c->stage_terms[i]) {
+            if (!use[term.col]) return kNotApplicable;
+            int u = 0;
+            for (; u < nu; ++u)
+                if (e.rows[u] == c->krow[c->kmap[term.col]]) break;
+            if (u == nu) return kNotApplicable;
+            e.c0[u] = term.c;
+            e.umask0 |= 1u << u;
+        }
+    }
     // i == 0: the chain starts from the state itself (stage 0 = f(t, y))
     e.y = i == 0 ? nullptr : c->y;
     e.h = h;
@@ -295,7 +310,8 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
         if (!needed) skipped |= 1ull << col;
         n_stored += needed;
     }
-    e.out = what_last == 0 ? c->work : c->ynew;
+    // skip_out: the next chain forms its own input (from_rows)
+    e.out = what_last == 0 ? (skip_out ? nullptr : c->work) : c->ynew;
     e.f_store_nt = c->epi_nt & 1;
     e.atol_vec = c->atol_is_vec ? c->atolv : nullptr;
     e.atol_s = c->atol_s;
@@ -308,7 +324,8 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     // (times the tile geometry's read amplification); the chain's K rows and the
     // last target out
     // nu counts the partial sums too
-    const double reads = (i == 0 ? 1 : 2) + nu, writes = n_stored + 1;
+    const double reads = ((i == 0 || from_rows) ? 1 : 2) + nu,
+                 writes = n_stored + (skip_out ? 0 : 1);
     (void)n_init;
     double amp = 1.0;
     e.read_amplification = &amp;
@@ -323,7 +340,7 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     if (p.on) p.ev.moved = 8.0 * (reads * amp + writes) * (double)c->len;
     if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
     if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "chain RHS entry returned %d", r); }
-    if (what_last == 0) std::swap(c->ystage, c->work);
+    if (what_last == 0 && !skip_out) std::swap(c->ystage, c->work);
     if (skipped) {
         c->missing_rows |= skipped;
         c->tail_missing = true;
@@ -332,6 +349,42 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
         c->tail_h = h;
     }
     return 0;
+}
+
+// the chain esq_rk_stages will take at stage i (same rules as its selection loop):
+// depth and last kind of the first candidate that crosses no block boundary and
+// has not been refused; false if there is none
+bool chain_candidate(const esq_ctx *c, int i, int i_to, int *depth, int *what) {
+    for (int D = c->chain_depth; D >= 2; --D) {
+        if (i + D > i_to) continue;
+        bool crosses = false;
+        for (const auto &b : c->blocks) crosses |= (b.J > i && b.J <= i + D);
+        if (crosses) continue;
+        int w = -1;
+        if (i + D == c->s && i_to == c->s)
+            w = c->fsal ? (may_fuse(c, ESQ_EPI_STAGE) ? 1 : -1)
+                        : (may_fuse(c, ESQ_EPI_SOLERR) ? 2 : -1);
+        else if (i + D < i_to && may_fuse(c, ESQ_EPI_STAGE))
+            w = 0;
+        if (w < 0) continue;
+        const size_t slot = (size_t)i * 8 + (size_t)D;
+        if (slot < c->chain_refused.size() && c->chain_refused[slot]) continue;
+        *depth = D;
+        *what = w;
+        return true;
+    }
+    return false;
+}
+// will the chain that follows at stage i form its own input (so that nobody has to
+// write it)?  Known from the second step on.
+bool next_forms_its_input(const esq_ctx *c, int i, int i_to) {
+    if (i_to != c->s || i >= i_to - 1 || !c->chain_from_rows) return false;
+    for (const auto &b : c->blocks)
+        if (b.J == i + 1) return false;          // a block sweep comes first
+    int D = 0, what = -1;
+    if (!chain_candidate(c, i, i_to, &D, &what) || what != 2) return false;
+    const size_t slot = (size_t)i * 8 + (size_t)D;
+    return slot < c->from_rows.size() && c->from_rows[slot] == 1;
 }
 
 bool may_use_src(const esq_ctx *c) {
@@ -597,6 +650,7 @@ int esq_replan(esq_ctx *c) {
     if (!c || !c->have_tab) return ESQ_EINVAL;
     const int s = c->s;
     c->chain_refused.assign((size_t)(s + 1) * 8, 0);
+    c->from_rows.assign((size_t)(s + 1) * 8, 0);
     c->end_fused_ok = -1;
     const bool chained = c->rhs_chain && c->chain_depth >= 2 &&
                          env_uint("ESQ_PLAN_CHAINED", 1) != 0;
@@ -805,7 +859,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
             int r = kNotApplicable;
             if (d1 && d1 + 1 <= ESQ_CHAIN_MAX_DEPTH)
                 r = sweep_chain(c, 0, d1 + 1, t, h, 0,
-                                c->lazy_rows && !c->keep_rows && i_to == c->s);
+                                c->lazy_rows && !c->keep_rows && i_to == c->s);   // (its
+            // successor is never the chain that ends the step: the output is written)
             if (r == 0) {
                 fused = true;
                 c->end_fused_ok = 1;
@@ -838,6 +893,13 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 else if (r != kNotApplicable) return r;
             }
         }
+        // the chain that starts here forms its own input from the rows it reads
+        // (known from its first launch on): nobody wrote the argument, nobody has to
+        bool arg_missing = false;
+        if (!ready && !block_done && chains && next_forms_its_input(c, i, i_to)) {
+            arg_missing = true;
+            ready = true;
+        }
         if (!ready) {
             if (block_done) {
                 // partial sums are in place; only the stage kernel is left
@@ -865,7 +927,7 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
             // stages i .. i + D - 1 in ONE marching sweep: the arguments of the
             // later stages stay in registers.  The longest chain that crosses no
             // blocked-accumulation boundary and fits the plugin is taken.
-            bool done = false;
+            bool done = false, handed_over = false;
             for (int D = c->chain_depth; D >= 2 && !done; --D) {
                 if (i + D > i_to) continue;
                 bool crosses = false;
@@ -886,7 +948,31 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 // steps only: a caller that runs the stages in pieces (BS5, CFMR7osc)
                 // reads rows with weights the tableau does not show
                 const bool lazy = c->lazy_rows && !c->keep_rows && c->rhs && i_to == c->s;
-                const int r = sweep_chain(c, i, D, t, h, what, lazy);
+                int r = kNotApplicable;
+                // a chain that ends the step: its input from the rows it reads anyway
+                if (what == 2 && c->chain_from_rows && slot < c->from_rows.size() &&
+                    c->from_rows[slot] != 2) {
+                    r = sweep_chain(c, i, D, t, h, what, lazy, /*from_rows=*/true);
+                    if (r == 0) {
+                        c->from_rows[slot] = 1;
+                    } else if (r == ESQ_ENOTSUP || r == kNotApplicable) {
+                        c->from_rows[slot] = 2;
+                    } else {
+                        return r;
+                    }
+                }
+                if (r != 0) {
+                    if (arg_missing) {           // (only if a chain changed its mind)
+                        const int ra = esq_rk_stage_accumulate(c, i, h);
+                        if (ra) return ra;
+                        arg_missing = false;
+                    }
+                    // a chain that hands over to one that forms its own input does
+                    // not write its last target
+                    const bool skip_out = what == 0 && next_forms_its_input(c, i + D, i_to);
+                    r = sweep_chain(c, i, D, t, h, what, lazy, false, skip_out);
+                    if (r == 0 && skip_out) handed_over = true;
+                }
                 if (r == ESQ_ENOTSUP || r == kNotApplicable) {
                     // a property of the tableau and the grid, not of this step
                     if (slot < c->chain_refused.size()) c->chain_refused[slot] = 1;
@@ -894,7 +980,7 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 }
                 if (r == 0) {
                     i += D - 1;                        // those stages are done too
-                    ready = what == 0;
+                    ready = what == 0 && !handed_over;
                     if (what >= 1) c->ynew_ready = true;
                     if (what == 2) c->solerr_ready = true;
                     done = true;
@@ -903,6 +989,10 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 }
             }
             if (done) continue;
+        }
+        if (arg_missing) {                       // no chain after all: the plain way
+            const int ra = esq_rk_stage_accumulate(c, i, h);
+            if (ra) return ra;
         }
         if (i + 1 < i_to && !bnext && may_fuse(c, ESQ_EPI_STAGE)) {
             // this stage's RHS sweep also forms the NEXT stage's argument

@@ -197,11 +197,22 @@ typedef struct esq_chain {
     unsigned kmask[ESQ_CHAIN_MAX_DEPTH];
     const double *y;
     double h;
+    /* from_rows != 0: T_0 is NOT read from y_in but formed by the sweep itself,
+     *     T_0 = y + h*(sum_u c0[u]*rows[u])      (bit u of umask0: rows[u] takes part)
+     * -- the argument of the chain's first stage from rows the chain reads anyway
+     * (same ascending FMA chain, same two roundings as the sweep that would have
+     * written it; y_in is then unspecified, y is not NULL).  Asked for only where
+     * it adds no row to rows[]; the library then tells the PREVIOUS chain not to
+     * write that argument (its `out` is NULL, kind_last == ESQ_EPI_STAGE).
+     * ESQ_ENOTSUP makes the library form the argument with its own kernel. */
+    int from_rows;
+    double c0[ESQ_CHAIN_MAX_ROWS];
+    unsigned umask0;
     double t[ESQ_CHAIN_MAX_DEPTH];
     double *f_out[ESQ_CHAIN_MAX_DEPTH];      /* NULL: do not store K_{i+k} (the library
                                               * re-evaluates the row for whoever reads
                                               * it, esq_rk_lazy_rows)             */
-    double *out;
+    double *out;                             /* ESQ_EPI_STAGE: NULL = not wanted */
     int f_store_nt;
     const double *atol_vec;                  /* SOLERR, as in esq_epilogue      */
     double atol_s, rtol;

@@ -1680,3 +1680,46 @@ def test_end_point_derivative_as_stage_zero_of_the_next_step(monkeypatch, name, 
     assert_allclose(a.y, b.y, rtol=1e-9, atol=1e-12)
     assert a.nfev == b.nfev
     assert int(esq.NFS[()]) > nfs0
+
+
+@pytest.mark.parametrize("name,plugin,N,rows", [
+    ("Pr8", "bruss", 124, 30), ("Pr8", "bruss", 50, 9), ("Pr8", "heat", 130, 30),
+    ("Pr7", "bruss", 64, 16)])
+def test_last_chain_forms_its_own_input(monkeypatch, name, plugin, N, rows):
+    """The chain that ends a step reads (almost) every earlier K row for the solution
+    and error sums anyway; where the argument of its first stage needs no other row
+    it forms that argument itself, T_0 = y + h * a_i . K (`esq_chain.from_rows`), and
+    the chain before it does not write it (`out = NULL`): one vector less written,
+    one less read.  From the second step on (the library learns it from the first
+    launch); states and K rows equal ESQ_CHAIN_FROM_ROWS=0 bit for bit, the bytes
+    the launches are designed to move do not."""
+    mk, y0, rho = _plugin(plugin, N)
+    h = 0.4 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
+    cls = getattr(esq, name)
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    a = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_CHAIN_FROM_ROWS", "0")
+    b = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_CHAIN_FROM_ROWS")
+    for s in (a, b):
+        assert s.step() is None                       # the step that learns
+        s._dev.profile_reset()
+        s._dev.profile_enable([0, 1, 2])
+    for _ in range(4):
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t
+        assert_allclose(a.error_norm_old, b.error_norm_old, rtol=1e-12)
+    assert_equal(a.y, b.y)
+    assert_equal(a.K, b.K)
+    assert a.nfev == b.nfev
+    moved = [sum(r[5] for r in s._dev.profile_kernels() if r[0].startswith("chain"))
+             for s in (a, b)]
+    labels = [r[0] for r in a._dev.profile_kernels()]
+    if any("+solerr" in lab and lab.startswith("chain") for lab in labels):
+        # one vector less written and read per step, two more halo rows of the other
+        # rows: a clear saving on tall tiles, a small one on short tiles
+        vec = 8.0 * y0.size * 4
+        assert moved[0] < moved[1] - (1.0 if rows >= 16 else 0.0) * vec, (moved, labels)
+    else:
+        assert moved[0] == moved[1]
