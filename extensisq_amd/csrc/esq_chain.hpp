@@ -89,6 +89,8 @@ struct ChainArgs {
     double *fk[D];                   // where K_k goes (nullptr: not stored)
     double *out;                     // last target
     int f_nt;
+    unsigned ld_nt;                  // non-temporal loads: bit 0 the input, bit 1 y,
+                                     // bit 8 + u: rows[u] (read for the last time)
     RedArgs red;
 };
 
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         const int pwl = PERIODIC ? (live ? pw : 0) : pw;
         auto ld_ys = [&](int r, int f) -> double2 {
             if (!PERIODIC && (!live || !row_ok(r))) return make_double2(0.0, 0.0);
-            return ld2(ys, (size_t)(fbase + f) * fstride + (size_t)wrap(r) * npairs + pwl);
+            const size_t k_ = (size_t)(fbase + f) * fstride + (size_t)wrap(r) * npairs + pwl;
+            return (ca.ld_nt & 1u) ? ld2_nt(ys, k_) : ld2(ys, k_);
         };
         const double2 zero = make_double2(0.0, 0.0);
         // every weight as a scalar of its own: taken straight from the argument
@@ -228,9 +231,12 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             if (!FROMROWS) ysn[f] = ld_ys(rho_ + dirn, f);                         \
             const size_t k2_ = (size_t)(fbase + f) * fstride + base_;              \
             _Pragma("unroll") for (int j = 0; j < NU; ++j)                         \
-                u[j][f] = act_ ? ld2_nt(ca.rows[j], k2_) : zero;                   \
+                u[j][f] = !act_ ? zero : ((ca.ld_nt >> (8 + j)) & 1u)                 \
+                              ? ld2_nt(ca.rows[j], k2_) : ld2(ca.rows[j], k2_);       \
             yrow[f] = zero;                                                        \
-            if (ca.y) yrow[f] = act_ ? ld2(ca.y, k2_) : zero;                      \
+            if (ca.y)                                                              \
+                yrow[f] = !act_ ? zero : (ca.ld_nt & 2u) ? ld2_nt(ca.y, k2_)           \
+                                                         : ld2(ca.y, k2_);        \
         }                                                                          \
     }
         // FROMROWS: T_0 of the row a set belongs to (same ascending FMA chain, the

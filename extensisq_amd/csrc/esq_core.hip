@@ -457,6 +457,13 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     c->lazy_rows = env_uint("ESQ_LAZY_ROWS", 1) != 0;
     c->lazy_end = env_uint("ESQ_LAZY_END", 1) != 0;
     c->chain_from_rows = env_uint("ESQ_CHAIN_FROM_ROWS", 1) != 0;
+    if (const char *e = getenv("ESQ_CHAIN_LDNT")) {          // "first,middle,last" bit masks
+        unsigned a = 4, b = 4, d = 4;
+        if (sscanf(e, "%u,%u,%u", &a, &b, &d) == 3) {
+            c->chain_ld_nt[0] = a; c->chain_ld_nt[1] = b; c->chain_ld_nt[2] = d;
+            c->chain_ld_nt_set = true;
+        }
+    }
     c->chain_depth = (int)env_uint("ESQ_CHAIN_DEPTH", 4);     // 5 and 6 exist too
     if (c->chain_depth > ESQ_CHAIN_MAX_DEPTH) c->chain_depth = ESQ_CHAIN_MAX_DEPTH;
     // launch geometry: grid-stride kernels, a few resident blocks per CU

@@ -117,6 +117,8 @@ struct esq_ctx {
     // the rows it reads (esq_chain.from_rows): 0 not tried, 1 it does, 2 declined
     std::vector<char> from_rows;
     bool chain_from_rows = true;          // ESQ_CHAIN_FROM_ROWS=0: never
+    unsigned chain_ld_nt[3] = {4, 4, 4};  // ESQ_CHAIN_LDNT: forced load policy of the
+    bool chain_ld_nt_set = false;         // first / middle / last chain (tuning)
     bool ynew_ready = false;     // YNEW already formed by the last stage's sweep
     bool solerr_ready = false;   // ... and the error partial sums too
     int red_count = 0;           // partials written by the last reducing sweep

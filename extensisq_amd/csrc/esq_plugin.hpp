@@ -217,6 +217,7 @@ ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
         a.c0[j] = (c->from_rows && j < NU && j < c->nu) ? c->c0[j] : 0.0;
     a.umask0 = c->from_rows ? c->umask0 : 0u;
     a.y = c->y; a.h = c->h; a.out = c->out; a.f_nt = c->f_store_nt;
+    a.ld_nt = (unsigned)c->load_nt;
     a.red.atol_vec = c->atol_vec; a.red.atol_s = c->atol_s; a.red.rtol = c->rtol;
     a.red.n_valid = c->n_valid; a.red.partials = c->partials;
     return a;

@@ -313,6 +313,30 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     // skip_out: the next chain forms its own input (from_rows)
     e.out = what_last == 0 ? (skip_out ? nullptr : c->work) : c->ynew;
     e.f_store_nt = c->epi_nt & 1;
+    // loads: a row (and y) that nothing after this sweep reads again is streamed,
+    // the others stay cacheable -- the next chain finds them in the Infinity Cache
+    // (Pr8, n = 1e7: K_0, K_2..K_4 cacheable in the middle chain: 0.527 -> 0.509 ms)
+    {
+        unsigned m = what_last == 2 ? 2u : 0u;             // y: last read of the step
+        for (int u = 0; u < nu; ++u) {
+            int col = -1;
+            for (int j = 0; j <= s && col < 0; ++j)
+                if (j < c->n_rows && e.rows[u] == c->krow[c->kmap[j]]) col = j;
+            bool later = false;                            // (a partial sum: read once)
+            if (col >= 0 && col < s) {
+                for (int st = i + depth + (what_last == 0 ? 1 : 0); st < s && !later; ++st)
+                    later = c->A[(size_t)st * s + col] != 0.0;
+                if (!later && what_last != 2)
+                    later = c->B[col] != 0.0 || c->E[col] != 0.0;
+            }
+            if (!later) m |= 1u << (8 + u);
+        }
+        if (c->chain_ld_nt_set) {                          // ESQ_CHAIN_LDNT (tuning)
+            const unsigned o = c->chain_ld_nt[i == 0 ? 0 : what_last == 2 ? 2 : 1];
+            m = (o & 3u) | ((o & 4u) ? 0xffffff00u : 0u);
+        }
+        e.load_nt = (int)m;
+    }
     e.atol_vec = c->atol_is_vec ? c->atolv : nullptr;
     e.atol_s = c->atol_s;
     e.rtol = c->rtol;

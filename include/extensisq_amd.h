@@ -214,6 +214,10 @@ typedef struct esq_chain {
                                               * it, esq_rk_lazy_rows)             */
     double *out;                             /* ESQ_EPI_STAGE: NULL = not wanted */
     int f_store_nt;
+    /* cache policy of the loads, a hint (bit 0: y_in, bit 1: y, bit 8 + u: rows[u]):
+     * set = nothing in this step reads the vector again (non-temporal load),
+     * clear = a later sweep of the step does (keep it in the Infinity Cache) */
+    int load_nt;
     const double *atol_vec;                  /* SOLERR, as in esq_epilogue      */
     double atol_s, rtol;
     size_t n_valid;
