@@ -17,8 +17,13 @@ LOCK-STEP: one fp64 RCCL all-reduce per step for the global error norm, nothing
 else crosses xGMI (weak scaling).  The no-collective variant (`replicas`) is
 timed in the same run and reported beside it.
 
-A "step" is one accepted 13-stage Pr8 step.  The timed region carries no
-events.  Right after it the same K steps are replayed with a HIP event pair on
+A "step" is one accepted 13-stage Pr8 step: W untimed warm-up steps of the
+measured solver, then exactly K timed ones.  Right before the warm-up steps the
+DEVICE is loaded for `--device-warmup-ms` (40) with steps of a scratch solver:
+an MI355X coming out of idle runs its first ~25 steps up to 15 % slower (power
+management, see device_warmup()); `config.cold_start` reports the same W + K
+window without that help, `config.sustained` 2 000 steps in one go.  The timed
+region carries no events.  Right after it the same K steps are replayed with a HIP event pair on
 EVERY kernel launch (dispatch timestamps on the solver's stream); from that
 replay come the per-kernel table and `roofline`:
     achieved = bytes the dominant kernel class MOVES (designed traffic, checked
