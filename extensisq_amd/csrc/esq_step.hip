@@ -691,8 +691,11 @@ int esq_replan(esq_ctx *c) {
         double best_words = cost(best);
         // fewest boundaries first: a plan with more boundaries must be strictly
         // better (every boundary is one more launch)
+        const bool dbg = getenv("ESQ_PLAN_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[esq plan] no boundary: %.2f\n", best_words);
         for (int b1 = 2; b1 < s; ++b1) {
             const double w = cost({b1});
+            if (dbg) fprintf(stderr, "[esq plan] J = %d: %.2f\n", b1, w);
             if (w >= 0 && w < best_words) { best_words = w; best = {b1}; }
         }
         for (int b1 = 2; b1 < s; ++b1)
