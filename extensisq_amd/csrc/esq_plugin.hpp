@@ -234,7 +234,8 @@ int dispatch_chain(const esq_chain *c, Launch &&launch) {
     if (c->kind_last != ESQ_EPI_STAGE && c->kind_last != ESQ_EPI_SOLERR)
         return ESQ_ENOTSUP;
     /* the from-rows form is instantiated for the solution/error kind, depth >= 3
-     * and 4+ memory rows (where a late stage's argument can be a subset of them) */ \
+     * and 4+ memory rows (where a late stage's argument can be a subset of them),
+     * and for either kind with 1..3 memory rows (the first chain of a step) */ \
 #define ESQ_CHAIN_CASE_(DD, K)                                                     \
     case K:                                                                        \
         if (c->from_rows) {                                                        \
@@ -242,6 +243,14 @@ int dispatch_chain(const esq_chain *c, Launch &&launch) {
                 if (c->kind_last != ESQ_EPI_SOLERR) return ESQ_ENOTSUP;            \
                 launch(make_chain_args<DD, K>(c),                                  \
                        std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::true_type{}); \
+                return 0;                                                          \
+            } else if constexpr (K >= 1 && K <= 3) {                               \
+                if (c->kind_last == ESQ_EPI_STAGE)                                 \
+                    launch(make_chain_args<DD, K>(c),                              \
+                           std::integral_constant<int, ESQ_EPI_STAGE>{}, std::true_type{}); \
+                else                                                               \
+                    launch(make_chain_args<DD, K>(c),                              \
+                           std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::true_type{}); \
                 return 0;                                                          \
             }                                                                      \
             return ESQ_ENOTSUP;                                                    \

@@ -277,7 +277,7 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     if (from_rows) {
         // the argument of stage i from the rows this chain reads anyway: only where it
         // needs no other row (no partial sum either) -- a pure saving
-        if (i < 2 || c->stage_init[i] >= 0 || c->stage_from[i] != 0) return kNotApplicable;
+        if (i < 1 || c->stage_init[i] >= 0 || c->stage_from[i] != 0) return kNotApplicable;
         e.from_rows = 1;
         for (const Term &term : c->stage_terms[i]) {
             if (!use[term.col]) return kNotApplicable;
@@ -908,7 +908,22 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
         c->k0_missing = false;
     }
     for (int i = i_first; i < i_to; ++i) {
-        if (i == 1 && !ready && i + 1 < i_to && may_use_src(c)) {
+        // the first chain of a step can start from the state: stage 1's argument
+        // y + h*a_10*K_0 from the K_0 it reads anyway (one stage more than the plan's
+        // depth, as with the fused end-point stage); tried until the plugin declines
+        bool first_from_rows = false;
+        if (i == 1 && !ready && chains && c->chain_from_rows && i_to == c->s) {
+            bool boundary = false;
+            for (const auto &b : c->blocks) boundary |= (b.J == 2);
+            const int d_hi = c->chain_depth < ESQ_CHAIN_MAX_DEPTH ? c->chain_depth + 1
+                                                                  : c->chain_depth;
+            for (int D = d_hi; D >= 2 && !boundary && !first_from_rows; --D) {
+                const size_t slot = (size_t)8 + (size_t)D;
+                first_from_rows = 1 + D <= i_to && slot < c->from_rows.size() &&
+                                  c->from_rows[slot] != 2;
+            }
+        }
+        if (i == 1 && !ready && !first_from_rows && i + 1 < i_to && may_use_src(c)) {
             // the first sweep forms its own input from y and K[0]: no stage-1
             // kernel, no stage argument in memory
             bool boundary = false;
@@ -923,7 +938,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
         // the chain that starts here forms its own input from the rows it reads
         // (known from its first launch on): nobody wrote the argument, nobody has to
         bool arg_missing = false;
-        if (!ready && !block_done && chains && next_forms_its_input(c, i, i_to)) {
+        if (!ready && !block_done && chains &&
+            (first_from_rows || next_forms_its_input(c, i, i_to))) {
             arg_missing = true;
             ready = true;
         }
@@ -955,7 +971,9 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
             // later stages stay in registers.  The longest chain that crosses no
             // blocked-accumulation boundary and fits the plugin is taken.
             bool done = false, handed_over = false;
-            for (int D = c->chain_depth; D >= 2 && !done; --D) {
+            const int d_top = first_from_rows && c->chain_depth < ESQ_CHAIN_MAX_DEPTH
+                                  ? c->chain_depth + 1 : c->chain_depth;
+            for (int D = d_top; D >= 2 && !done; --D) {
                 if (i + D > i_to) continue;
                 bool crosses = false;
                 for (const auto &b : c->blocks) crosses |= (b.J > i && b.J <= i + D);
@@ -976,18 +994,22 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 // reads rows with weights the tableau does not show
                 const bool lazy = c->lazy_rows && !c->keep_rows && c->rhs && i_to == c->s;
                 int r = kNotApplicable;
-                // a chain that ends the step: its input from the rows it reads anyway
-                if (what == 2 && c->chain_from_rows && slot < c->from_rows.size() &&
-                    c->from_rows[slot] != 2) {
-                    r = sweep_chain(c, i, D, t, h, what, lazy, /*from_rows=*/true);
+                // a chain that ends the step, or the first one of a step: its input
+                // from the rows it reads anyway
+                if ((what == 2 || first_from_rows) && c->chain_from_rows &&
+                    slot < c->from_rows.size() && c->from_rows[slot] != 2) {
+                    const bool skip_out = what == 0 && next_forms_its_input(c, i + D, i_to);
+                    r = sweep_chain(c, i, D, t, h, what, lazy, /*from_rows=*/true, skip_out);
                     if (r == 0) {
                         c->from_rows[slot] = 1;
+                        handed_over = skip_out;
                     } else if (r == ESQ_ENOTSUP || r == kNotApplicable) {
                         c->from_rows[slot] = 2;
                     } else {
                         return r;
                     }
                 }
+                if (r != 0 && D > c->chain_depth) continue;    // (that depth: from rows only)
                 if (r != 0) {
                     if (arg_missing) {           // (only if a chain changed its mind)
                         const int ra = esq_rk_stage_accumulate(c, i, h);
