@@ -596,6 +596,12 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
                     continue;
                 double units = (2 + nu + ninit) * kHalo[D] + kW * (D + 1);
                 if (nu > 6) units *= kWide;
+                // a two-stage chain moves its words a quarter slower than the deeper
+                // ones (heat, n = 5e6: chain2<6> 8.4 us per 40 MB word, chain3<4> /
+                // chain3<7> / chain4<4> 6.4-6.7): as many rows to walk, less to do
+                // per row.  Pr9 then takes its boundary at J = 9 (0.550 ms/step)
+                // instead of J = 10 (0.579)
+                if (D == 2) units *= 1.25;
                 total += units;
                 i += D;
                 done = true;
