@@ -205,7 +205,8 @@ inline unsigned chain_serpentine() {
 // tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
 // share one tile (the split sweeps: one per field)
 inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_block,
-                          int waves_per_tile, bool tall_if_one_round = false) {
+                          int waves_per_tile, bool tall_if_one_round = false,
+                          int min_rows = 0) {
     GeoChain g;
     const int W = 64 - 2 * (depth - 1);
     g.tpr = ((unsigned)N / 2 + W - 1) / W;
@@ -239,7 +240,11 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
             ++rounds;
             R = rows_for((size_t)256 * (size_t)waves_per_cu * rounds);
         }
-        if (R < depth + 2) R = depth + 2;
+        // (the halo rows are recomputed: the Brusselator's heavier rows want depth + 2,
+        // the heat sweeps fill the wave slots down to `depth` rows -- Ts5 at N = 1000:
+        // chain5<1> 31 us on 7-row tiles, 27 on 5-row tiles, 36 on 4-row tiles)
+        if (min_rows <= 0) min_rows = depth + 2;
+        if (R < min_rows) R = min_rows;
     }
     if (R > N) R = N;
     g.R = R;

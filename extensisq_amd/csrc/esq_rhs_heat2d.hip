@@ -162,7 +162,8 @@ int esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
         auto kern = esq::k_chain2d<1, false, CA::kD, CA::kNU, decltype(kind)::value, HeatFn, false,
                                    kFrom>;
         static const int wpc = chain_waves_per_cu(kern, (unsigned)kBlock);   // per instantiation
-        const GeoChain g = geo_chain(r->N, CA::kD, wpc, kBlock / 64, 1, /*tall_if_one_round=*/true);
+        const GeoChain g = geo_chain(r->N, CA::kD, wpc, kBlock / 64, 1, /*tall_if_one_round=*/true,
+                                     /*min_rows=*/CA::kD);
         if (chain->read_amplification)
             *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1) + (kFrom ? 2 : 0)) /
                                          g.R * 64.0 / (64 - 2 * (CA::kD - 1));

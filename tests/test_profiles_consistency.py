@@ -30,14 +30,15 @@ def test_bench_and_profiles_agree(config):
     # apart: the boxes run 5-10 % faster right after an idle or lighter spell) -- the
     # two routes to the figure agree to that; the PMC route may come out lower where
     # the working set is small enough for the halo rows of the marching sweeps to
-    # hit in L2 (ts5: 8 MB vectors), never higher than the designed bytes allow
+    # hit in L2 (ts5: 8 MB vectors on 5-row tiles, where the designed bytes count every
+    # halo row three times), never higher than the designed bytes allow
     assert dom["frac_of_8TBs_pmc"] <= 1.12 * r["frac"]
-    assert dom["frac_of_8TBs_pmc"] >= (0.70 if config == "ts5" else 0.88) * r["frac"]
+    assert dom["frac_of_8TBs_pmc"] >= (0.60 if config == "ts5" else 0.88) * r["frac"]
     assert abs(r["avg_launch_us"] * 1e3 - dom["avg_launch_ns_kernel_trace"]) \
         <= 0.12 * dom["avg_launch_ns_kernel_trace"]
     # designed bytes vs what the fabric carried
     assert dom["hbm_bytes_per_launch"] <= 1.10 * r["moved_bytes_per_launch"]
-    assert dom["hbm_bytes_per_launch"] >= (0.70 if config == "ts5" else 0.90) * \
+    assert dom["hbm_bytes_per_launch"] >= (0.60 if config == "ts5" else 0.90) * \
         r["moved_bytes_per_launch"]
     for name, k in prof["kernels"].items():
         if "bench_designed_bytes" in k and k["bench_designed_bytes"] > 1e6:
