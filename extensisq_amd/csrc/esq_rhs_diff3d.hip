@@ -113,18 +113,35 @@ int esq_rhs_diff3d_rkc(void *user, double t, const double *yjm1, const double *y
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != DIFF3D || n != r->n) return ESQ_EINVAL;
     if (r->N < 2) return ESQ_ENOTSUP;
-    constexpr int R = 8;
+    // planes per workgroup: with the five vectors of a Chebyshev stage resident in
+    // the Infinity Cache (n = 4e6: 160 MB) short marches win -- more workgroups in
+    // flight, the re-read planes are cache hits (N = 159, us per stage: R = 1 23.2,
+    // 2 22.5-23.4, 3 23.0-23.6, 4 23.4-24.7, 8 24.6-24.9, 16 23.3, 32 29.9; the step
+    // 2.20 ms at R = 2 against 2.47-2.60 at R = 8).  ESQ_DIFF3D_R overrides.
+    static const int Rsel = getenv("ESQ_DIFF3D_R") ? atoi(getenv("ESQ_DIFF3D_R")) : 2;
     const unsigned NN = (unsigned)r->N * (unsigned)r->N;
     const unsigned bpp = (NN + kBlock - 1) / kBlock;
-    const unsigned nb = bpp * (unsigned)((r->N + R - 1) / R);
-    const unsigned grid = ((nb + kXcd - 1) / kXcd) * kXcd;
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
-    hipExtLaunchKernelGGL((k_diff3d_v2<R, kRkc>), dim3(grid), dim3(kBlock), 0,
-                          (hipStream_t)stream, (hipEvent_t)start_event,
-                          (hipEvent_t)stop_event, 0, yjm1, (double *)nullptr, r->N,
-                          c, grid, bpp,
-                          make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out),
-                          esq::EpiRkcErr{});
+    auto go = [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        const unsigned nb = bpp * (unsigned)((r->N + R - 1) / R);
+        const unsigned grid = ((nb + kXcd - 1) / kXcd) * kXcd;
+        hipExtLaunchKernelGGL((k_diff3d_v2<R, kRkc>), dim3(grid), dim3(kBlock), 0,
+                              (hipStream_t)stream, (hipEvent_t)start_event,
+                              (hipEvent_t)stop_event, 0, yjm1, (double *)nullptr, r->N,
+                              c, grid, bpp,
+                              make_epi(yjm2, yn, fn, mu, nu, omn, hmus, ajm1, y_out),
+                              esq::EpiRkcErr{});
+    };
+    switch (Rsel) {
+        case 1: go(std::integral_constant<int, 1>{}); break;
+        case 2: go(std::integral_constant<int, 2>{}); break;
+        case 3: go(std::integral_constant<int, 3>{}); break;
+        case 4: go(std::integral_constant<int, 4>{}); break;
+        case 16: go(std::integral_constant<int, 16>{}); break;
+        case 32: go(std::integral_constant<int, 32>{}); break;
+        default: go(std::integral_constant<int, 8>{}); break;
+    }
     return (int)hipGetLastError();
 }
 // fused entry: only the end of a Chebyshev step (ESQ_EPI_RKCERR) is fused here
