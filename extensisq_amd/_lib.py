@@ -47,7 +47,7 @@ SIGNATURES = {
     "esq_set_rhs": (C.c_int, [_vp, _vp, _vp]),
     "esq_set_rhs_fused": (C.c_int, [_vp, _vp, C.c_int]),
     "esq_set_rhs_rkc": (C.c_int, [_vp, _vp]),
-    "esq_set_rhs_chain": (C.c_int, [_vp, _vp]),
+    "esq_set_rhs_chain": (C.c_int, [_vp, _vp, C.c_int]),
     "esq_rk_stage_accumulate": (C.c_int, [_vp, C.c_int, C.c_double]),
     "esq_rk_block_plan": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -583,10 +583,11 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     // the block plan was made for a chaining plugin: make it again for this one
     return (had_chain && c->have_tab) ? esq_replan(c) : 0;
 }
-int esq_set_rhs_chain(esq_ctx *c, esq_rhs_chain_fn fn) {
+int esq_set_rhs_chain(esq_ctx *c, esq_rhs_chain_fn fn, int caps) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
     c->rhs_chain = fn;
+    c->chain_caps = fn ? caps : 0;
     // the blocked-accumulation plan depends on how the plugin sweeps
     return c->have_tab ? esq_replan(c) : 0;
 }

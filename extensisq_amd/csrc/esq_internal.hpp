@@ -112,6 +112,7 @@ struct esq_ctx {
     int chain_depth = 4;                    // ESQ_CHAIN_DEPTH: 1 off, up to 4 stages per sweep
     // chains the plugin (or the library) has refused for this tableau / grid:
     // refused[i * 8 + D] -- not asked again every step (esq_replan clears it)
+    int chain_caps = 0;                     // ESQ_CHAIN_CAP_*: what the chain entry handles
     std::vector<char> chain_refused;
     // from_rows[i * 8 + D]: the chain of depth D at stage i forms its own input from
     // the rows it reads (esq_chain.from_rows): 0 not tried, 1 it does, 2 declined

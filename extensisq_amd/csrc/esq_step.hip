@@ -403,6 +403,9 @@ bool chain_candidate(const esq_ctx *c, int i, int i_to, int *depth, int *what) {
 // write it)?  Known from the second step on.
 bool next_forms_its_input(const esq_ctx *c, int i, int i_to) {
     if (i_to != c->s || i >= i_to - 1 || !c->chain_from_rows) return false;
+    if ((c->chain_caps & (ESQ_CHAIN_CAP_FROM_ROWS | ESQ_CHAIN_CAP_SKIP_OUT)) !=
+        (ESQ_CHAIN_CAP_FROM_ROWS | ESQ_CHAIN_CAP_SKIP_OUT))
+        return false;
     for (const auto &b : c->blocks)
         if (b.J == i + 1) return false;          // a block sweep comes first
     int D = 0, what = -1;
@@ -879,7 +882,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
         // of the chain the plan starts with -- stage 0 reads the state itself, its
         // argument never existed, K[0] is written once and not read back
         bool fused = false;
-        if (i_from == 1 && chains && c->end_fused_ok != 0 && may_fuse(c, ESQ_EPI_STAGE)) {
+        if (i_from == 1 && chains && c->end_fused_ok != 0 && may_fuse(c, ESQ_EPI_STAGE) &&
+            (c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE)) {
             int d1 = 0;
             for (int D = c->chain_depth; D >= 2 && !d1; --D) {
                 if (1 + D >= i_to) continue;
@@ -892,7 +896,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
             int r = kNotApplicable;
             if (d1 && d1 + 1 <= ESQ_CHAIN_MAX_DEPTH)
                 r = sweep_chain(c, 0, d1 + 1, t, h, 0,
-                                c->lazy_rows && !c->keep_rows && i_to == c->s);   // (its
+                                c->lazy_rows && !c->keep_rows && i_to == c->s &&
+                                    (c->chain_caps & ESQ_CHAIN_CAP_SKIP_ROWS));   // (its
             // successor is never the chain that ends the step: the output is written)
             if (r == 0) {
                 fused = true;
@@ -918,7 +923,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
         // y + h*a_10*K_0 from the K_0 it reads anyway (one stage more than the plan's
         // depth, as with the fused end-point stage); tried until the plugin declines
         bool first_from_rows = false;
-        if (i == 1 && !ready && chains && c->chain_from_rows && i_to == c->s) {
+        if (i == 1 && !ready && chains && c->chain_from_rows && i_to == c->s &&
+            (c->chain_caps & ESQ_CHAIN_CAP_FROM_ROWS)) {
             bool boundary = false;
             for (const auto &b : c->blocks) boundary |= (b.J == 2);
             const int d_hi = c->chain_depth < ESQ_CHAIN_MAX_DEPTH ? c->chain_depth + 1
@@ -998,11 +1004,13 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
                 // a context whose caller keeps asking for them (restore_rows).  Whole
                 // steps only: a caller that runs the stages in pieces (BS5, CFMR7osc)
                 // reads rows with weights the tableau does not show
-                const bool lazy = c->lazy_rows && !c->keep_rows && c->rhs && i_to == c->s;
+                const bool lazy = c->lazy_rows && !c->keep_rows && c->rhs && i_to == c->s &&
+                                  (c->chain_caps & ESQ_CHAIN_CAP_SKIP_ROWS);
                 int r = kNotApplicable;
                 // a chain that ends the step, or the first one of a step: its input
                 // from the rows it reads anyway
                 if ((what == 2 || first_from_rows) && c->chain_from_rows &&
+                    (c->chain_caps & ESQ_CHAIN_CAP_FROM_ROWS) &&
                     slot < c->from_rows.size() && c->from_rows[slot] != 2) {
                     const bool skip_out = what == 0 && next_forms_its_input(c, i + D, i_to);
                     r = sweep_chain(c, i, D, t, h, what, lazy, /*from_rows=*/true, skip_out);
@@ -1219,6 +1227,7 @@ int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
     // the end-point derivative can wait for the next step's first chain sweep
     const bool defer = !c->fsal && with_end_eval && c->lazy_end && c->end_fused_ok != 0 &&
                        c->rhs && c->rhs_chain && c->rhs_fused && !c->cplx &&
+                       (c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE) &&
                        c->chain_depth >= 2 && may_fuse(c, ESQ_EPI_STAGE);
     if (defer) {
         c->k0_missing = true;

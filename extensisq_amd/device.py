@@ -237,7 +237,8 @@ class DeviceContext:
         chain = rhs._chain_entry(self.lib)
         if chain is not None and fused is not None and use:
             self._chk(self.lib.esq_set_rhs_chain(self.handle,
-                                                 C.cast(chain, C.c_void_p)),
+                                                 C.cast(chain, C.c_void_p),
+                                                 int(rhs._chain_caps)),
                       "esq_set_rhs_chain")
         # RKC entry: derivative + Chebyshev recursion in one sweep
         rkc = rhs._rkc_entry(self.lib)
@@ -345,6 +346,10 @@ class DeviceRHS:
         """optional `esq_rhs_chain_fn` of this plugin"""
         return None
 
+    # ESQ_CHAIN_CAP_* bits of the chain entry (include/extensisq_amd.h): which
+    # optional forms of a chain it handles; 0 = plain chains only
+    _chain_caps = 0
+
     def _bind(self, ctx):
         if ctx.n != self.n:
             raise ValueError(f"RHS is for n={self.n}, solver state has n={ctx.n}")
@@ -394,6 +399,7 @@ class _Builtin(DeviceRHS):
     _symbol_fused = None
     _symbol_rkc = None
     _symbol_chain = None
+    _chain_caps = 15                  # the built-in sweeps handle every form
 
     def _rkc_entry(self, lib):
         return getattr(lib, self._symbol_rkc) if self._symbol_rkc else None

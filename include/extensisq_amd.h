@@ -305,7 +305,21 @@ int  esq_set_rhs_fused(esq_ctx *ctx, esq_rhs_fused_fn fn, int fuse_mask);
  * ESQ_CHAIN_DEPTH (default 4) stages per launch wherever plain stage sweeps (and
  * the solution/error sweep) follow each other.  Needs the fused entry too (the
  * remaining single stages). */
-int  esq_set_rhs_chain(esq_ctx *ctx, esq_rhs_chain_fn fn);
+/* `caps`: the optional forms of a chain the entry handles (anything else in an
+ * esq_chain it may still decline with ESQ_ENOTSUP, case by case); the library asks
+ * only for forms the plugin has declared:
+ *   FROM_STATE  chain->y == NULL (the base of the sums is y_in: a chain whose first
+ *               stage is the end-point derivative the previous accept left to it)
+ *   SKIP_ROWS   chain->f_out[k] == NULL (derivatives nothing later reads)
+ *   FROM_ROWS   chain->from_rows (the chain forms its own input)
+ *   SKIP_OUT    chain->out == NULL with ESQ_EPI_STAGE (the next chain forms its input)
+ * 0 = plain chains only: every row written, every input read from y_in. */
+#define ESQ_CHAIN_CAP_FROM_STATE 1
+#define ESQ_CHAIN_CAP_SKIP_ROWS  2
+#define ESQ_CHAIN_CAP_FROM_ROWS  4
+#define ESQ_CHAIN_CAP_SKIP_OUT   8
+#define ESQ_CHAIN_CAP_ALL        15
+int  esq_set_rhs_chain(esq_ctx *ctx, esq_rhs_chain_fn fn, int caps);
 /* register (or clear) the optional RKC entry: esq_rkc_stages then issues ONE
  * kernel per Chebyshev stage (RHS + recursion) instead of two */
 int  esq_set_rhs_rkc(esq_ctx *ctx, esq_rhs_rkc_fn fn);

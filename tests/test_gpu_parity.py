@@ -1723,3 +1723,37 @@ def test_last_chain_forms_its_own_input(monkeypatch, name, plugin, N, rows):
         assert moved[0] < moved[1] - (1.0 if rows >= 16 else 0.0) * vec, (moved, labels)
     else:
         assert moved[0] == moved[1]
+
+
+def test_chain_entry_without_declared_capabilities(monkeypatch):
+    """`esq_set_rhs_chain(ctx, fn, caps)`: the library asks a chain entry only for the
+    optional forms it has declared (ESQ_CHAIN_CAP_*).  With caps = 0 -- a plugin
+    written against plain chains -- every K row is written, every chain reads its
+    input from y_in, the end-point derivative has its own sweep; states and K rows
+    equal the full-capability run bit for bit."""
+    N = 124
+    mk, y0, rho = _plugin("bruss", N)
+    h = 0.4 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", "30")
+
+    class PlainChains(esq.Brusselator2D):
+        _chain_caps = 0
+
+    full = esq.Pr8(mk(), 0.0, y0, 1.0, **kw)
+    plain = esq.Pr8(PlainChains(N), 0.0, y0, 1.0, **kw)
+    for s in (full, plain):
+        s._dev.profile_enable([0, 1, 2])
+    for _ in range(4):
+        assert full.step() is None and plain.step() is None
+        assert full.t == plain.t
+        assert_allclose(full.error_norm_old, plain.error_norm_old, rtol=1e-12)
+    assert _lazy_state(plain)[0] == 0 and _lazy_state(full)[0] >= 2
+    assert_equal(full.y, plain.y)
+    assert_equal(full.K, plain.K)
+    labels = [r[0] for r in plain._dev.profile_kernels()]
+    assert any(lab.startswith("chain") for lab in labels), labels
+    assert not any("-K<" in lab or lab.startswith("chain5<0>") for lab in labels), labels
+    assert _end_point_counts(plain) == (0, 0)
+    moved = [sum(r[5] for r in s._dev.profile_kernels()) for s in (full, plain)]
+    assert moved[0] < moved[1]
