@@ -1289,7 +1289,10 @@ int esq_rk_error_vector(esq_ctx *c, double h, int last_step) {
 int esq_rk_row_id(esq_ctx *c, int logical_row, int last_step) {
     if (!c || logical_row < 0 || logical_row >= c->n_rows) return ESQ_EINVAL;
     ENTER_KEEP(c);
-    ENSURE_ROWS(c);                // the caller is about to read that row
+    if (c->tail_missing || c->k0_missing) {        // the caller is about to read that row
+        const int rr = esqi::restore_rows(c);
+        if (rr) return rr < 0 ? rr : ESQ_ESTATE;   // (ids are >= 0: never a positive HIP code)
+    }
     return last_step ? c->kmap_last[logical_row] : c->kmap[logical_row];
 }
 int esq_rk_download_last_K(esq_ctx *c, int row, double *host) {
