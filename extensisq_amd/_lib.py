@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libextensisq_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
 EPI_RKCERR = 6
@@ -48,6 +48,7 @@ SIGNATURES = {
     "esq_set_rhs_fused": (C.c_int, [_vp, _vp, C.c_int]),
     "esq_set_rhs_rkc": (C.c_int, [_vp, _vp]),
     "esq_set_rhs_chain": (C.c_int, [_vp, _vp, C.c_int]),
+    "esq_set_rhs_rkc_chain": (C.c_int, [_vp, _vp, C.c_int]),
     "esq_rk_stage_accumulate": (C.c_int, [_vp, C.c_int, C.c_double]),
     "esq_rk_block_plan": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -74,7 +75,7 @@ SIGNATURES = {
     "esq_rk_upload_last_K": (C.c_int, [_vp, C.c_int, _vp]),
     "esq_rkc_first_stage": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double]),
     "esq_rkc_stage": (C.c_int, [_vp] + [C.c_int] * 6 + [C.c_double] * 4),
-    "esq_rkc_stages": (C.c_int, [_vp] + [C.c_int] * 5 + [C.c_double, C.c_int, _vp,
+    "esq_rkc_stages": (C.c_int, [_vp] + [C.c_int] * 6 + [C.c_double, C.c_int, _vp,
                                                          C.POINTER(C.c_int)]),
     "esq_rkc_error_norm": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, _dp]),
     "esq_rkc_end_error": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, C.c_double,
@@ -116,6 +117,7 @@ SIGNATURES = {
     "esq_rhs_diff3d": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_size_t, _vp]),
     "esq_rhs_heat2d_rkc": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp] + [C.c_double] * 5 + [_vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_diff3d_rkc": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp] + [C.c_double] * 5 + [_vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_diff3d_rkc_chain": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_bruss2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_heat2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_bruss2d_chain": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),

@@ -167,7 +167,7 @@ int esq_rkc_eval_rhs(esq_ctx *c, int dst, double t, int src) {
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad row");
     return call_rhs(c, t, s, d);
 }
-int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
+int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                    double hmus1, int m, const double *scalars, int *y_row_out) {
     if (!c || !y_row_out || m < 1 || (m > 1 && !scalars)) return ESQ_EINVAL;
     ENTER(c);
@@ -175,14 +175,80 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
     //   jm1 = first-stage result, jm2 = yn; every stage writes into a free row
     int r = esq_rkc_first_stage(c, w0, yn, fn, hmus1);
     if (r) return r;
-    int jm1 = w0, jm2 = yn, free_a = w1, free_b = w2;
-    int ycur = w0;
-    for (int j = 2; j <= m; ++j) {
+    const int work[4] = {w0, w1, w2, w3};
+    const int nwork = w3 == ESQ_VEC_NONE ? 3 : 4;
+    for (int a = 0; a < nwork; ++a) {
+        if (!ROW(c, work[a]) || work[a] == yn || work[a] == fn)
+            return fail(c, ESQ_EINVAL, "bad work row");
+        for (int b = 0; b < a; ++b)
+            if (work[a] == work[b]) return fail(c, ESQ_EINVAL, "work rows must differ");
+    }
+    // a work row that holds neither of the two live iterates
+    auto free_row = [&](int jm1, int jm2, int not_this) -> int {
+        for (int a = 0; a < nwork; ++a)
+            if (work[a] != jm1 && work[a] != jm2 && work[a] != not_this) return work[a];
+        return ESQ_VEC_NONE;
+    };
+    int jm1 = w0, jm2 = yn;
+    int j = 2;
+    while (j <= m) {
         const double *sc = scalars + 5 * (size_t)(j - 2);
+        // ---- a chain of d stages: y_{j-1}, y_{j-2} in, y_{j+d-1}, y_{j+d-2} out
+        if (c->rhs_rkc_chain && nwork == 4 && c->rkc_depth >= 2) {
+            const int left = m - j + 1;
+            int d = left < c->rkc_depth ? left : c->rkc_depth;
+            // no single stage at the end: 5 = 3 + 2 rather than 4 + 1
+            if (left - d == 1 && d >= 3) --d;
+            while (d >= 2 && ((c->rkc_refused >> d) & 1u)) --d;
+            if (d >= 2) {
+                const int o1 = free_row(jm1, jm2, ESQ_VEC_NONE);
+                const int o2 = free_row(jm1, jm2, o1);
+                esq_rkc_chain ch;
+                memset(&ch, 0, sizeof(ch));
+                ch.depth = d;
+                ch.yjm1 = ROW(c, jm1); ch.yjm2 = ROW(c, jm2);
+                ch.yn = ROW(c, yn); ch.fn = ROW(c, fn);
+                for (int k = 0; k < d; ++k) {
+                    const double *s5 = sc + 5 * (size_t)k;
+                    ch.mu[k] = s5[0]; ch.nu[k] = s5[1];
+                    ch.omn[k] = (1.0 - s5[0]) - s5[1];    // (1.0 - mu - nu), left to right
+                    ch.hmus[k] = s5[2]; ch.ajm1[k] = s5[3]; ch.t[k] = s5[4];
+                }
+                const bool last = j + d > m;              // nothing reads y_{m-1}
+                ch.out = ROW(c, o1);
+                ch.out_prev = last ? nullptr : ROW(c, o2);
+                double amp = 1.0;
+                ch.read_amplification = &amp;
+                if (o1 == ESQ_VEC_NONE || o2 == ESQ_VEC_NONE || !ch.out)
+                    return fail(c, ESQ_EINVAL, "bad row");
+                char label[24];
+                snprintf(label, sizeof(label), "rkc_chain%d%s", d, last ? "-last" : "");
+                // booked: d x (RHS 16 B + recursion 48 B); moved: 4 inputs (x halo
+                // factor, filled in by the plugin) + 2 (1) outputs
+                Prof p(c, ESQ_PROF_RKC, label, -1, 64.0 * d * (double)c->len, false,
+                       0.0);
+                c->self_valid = false;
+                r = c->rhs_rkc_chain(c->rhs_user, &ch, c->len, (void *)c->stream,
+                                     (void *)p.start(), (void *)p.stop());
+                if (r == 0) {
+                    p.ev.moved = (4.0 * amp + (last ? 1.0 : 2.0)) * 8.0 * (double)c->len;
+                    jm2 = last ? jm1 : o2;
+                    jm1 = o1;
+                    j += d;
+                    continue;
+                }
+                p.cancel();
+                if (r != ESQ_ENOTSUP)
+                    return fail(c, ESQ_ERHS, "RKC chain entry returned %d", r);
+                c->rkc_refused |= 1u << d;
+                continue;                                  // a shorter chain, or one stage
+            }
+        }
+        const int dst = free_row(jm1, jm2, ESQ_VEC_NONE);
         bool done = false;
         if (c->rhs_rkc) {
             // ONE sweep: derivative of yjm1 and the recursion, no fy in memory
-            double *d = ROW(c, free_a), *a = ROW(c, jm1), *b = ROW(c, jm2),
+            double *d = ROW(c, dst), *a = ROW(c, jm1), *b = ROW(c, jm2),
                    *y0 = ROW(c, yn), *g = ROW(c, fn);
             if (!d || !a || !b || !y0 || !g) return fail(c, ESQ_EINVAL, "bad row");
             const double omn = (1.0 - sc[0]) - sc[1];
@@ -198,25 +264,19 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2,
             else p.cancel();
         }
         if (!done) {
-            // fy = rhs(t_stage, yjm1) into free_a, combination overwrites free_a
-            r = esq_rkc_eval_rhs(c, free_a, sc[4], jm1);
+            // fy = rhs(t_stage, yjm1) into dst, the combination overwrites it
+            r = esq_rkc_eval_rhs(c, dst, sc[4], jm1);
             if (r) return r;
-            r = esq_rkc_stage(c, free_a, free_a, jm1, jm2, yn, fn, sc[0], sc[1],
-                              sc[2], sc[3]);
+            r = esq_rkc_stage(c, dst, dst, jm1, jm2, yn, fn, sc[0], sc[1], sc[2], sc[3]);
             if (r) return r;
         }
-        ycur = free_a;
-        // shift: jm2 <- jm1, jm1 <- new; the old jm2 row becomes free
-        const int old_jm2 = jm2;
+        // shift: jm2 <- jm1, jm1 <- new; the old jm2 row becomes free (yn is
+        // never recycled: it is not a work row)
         jm2 = jm1;
-        jm1 = ycur;
-        if (old_jm2 == yn) {      // yn is never recycled
-            free_a = free_b;
-        } else {
-            free_a = old_jm2;
-        }
+        jm1 = dst;
+        ++j;
     }
-    *y_row_out = ycur;
+    *y_row_out = jm1;
     return 0;
 }
 int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,

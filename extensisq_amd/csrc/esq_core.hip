@@ -578,6 +578,9 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     c->rhs_fused = nullptr;
     c->fuse_mask = 0;
     c->rhs_rkc = nullptr;
+    c->rhs_rkc_chain = nullptr;
+    c->rkc_depth = 1;
+    c->rkc_refused = 0;
     const bool had_chain = c->rhs_chain != nullptr;
     c->rhs_chain = nullptr;
     // the block plan was made for a chaining plugin: make it again for this one
@@ -595,6 +598,18 @@ int esq_set_rhs_rkc(esq_ctx *c, esq_rhs_rkc_fn fn) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
     c->rhs_rkc = fn;
+    return 0;
+}
+int esq_set_rhs_rkc_chain(esq_ctx *c, esq_rhs_rkc_chain_fn fn, int max_depth) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    c->rhs_rkc_chain = fn;
+    c->rkc_refused = 0;
+    int d = fn ? max_depth : 1;
+    const int env = (int)env_uint("ESQ_RKC_DEPTH", 0);        // 0: the plugin's own
+    if (env > 0 && env < d) d = env;
+    if (d > ESQ_RKC_CHAIN_MAX_DEPTH) d = ESQ_RKC_CHAIN_MAX_DEPTH;
+    c->rkc_depth = d < 1 ? 1 : d;
     return 0;
 }
 int esq_set_rhs_fused(esq_ctx *c, esq_rhs_fused_fn fn, int fuse_mask) {

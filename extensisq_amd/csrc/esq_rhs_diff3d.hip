@@ -1,6 +1,7 @@
 // esq_rhs_diff3d.hip -- 3-D diffusion, 7-point Laplacian, Dirichlet 0
 // (BASELINE.json configs[3], the SSV2stab workload).
 #include "esq_rhs_common.hpp"
+#include "esq_rkc3d.hpp"
 
 using namespace esq_rhs;
 
@@ -94,14 +95,82 @@ __global__ __launch_bounds__(kBlock) void k_diff3d_v2(
     if (MODE == kRkcErr) esq::block_partial(local, err.red.partials);
 }
 
+// the seven-point Laplacian as the marching chain sweep sees it (esq_rkc3d.hpp):
+// the expression of k_diff3d / k_diff3d_v2, operation for operation
+struct Diff3dSt {
+    double c;
+    __device__ __forceinline__ double eval(double below, double above, double up,
+                                           double dn, double lf, double rt,
+                                           double centre) const {
+        return c * ((((below + above) + (up + dn)) + (lf + rt)) - 6.0 * centre);
+    }
+};
+
+// rows per thread by depth: the windows, the y_n / f_n delay lines and one plane
+// of operands in flight are (4 D + 7) JT doubles per thread; chosen so that a
+// 512-thread workgroup stays at two waves per SIMD (<= 256 VGPRs)
+template <int D> struct RkcCfg;
+template <> struct RkcCfg<2> { static constexpr int JT = 6, NW = 8; };
+template <> struct RkcCfg<3> { static constexpr int JT = 5, NW = 8; };
+template <> struct RkcCfg<4> { static constexpr int JT = 4, NW = 8; };
+
+template <int D>
+int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
+                 hipEvent_t e0, hipEvent_t e1) {
+    constexpr int JT = RkcCfg<D>::JT, NW = RkcCfg<D>::NW;
+    auto kern = esq::k_rkc3d_chain<D, JT, NW, Diff3dSt>;
+    static int slots = 0;                    // workgroups resident on the chip
+    if (slots == 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * NW, 0) !=
+                hipSuccess || per_cu < 1)
+            per_cu = 1;
+        slots = 256 * per_cu;
+    }
+    const esq::Geo3d g = esq::geo_rkc3d(r->N, D, JT, NW, slots, r->rkc_planes);
+    esq::Rkc3dArgs<D> a;
+    a.a = ch->yjm1; a.b = ch->yjm2; a.yn = ch->yn; a.fn = ch->fn;
+    a.out = ch->out; a.outp = ch->out_prev;
+    for (int k = 0; k < D; ++k) {
+        a.mu[k] = ch->mu[k]; a.nu[k] = ch->nu[k]; a.omn[k] = ch->omn[k];
+        a.hmus[k] = ch->hmus[k]; a.ajm1[k] = ch->ajm1[k];
+    }
+    if (ch->read_amplification) *ch->read_amplification = esq::amp_rkc3d(g, D);
+    const double c = (double)(r->N + 1) * (double)(r->N + 1);
+    hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(64 * NW), 0, stream, e0, e1, 0, a,
+                          Diff3dSt{c}, g);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
+
+// D Chebyshev stages per launch (esq_rhs_rkc_chain_fn).  Grids below 48^3 stay
+// with one launch per stage (a tile's run-in planes and halo points outweigh the
+// saving); ESQ_RKC_FORCE=1 when the plugin object is made lifts the rule (tests).
+int esq_rhs_diff3d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void *stream,
+                             void *start_event, void *stop_event) {
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != DIFF3D || n != r->n || !ch) return ESQ_EINVAL;
+    if (!ch->yjm1 || !ch->yjm2 || !ch->yn || !ch->fn || !ch->out) return ESQ_EINVAL;
+    if (r->N < 2 || (r->N < 48 && !r->rkc_force)) return ESQ_ENOTSUP;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
+    switch (ch->depth) {
+        case 2: return launch_rkc3d<2>(r, ch, s, e0, e1);
+        case 3: return launch_rkc3d<3>(r, ch, s, e0, e1);
+        case 4: return launch_rkc3d<4>(r, ch, s, e0, e1);
+        default: return ESQ_ENOTSUP;
+    }
+}
 
 int esq_rhs_diff3d_create(void **user_out, int N) {
     if (N < 1) return ESQ_EINVAL;
     Rhs r{};
     r.kind = DIFF3D; r.N = N; r.n = (size_t)N * N * N;
+    r.rkc_force = getenv("ESQ_RKC_FORCE") ? atoi(getenv("ESQ_RKC_FORCE")) : 0;
+    r.rkc_planes = getenv("ESQ_RKC_PLANES") ? atoi(getenv("ESQ_RKC_PLANES")) : 0;
     return make(user_out, r);
 }
 

@@ -246,6 +246,13 @@ class DeviceContext:
             self._chk(self.lib.esq_set_rhs_rkc(self.handle,
                                                C.cast(rkc, C.c_void_p)),
                       "esq_set_rhs_rkc")
+            # RKC chain entry: several Chebyshev stages per marching sweep
+            # (ESQ_RKC_DEPTH=1 in the environment: one launch per stage)
+            rkc_chain = rhs._rkc_chain_entry(self.lib)
+            if rkc_chain is not None:
+                self._chk(self.lib.esq_set_rhs_rkc_chain(
+                    self.handle, C.cast(rkc_chain[0], C.c_void_p),
+                    int(rkc_chain[1])), "esq_set_rhs_rkc_chain")
 
     # -- scalar-returning launches
     def _scalar(self, fn, what, *args):
@@ -346,6 +353,11 @@ class DeviceRHS:
         """optional `esq_rhs_chain_fn` of this plugin"""
         return None
 
+    def _rkc_chain_entry(self, lib):
+        """optional `esq_rhs_rkc_chain_fn` of this plugin and the deepest chain
+        it runs: (entry, max_depth) or None"""
+        return None
+
     # ESQ_CHAIN_CAP_* bits of the chain entry (include/extensisq_amd.h): which
     # optional forms of a chain it handles; 0 = plain chains only
     _chain_caps = 0
@@ -399,7 +411,14 @@ class _Builtin(DeviceRHS):
     _symbol_fused = None
     _symbol_rkc = None
     _symbol_chain = None
+    _symbol_rkc_chain = None
+    _rkc_chain_depth = 4
     _chain_caps = 15                  # the built-in sweeps handle every form
+
+    def _rkc_chain_entry(self, lib):
+        if not self._symbol_rkc_chain:
+            return None
+        return getattr(lib, self._symbol_rkc_chain), self._rkc_chain_depth
 
     def _rkc_entry(self, lib):
         return getattr(lib, self._symbol_rkc) if self._symbol_rkc else None
@@ -505,6 +524,7 @@ class Diffusion3D(_Builtin):
     _symbol = "esq_rhs_diff3d"
     _symbol_fused = "esq_rhs_diff3d_fused"      # end of a Chebyshev step only
     _symbol_rkc = "esq_rhs_diff3d_rkc"
+    _symbol_rkc_chain = "esq_rhs_diff3d_rkc_chain"
     _fuse_default = True
     _fuse_src = False
     _fuse_mask = 1 << _lib.EPI_RKCERR

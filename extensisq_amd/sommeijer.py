@@ -68,7 +68,7 @@ class SSV2stab(OdeSolver):
     as the reference (sommeijer.py:93-95) plus `device` and `lockstep`."""
 
     # physical row roles inside the context (rotated on the host)
-    _N_ROWS = 8
+    _N_ROWS = 9
 
     def __init__(self, fun, t0, y0, t_bound, max_step=np.inf, rtol=1e-3,
                  atol=1e-6, vectorized=False, first_step=None,
@@ -119,7 +119,7 @@ class SSV2stab(OdeSolver):
         self._lib = self._dev.lib
         self._ctx = self._dev.handle
         self._dev.set_tol(self.rtol, self.atol)
-        self._r = dict(yn=0, fn=1, w=[2, 3, 4], yold=5, fold=6, V=7)
+        self._r = dict(yn=0, fn=1, w=[2, 3, 4, 8], yold=5, fold=6, V=7)
         self._have_V = False
         self._n_norm = self.n
         self._lockstep = lockstep
@@ -234,7 +234,7 @@ class SSV2stab(OdeSolver):
             yrow = C.c_int()
             tab = np.ascontiguousarray(table)
             self._chk(self._lib.esq_rkc_stages(
-                self._ctx, r["yn"], r["fn"], w[0], w[1], w[2], hmus1, m,
+                self._ctx, r["yn"], r["fn"], w[0], w[1], w[2], w[3], hmus1, m,
                 as_ptr(tab), C.byref(yrow)), "esq_rkc_stages")
             self.nfev += m - 1
             return yrow.value
@@ -242,18 +242,15 @@ class SSV2stab(OdeSolver):
         self._chk(self._lib.esq_rkc_first_stage(self._ctx, w[0], r["yn"],
                                                 r["fn"], hmus1),
                   "esq_rkc_first_stage")
-        jm1, jm2, free, spare = w[0], r["yn"], w[1], w[2]
-        ycur = w[0]
+        jm1, jm2 = w[0], r["yn"]
         for mu, nu, hmus, ajm1, t_stage in table:
+            free = next(x for x in w if x not in (jm1, jm2))
             self._eval_rhs(free, t_stage, jm1)
             self._chk(self._lib.esq_rkc_stage(self._ctx, free, free, jm1, jm2,
                                               r["yn"], r["fn"], mu, nu, hmus,
                                               ajm1), "esq_rkc_stage")
-            ycur = free
-            released = jm2
-            jm2, jm1 = jm1, ycur
-            free = spare if released == r["yn"] else released
-        return ycur
+            jm2, jm1 = jm1, free
+        return jm1
 
     # ------------------------------------------------------ spectral radius
     def _rho(self, t):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ESQ_ABI_VERSION 3
+#define ESQ_ABI_VERSION 4
 
 /* error codes (negative = misuse) */
 #define ESQ_EINVAL   (-1)   /* bad argument (row/slot out of range, NULL, ...) */
@@ -247,6 +247,41 @@ typedef int (*esq_rhs_rkc_fn)(void *user, double t, const double *yjm1,
                               void *hip_stream, void *start_event,
                               void *stop_event);
 
+/*
+ * OPTIONAL RKC chain entry of a plugin: `depth` consecutive Chebyshev stages in
+ * ONE marching sweep (the loop body of sommeijer.py:309-329, `depth` times).
+ * With Y_0 = yjm1 and Y_{-1} = yjm2, for k = 0 .. depth-1
+ *     Y_{k+1} = mu[k]*Y_k + nu[k]*Y_{k-1} + omn[k]*yn
+ *               + hmus[k]*(fun(t[k], Y_k) - ajm1[k]*fn)
+ * every product and sum rounded, left to right, exactly as esq_rhs_rkc_fn does
+ * for one stage: the results are bit-identical to `depth` one-stage launches.
+ * Y_1 .. Y_{depth-2} never touch memory; Y_depth goes to `out`, Y_{depth-1} to
+ * `out_prev` (the two inputs of the next chain; out_prev == NULL: not wanted,
+ * the step's last chain).  out and out_prev alias none of the four inputs
+ * (tiles re-read their neighbours' points).  Per element and chain the memory
+ * sees 4 words read + 2 written instead of 5*depth.  How a 3-D stencil plugin
+ * does it (stage k marches k planes behind stage 0, a workgroup owns a patch of
+ * the plane and its waves exchange their edge rows through LDS):
+ * csrc/esq_rkc3d.hpp.  Return ESQ_ENOTSUP for any case the plugin does not chain
+ * (the library then runs shorter chains or one launch per stage).
+ */
+#define ESQ_RKC_CHAIN_MAX_DEPTH 8
+typedef struct esq_rkc_chain {
+    int depth;                               /* 2 .. ESQ_RKC_CHAIN_MAX_DEPTH    */
+    const double *yjm1, *yjm2, *yn, *fn;
+    double mu[ESQ_RKC_CHAIN_MAX_DEPTH], nu[ESQ_RKC_CHAIN_MAX_DEPTH];
+    double omn[ESQ_RKC_CHAIN_MAX_DEPTH];     /* (1 - mu) - nu, formed by the library */
+    double hmus[ESQ_RKC_CHAIN_MAX_DEPTH], ajm1[ESQ_RKC_CHAIN_MAX_DEPTH];
+    double t[ESQ_RKC_CHAIN_MAX_DEPTH];       /* t + h*theta_{j-1} of each stage */
+    double *out, *out_prev;
+    /* out (may be NULL): bytes read per byte of the four inputs (halo points are
+     * loaded by several tiles); booked in the launch's designed traffic */
+    double *read_amplification;
+} esq_rkc_chain;
+typedef int (*esq_rhs_rkc_chain_fn)(void *user, const esq_rkc_chain *chain,
+                                    size_t n, void *hip_stream, void *start_event,
+                                    void *stop_event);
+
 /* ---- lifecycle ---------------------------------------------------------- */
 int  esq_abi_version(void);
 /* devices this process can see (a launcher may restrict each rank to one) */
@@ -323,6 +358,11 @@ int  esq_set_rhs_chain(esq_ctx *ctx, esq_rhs_chain_fn fn, int caps);
 /* register (or clear) the optional RKC entry: esq_rkc_stages then issues ONE
  * kernel per Chebyshev stage (RHS + recursion) instead of two */
 int  esq_set_rhs_rkc(esq_ctx *ctx, esq_rhs_rkc_fn fn);
+/* register (or clear) the optional RKC chain entry: esq_rkc_stages then runs up
+ * to max_depth (<= ESQ_RKC_CHAIN_MAX_DEPTH; ESQ_RKC_DEPTH in the environment
+ * lowers it, 1 = one launch per stage) stages per launch when it is given four
+ * work rows.  Needs the one-stage RKC entry too (remainders, refused chains). */
+int  esq_set_rhs_rkc_chain(esq_ctx *ctx, esq_rhs_rkc_chain_fn fn, int max_depth);
 
 /* ---- explicit RK launches ----------------------------------------------- */
 /* YSTAGE = Y + h * sum_j A[i][j] * K[j]           common.py:355 (`dy`, `y+dy`)
@@ -457,8 +497,10 @@ int  esq_rkc_stage(esq_ctx *ctx, int dst, int fy, int yjm1, int yjm2, int yn,
                    int fn, double mu, double nu, double hmus, double ajm1);
 /* all m stages of one step incl. the RHS launches (sommeijer.py:273-329);
  * scalars[5*(j-2)..] = (mu, nu, hmus, ajm1, t_stage) for j = 2..m.  The result
- * is left in physical row *y_row_out. rows: yn, fn, and three work rows. */
-int  esq_rkc_stages(esq_ctx *ctx, int yn, int fn, int w0, int w1, int w2,
+ * is left in physical row *y_row_out. rows: yn, fn, three work rows and a fourth
+ * one or ESQ_VEC_NONE: with four, and a plugin that has an RKC chain entry, the
+ * stages run as chains (two iterates in, two out: a ping-pong of row pairs). */
+int  esq_rkc_stages(esq_ctx *ctx, int yn, int fn, int w0, int w1, int w2, int w3,
                     double hmus1, int m, const double *scalars, int *y_row_out);
 /* sum |(0.8*(yn - y) + 0.4*h*(fn + fy)) / (atol + rtol*max(|y|,|yn|))|^2
  *                                                   sommeijer.py:218-220      */
@@ -576,6 +618,9 @@ int  esq_rhs_diff3d_rkc(void *user, double t, const double *yjm1,
                         double mu, double nu, double omn, double hmus, double ajm1,
                         double *y_out, size_t n, void *stream, void *start_event,
                         void *stop_event);
+/* RKC chain entry (esq_rhs_rkc_chain_fn) */
+int  esq_rhs_diff3d_rkc_chain(void *user, const esq_rkc_chain *chain, size_t n,
+                              void *stream, void *start_event, void *stop_event);
 /* fused entries (esq_rhs_fused_fn) */
 int  esq_rhs_bruss2d_fused(void *user, double t, const double *y_in, double *f,
                            const esq_epilogue *epi, size_t n, void *stream,

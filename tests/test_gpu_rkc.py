@@ -183,6 +183,86 @@ def test_rkc_chained_stage_is_bit_identical(monkeypatch, plugin, N):
     assert a.nfev == b.nfev and a.nfev > 20
 
 
+def _stage_run(N, m, h_factor=1.0):
+    """all m stages of one Chebyshev step on the 3-D diffusion plugin from a
+    non-smooth state (every point different); returns the final iterate and the
+    second-to-last one is not needed"""
+    rhs = esq.Diffusion3D(N)
+    rho = rhs.spectral_radius()
+    rng = np.random.default_rng(7 + N)
+    y0 = pb.diff3d_y0(N) + 0.1 * rng.standard_normal(N ** 3)
+    s = esq.SSV2stab(rhs, 0.0, y0, 1.0, rtol=1e-3, atol=1e-3, const_jac=True,
+                     first_step=1e-6, rho_jac=lambda t, y: rho)
+    h = h_factor * (m * m - 1) / (1.54 * rho)
+    yrow = s._stages(0.0, h, m)
+    return s._dev.download(SLOT_K, yrow), s
+
+
+@pytest.mark.parametrize("N,planes", [(5, 0), (13, 3), (24, 0), (41, 7), (57, 0),
+                                      (64, 5), (70, 16)])
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_rkc_chain_sweeps_are_bit_identical(monkeypatch, N, planes, depth):
+    """ESQ_RKC_DEPTH stages per marching sweep (esq_rhs_rkc_chain_fn, the 3-D
+    plugin's patch sweeps: esq_rkc3d.hpp) against one launch per stage: the final
+    iterate of m stages bit for bit, for stage counts that end in chains of every
+    length and in a single stage, grids of one and of several patches per plane,
+    forced tile depths (run-in planes, plane ranges that do not divide N)"""
+    monkeypatch.setenv("ESQ_RKC_FORCE", "1")
+    for m in (2, 3, 4, 5, 6, 7, 10, 23):
+        monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+        ref, s1 = _stage_run(N, m)
+        monkeypatch.setenv("ESQ_RKC_DEPTH", str(depth))
+        monkeypatch.setenv("ESQ_RKC_PLANES", str(planes))
+        got, s2 = _stage_run(N, m)
+        monkeypatch.delenv("ESQ_RKC_PLANES")
+        assert np.isfinite(ref).all()
+        np.testing.assert_array_equal(got, ref, err_msg=f"m = {m}")
+        assert s1.nfev == s2.nfev
+        names = [k[0] for k in _profiled_kernels(s2, m)]
+        if m - 1 >= 2:
+            assert any(k.startswith("rkc_chain") for k in names), names
+
+
+def _profiled_kernels(s, m):
+    """kernel labels of one more run of the stages (the launch plan, by name)"""
+    from extensisq_amd._lib import PROF_RKC
+    s._dev.profile_reset()
+    s._dev.profile_enable([PROF_RKC])
+    rho = s.rho_jac(0.0, None)
+    s._stages(0.0, (m * m - 1) / (1.54 * rho), m)
+    s._dev.profile_enable(None)
+    return s._dev.profile_kernels()
+
+
+def test_rkc_chain_plan_and_whole_steps(monkeypatch):
+    """whole adaptive steps (first stage, chains, fused tail, controller) with
+    chain sweeps against one launch per stage: identical t, y, error norms and
+    counters; and the launch plan of m = 100: 99 stages = 24 chains of 4 + one of
+    3, the last one without its second output"""
+    N = 48
+    rhs = esq.Diffusion3D(N)
+    rho = rhs.spectral_radius()
+    h0 = (100 ** 2 - 1) / (1.54 * rho) * 0.999
+    kw = dict(rtol=1e-3, atol=1e-3, const_jac=True, first_step=h0,
+              rho_jac=lambda t, y: rho)
+    y0 = pb.diff3d_y0(N)
+    a = esq.SSV2stab(rhs, 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+    b = esq.SSV2stab(esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_RKC_DEPTH")
+    for _ in range(3):
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t and a.errold == b.errold and a.absh == b.absh
+        np.testing.assert_array_equal(a.y, b.y)
+    assert a.nfev == b.nfev and int(dev_rkc.maxm[()]) == 100
+    tab = {k[0]: k[2] for k in _profiled_kernels(a, 100)}
+    assert tab == {"k_rkc_first": 1, "rkc_chain4": 24, "rkc_chain3-last": 1}, tab
+    tab = {k[0]: k[2] for k in _profiled_kernels(a, 6)}       # 5 = 3 + 2
+    assert tab == {"k_rkc_first": 1, "rkc_chain3": 1, "rkc_chain2-last": 1}, tab
+    tab = {k[0]: k[2] for k in _profiled_kernels(b, 6)}
+    assert tab == {"k_rkc_first": 1, "rhs_rkc": 5}, tab
+
+
 @pytest.mark.parametrize("case", ["heat8", "heat130", "diff12"])
 def test_pde_steps_golden_rkc(golden_dir, case):
     """SSV2stab with the device plugins (sweep + Chebyshev recursion in one kernel)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py (run on the GPU box from the repo root):
-#   tools/profile_bench.sh [config ...]        (default: pr8)
+#   tools/profile_bench.sh [config[@grid] ...]  (default: pr8; pr8@7070 = n 1e8)
 # per config:
 #   1. kernel trace + stats of the driver-style bench command
 #   2. HBM traffic counters, one --pmc pass each (FETCH_SIZE, WRITE_SIZE) --
@@ -14,7 +14,13 @@ OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 # a fresh box runs its first seconds of GPU work measurably slower: warm it up
 python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras > /dev/null 2>&1
-for CFG in "${@:-pr8}"; do
+for SPEC in "${@:-pr8}"; do
+    # "cfg@N": config `cfg` on an N-point grid (--grid N); outputs tagged cfg_N
+    CFG=${SPEC%@*}
+    GRID=""
+    TAG=$CFG
+    STEPS=20
+    if [ "$SPEC" != "$CFG" ]; then GRID="--grid ${SPEC#*@}"; TAG=${CFG}_${SPEC#*@}; STEPS=${ESQ_PROF_STEPS:-10}; fi
     if [ "$CFG" = driver ]; then
         # the driver's own command line (its flags), extras and CPU baseline included
         python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 \
@@ -23,16 +29,16 @@ for CFG in "${@:-pr8}"; do
             python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/prof_driver_stats.log 2>&1
         continue
     fi
-    python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras \
-        > $OUT/prof_${CFG}_bench.json 2> $OUT/prof_${CFG}_bench.err
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${CFG}_stats -o bench -- \
-        python3 $ROOT/bench.py --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras \
-        > $OUT/prof_${CFG}_stats.log 2>&1
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${CFG}_fetch -o bench -- \
-        python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp --no-extras \
-        > $OUT/prof_${CFG}_fetch.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${CFG}_write -o bench -- \
-        python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp --no-extras \
-        > $OUT/prof_${CFG}_write.log 2>&1
+    python3 $ROOT/bench.py --config $CFG $GRID --steps $STEPS --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras \
+        > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_${TAG}_bench.err
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -o bench -- \
+        python3 $ROOT/bench.py --config $CFG $GRID --steps $STEPS --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras \
+        > $OUT/prof_${TAG}_stats.log 2>&1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_fetch -o bench -- \
+        python3 $ROOT/bench.py --config $CFG $GRID --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp --no-extras \
+        > $OUT/prof_${TAG}_fetch.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_write -o bench -- \
+        python3 $ROOT/bench.py --config $CFG $GRID --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp --no-extras \
+        > $OUT/prof_${TAG}_write.log 2>&1
 done
 ls $OUT | grep prof_ | head -40

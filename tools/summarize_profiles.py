@@ -89,14 +89,16 @@ def one(tag, cfg):
         s = stats[label(r["Name"])]
         s[0] += int(r["Calls"])
         s[1] += float(r["TotalDurationNs"])
+    base, _, grid = cfg.partition("_")       # "pr8_7070": tools/profile_bench.sh pr8@7070
+    flags = f"--config {base}" + (f" --grid {grid}" if grid else "")
     out = {"command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- "
-                      f"python3 bench.py --config {cfg} --steps 3 --warmup 1; "
+                      f"python3 bench.py {flags} --steps 3 --warmup 1; "
                       f"kernel times: rocprofv3 --kernel-trace --stats -- python3 "
-                      f"bench.py --config {cfg} --steps 20 --warmup 5",
+                      f"bench.py {flags} --steps {20 if not grid else 10} --warmup 5",
            "note": "bytes per launch; fetch = 2 x FETCH_SIZE KiB (gfx950 "
                    "correction), write = WRITE_SIZE KiB",
            "kernels": {}}
-    dom = STAGE if cfg != "rkc" else RKC
+    dom = STAGE if base != "rkc" else RKC
     d_bytes = d_ns = d_calls = 0.0
     all_bytes = all_ns = 0.0
     # bench.py labels a chain sweep that does not write its K rows "...-K<n>"; it
