@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libextensisq_amd.so")
+# ESQ_LIB: another build of the same library (A/B runs of compile-time variants,
+# `make VARIANT=...` in csrc/); must sit next to the package like the default one
+LIB_PATH = os.environ.get("ESQ_LIB") or os.path.join(_HERE, "libextensisq_amd.so")
 
 ABI_VERSION = 4
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2

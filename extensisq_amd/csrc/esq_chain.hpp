@@ -384,8 +384,8 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                     double2 cc[NF], lap[NF], fK[NF];
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
-                        const double lf = __shfl_up(wc[k][f].y, 1, 64);
-                        const double rt = __shfl_down(wc[k][f].x, 1, 64);
+                        const double lf = lane_left(wc[k][f].y);
+                        const double rt = lane_right(wc[k][f].x);
                         cc[f] = wc[k][f];
                         lap[f].x = ((wm[k][f].x + wp[k][f].x) + (lf + wc[k][f].y)) -
                                    4.0 * wc[k][f].x;

@@ -40,7 +40,7 @@ struct Rhs {
     // tuning / test knobs, read from the environment ONCE when the plugin object is
     // made (ESQ_RKC_FORCE: chain sweeps on grids of any size; ESQ_RKC_PLANES:
     // planes per tile of the 3-D chain sweeps, 0 = chosen by geo_rkc3d)
-    int rkc_force, rkc_planes;
+    int rkc_force, rkc_planes, rkc_jt, rkc_nw;
 };
 
 // band remap: logical block id such that XCD x (label blockIdx%8) sweeps the
@@ -130,8 +130,8 @@ struct RowWin {
     __device__ __forceinline__ void sides(int i, double2 c, double &lf,
                                           double &rt) const {
         const int lane = threadIdx.x & 63;
-        lf = __shfl_up(c.y, 1, 64);
-        rt = __shfl_down(c.x, 1, 64);
+        lf = esq::lane_left(c.y);
+        rt = esq::lane_right(c.x);
         if (!live) return;
         const size_t r = base + (size_t)i * N;
         if (lane == 0 || pair == 0) {

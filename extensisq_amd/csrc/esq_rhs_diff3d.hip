@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_diff3d_v2(
         const int i = i0 + r;
         if (i >= N) break;
         const double above = at(i + 1);
-        double c0 = __shfl_up(centre, 1, 64), c1 = __shfl_down(centre, 1, 64);
+        double c0 = esq::lane_left(centre), c1 = esq::lane_right(centre);
         if (live) {
             const double *pl = u + (size_t)i * NN;
             if (l == 0) c0 = 0.0; else if (lane == 0) c0 = pl[p - 1];
@@ -106,18 +106,13 @@ struct Diff3dSt {
     }
 };
 
-// rows per thread by depth: the windows, the y_n / f_n delay lines and one plane
-// of operands in flight are (4 D + 7) JT doubles per thread; chosen so that a
-// 512-thread workgroup stays at two waves per SIMD (<= 256 VGPRs)
-template <int D> struct RkcCfg;
-template <> struct RkcCfg<2> { static constexpr int JT = 6, NW = 8; };
-template <> struct RkcCfg<3> { static constexpr int JT = 5, NW = 8; };
-template <> struct RkcCfg<4> { static constexpr int JT = 4, NW = 8; };
-
-template <int D>
+// rows per thread and waves per workgroup by depth: the windows, the y_n / f_n
+// delay lines and one plane of operands in flight are (4 D + 7) JT doubles per
+// thread.  ESQ_RKC_CFG="JT,NW" (read when the plugin object is made) picks another
+// instantiated shape (tuning).
+template <int D, int JT, int NW>
 int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
                  hipEvent_t e0, hipEvent_t e1) {
-    constexpr int JT = RkcCfg<D>::JT, NW = RkcCfg<D>::NW;
     auto kern = esq::k_rkc3d_chain<D, JT, NW, Diff3dSt>;
     static int slots = 0;                    // workgroups resident on the chip
     if (slots == 0) {
@@ -127,6 +122,7 @@ int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
             per_cu = 1;
         slots = 256 * per_cu;
     }
+    if (NW * JT - 2 * D < 1) return ESQ_ENOTSUP;
     const esq::Geo3d g = esq::geo_rkc3d(r->N, D, JT, NW, slots, r->rkc_planes);
     esq::Rkc3dArgs<D> a;
     a.a = ch->yjm1; a.b = ch->yjm2; a.yn = ch->yn; a.fn = ch->fn;
@@ -141,6 +137,31 @@ int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
                           Diff3dSt{c}, g);
     return (int)hipGetLastError();
 }
+#define ESQ_RKC_SHAPE(DD, JJ, WW) \
+    if (jt == JJ && nw == WW) return launch_rkc3d<DD, JJ, WW>(r, ch, stream, e0, e1);
+template <int D>
+int launch_rkc3d_d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
+                   hipEvent_t e0, hipEvent_t e1) {
+    // defaults (N = 159 / 400, ms per step, tools/rkc_shape_sweep.sh): depth 4 as
+    // sixteen waves of two rows (four waves per SIMD) 1.35 / 20.7, as eight waves of
+    // four rows 1.43 / 22.4; depth 3 on 5 x 8 1.56 / 21.4; depth 2 on 4 x 8 1.92
+    constexpr int djt = D == 2 ? 4 : D == 3 ? 5 : D == 4 ? 2 : D == 5 ? 4 : 3;
+    constexpr int dnw = D == 4 ? 16 : 8;
+    const int jt = r->rkc_jt > 0 ? r->rkc_jt : djt, nw = r->rkc_nw > 0 ? r->rkc_nw : dnw;
+    if constexpr (D == 2) {
+        ESQ_RKC_SHAPE(2, 6, 8) ESQ_RKC_SHAPE(2, 3, 16) ESQ_RKC_SHAPE(2, 4, 8)
+    } else if constexpr (D == 3) {
+        ESQ_RKC_SHAPE(3, 5, 8) ESQ_RKC_SHAPE(3, 2, 16) ESQ_RKC_SHAPE(3, 4, 8)
+    } else if constexpr (D == 4) {
+        ESQ_RKC_SHAPE(4, 4, 8) ESQ_RKC_SHAPE(4, 2, 16) ESQ_RKC_SHAPE(4, 3, 8)
+    } else if constexpr (D == 5) {
+        ESQ_RKC_SHAPE(5, 4, 8) ESQ_RKC_SHAPE(5, 3, 8)
+    } else if constexpr (D == 6) {
+        ESQ_RKC_SHAPE(6, 3, 8)
+    }
+    return ESQ_ENOTSUP;
+}
+#undef ESQ_RKC_SHAPE
 
 }  // namespace
 
@@ -158,9 +179,11 @@ int esq_rhs_diff3d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
     switch (ch->depth) {
-        case 2: return launch_rkc3d<2>(r, ch, s, e0, e1);
-        case 3: return launch_rkc3d<3>(r, ch, s, e0, e1);
-        case 4: return launch_rkc3d<4>(r, ch, s, e0, e1);
+        case 2: return launch_rkc3d_d<2>(r, ch, s, e0, e1);
+        case 3: return launch_rkc3d_d<3>(r, ch, s, e0, e1);
+        case 4: return launch_rkc3d_d<4>(r, ch, s, e0, e1);
+        case 5: return launch_rkc3d_d<5>(r, ch, s, e0, e1);
+        case 6: return launch_rkc3d_d<6>(r, ch, s, e0, e1);
         default: return ESQ_ENOTSUP;
     }
 }
@@ -171,6 +194,8 @@ int esq_rhs_diff3d_create(void **user_out, int N) {
     r.kind = DIFF3D; r.N = N; r.n = (size_t)N * N * N;
     r.rkc_force = getenv("ESQ_RKC_FORCE") ? atoi(getenv("ESQ_RKC_FORCE")) : 0;
     r.rkc_planes = getenv("ESQ_RKC_PLANES") ? atoi(getenv("ESQ_RKC_PLANES")) : 0;
+    r.rkc_jt = r.rkc_nw = 0;
+    if (const char *e = getenv("ESQ_RKC_CFG")) sscanf(e, "%d,%d", &r.rkc_jt, &r.rkc_nw);
     return make(user_out, r);
 }
 

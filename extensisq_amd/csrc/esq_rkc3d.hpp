@@ -36,24 +36,9 @@
 #include <stdlib.h>
 
 #include "../../include/extensisq_amd.h"
+#include "esq_terms.hpp"
 
 namespace esq {
-
-// lane l <- lane l - 1 (lane 0 gets 0.0) / lane l + 1 (lane 63 gets 0.0): one
-// v_mov_b32_dpp wave_shr:1 / wave_shl:1 per half.  (__shfl_up / __shfl_down
-// compile to two ds_bpermute_b32 each: LDS-queue latency on the dependency chain.)
-__device__ __forceinline__ double lane_left(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_right(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
 
 template <int D>
 struct Rkc3dArgs {

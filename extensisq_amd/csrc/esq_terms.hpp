@@ -43,4 +43,34 @@ __device__ __forceinline__ void st2_nt(double *p, size_t i, double2 v) {
     __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(p) + i);
 }
 
+// The neighbouring lane's value: lane l <- lane l - 1 (lane 0 gets 0.0) / lane
+// l + 1 (lane 63 gets 0.0) -- one `v_mov_b32_dpp wave_shr:1 / wave_shl:1` per
+// half and nothing else.  `__shfl_up / __shfl_down(v, 1, 64)` compile to two
+// `ds_bpermute_b32` each: the LDS queue's latency and an `s_waitcnt lgkmcnt` on
+// the stencil's dependency chain.  Callers never use what lane 0 (63) receives
+// from outside the wave.  ESQ_LANE_DPP=0 at compile time: the shuffles (A/B).
+#ifndef ESQ_LANE_DPP
+#define ESQ_LANE_DPP 1
+#endif
+__device__ __forceinline__ double lane_left(double v) {
+#if ESQ_LANE_DPP
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+#else
+    return __shfl_up(v, 1, 64);
+#endif
+}
+__device__ __forceinline__ double lane_right(double v) {
+#if ESQ_LANE_DPP
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+#else
+    return __shfl_down(v, 1, 64);
+#endif
+}
+
 }  // namespace esq

@@ -412,7 +412,7 @@ class _Builtin(DeviceRHS):
     _symbol_rkc = None
     _symbol_chain = None
     _symbol_rkc_chain = None
-    _rkc_chain_depth = 4
+    _rkc_chain_depth = int(os.environ.get("ESQ_RKC_MAXDEPTH", "4"))
     _chain_caps = 15                  # the built-in sweeps handle every form
 
     def _rkc_chain_entry(self, lib):

@@ -1,8 +1,11 @@
 #!/bin/bash
 # Where the waves of each sweep spend their cycles (one --pmc group per pass,
-# --kernel-trace only): tools/sq_probe.sh <config>.  Output on stdout and in
+# --kernel-trace only): tools/sq_probe.sh <config>[@grid].  Output on stdout and in
 # gpurun_out/sq_probe_<config>_<k>/
-CFG=${1:-pr8}
+SPEC=${1:-pr8}
+CFG=${SPEC%@*}
+GRID=""
+if [ "$SPEC" != "$CFG" ]; then GRID="--grid ${SPEC#*@}"; fi
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -14,7 +17,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY 
            "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT"; do
   k=$((k+1))
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/sq_probe_${CFG}_$k -o p -- \
-      python3 $ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp --no-extras > $OUT/sq_probe_${CFG}_$k.log 2>&1
+      python3 $ROOT/bench.py --config $CFG $GRID --steps 3 --warmup 1 --no-cpu-baseline --no-solve-ivp --no-extras > $OUT/sq_probe_${CFG}_$k.log 2>&1
 done
 python3 - <<PY
 import csv, collections, glob, re
@@ -24,7 +27,9 @@ for f in glob.glob("$OUT/sq_probe_${CFG}_*/p_counter_collection.csv"):
         name=r["Kernel_Name"]
         c=re.search(r"k_chain2d<\d+, (?:true|false), (\d+), (\d+), (\d+)", name)
         m=re.search(r"k_(\w+)_sweep<.*Epi(\w+?)<(\d+)", name)
-        if c: lab = f"chain{c.group(1)}{'+solerr' if c.group(3)=='3' else ''}<{c.group(2)}>"
+        k3=re.search(r"k_rkc3d_chain<(\d+), (\d+), (\d+)", name)
+        if k3: lab = f"rkc_chain{k3.group(1)}[JT={k3.group(2)},NW={k3.group(3)}]"
+        elif c: lab = f"chain{c.group(1)}{'+solerr' if c.group(3)=='3' else ''}<{c.group(2)}>"
         else: lab = f"{m.group(2)}<{m.group(3)}>" + ("/src" if "SrcAxpy" in name else "") if m else re.sub(r"\(.*","",name)[-30:]
         agg[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for lab in sorted(agg):
