@@ -26,10 +26,15 @@ window without that help, `config.sustained` 2 000 steps in one go.  The timed
 region carries no events.  Right after it the same K steps are replayed with a HIP event pair on
 EVERY kernel launch (dispatch timestamps on the solver's stream); from that
 replay come the per-kernel table and `roofline`:
-    achieved = bytes the dominant kernel class MOVES (designed traffic, checked
-               against the rocprofv3 PMC counters in profiles/) / its device time
+    achieved = the COMPULSORY bytes of the dominant kernel class (every vector a
+               launch reads counted once, every output once: `lower_bound_bytes`)
+               / its device time
     frac     = achieved / 8 TB/s                                   (<= 1)
-    algorithmic_gbs = SURVEY.md §8d bytes / the same time (can exceed the fabric
+    l2_side_gbs = the same with the halo points the marching sweeps' tiles read
+               twice included (mostly L2 hits: not memory-interface traffic)
+    traffic  = bytes per launch the rocprofv3 PMC counters saw (profiles/); it
+               lies between the two byte counts above
+    algorithmic_gbs = SURVEY.md §8d bytes / the same time (exceeds the fabric
                rate: blocked accumulation and chaining move fewer bytes)
 `cpu_baseline` times the NumPy oracle (the restated reference algorithm) on the
 host cores of this box, rank 0, N = 1 only, on a bounded sample of the workload.
@@ -184,7 +189,7 @@ def dry_run(args, rank, world, ctl):
         meta = workload_meta(args.config, args.grid)
         table = {"dry-run": {"class": meta["klass"], "launches": args.steps,
                              "total_ms": 1e3 * elapsed, "moved_bytes": 8.0 * n,
-                             "algorithmic_bytes": 8.0 * n}}
+                             "floor_bytes": 8.0 * n, "algorithmic_bytes": 8.0 * n}}
         timing = dict(elapsed=elapsed, elapsed_min=fastest, elapsed_prof=elapsed,
                       rejected=0, nfev_timed=0)
         lock = world > 1 and not args.replicas
@@ -229,8 +234,9 @@ def workload_meta(name, N):
     return dict(label=f"SSV2stab (RKC, m~100 stages/step) on 3-D diffusion N={N}",
                 metric="accepted RKC steps/s x state-dim (fp64), SSV2stab n=4e6",
                 bytes_per_elt_step=None, klass=PROF_RKC,
-                kernel="RKC stage class: rhs_rkc (stencil sweep + three-term Chebyshev "
-                       "recursion in one kernel) / k_rkc_first")
+                kernel="RKC stage class: rkc_chain<D> (D consecutive Chebyshev stages "
+                       "in one marching sweep of the 3-D plugin) / rhs_rkc (one stage: "
+                       "stencil sweep + three-term recursion) / k_rkc_first")
 
 
 def make_workload(name, N, rank):
@@ -283,8 +289,9 @@ def make_workload(name, N, rank):
         cls=esq.SSV2stab, oracle="SSV2stab", rhs=rhs, y0=y0, kw=kw, N=N,
         cpu_problem=("diff3d_rhs", "diff3d_y0"),
         bytes_per_elt_step=None, klass=PROF_RKC,
-        kernel="RKC stage class: rhs_rkc (stencil sweep + three-term Chebyshev "
-               "recursion in one kernel) / k_rkc_first")
+        kernel="RKC stage class: rkc_chain<D> (D consecutive Chebyshev stages in one "
+               "marching sweep of the 3-D plugin) / rhs_rkc (one stage: stencil sweep + "
+               "three-term recursion) / k_rkc_first")
 
 
 def blas_threads():
@@ -354,17 +361,22 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
             "class": r["class"], "launches": launches,
             "avg_us": 1e3 * ms / launches if launches else None,
             "moved_bytes_per_launch": r["moved_bytes"] / launches if launches else None,
+            "floor_bytes_per_launch": r["floor_bytes"] / launches if launches else None,
             "algorithmic_bytes_per_launch":
                 r["algorithmic_bytes"] / launches if launches else None,
-            "gbs": r["moved_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else None}
+            "gbs": r["floor_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            "l2_side_gbs": r["moved_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else None}
     dom = [r for r in table.values() if r["class"] == meta["klass"]]
     ms = sum(r["total_ms"] for r in dom)
     cnt = sum(r["launches"] for r in dom)
     moved = sum(r["moved_bytes"] for r in dom)
+    floor = sum(r["floor_bytes"] for r in dom)
     alg = sum(r["algorithmic_bytes"] for r in dom)
-    achieved = moved / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(args.config)
+    achieved = floor / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(args.config if not args.grid else
+                                       f"{args.config}_{args.grid}")
     all_moved = sum(r["moved_bytes"] for r in table.values())
+    all_floor = sum(r["floor_bytes"] for r in table.values())
     all_ms = sum(r["total_ms"] for r in table.values())
     return {
         "metric": meta["metric"],
@@ -404,11 +416,21 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
             "bound": "hbm", "kernel": meta["kernel"],
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "definition": "bytes the class is designed to move (the halo rows and "
-                          "columns the marching sweeps read twice included) / its "
-                          "device time (HIP events on every launch of a K-step "
-                          "replay right after the timed region)",
+            "definition": "compulsory bytes of the class (every vector a launch "
+                          "reads counted once, every output written once; the halo "
+                          "points its tiles read twice NOT counted) / its device "
+                          "time (HIP events on every launch of a K-step replay "
+                          "right after the timed region)",
+            # the halo-inclusive designed traffic on the same time: what the L2s
+            # serve, not what crosses the memory interface
+            "l2_side_gbs": moved / (ms * 1e-3) / 1e9 if ms > 0 else None,
             "traffic": traffic, "traffic_source": traffic_src,
+            # committed PMC bytes per launch on the live launch time
+            "traffic_frac": (traffic / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            if traffic and cnt and ms > 0 else None,
+            # compulsory traffic of the launch sequence actually run, per step
+            "lower_bound_bytes": all_floor / args.steps,
+            "lower_bound_bytes_per_launch": floor / cnt if cnt else None,
             "launches_timed": cnt,
             "avg_launch_us": 1e3 * ms / cnt if cnt else None,
             "moved_bytes_per_launch": moved / cnt if cnt else None,
@@ -418,7 +440,8 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
                 all_ms * 1e-3 / timing["elapsed_prof"] if timing["elapsed_prof"] else None,
             # every kernel of the step: moved bytes / wall time of the
             # TIMED region (launch gaps and the host controller included)
-            "whole_step_gbs": all_moved / elapsed / 1e9,
+            "whole_step_gbs": all_floor / elapsed / 1e9,
+            "whole_step_l2_side_gbs": all_moved / elapsed / 1e9,
             "whole_step_algorithmic_gbs": (
                 meta["bytes_per_elt_step"] * n * args.steps / elapsed / 1e9)
             if meta["bytes_per_elt_step"] else None,
@@ -431,8 +454,8 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
 def raw_table(dev):
     """per-kernel totals of the profiled replay"""
     return {name: {"class": klass, "launches": launches, "total_ms": ms,
-                   "moved_bytes": moved, "algorithmic_bytes": alg}
-            for name, klass, launches, ms, alg, moved in dev.profile_kernels()}
+                   "moved_bytes": moved, "floor_bytes": floor, "algorithmic_bytes": alg}
+            for name, klass, launches, ms, alg, moved, floor in dev.profile_kernels()}
 
 
 def main():

@@ -232,6 +232,7 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                                      (void *)p.start(), (void *)p.stop());
                 if (r == 0) {
                     p.ev.moved = (4.0 * amp + (last ? 1.0 : 2.0)) * 8.0 * (double)c->len;
+                    p.ev.floor = (4.0 + (last ? 1.0 : 2.0)) * 8.0 * (double)c->len;
                     jm2 = last ? jm1 : o2;
                     jm1 = o1;
                     j += d;

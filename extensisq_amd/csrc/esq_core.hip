@@ -135,6 +135,7 @@ Prof::Prof(esq_ctx *ctx, int klass, const char *name, int nt, double bytes,
     ev.klass = klass;
     ev.bytes = bytes;
     ev.moved = moved < 0.0 ? bytes : moved;
+    ev.floor = -1.0;
     if (nt >= 0) snprintf(ev.name, sizeof(ev.name), "%s<%d>", name, nt);
     else snprintf(ev.name, sizeof(ev.name), "%s", name);
     if (recorded) (void)hipEventRecord(ev.start, c->stream);
@@ -167,6 +168,7 @@ void prof_drain(esq_ctx *c) {
             pk.ms += ms;
             pk.bytes += ev.bytes;
             pk.moved += ev.moved;
+            pk.floor += ev.floor < 0.0 ? ev.moved : ev.floor;
         }
         c->prof_pool.push_back(ev.start);
         c->prof_pool.push_back(ev.stop);
@@ -678,9 +680,10 @@ int esq_profile_kernels(esq_ctx *c, char *buf, size_t buflen) {
     buf[0] = 0;
     for (const auto &kv : c->prof_kernels) {
         const ProfKernel &k = kv.second;
-        const int w = snprintf(buf + used, buflen - used, "%s\t%d\t%ld\t%.9g\t%.17g\t%.17g\n",
+        const int w = snprintf(buf + used, buflen - used,
+                               "%s\t%d\t%ld\t%.9g\t%.17g\t%.17g\t%.17g\n",
                                kv.first.c_str(), k.klass, k.launches, k.ms, k.bytes,
-                               k.moved);
+                               k.moved, k.floor);
         if (w < 0 || (size_t)w >= buflen - used)
             return fail(c, ESQ_EINVAL, "profile table needs a larger buffer");
         used += (size_t)w;

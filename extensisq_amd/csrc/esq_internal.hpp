@@ -40,12 +40,14 @@ struct ProfEvent {
     int klass;
     double bytes;      // algorithmic bytes (SURVEY.md §8d definition)
     double moved;      // bytes the launch is designed to move
+    double floor;      // ... without the halo points tiles read twice: every vector
+                       // read once, every output written once (< 0: same as moved)
     char name[40];     // kernel label for the per-kernel table (esq_profile_kernels)
 };
 struct ProfKernel {    // per-label totals since the last reset
     int klass = 0;
     long launches = 0;
-    double ms = 0.0, bytes = 0.0, moved = 0.0;
+    double ms = 0.0, bytes = 0.0, moved = 0.0, floor = 0.0;
 };
 // pinned host slot a reduction's result lands in: the value(s), then the
 // sequence number of the reduction (system-scope release), polled by the host

@@ -361,7 +361,10 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     const int r = c->rhs_chain(c->rhs_user, i == 0 ? c->y : c->ystage, &e, c->len,
                                (void *)c->stream, (void *)p.start(), (void *)p.stop());
     // designed traffic incl. the halo rows / columns the plugin's tiles re-read
-    if (p.on) p.ev.moved = 8.0 * (reads * amp + writes) * (double)c->len;
+    if (p.on) {
+        p.ev.moved = 8.0 * (reads * amp + writes) * (double)c->len;
+        p.ev.floor = 8.0 * (reads + writes) * (double)c->len;
+    }
     if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
     if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "chain RHS entry returned %d", r); }
     if (what_last == 0 && !skip_out) std::swap(c->ystage, c->work);

@@ -297,15 +297,16 @@ class DeviceContext:
 
     def profile_kernels(self):
         """per-kernel rows since the last reset:
-        (name, class, launches, total_ms, algorithmic_bytes, moved_bytes)"""
+        (name, class, launches, total_ms, algorithmic_bytes, moved_bytes,
+        floor_bytes)"""
         buf = C.create_string_buffer(1 << 16)
         self._chk(self.lib.esq_profile_kernels(self.handle, buf, len(buf)),
                   "esq_profile_kernels")
         rows = []
         for line in buf.value.decode().splitlines():
-            name, klass, launches, ms, alg, moved = line.split("\t")
+            name, klass, launches, ms, alg, moved, floor = line.split("\t")
             rows.append((name, int(klass), int(launches), float(ms), float(alg),
-                         float(moved)))
+                         float(moved), float(floor)))
         return rows
 
     def profile_read_moved(self, klass):

@@ -667,8 +667,12 @@ int  esq_profile_read(esq_ctx *ctx, int klass, double *total_ms, long *launches,
  * several stages) */
 int  esq_profile_read_moved(esq_ctx *ctx, int klass, double *moved_bytes);
 /* per-kernel table since the last reset, one line per kernel label:
- *   name \t class \t launches \t total_ms \t algorithmic_bytes \t moved_bytes \n
- * (NUL-terminated text in buf; bench.py's `roofline.kernels`) */
+ *   name \t class \t launches \t total_ms \t algorithmic_bytes \t moved_bytes
+ *        \t floor_bytes \n
+ * moved_bytes: the launches' designed traffic, the halo points the marching
+ * sweeps' tiles read twice included (mostly L2 hits); floor_bytes: the same with
+ * every vector read once and every output written once -- what must cross the
+ * memory interface (NUL-terminated text in buf; bench.py's `roofline.kernels`) */
 int  esq_profile_kernels(esq_ctx *ctx, char *buf, size_t buflen);
 int  esq_profile_reset(esq_ctx *ctx);
 

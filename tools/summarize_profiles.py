@@ -12,8 +12,9 @@ reads, MI355X_MICROARCH.md §HBM); WRITE_SIZE is exact; both are in KiB.
 
 Kernel names are folded onto the labels of bench.py's `roofline.kernels` table so
 that the two sources can be laid side by side: the figure printed here
-(PMC bytes / rocprof kernel time / 8 TB/s) must agree with bench.py's
-`roofline.frac` (designed bytes / event time / 8 TB/s).
+(PMC bytes / rocprof kernel time / 8 TB/s) must lie between bench.py's
+`roofline.frac` (compulsory bytes / event time / 8 TB/s) and the same with the
+designed L2-side bytes (halo re-reads included).
 """
 import collections
 import csv
@@ -30,7 +31,7 @@ PEAK = 8.0e12
 
 STAGE = ("k_lincomb", "k_block_acc", "rhs+stage", "rhs1+stage", "rhs+block") + tuple(
     f"chain{d}{suffix}" for d in range(2, 7) for suffix in ("", "+solerr"))
-RKC = ("rhs_rkc", "k_rkc_first", "k_rkc_stage")
+RKC = ("rhs_rkc", "k_rkc_first", "k_rkc_stage") + tuple(f"rkc_chain{d}" for d in range(2, 9))
 
 
 def label(name):
@@ -40,6 +41,9 @@ def label(name):
     if m:
         sol = "+solerr" if m.group(3) == "3" else ""
         return f"chain{m.group(1)}{sol}<{m.group(2)}>"
+    m = re.search(r"k_rkc3d_chain<(\d+)", name)
+    if m:                                   # 3-D Chebyshev chain sweeps (round 4)
+        return f"rkc_chain{m.group(1)}"
     if re.search(r"_sweep<.*EpiRkcErr", name):
         return "rhs+rkcerr"
     if re.search(r"_sweep<.*EpiRkc\b", name):
@@ -101,10 +105,16 @@ def one(tag, cfg):
     dom = STAGE if base != "rkc" else RKC
     d_bytes = d_ns = d_calls = 0.0
     all_bytes = all_ns = 0.0
-    # bench.py labels a chain sweep that does not write its K rows "...-K<n>"; it
-    # is the same kernel for rocprofv3
-    events = {k.replace("-K<", "<"): v
-              for k, v in (bench or {}).get("roofline", {}).get("kernels", {}).items()}
+    # bench.py labels a chain sweep that does not write its K rows "...-K<n>" and a
+    # step's last Chebyshev chain "...-last"; each is the same kernel for rocprofv3
+    events = {}
+    for k, v in (bench or {}).get("roofline", {}).get("kernels", {}).items():
+        e = events.setdefault(k.replace("-K<", "<").replace("-last", ""),
+                              {"launches": 0, "us": 0.0, "moved": 0.0, "floor": 0.0})
+        e["launches"] += v["launches"]
+        e["us"] += v["avg_us"] * v["launches"]
+        e["moved"] += v["moved_bytes_per_launch"] * v["launches"]
+        e["floor"] += v.get("floor_bytes_per_launch", v["moved_bytes_per_launch"]) * v["launches"]
     for k in sorted(stats):
         calls, ns = stats[k]
         f_b = 2.0 * fetch.get(k, (0.0, 0))[0] * 1024.0
@@ -112,9 +122,11 @@ def one(tag, cfg):
         rec = {"calls_kernel_trace": calls, "avg_ns_kernel_trace": ns / calls,
                "fetch_bytes": f_b, "write_bytes": w_b, "hbm_bytes": f_b + w_b,
                "gbs": (f_b + w_b) / (ns / calls) if calls else None}
-        if k in events:
-            rec["bench_avg_us_events"] = events[k]["avg_us"]
-            rec["bench_designed_bytes"] = events[k]["moved_bytes_per_launch"]
+        if k in events and events[k]["launches"]:
+            e = events[k]
+            rec["bench_avg_us_events"] = e["us"] / e["launches"]
+            rec["bench_designed_bytes"] = e["moved"] / e["launches"]
+            rec["bench_floor_bytes"] = e["floor"] / e["launches"]
         out["kernels"][k] = rec
         all_bytes += (f_b + w_b) * calls
         all_ns += ns
@@ -135,7 +147,8 @@ def one(tag, cfg):
     if bench:
         out["bench_roofline"] = {k: bench["roofline"].get(k) for k in (
             "achieved", "frac", "avg_launch_us", "moved_bytes_per_launch",
-            "algorithmic_gbs", "whole_step_gbs")}
+            "lower_bound_bytes_per_launch", "l2_side_gbs", "algorithmic_gbs",
+            "whole_step_gbs")}
         out["bench_value"] = bench["value"]
         out["bench_ms_per_step"] = bench["ms_per_step"]
     with open(os.path.join(P, f"{tag}_pmc_traffic_{cfg}.json"), "w") as fh:
