@@ -132,6 +132,12 @@ static double *vec_ptr(esq_ctx *c, int r) {
     }
 }
 #define ROW(c, r) vec_ptr((c), (r))
+// a vector id whose overwriting changes what the rows evaluated on demand
+// (esq_rk_lazy_rows) would be computed from: they are evaluated first
+#define ENSURE_ROWS_BEFORE_WRITE(c, id)                                   \
+    do {                                                                  \
+        if ((id) >= 0 || (id) == ESQ_VEC_Y || (id) == ESQ_VEC_YNEW) ENSURE_ROWS(c); \
+    } while (0)
 
 int esq_rkc_first_stage(esq_ctx *c, int dst, int yn, int fn, double hmus) {
     if (!c) return ESQ_EINVAL;
@@ -390,6 +396,7 @@ int esq_vec_wdot(esq_ctx *c, int a, int b, int y1, int y2, double floor_,
 int esq_vec_fill(esq_ctx *c, int dst, double value, double value_im) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
+    ENSURE_ROWS_BEFORE_WRITE(c, dst);
     double *d = ROW(c, dst);
     if (!d) return fail(c, ESQ_EINVAL, "bad vector id %d", dst);
     if (c->cplx)
@@ -404,6 +411,8 @@ int esq_vec_fill(esq_ctx *c, int dst, double value, double value_im) {
 int esq_vec_copy(esq_ctx *c, int dst, int src) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
+    ENSURE_ROWS_BEFORE_WRITE(c, dst);
+    if (src >= 0) ENSURE_ROWS(c);
     double *d = ROW(c, dst), *s = ROW(c, src);
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad vector id");
     HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),
@@ -419,6 +428,7 @@ int esq_vec_eval_rhs(esq_ctx *c, int dst, double t, int src) {
 }
 int esq_vec_upload(esq_ctx *c, int dst, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
+    ENSURE_ROWS_BEFORE_WRITE(c, dst);
     const bool was_idle = c->idle;
     ENTER(c);
     double *d = ROW(c, dst);

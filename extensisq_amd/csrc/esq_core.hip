@@ -530,7 +530,12 @@ size_t esq_vector_len(const esq_ctx *c) { return c ? c->len : 0; }
 
 int esq_upload(esq_ctx *c, int slot, int row, const double *host) {
     if (!c || !host) return ESQ_EINVAL;
-    if (slot == ESQ_SLOT_K) ENSURE_ROWS(c);   // a later restore must not undo the upload
+    // a later restore must not undo the upload -- and must not see it: rows that are
+    // evaluated on demand (esq_rk_lazy_rows) are functions of the state as the step
+    // left it (K[0] = f(t, y) of the accepted state: the reference's `self.f` stays
+    // what it was when `solver.y` is assigned, common.py:298), so they are
+    // evaluated BEFORE the state changes
+    if (slot == ESQ_SLOT_K || slot == ESQ_SLOT_Y || slot == ESQ_SLOT_YNEW) ENSURE_ROWS(c);
     const bool was_idle = c->idle;
     ENTER(c);
     double *d = slot_ptr(c, slot, row);
@@ -550,7 +555,9 @@ int esq_download(esq_ctx *c, int slot, int row, double *host) {
 int esq_copy(esq_ctx *c, int dst_slot, int dst_row, int src_slot, int src_row) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
-    if (dst_slot == ESQ_SLOT_K || src_slot == ESQ_SLOT_K) ENSURE_ROWS(c);
+    if (dst_slot == ESQ_SLOT_K || src_slot == ESQ_SLOT_K || dst_slot == ESQ_SLOT_Y ||
+        dst_slot == ESQ_SLOT_YNEW)
+        ENSURE_ROWS(c);
     double *d = slot_ptr(c, dst_slot, dst_row), *s = slot_ptr(c, src_slot, src_row);
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad slot/row");
     HIPCHK(c, hipMemcpyAsync(d, s, c->len_pad * sizeof(double),

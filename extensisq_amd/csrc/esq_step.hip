@@ -855,12 +855,18 @@ int esq_rk_block_plan(esq_ctx *c, int *boundaries, int max_boundaries,
 int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row) {
     if (!c) return ESQ_EINVAL;
     ENTER(c);
-    if (dst_row == 0 && src_slot != ESQ_SLOT_K) c->k0_missing = false;   // evaluated here
-    if (src_slot == ESQ_SLOT_K || dst_row != 0) ENSURE_ROWS(c);
+    // logical row 0 from a vector that is not a K row: this call IS the evaluation
+    // the deferred end-point derivative was waiting for -- but the flag goes only
+    // once the row is in memory (restore_rows' rule: after a failure the next
+    // reader tries again instead of reading what is not there)
+    const bool is_k0 = dst_row == 0 && src_slot != ESQ_SLOT_K;
+    if (!is_k0) ENSURE_ROWS(c);
     double *dst = slot_ptr(c, ESQ_SLOT_K, dst_row);
     double *src = slot_ptr(c, src_slot, src_row);
     if (!dst || !src) return fail(c, ESQ_EINVAL, "bad row/slot");
-    return call_rhs(c, t, src, dst);
+    const int r = call_rhs(c, t, src, dst);
+    if (r == 0 && is_k0) c->k0_missing = false;
+    return r;
 }
 
 int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {

@@ -7,6 +7,7 @@ K and y_new agree to 1e-13 relative (max-norm, scaled by max|K|), error_norm
 and the next step size to 1e-10 relative; trajectories: identical accepted /
 rejected step counts and nfev, t_k to 1e-9 relative.
 """
+import ctypes as C
 import json
 import os
 
@@ -480,6 +481,122 @@ def test_full_size_pr8_step_matches_oracle():
     check_step(d, o.K, o.y, o.error_norm_old, o.h_abs, y_old, o.h_previous,
                1e-6, 1e-9, k_rtol=2e-13, lipschitz=pb.bruss2d_rho(N))
     assert d.nfev == o.nfev == 14
+
+
+@pytest.mark.parametrize("name,plugin,N,plan", [
+    ("Pr8", "bruss", 2236, ["chain4+solerr-K<8>", "chain4<4>", "chain5<0>"]),
+    ("Pr9", "heat", 2236, None)])
+def test_full_size_three_steps_match_oracle(name, plugin, N, plan):
+    """BASELINE.json configs[2] / configs[4] sizes, THREE steps against the oracle:
+    the first step starts from the constructor's K[0]; from the second on the
+    step is the launch sequence bench.py times -- the end-point derivative as
+    stage 0 of the first chain sweep, the chain that forms its own input from the
+    rows it reads, the K rows nothing reads left unwritten.  Nothing is read from
+    the device solver in between (that would evaluate those rows the plain way);
+    at the end `K` (restored on demand) and `y` meet the oracle's.  The two runs
+    start steps 2 and 3 from states that differ in the last digits, so the
+    single-step bounds are widened by the RHS's amplification over two steps."""
+    if plugin == "bruss":
+        rhs, cpu, y0, rho = (esq.Brusselator2D(N), pb.bruss2d_rhs(N), pb.bruss2d_y0(N),
+                             pb.bruss2d_rho(N))
+    else:
+        rhs, cpu, y0, rho = (esq.Heat2D(N), pb.heat2d_rhs(N), pb.heat2d_y0(N),
+                             pb.heat2d_rho(N))
+    h = 1.0 / rho
+    # (tolerances at which the controller keeps h at max_step: both runs then take
+    # bitwise the same step sizes)
+    rtol, atol = (1e-6, 1e-9) if plugin == "bruss" else (1e-3, 1e-6)
+    kw = dict(first_step=h, max_step=h, rtol=rtol, atol=atol, nfev_stiff_detect=0)
+    d, o = _pair(name, rhs, cpu, 0.0, y0, 1.0, **kw)
+    from extensisq_amd._lib import PROF_RHS, PROF_SOLERR, PROF_STAGE
+    errs = []
+    for k in range(3):
+        if k == 2:                      # the launch plan of the third step, by name
+            d._dev.profile_reset()
+            d._dev.profile_enable([PROF_STAGE, PROF_RHS, PROF_SOLERR])
+        assert d.step() is None and o.step() is None
+        assert d.t == o.t
+        errs.append((d.error_norm_old, o.error_norm_old))
+    d._dev.profile_enable(None)
+    labels = sorted(row[0] for row in d._dev.profile_kernels())
+    assert d.nfev == o.nfev and int(esq.NFS[()]) == 0
+    missing = C.c_int()
+    d._chk(d._lib.esq_rk_lazy_rows(d._ctx, C.byref(missing), None, None, None, None),
+           "esq_rk_lazy_rows")
+    if plan is not None:
+        assert missing.value > 0          # the rows were NOT in memory until now
+    kmax, ymax = np.abs(o.K).max(), np.abs(o.y).max()
+    k_atol = 10 * (2e-13 * kmax + 8 * np.finfo(float).eps * rho * ymax)
+    assert_allclose(d.y, o.y, rtol=1e-11, atol=h * k_atol)
+    assert_allclose(d.K, o.K, rtol=0, atol=k_atol)
+    for got, ref in errs:
+        assert_allclose(got, ref, rtol=1e-5)
+    if plan is not None:
+        assert labels == plan
+
+
+def test_full_size_free_controller_with_rejections_matches_oracle():
+    """configs[2] size, the controller left alone from a first step 40 x the
+    stability limit: the attempts that are rejected, the retries and the accepted
+    steps that follow are the oracle's -- same counts of accepted steps, rejected
+    steps and RHS evaluations, same times -- with the chain sweeps doing the
+    work (a rejected step re-uses K[0]; its retry starts from the rows)"""
+    N = 2236
+    y0 = pb.bruss2d_y0(N)
+    h_stab = 1.0 / pb.bruss2d_rho(N)
+    kw = dict(first_step=40 * h_stab, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+    d, o = _pair("Pr8", esq.Brusselator2D(N), pb.bruss2d_rhs(N), 0.0, y0,
+                 60 * h_stab, **kw)
+    accepted = 0
+    while o.status == "running" and accepted < 5:
+        assert o.step() is None
+        accepted += 1
+    nfs_ref = int(rk_oracle.NFS[()])
+    for _ in range(accepted):
+        assert d.step() is None
+    assert int(esq.NFS[()]) == nfs_ref and nfs_ref >= 1
+    assert d.nfev == o.nfev
+    assert_allclose(d.t, o.t, rtol=1e-9)
+    assert_allclose(d.h_abs, o.h_abs, rtol=1e-6)
+    assert_allclose(d.y, o.y, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,mk,y0f", [
+    ("Pr8", lambda: esq.Brusselator2D(64), lambda: pb.bruss2d_y0(64)),
+    ("Pr9", lambda: esq.Heat2D(96), lambda: pb.heat2d_y0(96)),
+    ("Ts5", lambda: esq.Heat2D(96), lambda: pb.heat2d_y0(96))])
+def test_assigning_the_state_keeps_the_old_derivative(monkeypatch, name, mk, y0f):
+    """`solver.y = value` between steps (events, callbacks, user code): in the
+    reference `self.f` stays what it was (common.py:298), so the next step's
+    K[0] is the derivative of the OLD state.  With the end-point derivative left
+    to the next step's first chain sweep (ESQ_LAZY_END) the library evaluates it
+    before the upload changes the state: runs with and without the deferral are
+    bit-identical, and K[0] is the stale derivative"""
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", "8")          # chains on these small grids
+    y0 = y0f()
+    rho = mk().spectral_radius()
+    h = 0.5 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+    a = DEV[name](mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_LAZY_END", "0")
+    b = DEV[name](mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_LAZY_END")
+    cpu = pb.bruss2d_rhs(64) if name == "Pr8" else pb.heat2d_rhs(96)
+    o = rk_oracle.METHODS[name](cpu, 0.0, y0, 1.0, **kw)
+    for k in range(3):
+        for s in (a, b, o):
+            assert s.step() is None
+            s.y = (0.5 + 0.25 * k) * s.y           # no K[0] re-evaluation by hand
+    for s in (a, b, o):
+        assert s.step() is None
+    assert a.t == b.t
+    assert_allclose(a.t, o.t, rtol=1e-12)
+    assert_equal(a.y, b.y)
+    assert_equal(a.K, b.K)
+    assert a.nfev == b.nfev == o.nfev
+    # K[0] of the last step is f(t, y BEFORE the last assignment), as in the oracle
+    assert_allclose(a.K[0], o.K[0], rtol=0, atol=1e-9 * np.abs(o.K[0]).max())
+    assert_allclose(a.y, o.y, rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.parametrize("name,plugin,N", [("Pr8", "bruss", 2236), ("Ts5", "heat", 1000),
