@@ -166,6 +166,62 @@ def spawn_ranks(args):
     return rc
 
 
+def pin_to_gpu_numa(local):
+    """Before this rank touches its GPU: run on the CPUs of that GPU's NUMA node
+    (the pinned result slot, the control plane and Python's controller then sit
+    next to the device's PCIe root).  Plain sysfs reads and sched_setaffinity in
+    this fresh process -- no GPU call, no re-exec.  The `local`-th AMD display /
+    processing-accelerator function in PCI order is taken to be HIP device
+    `local`; anything missing or inconclusive (no NUMA information, a restricted
+    visibility list) leaves the affinity alone.  Returns what was done."""
+    try:
+        if os.environ.get("ESQ_BENCH_NO_PIN"):
+            return {"pinned": False, "why": "ESQ_BENCH_NO_PIN set"}
+        # visibility lists of plain indices are followed (HIP's list indexes into
+        # ROCr's); anything else (UUIDs) is not guessed at
+        index = local
+        for key in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+            val = os.environ.get(key)
+            if key == "CUDA_VISIBLE_DEVICES" and os.environ.get("HIP_VISIBLE_DEVICES"):
+                continue
+            if val:
+                items = [v.strip() for v in val.split(",")]
+                if not all(v.isdigit() for v in items) or index >= len(items):
+                    return {"pinned": False, "why": f"{key}={val!r} not followed"}
+                index = int(items[index])
+        base = "/sys/bus/pci/devices"
+        gpus = []
+        for dev in sorted(os.listdir(base)):
+            try:
+                with open(os.path.join(base, dev, "vendor")) as fh:
+                    if fh.read().strip() != "0x1002":
+                        continue
+                with open(os.path.join(base, dev, "class")) as fh:
+                    klass = int(fh.read().strip(), 16) >> 8
+                if klass not in (0x0300, 0x0302, 0x0380, 0x1200):
+                    continue
+                with open(os.path.join(base, dev, "numa_node")) as fh:
+                    gpus.append((dev, int(fh.read().strip())))
+            except (OSError, ValueError):
+                continue
+        if index >= len(gpus) or gpus[index][1] < 0:
+            return {"pinned": False, "why": "no NUMA node known for this GPU",
+                    "gpus_in_sysfs": len(gpus)}
+        node = gpus[index][1]
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as fh:
+            cpus = set()
+            for part in fh.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"pinned": False, "why": "node CPUs not in this process's set"}
+        os.sched_setaffinity(0, cpus)
+        return {"pinned": True, "numa_node": node, "cpus": len(cpus), "pci": gpus[index][0]}
+    except Exception as exc:                                   # noqa: BLE001
+        return {"pinned": False, "why": repr(exc)}
+
+
 def dry_run(args, rank, world, ctl):
     """control-plane rehearsal without a GPU (tests/test_bench_cpu.py): spawn,
     rendezvous, id exchange, barrier, min/max-over-ranks timing -- and the SAME
@@ -196,7 +252,12 @@ def dry_run(args, rank, world, ctl):
         out = assemble(args, meta, world, 1000, timing, table,
                        lockstep_on=lock, rccl_nranks=world if lock else None,
                        preflight="dry-run" if lock else None,
-                       replicas={"value": 1.0, "ms_per_step": 1.0} if lock else None)
+                       replicas={"value": 1.0, "ms_per_step": 1.0} if lock else None,
+                       allreduce_us={"median": 0.0, "p99": 0.0,
+                                     "median_without_collective": 0.0,
+                                     "collective_median": 0.0, "calls": 0,
+                                     "path": "dry-run"} if lock else None,
+                       affinity=pin_to_gpu_numa(rank))
         out["metric"] = "dry-run"
         out["value"] = n_total / elapsed
         out["max_elapsed"] = elapsed
@@ -350,7 +411,7 @@ def pmc_traffic(config):
 
 
 def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
-             preflight, replicas):
+             preflight, replicas, allreduce_us=None, affinity=None):
     """the ONE JSON line (rank 0).  `table`: per-kernel totals of the profiled
     replay {label: {class, launches, total_ms, moved_bytes, algorithmic_bytes}}"""
     elapsed = timing["elapsed"]
@@ -398,6 +459,14 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
             "rccl_nranks": rccl_nranks,
             "rccl_preflight": preflight,
             "replicas_no_collective": replicas,
+            # lock-step only: one reduction with / without the RCCL all-reduce
+            # (lockstep.time_allreduce), and what lock-step costs per step against
+            # fully independent solvers of the same run
+            "allreduce_us": allreduce_us,
+            "lockstep_minus_replicas_ms": (1e3 * elapsed / args.steps - replicas["ms_per_step"])
+            if replicas else None,
+            # rank 0's CPU affinity (every rank pins itself to its GPU's NUMA node)
+            "cpu_affinity": affinity,
             # skew between the ranks: the timed region of the slowest / fastest
             "ms_per_step_rank_max": 1e3 * elapsed / args.steps,
             "ms_per_step_rank_min": 1e3 * timing["elapsed_min"] / args.steps,
@@ -473,6 +542,7 @@ def main():
     ctl = lockstep.ControlGroup(rank, world)
     if args.dry_run:
         return dry_run(args, rank, world, ctl)
+    affinity = pin_to_gpu_numa(local)              # before the first GPU call
 
     import extensisq_amd as esq
     from extensisq_amd._lib import (PROF_RHS, PROF_RKC, PROF_SOLERR, PROF_STAGE,
@@ -490,6 +560,7 @@ def main():
     group = None
     rccl_nranks = None
     preflight = None
+    allreduce_us = None
     try:
         if (world > 1 and not args.replicas) or args.force_lockstep:
             group = lockstep.init_lockstep(rank, world, local, n,
@@ -500,6 +571,7 @@ def main():
             # before anything is timed: the collectives the run depends on,
             # checked against values every rank can compute for itself
             preflight = lockstep.preflight(group, rank, world, local, ctl)
+            allreduce_us = lockstep.time_allreduce(group, local, ctl)
 
         def timed(lock_group):
             solver = w["cls"](w["rhs"], 0.0, w["y0"], 1.0e9, device=local,
@@ -564,7 +636,8 @@ def main():
                       rejected=rejected, nfev_timed=nfev_timed, cold=cold)
         out = assemble(args, meta, world, n, timing, table,
                        lockstep_on=group is not None, rccl_nranks=rccl_nranks,
-                       preflight=preflight, replicas=replicas)
+                       preflight=preflight, replicas=replicas,
+                       allreduce_us=allreduce_us, affinity=affinity)
         if world == 1:
             # further driver-visible figures of the same workload -- none of them
             # the headline

@@ -269,9 +269,15 @@ class LockstepGroup:
     def sync_aborted(self):
         """forget the communicator if the library has aborted it; returns True
         if the handle is gone"""
-        for dev in self._contexts:
-            if getattr(dev, "handle", None) and dev.lib.esq_comm_is_aborted(dev.handle):
-                self.comm = None
+        live = [d for d in self._contexts if getattr(d, "handle", None)]
+        if self.comm and any(d.lib.esq_comm_is_aborted(d.handle) for d in live):
+            # the library freed the handle when it aborted it: every other context
+            # attached to the same communicator must drop its pointer too, or its
+            # next reduction calls ncclAllReduce on a dead communicator
+            for d in live:
+                if not d.lib.esq_comm_is_aborted(d.handle):
+                    d.lib.esq_set_comm(d.handle, None)
+            self.comm = None
         return not self.comm
 
     def host_reduce(self, dev, values, op="sum"):

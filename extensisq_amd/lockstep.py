@@ -296,6 +296,54 @@ def preflight(group, rank, world, device, ctl=None):
     return "ok"
 
 
+def time_allreduce(group, device, ctl=None, count=200):
+    """What one lock-step reduction costs on this communicator: `count` error-norm
+    reductions of a 1024-element vector (k_sumsq -> k_final_sum -> ncclAllReduce of
+    ONE double -> publish into the pinned slot -> the spinning host: exactly the
+    path every step attempt takes) timed call by call, then the same calls on the
+    same context without the communicator.  Returns microseconds: median and p99
+    with the all-reduce, the median without it, and their difference -- the price
+    of the collective itself."""
+    import time
+
+    import numpy as np
+    from ._lib import SLOT_Y, VEC_NONE, VEC_Y
+    from .device import DeviceContext
+    dev = DeviceContext(1024, 2, False, device)
+
+    def run():
+        out = C.c_double()
+        stamps = []
+        for _ in range(count + 20):
+            t0 = time.perf_counter()
+            dev._chk(dev.lib.esq_vec_sumsq(dev.handle, VEC_Y, VEC_NONE, C.byref(out)),
+                     "esq_vec_sumsq")
+            stamps.append(time.perf_counter() - t0)
+        us = np.sort(np.array(stamps[20:])) * 1e6          # 20 warm-up calls
+        return float(np.median(us)), float(us[min(len(us) - 1, int(0.99 * len(us)))])
+
+    try:
+        dev.upload(SLOT_Y, 0, np.ones(1024))
+        dev._chk(dev.lib.esq_set_comm(dev.handle, group.comm), "esq_set_comm")
+        group.attach(dev)
+        if ctl is not None:
+            ctl.barrier()
+        med, p99 = run()
+        group._contexts = [d for d in group._contexts if d is not dev]
+        dev._chk(dev.lib.esq_set_comm(dev.handle, None), "esq_set_comm")
+        if ctl is not None:
+            ctl.barrier()
+        base, _ = run()
+    finally:
+        group._contexts = [d for d in group._contexts if d is not dev]
+        dev.close()
+    return {"median": med, "p99": p99, "median_without_collective": base,
+            "collective_median": med - base, "calls": count,
+            "path": "error-norm reduction of a 1024-element vector: k_sumsq + "
+                    "k_final_sum + ncclAllReduce(1 double) + publish to the pinned "
+                    "slot, host-timed call by call"}
+
+
 def comm_size(group):
     """number of ranks RCCL reports for the group's communicator"""
     out = C.c_int(0)

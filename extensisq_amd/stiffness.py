@@ -64,7 +64,10 @@ class _Workspace:
         base = solver._stiff_rows
         self.v = [base, base + 1, base + 2, base + 3]
         self.probe = base + 4
-        self.f_row = self.lib.esq_rk_row_id(self.ctx, 0, 0)   # f(t, y)
+        rid = self.lib.esq_rk_row_id(self.ctx, 0, 0)          # f(t, y)
+        if rid < 0:      # an error code, not a vector id (ids of rows are >= 0; the
+            solver._chk(rid, "esq_rk_row_id")    # negative ids name the fixed slots)
+        self.f_row = rid
         self.floor = sqrt(np.finfo(np.float64).tiny)
 
     def dot(self, a, b):

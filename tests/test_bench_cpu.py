@@ -113,8 +113,16 @@ def test_json_line_has_the_same_shape_for_one_and_eight_ranks():
     eight = run(8, clean_env())
     # replicas_no_collective is measured only where there is a collective to drop
     extra = {"/config/replicas_no_collective/value",
-             "/config/replicas_no_collective/ms_per_step"}
+             "/config/replicas_no_collective/ms_per_step"} | {
+        "/config/allreduce_us/" + k for k in ("median", "p99", "median_without_collective",
+                                              "collective_median", "calls", "path")}
     assert _shape(one) == _shape(one_world) == _shape(eight) - extra
+    # the lock-step line carries the price of one reduction and of lock-step itself
+    assert eight["config"]["allreduce_us"]["p99"] >= eight["config"]["allreduce_us"]["median"]
+    assert eight["config"]["lockstep_minus_replicas_ms"] is not None
+    assert one["config"]["allreduce_us"] is None
+    assert one["config"]["lockstep_minus_replicas_ms"] is None
+    assert "pinned" in eight["config"]["cpu_affinity"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline", "cpu_baseline"):

@@ -164,3 +164,39 @@ def test_rms_from_sumsq_lockstep_bookkeeping():
     s = bare(Pr9)
     s._n_norm = 8 * 100
     assert s._rms_from_sumsq(800.0 * 4.0) == 2.0
+
+
+def test_an_aborted_communicator_is_dropped_by_every_attached_context():
+    """when the library has aborted (and freed) the communicator on ONE
+    context, LockstepGroup.sync_aborted must clear the pointer on every other
+    context attached to it -- their next reduction would otherwise call
+    ncclAllReduce on a dead handle"""
+    from extensisq_amd.common import LockstepGroup
+
+    class FakeLib:
+        def __init__(self):
+            self.aborted, self.cleared = set(), []
+
+        def esq_comm_is_aborted(self, handle):
+            return 1 if handle in self.aborted else 0
+
+        def esq_set_comm(self, handle, comm):
+            assert comm is None
+            self.cleared.append(handle)
+            return 0
+
+    class FakeDev:
+        def __init__(self, lib, handle):
+            self.lib, self.handle = lib, handle
+
+    lib = FakeLib()
+    grp = LockstepGroup(comm=0xdead, n_total=30)
+    devs = [FakeDev(lib, h) for h in (11, 12, 13)]
+    for d in devs:
+        grp.attach(d)
+    assert grp.sync_aborted() is False and lib.cleared == []
+    lib.aborted.add(12)
+    devs[2].handle = None                     # a closed context is left alone
+    assert grp.sync_aborted() is True
+    assert lib.cleared == [11] and grp.comm is None
+    assert grp.sync_aborted() is True and lib.cleared == [11]
