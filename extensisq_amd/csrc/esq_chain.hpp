@@ -37,7 +37,17 @@
 #include "esq_epilogue.hpp"
 #include "esq_terms.hpp"
 
+#ifndef ESQ_CHAIN_EXP
+#define ESQ_CHAIN_EXP 0
+#endif
 namespace esq {
+#if ESQ_CHAIN_EXP == 1 || ESQ_CHAIN_EXP == 3   // what-if timing: no loads at all (results wrong)
+#define ESQ_XLD(P, K) make_double2(1e-3 * (double)(threadIdx.x & 63), 2e-3)
+#define ESQ_XLDNT(P, K) make_double2(1e-3 * (double)(threadIdx.x & 63), 2e-3)
+#else
+#define ESQ_XLD(P, K) ld2(P, K)
+#define ESQ_XLDNT(P, K) ld2_nt(P, K)
+#endif
 
 // Register budget of the two-field (Brusselator) instantiations, from
 // `hipcc -Rpass-analysis=kernel-resource-usage`: the largest number of memory
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         auto ld_ys = [&](int r, int f) -> double2 {
             if (!PERIODIC && (!live || !row_ok(r))) return make_double2(0.0, 0.0);
             const size_t k_ = (size_t)(fbase + f) * fstride + (size_t)wrap(r) * npairs + pwl;
-            return (ca.ld_nt & 1u) ? ld2_nt(ys, k_) : ld2(ys, k_);
+            return (ca.ld_nt & 1u) ? ESQ_XLDNT(ys, k_) : ESQ_XLD(ys, k_);
         };
         const double2 zero = make_double2(0.0, 0.0);
         // every weight as a scalar of its own: taken straight from the argument
@@ -173,6 +183,18 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         // row in chain4+solerr<8>, half of its vector instructions)
         double w_cu[D][ChainArgs<D, NU>::NUa], w_eu[ChainArgs<D, NU>::NUa], w_ck[D][D],
             w_ek[D];
+#if ESQ_CHAIN_EXP >= 2
+#pragma unroll
+        for (int e = 0; e < D; ++e) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) w_cu[e][j] = 0.25 + 0.01 * (e + j);
+#pragma unroll
+            for (int k = 0; k < D; ++k) w_ck[e][k] = 0.125 + 0.01 * (e + k);
+            w_ek[e] = 0.03 * e;
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) w_eu[j] = 0.01 * j;
+#else
 #pragma unroll
         for (int e = 0; e < D; ++e) {
 #pragma unroll
@@ -189,11 +211,16 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         for (int j = 0; j < NU; ++j) {
             asm("s_mov_b64 %0, %1" : "=s"(w_eu[j]) : "s"(ca.eu[j]));
         }
+#endif
         double w_c0[ChainArgs<D, NU>::NUa];
         if constexpr (FROMROWS) {
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
+#if ESQ_CHAIN_EXP >= 2
+                w_c0[j] = 0.2 + 0.01 * j;
+#else
                 asm("s_mov_b64 %0, %1" : "=s"(w_c0[j]) : "s"(ca.c0[j]));
+#endif
             }
         }
         // windows of the D stages: rows rho_k - 1, rho_k, rho_k + 1 of T_k
@@ -232,15 +259,20 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             const size_t k2_ = (size_t)(fbase + f) * fstride + base_;              \
             _Pragma("unroll") for (int j = 0; j < NU; ++j)                         \
                 u[j][f] = !act_ ? zero : ((ca.ld_nt >> (8 + j)) & 1u)                 \
-                              ? ld2_nt(ca.rows[j], k2_) : ld2(ca.rows[j], k2_);       \
+                              ? ESQ_XLDNT(ca.rows[j], k2_) : ESQ_XLD(ca.rows[j], k2_);       \
             yrow[f] = zero;                                                        \
             if (ca.y)                                                              \
-                yrow[f] = !act_ ? zero : (ca.ld_nt & 2u) ? ld2_nt(ca.y, k2_)           \
-                                                         : ld2(ca.y, k2_);        \
+                yrow[f] = !act_ ? zero : (ca.ld_nt & 2u) ? ESQ_XLDNT(ca.y, k2_)        \
+                                                         : ESQ_XLD(ca.y, k2_);     \
         }                                                                          \
     }
         // FROMROWS: T_0 of the row a set belongs to (same ascending FMA chain, the
         // same two roundings as the sweep that would have written it)
+#if ESQ_CHAIN_EXP >= 2
+#define ESQ_XBIT(M, J) true
+#else
+#define ESQ_XBIT(M, J) (((M) >> (J)) & 1u)
+#endif
 #define ESQ_CHAIN_FORM_T0(IT, U_, Y_, DST)                                                 \
     {                                                                              \
         const int rho_ = rbase + dirn * ((IT) + 1);                                \
@@ -248,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                           \
             double2 s0_ = zero;                                                    \
             _Pragma("unroll") for (int j = 0; j < NU; ++j) {                       \
-                if ((um0 >> j) & 1u) {                                             \
+                if (ESQ_XBIT(um0, j)) {                                            \
                     asm volatile("");                                              \
                     s0_.x = fma(w_c0[j], U_[j][f].x, s0_.x);                       \
                     s0_.y = fma(w_c0[j], U_[j][f].y, s0_.y);                       \
@@ -265,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
     _Pragma("unroll") for (int f = 0; f < NF; ++f) {                               \
         double2 s_ = zero, se_ = zero;                                             \
         _Pragma("unroll") for (int j = 0; j < NU; ++j) {                           \
-            if ((um[e] >> j) & 1u) {                   /* uniform */               \
+            if (ESQ_XBIT(um[e], j)) {                  /* uniform */               \
                 asm volatile("");    /* a real branch, not 2 selects per fma */    \
                 s_.x = fma(w_cu[e][j], uc[j][f].x, s_.x);                          \
                 s_.y = fma(w_cu[e][j], uc[j][f].y, s_.y);                          \
@@ -410,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                         // K_k enters the sums of the later targets
 #pragma unroll
                         for (int e = k; e < D; ++e) {
-                            if ((km[e] >> k) & 1u) {               // uniform
+                            if (ESQ_XBIT(km[e], k)) {              // uniform
                                 asm volatile("");
                                 acc[e][k][f].x = fma(w_ck[e][k], fK[f].x, acc[e][k][f].x);
                                 acc[e][k][f].y = fma(w_ck[e][k], fK[f].y, acc[e][k][f].y);
