@@ -68,6 +68,10 @@ def parse():
                     help="grid size N of the workload (default: BASELINE.json)")
     ap.add_argument("--config", default="pr8", choices=["pr8", "ts5", "pr9", "rkc"],
                     help="pr8 = the BASELINE.json metric config (default)")
+    ap.add_argument("--plugin", default=None, choices=["diff3d"],
+                    help="run the config's METHOD on another device RHS plugin: diff3d = "
+                         "3-D diffusion (default grid 159, n = 4 019 679); not the "
+                         "BASELINE.json workload -- for DESIGN.md's plugin table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-solve-ivp", action="store_true",
@@ -242,7 +246,7 @@ def dry_run(args, rank, world, ctl):
     if os.environ.get("ESQ_BENCH_DRY_FAIL_RANK") == str(rank):
         sys.exit(3)                       # a failing rank must fail the whole run
     if rank == 0:
-        meta = workload_meta(args.config, args.grid)
+        meta = workload_meta(args.config, args.grid, args.plugin)
         table = {"dry-run": {"class": meta["klass"], "launches": args.steps,
                              "total_ms": 1e3 * elapsed, "moved_bytes": 8.0 * n,
                              "floor_bytes": 8.0 * n, "algorithmic_bytes": 8.0 * n}}
@@ -273,9 +277,16 @@ STAGE_KERNEL = ("stage class: marching chain sweeps (up to 4 RHS evaluations + t
                 "stage's accumulate or the blocked accumulation as epilogue")
 
 
-def workload_meta(name, N):
+def workload_meta(name, N, plugin=None):
     """what the JSON says about a config (no arrays, no GPU)"""
     PROF_STAGE, PROF_RKC = 0, 3               # extensisq_amd._lib.PROF_*
+    if plugin == "diff3d" and name != "rkc":
+        N = N or 159
+        return dict(label=f"{name.capitalize()} on 3-D diffusion N={N} (plugin run, not "
+                          f"the BASELINE.json workload)",
+                    metric=f"accepted RK steps/s x state-dim (fp64), {name.capitalize()} "
+                           f"on the 3-D plugin",
+                    bytes_per_elt_step=None, klass=PROF_STAGE, kernel=STAGE_KERNEL)
     if name == "pr8":
         N = N or 2236
         return dict(label=f"Pr8 (13 stages) on 2-D Brusselator reaction-diffusion N={N}",
@@ -300,11 +311,23 @@ def workload_meta(name, N):
                        "stencil sweep + three-term recursion) / k_rkc_first")
 
 
-def make_workload(name, N, rank):
+def make_workload(name, N, rank, plugin=None):
     """returns a dict: device solver factory, oracle factory, byte counts"""
     import extensisq_amd as esq
     from extensisq_amd import workloads as wl
     from extensisq_amd._lib import PROF_RKC, PROF_STAGE
+    if plugin == "diff3d" and name != "rkc":
+        N = N or 159
+        rhs = esq.Diffusion3D(N)
+        h = 1.0 / rhs.spectral_radius()
+        cls = {"pr8": "Pr8", "ts5": "Ts5", "pr9": "Pr9"}[name]
+        meta = workload_meta(name, N, plugin)
+        return dict(label=meta["label"], metric=meta["metric"], cls=getattr(esq, cls),
+                    oracle=cls, rhs=rhs, y0=wl.diff3d_y0(N),
+                    kw=dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-6,
+                            nfev_stiff_detect=0),
+                    N=N, cpu_problem=("diff3d_rhs", "diff3d_y0"),
+                    bytes_per_elt_step=None, klass=PROF_STAGE, kernel=STAGE_KERNEL)
     if name == "pr8":
         N = N or 2236
         rhs, y0, h = wl.pr8_brusselator(N, shard=rank)
@@ -554,8 +577,8 @@ def main():
         # the launcher restricted this rank's visibility (one GPU per rank)
         local = local % visible
 
-    meta = workload_meta(args.config, args.grid)
-    w = make_workload(args.config, args.grid, rank)
+    meta = workload_meta(args.config, args.grid, args.plugin)
+    w = make_workload(args.config, args.grid, rank, args.plugin)
     n = w["y0"].size
     group = None
     rccl_nranks = None

@@ -31,6 +31,11 @@
 //     epi.finish(in, fresh, centre, i2, local);    // stores; adds to `local`
 //     ... after the loop, by ALL threads of the block:
 //     if (E::kReduce) block_partial(local, epi.red.partials);
+//
+// Every epilogue also has a ONE-DOUBLE-PER-THREAD twin of the three calls --
+// `In1`, load1(in, i), store_f1(f, i, fresh), finish1(in, fresh, centre, i, local),
+// i = element index -- for sweeps whose geometry rules out 16-byte accesses (3-D
+// grids with an odd edge: csrc/esq_rhs_diff3d.hip).  Same operations, same order.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -119,6 +124,23 @@ __device__ __forceinline__ double ratio_sq(double2 err, double2 ya, double2 yb,
     }
 }
 
+// one real element (the scalar twins of the epilogues)
+__device__ __forceinline__ double ratio_sq1(double err, double ya, double yb,
+                                            const double *atol_vec, double atol_s,
+                                            double rtol, size_t i, size_t n_valid) {
+    if (i >= n_valid) return 0.0;
+    const double at = atol_vec ? atol_vec[i] : atol_s;
+    const double sc = at + rtol * pmax(fabs(ya), fabs(yb));
+    const double r = err / sc;
+    return r * r;
+}
+__device__ __forceinline__ double ld1_nt(const double *p, size_t i) {
+    return __builtin_nontemporal_load(p + i);
+}
+__device__ __forceinline__ void st1_nt(double *p, size_t i, double v) {
+    __builtin_nontemporal_store(v, p + i);
+}
+
 // tolerances + destination of a weighted-RMS reduction (real states)
 struct RedArgs {
     const double *atol_vec;
@@ -139,6 +161,13 @@ struct EpiNone {
     }
     __device__ __forceinline__ void finish(const In &, double2, double2, size_t,
                                            double &) const {}
+    struct In1 {};
+    __device__ __forceinline__ void load1(In1 &, size_t) const {}
+    __device__ __forceinline__ void store_f1(double *f, size_t i, double v) const {
+        if (f_nt) st1_nt(f, i, v); else f[i] = v;
+    }
+    __device__ __forceinline__ void finish1(const In1 &, double, double, size_t,
+                                            double &) const {}
 };
 
 // out = base + h * (init + sum_j c_j K_j + c_self * fresh);  base = y, or the
@@ -180,6 +209,27 @@ struct EpiStage {
         const double2 b = y ? in.yb : centre;
         st2(out, i2, make_double2(__dadd_rn(b.x, __dmul_rn(h, acc.x)),
                                   __dadd_rn(b.y, __dmul_rn(h, acc.y))));
+    }
+    struct In1 {
+        double v[NT > 0 ? NT : 1], yb, acc0;
+    };
+    __device__ __forceinline__ void load1(In1 &in, size_t i) const {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) in.v[j] = ld1_nt(tm.p[j], i);
+        in.yb = y ? y[i] : 0.0;
+        in.acc0 = init ? ld1_nt(init, i) : 0.0;
+    }
+    __device__ __forceinline__ void store_f1(double *f, size_t i, double v) const {
+        if (f_nt) st1_nt(f, i, v); else f[i] = v;
+    }
+    __device__ __forceinline__ void finish1(const In1 &in, double fresh, double centre,
+                                            size_t i, double &) const {
+        double acc = in.acc0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc = fma(tm.c[j], in.v[j], acc);
+        if (c_self != 0.0) acc = fma(c_self, fresh, acc);          // uniform
+        const double b = y ? in.yb : centre;
+        out[i] = __dadd_rn(b, __dmul_rn(h, acc));
     }
 };
 
@@ -237,6 +287,31 @@ struct EpiBlock {
             }
         }
     }
+    struct In1 {
+        double v[NT > 0 ? NT : 1];
+    };
+    __device__ __forceinline__ void load1(In1 &in, size_t i) const {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) in.v[j] = ld1_nt(p[j], i);
+    }
+    __device__ __forceinline__ void store_f1(double *f, size_t i, double v) const {
+        if (f_nt) st1_nt(f, i, v); else f[i] = v;
+    }
+    __device__ __forceinline__ void finish1(const In1 &in, double fresh, double,
+                                            size_t i, double &) const {
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+            if (o < no) {                              // uniform
+                double acc = init[o] ? ld1_nt(init[o], i) : 0.0;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (w[j][o] != 0.0) acc = fma(w[j][o], in.v[j], acc);
+                if (w_self[o] != 0.0) acc = fma(w_self[o], fresh, acc);
+                if (o == 0 && y) out[o][i] = __dadd_rn(y[i], __dmul_rn(h, acc));
+                else st1_nt(out[o], i, acc);
+            }
+        }
+    }
 };
 
 // y_new = y + h*(sum b_j K_j + b_self*fresh); err = h*(sum e_j K_j + e_self*fresh);
@@ -289,6 +364,34 @@ struct EpiSolErr {
         local += ratio_sq<CPLX>(er, in.yb, yn, red.atol_vec, red.atol_s, red.rtol,
                                 i2, red.n_valid);
     }
+    struct In1 {
+        double v[NT > 0 ? NT : 1], yb;
+    };
+    __device__ __forceinline__ void load1(In1 &in, size_t i) const {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) in.v[j] = ld1_nt(tm.p[j], i);
+        in.yb = y[i];
+    }
+    __device__ __forceinline__ void store_f1(double *f, size_t i, double v) const {
+        if (f_nt) st1_nt(f, i, v); else f[i] = v;
+    }
+    __device__ __forceinline__ void finish1(const In1 &in, double fresh, double,
+                                            size_t i, double &local) const {
+        static_assert(!CPLX, "the scalar twin is for real states");
+        double sb = 0.0, se = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            sb = fma(tm.b[j], in.v[j], sb);
+            se = fma(tm.e[j], in.v[j], se);
+        }
+        sb = fma(b_self, fresh, sb);
+        se = fma(e_self, fresh, se);
+        const double yn = __dadd_rn(in.yb, __dmul_rn(h, sb));
+        const double er = __dmul_rn(h, se);
+        ynew[i] = yn;
+        local += ratio_sq1(er, in.yb, yn, red.atol_vec, red.atol_s, red.rtol, i,
+                           red.n_valid);
+    }
 };
 
 // FSAL: the sweep's input IS y_new, fresh = K_s;
@@ -330,6 +433,28 @@ struct EpiErrNorm {
         local += ratio_sq<CPLX>(er, in.yb, centre, red.atol_vec, red.atol_s,
                                 red.rtol, i2, red.n_valid);
     }
+    struct In1 {
+        double v[NT > 0 ? NT : 1], yb;
+    };
+    __device__ __forceinline__ void load1(In1 &in, size_t i) const {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) in.v[j] = tm.p[j][i];
+        in.yb = y[i];
+    }
+    __device__ __forceinline__ void store_f1(double *f, size_t i, double v) const {
+        if (f_nt) st1_nt(f, i, v); else f[i] = v;
+    }
+    __device__ __forceinline__ void finish1(const In1 &in, double fresh, double centre,
+                                            size_t i, double &local) const {
+        static_assert(!CPLX, "the scalar twin is for real states");
+        double se = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) se = fma(tm.c[j], in.v[j], se);
+        se = fma(e_self, fresh, se);
+        const double er = __dmul_rn(h, se);
+        local += ratio_sq1(er, in.yb, centre, red.atol_vec, red.atol_s, red.rtol, i,
+                           red.n_valid);
+    }
 };
 
 // Chebyshev recursion (sommeijer.py:312-313), same operation order as
@@ -360,6 +485,19 @@ struct EpiRkc {
                                            double &) const {
         st2(out, i2, make_double2(one(centre.x, in.b.x, in.c0.x, in.g.x, fresh.x),
                                   one(centre.y, in.b.y, in.c0.y, in.g.y, fresh.y)));
+    }
+    struct In1 {
+        double b, c0, g;
+    };
+    __device__ __forceinline__ void load1(In1 &in, size_t i) const {
+        in.b = yjm2[i];
+        in.c0 = yn[i];
+        in.g = fn[i];
+    }
+    __device__ __forceinline__ void store_f1(double *, size_t, double) const {}
+    __device__ __forceinline__ void finish1(const In1 &in, double fresh, double centre,
+                                            size_t i, double &) const {
+        out[i] = one(centre, in.b, in.c0, in.g, fresh);
     }
 };
 
@@ -394,6 +532,22 @@ struct EpiRkcErr {
                                         one(centre.y, in.b.y, in.g.y, fresh.y));
         local += ratio_sq<false>(er, centre, in.b, red.atol_vec, red.atol_s,
                                  red.rtol, i2, red.n_valid);
+    }
+    struct In1 {
+        double b, g;
+    };
+    __device__ __forceinline__ void load1(In1 &in, size_t i) const {
+        in.b = yn[i];
+        in.g = fn[i];
+    }
+    __device__ __forceinline__ void store_f1(double *f, size_t i, double v) const {
+        if (f_nt) st1_nt(f, i, v); else f[i] = v;
+    }
+    __device__ __forceinline__ void finish1(const In1 &in, double fresh, double centre,
+                                            size_t i, double &local) const {
+        const double er = one(centre, in.b, in.g, fresh);
+        local += ratio_sq1(er, centre, in.b, red.atol_vec, red.atol_s, red.rtol, i,
+                           red.n_valid);
     }
 };
 

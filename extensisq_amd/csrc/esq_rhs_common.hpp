@@ -40,7 +40,7 @@ struct Rhs {
     // tuning / test knobs, read from the environment ONCE when the plugin object is
     // made (ESQ_RKC_FORCE: chain sweeps on grids of any size; ESQ_RKC_PLANES:
     // planes per tile of the 3-D chain sweeps, 0 = chosen by geo_rkc3d)
-    int rkc_force, rkc_planes, rkc_jt, rkc_nw;
+    int rkc_force, rkc_planes, rkc_jt, rkc_nw, diff3d_r;
 };
 
 // band remap: logical block id such that XCD x (label blockIdx%8) sweeps the

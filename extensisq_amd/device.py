@@ -523,12 +523,11 @@ class Diffusion3D(_Builtin):
     """7-point diffusion on an N^3 interior grid, Dirichlet 0
     (BASELINE.json configs[3])."""
     _symbol = "esq_rhs_diff3d"
-    _symbol_fused = "esq_rhs_diff3d_fused"      # end of a Chebyshev step only
+    _symbol_fused = "esq_rhs_diff3d_fused"
     _symbol_rkc = "esq_rhs_diff3d_rkc"
     _symbol_rkc_chain = "esq_rhs_diff3d_rkc_chain"
     _fuse_default = True
-    _fuse_src = False
-    _fuse_mask = 1 << _lib.EPI_RKCERR
+    _fuse_src = False                 # no on-the-fly first-stage input in 3-D
 
     def __init__(self, N):
         super().__init__()

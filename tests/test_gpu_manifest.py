@@ -34,6 +34,7 @@ REQUIRED = {
     "test_gpu_parity.py::test_full_size_pr9_heat_step_matches_oracle": 1,
     "test_gpu_parity.py::test_full_size_linearity_and_exactness": 1,
     "test_gpu_parity.py::test_full_size_three_steps_match_oracle": 2,
+    "test_gpu_parity.py::test_diffusion3d_erk_fused_sweeps": 12,
     "test_gpu_parity.py::test_full_size_free_controller_with_rejections_matches_oracle": 1,
     "test_gpu_parity.py::test_assigning_the_state_keeps_the_old_derivative": 3,
     "test_gpu_parity.py::test_full_size_fused_equals_unfused": 3,

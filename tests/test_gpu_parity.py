@@ -599,6 +599,52 @@ def test_assigning_the_state_keeps_the_old_derivative(monkeypatch, name, mk, y0f
     assert_allclose(a.y, o.y, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("N", [13, 40, 64, 159])
+@pytest.mark.parametrize("name", ["Pr8", "Ts5", "BS5"])
+def test_diffusion3d_erk_fused_sweeps(monkeypatch, name, N):
+    """explicit pairs on the 3-D plugin (the reference treats every `fun` alike,
+    common.py:353-356; its own demo problems are 3-D): with the plugin's fused
+    entry every RHS sweep carries the stage arithmetic that follows it (stage
+    argument, blocked accumulation, solution + error sums, FSAL error norm) --
+    bit-identical to the one-kernel-per-operation sequence (ESQ_CHAIN=0), the first
+    step within the single-step bounds of the oracle, odd and even grids, up to
+    the BASELINE.json configs[3] grid N = 159 (n = 4 019 679)"""
+    y0 = pb.diff3d_y0(N)
+    if N < 100:
+        y0 = y0 + 1e-3 * np.random.default_rng(N).standard_normal(N ** 3)
+    rho = 12.0 * (N + 1) ** 2
+    h = 1.0 / rho
+    # (tolerances at which no attempt is rejected: every run takes bitwise the same h)
+    kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+    fused = DEV[name](esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_CHAIN", "0")
+    plain = DEV[name](esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_CHAIN")
+    plain._prelaunch = False
+    o = rk_oracle.METHODS[name](pb.diff3d_rhs(N), 0.0, y0, 1.0, **kw)
+    y_old = o.y
+    assert fused.step() is None and plain.step() is None and o.step() is None
+    assert int(esq.NFS[()]) == 0 and int(rk_oracle.NFS[()]) == 0
+    check_step(fused, o.K, o.y, o.error_norm_old, o.h_abs, y_old, o.h_previous,
+               1e-3, 1e-6, k_rtol=2e-13, lipschitz=rho)
+    from extensisq_amd._lib import PROF_RHS, PROF_SOLERR, PROF_STAGE
+    fused._dev.profile_reset()
+    fused._dev.profile_enable([PROF_STAGE, PROF_RHS, PROF_SOLERR])
+    for _ in range(2):
+        assert fused.step() is None and plain.step() is None
+        assert fused.t == plain.t
+        assert_allclose(fused.error_norm_old, plain.error_norm_old, rtol=1e-11)
+    fused._dev.profile_enable(None)
+    labels = {row[0].split("<")[0] for row in fused._dev.profile_kernels()}
+    assert "rhs+stage" in labels, labels
+    if name == "Pr8":       # every RHS evaluation of the step is a fused sweep
+        assert "rhs_plugin" not in labels and "k_lincomb" not in labels, labels
+        assert {"rhs+block", "rhs+solerr"} <= labels, labels
+    assert_equal(fused.y, plain.y)
+    assert_equal(fused.K, plain.K)
+    assert fused.nfev == plain.nfev
+
+
 @pytest.mark.parametrize("name,plugin,N", [("Pr8", "bruss", 2236), ("Ts5", "heat", 1000),
                                            ("Pr9", "heat", 2236)])
 def test_full_size_fused_equals_unfused(monkeypatch, name, plugin, N):
