@@ -263,26 +263,35 @@ struct EpiBlock {
 #pragma unroll
         for (int o = 0; o < kMaxOut; ++o) {
             if (o < no) {                              // uniform
+                // the output's column of weights is fetched HERE (an index the
+                // compiler cannot see through): hoisted to the top of the kernel,
+                // the up to 20 x 12 weights of all outputs live in scalar registers
+                // at once and spill (EpiBlock<7>: 80-176 spilled SGPRs by
+                // instantiation, the heat block sweep 118 vs 147 us)
+                int oo = o;
+                asm volatile("" : "+s"(oo));
                 double2 acc = make_double2(0.0, 0.0);
-                if (init[o]) acc = ld2_nt(init[o], i2);
+                if (init[oo]) acc = ld2_nt(init[oo], i2);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    if (w[j][o] != 0.0) {              // uniform (SGPR weights)
-                        acc.x = fma(w[j][o], in.v[j].x, acc.x);
-                        acc.y = fma(w[j][o], in.v[j].y, acc.y);
+                    const double wj = w[j][oo];
+                    if (wj != 0.0) {                   // uniform (SGPR weights)
+                        acc.x = fma(wj, in.v[j].x, acc.x);
+                        acc.y = fma(wj, in.v[j].y, acc.y);
                     }
                 }
-                if (w_self[o] != 0.0) {
-                    acc.x = fma(w_self[o], fresh.x, acc.x);
-                    acc.y = fma(w_self[o], fresh.y, acc.y);
+                const double ws = w_self[oo];
+                if (ws != 0.0) {
+                    acc.x = fma(ws, fresh.x, acc.x);
+                    acc.y = fma(ws, fresh.y, acc.y);
                 }
                 if (o == 0 && y) {
                     const double2 yb = ld2(y, i2);
                     acc.x = __dadd_rn(yb.x, __dmul_rn(h, acc.x));
                     acc.y = __dadd_rn(yb.y, __dmul_rn(h, acc.y));
-                    st2(out[o], i2, acc);      // stage argument: read next
+                    st2(out[oo], i2, acc);     // stage argument: read next
                 } else {
-                    st2_nt(out[o], i2, acc);   // partial sums: stream out
+                    st2_nt(out[oo], i2, acc);  // partial sums: stream out
                 }
             }
         }

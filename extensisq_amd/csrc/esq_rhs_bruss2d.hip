@@ -39,65 +39,10 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d(
     }
 }
 
-// ---------------------------------------------------------------------------
-// SWEEPS.  One wave tile = 64 column pairs of ONE grid row; all three window
-// rows are requested up front, together with the epilogue's operands, so every
-// load of the thread is in flight before the first use.  `Epi` (esq_epilogue.hpp)
-// says what happens to the fresh derivative: store only (EpiNone), next stage
-// argument (EpiStage), blocked accumulation (EpiBlock), solution + error norm
-// (EpiSolErr), FSAL error norm (EpiErrNorm), Chebyshev recursion (EpiRkc).
-// The epilogues are pointwise: nothing is recomputed on halos.
-// ---------------------------------------------------------------------------
-template <class Epi, class Src>
-__global__ __launch_bounds__(kBlock) void k_bruss2d_sweep(
-    Src ys, double *__restrict__ f, Epi epi, int N,
-    double d, double A, double B, unsigned nblocks, unsigned wpr) {
-    const unsigned tile = band_block(blockIdx.x, nblocks) * (kBlock / 64) + (threadIdx.x >> 6);
-    const int i = (int)(tile / wpr);
-    double local = 0.0;
-    if (i < N) {                                           // wave-uniform
-        const size_t NN = (size_t)N * N;
-        RowWin<true, Src> U, V;
-        U.src = V.src = ys;
-        U.base = 0; V.base = NN;
-        U.N = V.N = N;
-        U.npairs = V.npairs = (unsigned)N / 2;
-        U.pair = V.pair = (tile % wpr) * 64 + (threadIdx.x & 63);
-        U.live = V.live = U.pair < U.npairs;
-        const size_t k2 = ((size_t)i * N) / 2 + (U.live ? U.pair : 0);   // N even
-        const size_t v2 = NN / 2 + k2;
-        typename Epi::In cu, cv;
-        epi.load(cu, k2);
-        epi.load(cv, v2);
-        const double2 uu = U.row(i - 1), uc = U.row(i), ud = U.row(i + 1);
-        const double2 vu = V.row(i - 1), vc = V.row(i), vd = V.row(i + 1);
-        double ul, urt, vl, vrt;
-        U.sides(i, uc, ul, urt);
-        V.sides(i, vc, vl, vrt);
-        double2 fu, fv;
-        {
-            const double lapx = ((uu.x + ud.x) + (ul + uc.y)) - 4.0 * uc.x;
-            const double lapy = ((uu.y + ud.y) + (uc.x + urt)) - 4.0 * uc.y;
-            const double lvx = ((vu.x + vd.x) + (vl + vc.y)) - 4.0 * vc.x;
-            const double lvy = ((vu.y + vd.y) + (vc.x + vrt)) - 4.0 * vc.y;
-            const double uuvx = uc.x * uc.x * vc.x, uuvy = uc.y * uc.y * vc.y;
-            fu.x = ((A + uuvx) - (B + 1.0) * uc.x) + d * lapx;
-            fu.y = ((A + uuvy) - (B + 1.0) * uc.y) + d * lapy;
-            fv.x = (B * uc.x - uuvx) + d * lvx;
-            fv.y = (B * uc.y - uuvy) + d * lvy;
-        }
-        if (U.live) {
-            epi.store_f(f, k2, fu);
-            epi.store_f(f, v2, fv);
-            epi.finish(cu, fu, uc, k2, local);
-            epi.finish(cv, fv, vc, v2, local);
-        }
-    }
-    if (Epi::kReduce) esq::block_partial(local, epi.red.partials);
-}
-
-// pointwise part of the Brusselator for the two-stage marching sweep: centres
-// and five-point Laplacians of (u, v) -> (du, dv), same operation order as above
+// The plugin's pointwise functor: centres and five-point Laplacians of (u, v) ->
+// (du, dv), same operation order as k_bruss2d.  Everything else -- the one-stage
+// sweep with its epilogues, the marching chain sweeps, the launch geometry -- is
+// esq_stencil2d.hpp, shared with the heat plugin and with user plugins.
 struct BrussFn {
     double d, A, B;
     __device__ __forceinline__ void eval(const double2 (&c)[2], const double2 (&lap)[2],
@@ -119,6 +64,14 @@ struct BrussFn {
     }
 };
 
+// one field per wave in the chain sweeps (default), or both fields in one wave
+// (ESQ_CHAIN_SPLIT=0: the first version, narrower register caps)
+using BrussSplit = esq::Stencil2D<2, true, BrussFn, true>;
+using BrussJoint = esq::Stencil2D<2, true, BrussFn, false>;
+inline BrussFn fn_of(const Rhs *r) {
+    return BrussFn{r->alpha * ((double)r->N * (double)r->N), r->a, r->b};
+}
+
 }  // namespace
 
 extern "C" {
@@ -138,14 +91,8 @@ int esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != BRUSS2D || n != r->n) return ESQ_EINVAL;
     const double d = r->alpha * ((double)r->N * (double)r->N);
-    if (r->N % 2 == 0 && r->N >= 4 && rhs_variant() != 1) {
-        const Geo2d g = geo2d(r->N);
-        esq::EpiNone ep{};
-        hipLaunchKernelGGL((k_bruss2d_sweep<esq::EpiNone, SrcPlain>), dim3(g.grid),
-                           dim3(kBlock), 0, (hipStream_t)stream, SrcPlain{y}, f, ep, r->N, d, r->a, r->b,
-                           g.grid, g.wpr);
-        return (int)hipGetLastError();
-    }
+    if (BrussSplit::grid_ok(r->N) && rhs_variant() != 1)
+        return BrussSplit::rhs(fn_of(r), r->N, y, f, stream);
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;
     unsigned nblocks = bpr * (unsigned)r->N;
     const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
@@ -165,33 +112,7 @@ int esq_rhs_bruss2d_fused(void *user, double t, const double *y_in, double *f,
     (void)t;
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != BRUSS2D || n != r->n || !epi) return ESQ_EINVAL;
-    if (r->N % 2 != 0 || r->N < 4) return ESQ_ENOTSUP;
-    const Geo2d g = geo2d(r->N);
-    if (esq::epilogue_reduces(epi)) {
-        if ((int)g.grid > epi->partials_cap) return ESQ_ENOTSUP;
-        if (epi->partials_used) *epi->partials_used = (int)g.grid;
-    }
-    const double d = r->alpha * ((double)r->N * (double)r->N);
-    if (epi->in_row && !first_stage_ok(epi)) return ESQ_ENOTSUP;
-    const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
-        using E = decltype(ep);
-        if constexpr (kFirstStage<E>) {
-            if (epi->in_row) {
-                hipExtLaunchKernelGGL((k_bruss2d_sweep<E, SrcAxpy>), dim3(g.grid),
-                                      dim3(kBlock), 0, (hipStream_t)stream,
-                                      (hipEvent_t)start_event, (hipEvent_t)stop_event,
-                                      0, axpy_of(epi), f, ep, r->N, d, r->a, r->b,
-                                      g.grid, g.wpr);
-                return;
-            }
-        }
-        hipExtLaunchKernelGGL((k_bruss2d_sweep<E, SrcPlain>), dim3(g.grid),
-                              dim3(kBlock), 0, (hipStream_t)stream,
-                              (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
-                              SrcPlain{y_in}, f, ep, r->N, d, r->a, r->b, g.grid,
-                              g.wpr);
-    });
-    return rc ? rc : (int)hipGetLastError();
+    return BrussSplit::fused(fn_of(r), r->N, y_in, f, epi, stream, start_event, stop_event);
 }
 
 int esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chain,
@@ -199,46 +120,9 @@ int esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chain
                           void *stop_event) {
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != BRUSS2D || n != r->n || !chain) return ESQ_EINVAL;
-    if (r->N % 2 != 0 || r->N < 16) return ESQ_ENOTSUP;
-    if (!chain_fits_grid(r->N, chain->depth)) return ESQ_ENOTSUP;
-    // register budget (esq_chain.hpp, ChainCaps): one field per wave keeps two
-    // waves per SIMD up to depth 4 with 9 memory rows; ESQ_CHAIN_SPLIT=0 runs
-    // both fields in one wave (the first version; narrower caps)
     static const bool split = !getenv("ESQ_CHAIN_SPLIT") || atoi(getenv("ESQ_CHAIN_SPLIT")) != 0;
-    if (!esq::chain_within_caps(chain->depth, chain->kind_last == ESQ_EPI_SOLERR,
-                                chain->nu, split))
-        return ESQ_ENOTSUP;
-    const BrussFn fn{r->alpha * ((double)r->N * (double)r->N), r->a, r->b};
-    int rc_launch = 0;
-    auto body = [&](auto ca, auto kind, auto split_c, auto from_c) {
-        using CA = decltype(ca);
-        constexpr bool kSplit = decltype(split_c)::value;
-        constexpr bool kFrom = decltype(from_c)::value && kSplit;
-        if (decltype(from_c)::value && !kSplit) { rc_launch = ESQ_ENOTSUP; return; }
-        auto kern = esq::k_chain2d<2, true, CA::kD, CA::kNU, decltype(kind)::value, BrussFn, kSplit,
-                                   kFrom>;
-        const unsigned block = kSplit ? 128u : (unsigned)kBlock;
-        static const int wpc = chain_waves_per_cu(kern, block);       // per instantiation
-        const GeoChain g = geo_chain(r->N, CA::kD, wpc, kSplit ? 1 : kBlock / 64, kSplit ? 2 : 1);
-        if (decltype(kind)::value == ESQ_EPI_SOLERR) {
-            if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
-            if (chain->partials_used) *chain->partials_used = (int)g.grid;
-        }
-        if (chain->read_amplification)
-            *chain->read_amplification = (double)(g.R + 2 * (CA::kD - 1) + (kFrom ? 2 : 0)) /
-                                         g.R * 64.0 / (64 - 2 * (CA::kD - 1));
-        hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(block), 0, (hipStream_t)stream,
-                              (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in,
-                              ca, fn, r->N, g.R, g.tpr, g.ntiles, g.nblocks,
-                              (unsigned)kXcd, chain_serpentine());
-    };
-    const int rc = split
-        ? esq::dispatch_chain<6>(chain, [&](auto ca, auto kind, auto from_c) {
-              body(ca, kind, std::true_type{}, from_c); })
-        : esq::dispatch_chain<4>(chain, [&](auto ca, auto kind, auto from_c) {
-              body(ca, kind, std::false_type{}, from_c); });
-    if (rc) return rc;
-    return rc_launch ? rc_launch : (int)hipGetLastError();
+    return split ? BrussSplit::chain(fn_of(r), r->N, y_in, chain, stream, start_event, stop_event)
+                 : BrussJoint::chain(fn_of(r), r->N, y_in, chain, stream, start_event, stop_event);
 }
 
 }  // extern "C"

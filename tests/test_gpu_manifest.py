@@ -43,6 +43,7 @@ REQUIRED = {
     "test_gpu_parity.py::test_solve_ivp_device_rhs_t_eval_and_events": 3,
     "test_gpu_parity.py::test_user_plugin_compiled_with_hipcc": 1,
     "test_gpu_parity.py::test_user_plugin_with_fused_entry": 3,
+    "test_gpu_parity.py::test_user_compiled_chain_plugin": 2,
     "test_gpu_parity.py::test_user_defined_tableau": 1,
     "test_gpu_parity.py::test_step_limits_and_failures": 8,
     "test_gpu_parity.py::test_classes_contract": 8,

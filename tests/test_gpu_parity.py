@@ -1104,6 +1104,163 @@ def _user_fused_plugin(tmp_path_factory, ctypes, shutil, subprocess):
     return _FUSED_SO["so"]
 
 
+# --------------------------------- a user's stencil plugin with all three entries
+# INTEGRATION.md §4 prints this source: a third 2-D stencil -- the Gray-Scott
+# reaction-diffusion system, two fields, periodic -- whose author writes the
+# pointwise functor and six lines per entry point; the sweeps, the epilogues, the
+# marching chain sweeps and their launch geometry come from esq_stencil2d.hpp.
+GRAY_SCOTT_PLUGIN_SRC = r'''
+#include "esq_stencil2d.hpp"            // -I <repo>/extensisq_amd/csrc
+
+// u_t = Du lap(u) - u v^2 + F (1 - u),   v_t = Dv lap(v) + u v^2 - (F + k) v
+// on an N x N periodic grid, state = [u.ravel(), v.ravel()]
+struct GrayScott {
+    double du, dv, F, k;                // Du / dx^2, Dv / dx^2, feed, kill
+    __device__ __forceinline__ void eval(const double2 (&c)[2], const double2 (&lap)[2],
+                                         double2 (&f)[2]) const {
+        f[0] = eval_one(0, c, lap[0]);
+        f[1] = eval_one(1, c, lap[1]);
+    }
+    __device__ __forceinline__ double2 eval_one(int field, const double2 (&c)[2],
+                                                double2 lap) const {
+        const double uvvx = c[0].x * c[1].x * c[1].x, uvvy = c[0].y * c[1].y * c[1].y;
+        if (field == 0)
+            return make_double2((du * lap.x - uvvx) + F * (1.0 - c[0].x),
+                                (du * lap.y - uvvy) + F * (1.0 - c[0].y));
+        return make_double2((dv * lap.x + uvvx) - (F + k) * c[1].x,
+                            (dv * lap.y + uvvy) - (F + k) * c[1].y);
+    }
+};
+struct User { int N; GrayScott fn; };
+using P = esq::Stencil2D<2, /*PERIODIC=*/true, GrayScott>;
+
+extern "C" int gs_rhs(void *user, double, const double *y, double *f, size_t n, void *stream) {
+    const User *u = (const User *)user;
+    if (n != 2 * (size_t)u->N * u->N) return ESQ_EINVAL;
+    return P::rhs(u->fn, u->N, y, f, stream);
+}
+extern "C" int gs_fused(void *user, double, const double *y, double *f, const esq_epilogue *epi,
+                        size_t, void *stream, void *e0, void *e1) {
+    const User *u = (const User *)user;
+    return P::fused(u->fn, u->N, y, f, epi, stream, e0, e1);
+}
+extern "C" int gs_chain(void *user, const double *y, const esq_chain *chain, size_t,
+                        void *stream, void *e0, void *e1) {
+    const User *u = (const User *)user;
+    return P::chain(u->fn, u->N, y, chain, stream, e0, e1);
+}
+'''
+
+_GS_SO = {}
+
+
+def _gray_scott_plugin(tmp_path_factory):
+    import shutil
+    import subprocess
+    if "so" not in _GS_SO:
+        d = tmp_path_factory.mktemp("gs_plugin")
+        src, so = d / "gray_scott.hip", d / "libgray_scott.so"
+        src.write_text(GRAY_SCOTT_PLUGIN_SRC)
+        root = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                        "-shared", "-ffp-contract=off",
+                        "-I", os.path.join(root, "extensisq_amd", "csrc"),
+                        str(src), "-o", str(so)], check=True)
+        _GS_SO["so"] = so
+    return _GS_SO["so"]
+
+
+def _gray_scott_numpy(N, du, dv, F, k):
+    """NumPy twin of the functor, same operation order"""
+    def fun(t, y):
+        u, v = y[:N * N].reshape(N, N), y[N * N:].reshape(N, N)
+
+        def lap(a):
+            return ((np.roll(a, 1, 0) + np.roll(a, -1, 0))
+                    + (np.roll(a, 1, 1) + np.roll(a, -1, 1))) - 4.0 * a
+        uvv = u * v * v
+        fu = (du * lap(u) - uvv) + F * (1.0 - u)
+        fv = (dv * lap(v) + uvv) - (F + k) * v
+        return np.concatenate([fu.ravel(), fv.ravel()])
+    return fun
+
+
+@pytest.mark.parametrize("name", ["Pr8", "Ts5"])
+def test_user_compiled_chain_plugin(monkeypatch, tmp_path_factory, name):
+    """a THIRD stencil, compiled by the user with hipcc against esq_stencil2d.hpp
+    only, with all three entries registered through CFunctionRHS: its RHS agrees
+    bit for bit with the NumPy twin of the functor, its chained steps (marching
+    sweeps of up to 4-5 stages, one field per wave) are bit-identical to its own
+    one-sweep-per-stage steps (ESQ_CHAIN_DEPTH=1) and to the entry-free run, and
+    within the single-step bounds of the oracle on the twin"""
+    import ctypes
+    from extensisq_amd import _lib
+    lib = ctypes.CDLL(str(_gray_scott_plugin(tmp_path_factory)))
+
+    class GS(ctypes.Structure):
+        _fields_ = [("du", ctypes.c_double), ("dv", ctypes.c_double),
+                    ("F", ctypes.c_double), ("k", ctypes.c_double)]
+
+    class User(ctypes.Structure):
+        _fields_ = [("N", ctypes.c_int), ("fn", GS)]
+
+    N = 96
+    du, dv, F, k = 0.16 * 4.0, 0.08 * 4.0, 0.035, 0.06
+    user = User(N, GS(du, dv, F, k))
+    ptr = lambda f: ctypes.cast(f, ctypes.c_void_p)      # noqa: E731
+    rhs_ptr = ptr(lib.gs_rhs).value
+
+    class Plugin(esq.CFunctionRHS):
+        _fuse_default = True
+        _chain_caps = 15
+
+        def _fused_entry(self, lib_):
+            return ptr(lib.gs_fused)
+
+        def _chain_entry(self, lib_):
+            return ptr(lib.gs_chain)
+
+    rng = np.random.default_rng(5)
+    u0 = 1.0 - 0.5 * rng.random((N, N))
+    v0 = 0.25 * rng.random((N, N))
+    y0 = np.concatenate([u0.ravel(), v0.ravel()])
+    twin = _gray_scott_numpy(N, du, dv, F, k)
+    plain = esq.CFunctionRHS(rhs_ptr, ctypes.addressof(user), y0.size)
+    assert_equal(plain(0.0, y0), twin(0.0, y0))          # the RHS: bit for bit
+    rho = 8.0 * du + 1.0
+    h = 0.5 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+    cls = DEV[name]
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", "12")           # chains on this small grid
+    chained = cls(Plugin(rhs_ptr, ctypes.addressof(user), y0.size), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_CHAIN_DEPTH", "1")
+    single = cls(Plugin(rhs_ptr, ctypes.addressof(user), y0.size), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_CHAIN_DEPTH")
+    bare = cls(plain, 0.0, y0, 1.0, **kw)
+    o = rk_oracle.METHODS[name](twin, 0.0, y0, 1.0, **kw)
+    y_old = o.y
+    for s in (chained, single, bare, o):
+        assert s.step() is None
+    check_step(chained, o.K, o.y, o.error_norm_old, o.h_abs, y_old, o.h_previous,
+               1e-6, 1e-9, k_rtol=2e-13, lipschitz=rho)
+    chained._dev.profile_reset()
+    chained._dev.profile_enable([_lib.PROF_STAGE, _lib.PROF_SOLERR, _lib.PROF_RHS])
+    for _ in range(3):
+        for s in (chained, single, bare):
+            assert s.step() is None
+        assert chained.t == single.t == bare.t
+    chained._dev.profile_enable(None)
+    labels = {row[0].split("<")[0] for row in chained._dev.profile_kernels()}
+    assert any(lab.startswith("chain") for lab in labels), labels
+    assert "rhs_plugin" not in labels, labels
+    assert_equal(chained.y, single.y)
+    assert_equal(chained.y, bare.y)
+    assert_equal(chained.K, single.K)
+    assert_equal(chained.K, bare.K)
+    assert chained.nfev == single.nfev == bare.nfev
+
+
 # -------------------------------------------------- CKdisc (variable order)
 @pytest.mark.parametrize("case", ["readme", "duffing", "rational_bwd", "complex",
                                   "sawtooth", "kink", "bruss1d"])
