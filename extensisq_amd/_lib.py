@@ -19,6 +19,8 @@ EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
 EPI_RKCERR = 6
 FUSE_ALL = 0x5e
 FUSE_SRC = 0x20
+FUSE_QUERY = 0x80
+CHAIN_CAP_ALL, CHAIN_CAP_QUERY = 15, 16
 CREATE_HOST_SLAB = 1
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
 PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC = range(4)
@@ -67,6 +69,9 @@ SIGNATURES = {
     "esq_rk_row_id": (C.c_int, [_vp, C.c_int, C.c_int]),
     "esq_rk_download_last_K": (C.c_int, [_vp, C.c_int, _vp]),
     "esq_rk_lazy_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "esq_plan_describe": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_char_p, C.c_size_t]),
     "esq_dense_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int,
                                    _vpp]),
     "esq_dense_eval": (C.c_int, [_vp, C.c_double, _vp]),

@@ -586,6 +586,7 @@ int esq_set_rhs(esq_ctx *c, esq_rhs_fn fn, void *user) {
     c->rhs_user = user;
     c->rhs_fused = nullptr;
     c->fuse_mask = 0;
+    drop_plans(c);
     c->rhs_rkc = nullptr;
     c->rhs_rkc_chain = nullptr;
     c->rkc_depth = 1;
@@ -626,8 +627,7 @@ int esq_set_rhs_fused(esq_ctx *c, esq_rhs_fused_fn fn, int fuse_mask) {
     ENTER(c);
     c->rhs_fused = fn;
     c->fuse_mask = fn ? fuse_mask : 0;
-    c->src_declined = false;
-    std::fill(c->chain_refused.begin(), c->chain_refused.end(), 0);
+    drop_plans(c);
     return 0;
 }
 
@@ -636,9 +636,15 @@ int esq_aux_rows(esq_ctx *c, int count, int *first_id) {
     ENTER(c);
     double *mem = nullptr;
     const size_t bytes = (size_t)count * c->stride * sizeof(double);
-    HIPCHK(c, hipMalloc(&mem, bytes));
-    HIPCHK(c, hipMemsetAsync(mem, 0, bytes, c->stream));
-    c->aux_slabs.push_back(mem);
+    if (c->detached) {
+        // no device behind this context (esq_plan_describe): distinct fake addresses
+        mem = reinterpret_cast<double *>(((uintptr_t)2 << 40) +
+                                         (uintptr_t)c->n_rows * c->stride * sizeof(double));
+    } else {
+        HIPCHK(c, hipMalloc(&mem, bytes));
+        HIPCHK(c, hipMemsetAsync(mem, 0, bytes, c->stream));
+        c->aux_slabs.push_back(mem);
+    }
     *first_id = c->n_rows;
     for (int r = 0; r < count; ++r) {
         c->krow.push_back(mem + (size_t)r * c->stride);

@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,34 @@ struct HostSlot {
 struct Term {
     int col;
     double c;
+};
+
+// ---- the step as a program (esq_step.hip: build_plan / run_plan) --------------
+// One entry = one launch (or library kernel pair) of esq_rk_stages.  A plan is
+// built ONCE per (stage range, what the step starts from) by asking the plugin's
+// entries side-effect-free queries (esq_chain.dry_run / esq_epilogue.dry_run) and
+// replayed every step.
+enum PlanOp : unsigned char {
+    OP_RHS_K0,        // K[0] = f(t, y): the end-point derivative the last accept deferred
+    OP_CHAIN,         // `depth` stages from stage i in one marching sweep (i == 0: from K[0])
+    OP_SRC_STAGE,     // stage 1's sweep forms its input from y and K[0] (ESQ_FUSE_SRC)
+    OP_ACCUM,         // argument of stage i: blocked accumulation at a boundary / k_lincomb
+    OP_LINCOMB,       // argument of stage i after a block sweep left only the partial sums
+    OP_STAGE_SWEEP,   // RHS sweep of stage i + argument of stage i + 1
+    OP_BLOCK_SWEEP,   // RHS sweep of stage i + blocked accumulation at boundary i + 1
+    OP_YNEW_SWEEP,    // FSAL: RHS sweep of the last stage + y_new
+    OP_SOLERR_SWEEP,  // others: RHS sweep of the last stage + y_new + error partial sums
+    OP_RHS            // plain RHS launch of stage i
+};
+struct PlanStep {
+    unsigned char op;
+    signed char i, depth, what;       // what: 0 next argument, 1 y_new (FSAL), 2 y_new + error
+    bool lazy, from_rows, skip_out;   // chain forms
+    float reads, writes;              // designed words per element (halo re-reads not counted)
+};
+struct Plan {
+    std::vector<PlanStep> steps;
+    bool ynew_ready = false, solerr_ready = false;   // formed by the last launch
 };
 
 }  // namespace esqi
@@ -107,7 +136,6 @@ struct esq_ctx {
     void *rhs_user = nullptr;
     esq_rhs_fused_fn rhs_fused = nullptr;   // optional RHS + epilogue entry
     int fuse_mask = 0;                      // epilogue kinds the library may request
-    bool src_declined = false;              // the PLUGIN returned ENOTSUP for ESQ_FUSE_SRC
     bool src_pays = false;                  // working set inside the Infinity Cache
     esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
     esq_rhs_rkc_chain_fn rhs_rkc_chain = nullptr;   // optional multi-stage RKC sweep
@@ -115,13 +143,14 @@ struct esq_ctx {
     unsigned rkc_refused = 0;               // bit D: the plugin declined depth D
     esq_rhs_chain_fn rhs_chain = nullptr;   // optional multi-stage marching sweep
     int chain_depth = 4;                    // ESQ_CHAIN_DEPTH: 1 off, up to 4 stages per sweep
-    // chains the plugin (or the library) has refused for this tableau / grid:
-    // refused[i * 8 + D] -- not asked again every step (esq_replan clears it)
     int chain_caps = 0;                     // ESQ_CHAIN_CAP_*: what the chain entry handles
-    std::vector<char> chain_refused;
-    // from_rows[i * 8 + D]: the chain of depth D at stage i forms its own input from
-    // the rows it reads (esq_chain.from_rows): 0 not tried, 1 it does, 2 declined
-    std::vector<char> from_rows;
+    // the step programs of this context by key (stage range, ready, k0_missing,
+    // lazy rows), and the launches a plugin WITHOUT the query capability has refused
+    // at run time (signature of the plan step); both dropped when the tableau or a
+    // plugin entry changes (esqi::drop_plans)
+    std::map<unsigned, esqi::Plan> plans;
+    std::set<unsigned long long> refused;
+    bool detached = false;                // no device behind the context (esq_plan_describe)
     bool chain_from_rows = true;          // ESQ_CHAIN_FROM_ROWS=0: never
     unsigned chain_ld_nt[3] = {4, 4, 4};  // ESQ_CHAIN_LDNT: forced load policy of the
     bool chain_ld_nt_set = false;         // first / middle / last chain (tuning)
@@ -167,7 +196,6 @@ struct esq_ctx {
     bool lazy_end = true;
     bool k0_missing = false;
     double k0_t = 0.0;
-    int end_fused_ok = -1;                // -1 not tried yet, 0 the plugin declined
     long end_fused = 0, end_plain = 0;    // how the end-point evaluations ran
     // launch geometry
     unsigned grid_stream = 0;         // grid for streaming kernels
@@ -263,6 +291,8 @@ int build_row_terms2(esq_ctx *c, const double *b, int nb, const double *e, int n
 // ---- esq_step.hip --------------------------------------------------------------
 // re-evaluate the rows of K the last chain sweep did not write (lazy_rows)
 int restore_rows(esq_ctx *c);
+// forget the step programs (the tableau, a plugin entry or a tuning knob changed)
+void drop_plans(esq_ctx *c);
 // ---- esq_core.hip ------------------------------------------------------------
 // sink of the next reduction / completion signal (bumps red_seq)
 ResultSink next_sink(esq_ctx *c, bool to_host_value);

@@ -107,8 +107,9 @@ EpiErrNorm<NT, CPLX> make_errnorm(const esq_epilogue *e) {
 
 // (kind, nt) -> launch(device-side epilogue object).  Returns 0 after the call,
 // ESQ_EINVAL for an inconsistent description, ESQ_ENOTSUP outside the
-// instantiated ranges.
-#define ESQ_EPI_CASE_(MAKE, K) case K: launch(MAKE<K>(epi)); return 0;
+// instantiated ranges.  epi->dry_run: the same answer without the call (the
+// library's side-effect-free query, ESQ_FUSE_QUERY).
+#define ESQ_EPI_CASE_(MAKE, K) case K: if (!epi->dry_run) launch(MAKE<K>(epi)); return 0;
 #define ESQ_EPI_CASES_0_8_(MAKE)                                                 \
     ESQ_EPI_CASE_(MAKE, 0) ESQ_EPI_CASE_(MAKE, 1) ESQ_EPI_CASE_(MAKE, 2)         \
     ESQ_EPI_CASE_(MAKE, 3) ESQ_EPI_CASE_(MAKE, 4) ESQ_EPI_CASE_(MAKE, 5)         \
@@ -143,7 +144,7 @@ int dispatch_epilogue(const esq_epilogue *epi, Launch &&launch) {
     if (epi->kind == ESQ_EPI_RKCERR) {
         if (epi->is_complex || !epi->rows[0] || !epi->rows[1] || !epi->partials)
             return ESQ_EINVAL;
-        launch(make_rkcerr(epi));
+        if (!epi->dry_run) launch(make_rkcerr(epi));
         return 0;
     }
     if (epi->is_complex && epilogue_reduces(epi)) {
@@ -241,10 +242,12 @@ int dispatch_chain(const esq_chain *c, Launch &&launch) {
         if (c->from_rows) {                                                        \
             if constexpr (DD >= 3 && K >= 4) {                                     \
                 if (c->kind_last != ESQ_EPI_SOLERR) return ESQ_ENOTSUP;            \
+                if (c->dry_run) return 0;                                          \
                 launch(make_chain_args<DD, K>(c),                                  \
                        std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::true_type{}); \
                 return 0;                                                          \
             } else if constexpr (K >= 1 && K <= 3) {                               \
+                if (c->dry_run) return 0;                                          \
                 if (c->kind_last == ESQ_EPI_STAGE)                                 \
                     launch(make_chain_args<DD, K>(c),                              \
                            std::integral_constant<int, ESQ_EPI_STAGE>{}, std::true_type{}); \
@@ -255,6 +258,7 @@ int dispatch_chain(const esq_chain *c, Launch &&launch) {
             }                                                                      \
             return ESQ_ENOTSUP;                                                    \
         }                                                                          \
+        if (c->dry_run) return 0;                                                  \
         if (c->kind_last == ESQ_EPI_STAGE)                                         \
             launch(make_chain_args<DD, K>(c),                                      \
                    std::integral_constant<int, ESQ_EPI_STAGE>{}, std::false_type{}); \

@@ -69,7 +69,7 @@ int diag_fused(Rhs *r, double2 forcing, const double *y_in, double *f,
     if (blocks > 2048) blocks = 2048;
     if (esq::epilogue_reduces(epi)) {
         if ((int)blocks > epi->partials_cap) return ESQ_ENOTSUP;
-        if (epi->partials_used) *epi->partials_used = (int)blocks;
+        if (epi->partials_used && !epi->dry_run) *epi->partials_used = (int)blocks;
     }
     if (epi->in_row && !first_stage_ok(epi)) return ESQ_ENOTSUP;
     if ((epi->is_complex != 0) != CPLX) return ESQ_EINVAL;
@@ -90,7 +90,7 @@ int diag_fused(Rhs *r, double2 forcing, const double *y_in, double *f,
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
                               SrcPlain{y_in}, f, ep, r->lam_dev, forcing, n, n2);
     });
-    return rc ? rc : (int)hipGetLastError();
+    return (rc || epi->dry_run) ? rc : (int)hipGetLastError();
 }
 
 int diag_create(void **user_out, int kind, int device, const double *lam_host,

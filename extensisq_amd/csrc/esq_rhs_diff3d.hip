@@ -344,7 +344,7 @@ int esq_rhs_diff3d_fused(void *user, double t, const double *y_in, double *f,
     const unsigned grid = pairs ? grid_diff3d_pairs(r) : grid_diff3d<R>(r);
     if (esq::epilogue_reduces(epi)) {
         if ((int)grid > epi->partials_cap) return ESQ_ENOTSUP;
-        if (epi->partials_used) *epi->partials_used = (int)grid;
+        if (epi->partials_used && !epi->dry_run) *epi->partials_used = (int)grid;
     }
     const int rc = esq::dispatch_epilogue(epi, [&](auto ep) {
         if (pairs)
@@ -354,7 +354,7 @@ int esq_rhs_diff3d_fused(void *user, double t, const double *y_in, double *f,
             launch_diff3d<R>(r, y_in, f, ep, (hipStream_t)stream, (hipEvent_t)start_event,
                              (hipEvent_t)stop_event);
     });
-    return rc ? rc : (int)hipGetLastError();
+    return (rc || epi->dry_run) ? rc : (int)hipGetLastError();
 }
 int esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
                    void *stream) {

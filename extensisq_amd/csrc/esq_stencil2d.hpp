@@ -322,7 +322,7 @@ struct Stencil2D {
         const Geo2d g = geo2d(N);
         if (epilogue_reduces(epi)) {
             if ((int)g.grid > epi->partials_cap) return ESQ_ENOTSUP;
-            if (epi->partials_used) *epi->partials_used = (int)g.grid;
+            if (epi->partials_used && !epi->dry_run) *epi->partials_used = (int)g.grid;
         }
         if (epi->in_row && !first_stage_ok(epi)) return ESQ_ENOTSUP;
         const int rc = dispatch_epilogue(epi, [&](auto ep) {
@@ -341,7 +341,7 @@ struct Stencil2D {
                                   (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
                                   SrcPlain{y_in}, f, ep, fn, N, g.grid, g.wpr);
         });
-        return rc ? rc : (int)hipGetLastError();
+        return (rc || epi->dry_run) ? rc : (int)hipGetLastError();
     }
 
     // sweep + Chebyshev recursion, f not stored                 (esq_rhs_rkc_fn)
@@ -369,6 +369,8 @@ struct Stencil2D {
         if (NF > 1 && !chain_within_caps(chain->depth, chain->kind_last == ESQ_EPI_SOLERR,
                                          chain->nu, split))
             return ESQ_ENOTSUP;
+        // (several fields in one wave: no kernel forms its own input)
+        if (chain->from_rows && !(split || NF == 1)) return ESQ_ENOTSUP;
         int rc_launch = 0;
         auto body = [&](auto ca, auto kind, auto split_c, auto from_c) {
             using CA = decltype(ca);
@@ -399,7 +401,7 @@ struct Stencil2D {
         const int rc = dispatch_chain<(split || NF == 1) ? 6 : 4>(
             chain, [&](auto ca, auto kind, auto from_c) {
                 body(ca, kind, std::integral_constant<bool, split>{}, from_c); });
-        if (rc) return rc;
+        if (rc || chain->dry_run) return rc;
         return rc_launch ? rc_launch : (int)hipGetLastError();
     }
 };

@@ -2,6 +2,9 @@
 // blocked-accumulation plan, stage sweeps (RHS plugin + epilogue), solution and
 // error norm, accept (extensisq/common.py:222-356).  Host orchestration only;
 // the kernels are in esq_kernels.hpp / esq_epilogue.hpp / the RHS plugins.
+#include <algorithm>
+#include <functional>
+
 #include "esq_internal.hpp"
 #include "esq_chain.hpp"
 
@@ -149,17 +152,35 @@ bool may_fuse(const esq_ctx *c, int kind) {
     return c->rhs_fused && ((c->fuse_mask >> kind) & 1);
 }
 
+// A QUERY instead of a launch (build_plan): the sweep_* builders describe the
+// launch exactly as they would make it, ask the plugin whether it would take it
+// (esq_epilogue.dry_run / esq_chain.dry_run: nothing is enqueued, nothing written)
+// and report the designed words per element.  An entry that has not declared the
+// query capability is taken to accept: its refusals are learnt from launches.
+struct Dry {
+    double reads = 0.0, writes = 0.0;
+    bool made = false;                 // block sweep: also wrote the boundary stage's argument
+};
+int ask_fused(esq_ctx *c, double t, const double *y_in, double *f_out, esq_epilogue &e) {
+    if (!(c->fuse_mask & ESQ_FUSE_QUERY)) return 0;
+    e.dry_run = 1;
+    const int r = c->rhs_fused(c->rhs_user, t, y_in, f_out, &e, c->len, (void *)c->stream,
+                               nullptr, nullptr);
+    return r == 0 ? 0 : ESQ_ENOTSUP;
+}
+
 // RHS sweep of stage i + the accumulate of stage nx = i + 1 (ESQ_EPI_STAGE).
 // from_state (stage 1 only): the sweep forms its own input y + h*a_10*K[0] on
 // the fly instead of reading YSTAGE (ESQ_FUSE_SRC)
-int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = false) {
+int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = false,
+                     Dry *dry = nullptr) {
     const int nx = i + 1;
     esq_epilogue e;
     epi_common(c, e, ESQ_EPI_STAGE);
     Terms tm;
     int nnz_all = 0;
     const int nt = stage_terms(c, nx, i, tm, &e.init, &nnz_all, &e.c_self);
-    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    if (nt < 0) return dry ? kNotApplicable : fail(c, ESQ_EINVAL, "too many terms");
     e.nt = nt;
     for (int j = 0; j < nt; ++j) { e.rows[j] = tm.p[j]; e.c[j] = tm.c[j]; }
     e.y = c->y;
@@ -172,6 +193,10 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = fa
         e.in_row = c->krow[c->kmap[0]];
         e.in_c = c->A[(size_t)c->s];                 // A[1][0]
         e.in_h = h;
+        if (dry) {
+            dry->reads = 2; dry->writes = 2;
+            return ask_fused(c, t + c->C[i] * h, nullptr, c->krow[c->kmap[i]], e);
+        }
         // booked: stage 1's accumulate (1 + 2 words) + the RHS + stage 2's
         // accumulate; moved: y and K[0] in (stage 2's row K[0] is the same
         // vector), K[1] and the argument of stage 2 out
@@ -180,6 +205,10 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = fa
         const int r = run_fused(c, t + c->C[i] * h, nullptr, c->krow[c->kmap[i]], e, p);
         if (r == 0) std::swap(c->ystage, c->work);
         return r;
+    }
+    if (dry) {
+        dry->reads = nt + 2 + (e.init ? 1 : 0); dry->writes = 2;
+        return ask_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e);
     }
     // booked on the stage class: next stage's algorithmic bytes + the RHS's
     // 16 B; moved: ys_in, rows, init, y in; K[i], ys_out out
@@ -196,7 +225,8 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = fa
 // (non-FSAL: weights B and E).  Returns 0, kNotApplicable / ESQ_ENOTSUP (the
 // caller tries a shorter chain or single sweeps) or an error.
 int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
-                bool lazy_rows = false, bool from_rows = false, bool skip_out = false) {
+                bool lazy_rows = false, bool from_rows = false, bool skip_out = false,
+                Dry *dry = nullptr) {
     const int s = c->s;
     if (depth < 2 || depth > ESQ_CHAIN_MAX_DEPTH || s > 62) return kNotApplicable;
     esq_chain e;
@@ -351,6 +381,16 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     const double reads = ((i == 0 || from_rows) ? 1 : 2) + nu,
                  writes = n_stored + (skip_out ? 0 : 1);
     (void)n_init;
+    if (dry) {
+        dry->reads = reads; dry->writes = writes;
+        if (!(c->chain_caps & ESQ_CHAIN_CAP_QUERY)) return 0;
+        int used = 0;
+        e.partials_used = &used;
+        e.dry_run = 1;
+        const int rq = c->rhs_chain(c->rhs_user, i == 0 ? c->y : c->ystage, &e, c->len,
+                                    (void *)c->stream, nullptr, nullptr);
+        return rq == 0 ? 0 : ESQ_ENOTSUP;
+    }
     double amp = 1.0;
     e.read_amplification = &amp;
     char label[24];
@@ -378,54 +418,14 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     return 0;
 }
 
-// the chain esq_rk_stages will take at stage i (same rules as its selection loop):
-// depth and last kind of the first candidate that crosses no block boundary and
-// has not been refused; false if there is none
-bool chain_candidate(const esq_ctx *c, int i, int i_to, int *depth, int *what) {
-    for (int D = c->chain_depth; D >= 2; --D) {
-        if (i + D > i_to) continue;
-        bool crosses = false;
-        for (const auto &b : c->blocks) crosses |= (b.J > i && b.J <= i + D);
-        if (crosses) continue;
-        int w = -1;
-        if (i + D == c->s && i_to == c->s)
-            w = c->fsal ? (may_fuse(c, ESQ_EPI_STAGE) ? 1 : -1)
-                        : (may_fuse(c, ESQ_EPI_SOLERR) ? 2 : -1);
-        else if (i + D < i_to && may_fuse(c, ESQ_EPI_STAGE))
-            w = 0;
-        if (w < 0) continue;
-        const size_t slot = (size_t)i * 8 + (size_t)D;
-        if (slot < c->chain_refused.size() && c->chain_refused[slot]) continue;
-        *depth = D;
-        *what = w;
-        return true;
-    }
-    return false;
-}
-// will the chain that follows at stage i form its own input (so that nobody has to
-// write it)?  Known from the second step on.
-bool next_forms_its_input(const esq_ctx *c, int i, int i_to) {
-    if (i_to != c->s || i >= i_to - 1 || !c->chain_from_rows) return false;
-    if ((c->chain_caps & (ESQ_CHAIN_CAP_FROM_ROWS | ESQ_CHAIN_CAP_SKIP_OUT)) !=
-        (ESQ_CHAIN_CAP_FROM_ROWS | ESQ_CHAIN_CAP_SKIP_OUT))
-        return false;
-    for (const auto &b : c->blocks)
-        if (b.J == i + 1) return false;          // a block sweep comes first
-    int D = 0, what = -1;
-    if (!chain_candidate(c, i, i_to, &D, &what) || what != 2) return false;
-    const size_t slot = (size_t)i * 8 + (size_t)D;
-    return slot < c->from_rows.size() && c->from_rows[slot] == 1;
-}
-
 bool may_use_src(const esq_ctx *c) {
-    return c->src_pays && may_fuse(c, ESQ_EPI_STAGE) && (c->fuse_mask & ESQ_FUSE_SRC) &&
-           !c->src_declined;
+    return c->src_pays && may_fuse(c, ESQ_EPI_STAGE) && (c->fuse_mask & ESQ_FUSE_SRC);
 }
 
 // RHS sweep of stage i = J - 1 + the blocked accumulation at boundary J with
 // K_i as the block's last column (ESQ_EPI_BLOCK)
 int sweep_block(esq_ctx *c, const esq_ctx::Block &b, int i, double t, double h,
-                bool *made_ystage) {
+                bool *made_ystage, Dry *dry = nullptr) {
     esq_epilogue e;
     epi_common(c, e, ESQ_EPI_BLOCK);
     const int no = (int)b.stages.size();
@@ -461,6 +461,10 @@ int sweep_block(esq_ctx *c, const esq_ctx::Block &b, int i, double t, double h,
         *made_ystage = true;
     }
     e.f_store_nt = (c->epi_nt >> 1) & 1;
+    if (dry) {
+        dry->reads = reads; dry->writes = no + 1; dry->made = *made_ystage;
+        return ask_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e);
+    }
     Prof p(c, ESQ_PROF_STAGE, "rhs+block", nt, alg, false,
            8.0 * (reads + no + 1) * (double)c->len);
     const int r = run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
@@ -470,7 +474,7 @@ int sweep_block(esq_ctx *c, const esq_ctx::Block &b, int i, double t, double h,
 }
 
 // FSAL pairs: RHS sweep of the last stage also forms y_new (ESQ_EPI_STAGE)
-int sweep_ynew(esq_ctx *c, int i, double t, double h) {
+int sweep_ynew(esq_ctx *c, int i, double t, double h, Dry *dry = nullptr) {
     esq_epilogue e;
     epi_common(c, e, ESQ_EPI_STAGE);
     int nt = 0, nnz_all = 0;
@@ -488,13 +492,17 @@ int sweep_ynew(esq_ctx *c, int i, double t, double h) {
     e.h = h;
     e.out = c->ynew;
     e.f_store_nt = c->epi_nt & 1;
+    if (dry) {
+        dry->reads = nt + 2; dry->writes = 2;
+        return ask_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e);
+    }
     Prof p(c, ESQ_PROF_STAGE, "rhs+stage", nt, 8.0 * (nnz_all + 4) * (double)c->len,
            false, 8.0 * (nt + 4) * (double)c->len);
     return run_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e, p);
 }
 
 // non-FSAL pairs: RHS sweep of the last stage + y_new + error partial sums
-int sweep_solerr(esq_ctx *c, int i, double t, double h) {
+int sweep_solerr(esq_ctx *c, int i, double t, double h, Dry *dry = nullptr) {
     esq_epilogue e;
     epi_common(c, e, ESQ_EPI_SOLERR);
     int nt = 0;
@@ -513,6 +521,12 @@ int sweep_solerr(esq_ctx *c, int i, double t, double h) {
     e.h = h;
     e.out = c->ynew;
     e.f_store_nt = (c->epi_nt >> 2) & 1;   // K_{s-1}: next read by the dense output
+    if (dry) {
+        int used = 0;
+        e.partials_used = &used;
+        dry->reads = nt + 2; dry->writes = 2;
+        return ask_fused(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]], e);
+    }
     // booked: the RHS's 16 B + the fused solution/error pass (rows incl. the
     // fresh one + y + y_new); moved: ys_in, rows, y in; K_i, y_new out
     Prof p(c, ESQ_PROF_SOLERR, "rhs+solerr", nt, 8.0 * (nt + 1 + 2 + 2) * (double)c->len,
@@ -633,7 +647,389 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
     return total;
 }
 
+// ---------------------------------------------------------------------------
+// THE STEP AS A PROGRAM.  esq_rk_stages(i_from, i_to) runs a launch list that is
+// built once per key -- (stage range, is stage 1's argument in YSTAGE already, is
+// K[0] still to be evaluated, may rows be left unwritten) -- and replayed every
+// step.  build_plan walks the stages once and, for every launch it considers,
+// asks the plugin's entry a side-effect-free question (Dry: the launch described
+// exactly as it would be made, esq_chain.dry_run / esq_epilogue.dry_run).  The
+// preferences, in order, per stage i:
+//   * the longest marching chain from i that crosses no blocked-accumulation
+//     boundary (i == 0: the deferred end-point derivative in front of the first
+//     chain); a chain that ends the step, or starts it, in the form that makes its
+//     own input from the rows it reads (the launch before it then does not write
+//     that argument);
+//   * stage 1 from the state (ESQ_FUSE_SRC) where the working set is cache-resident;
+//   * the RHS sweep with the next stage's argument / the blocked accumulation /
+//     y_new (+ error sums) as its epilogue;
+//   * the plain RHS launch + the library's own kernels.
+// A plugin entry WITHOUT the query capability is taken to accept; if a launch of
+// it is refused at run time, the refusal is remembered (c->refused), the step is
+// finished the plain way and the plans are rebuilt without that launch.
+// ---------------------------------------------------------------------------
+unsigned plan_key(int i_from, int i_to, bool ready, bool k0_missing, bool lazy) {
+    return (unsigned)i_from | ((unsigned)i_to << 8) | (ready ? 1u << 16 : 0u) |
+           (k0_missing ? 1u << 17 : 0u) | (lazy ? 1u << 18 : 0u);
+}
+unsigned long long step_signature(const PlanStep &st) {
+    return (unsigned long long)st.op | ((unsigned long long)(unsigned char)st.i << 8) |
+           ((unsigned long long)(unsigned char)st.depth << 16) |
+           ((unsigned long long)(unsigned char)st.what << 24) |
+           ((unsigned long long)st.from_rows << 32) | ((unsigned long long)st.skip_out << 33) |
+           ((unsigned long long)st.lazy << 34);
+}
+const esq_ctx::Block *block_at(const esq_ctx *c, int J) {
+    for (const auto &b : c->blocks)
+        if (b.J == J) return &b;
+    return nullptr;
+}
+
+// Cost of a launch in the planner's units: one 8-byte word per element read by a
+// streaming kernel = 1.  Measured rates behind the constants (profiles/
+// r03_experiments.md, r04_experiments.md): the chain sweeps read their halo rows
+// and columns twice (kHalo by depth) and move a word ~15 % slower than the
+// library's streaming kernels; a written word costs about a quarter more than a
+// read one; two-stage chains walk as many rows for less work (+25 %); every launch
+// costs a kernel boundary (~2 us, expressed in words of this context's size).
+double step_cost(const esq_ctx *c, const PlanStep &st) {
+    static const double kHalo[8] = {1.0, 1.0, 1.10, 1.20, 1.31, 1.38, 1.46, 1.55};
+    const double kW = 1.25;
+    const double word_us = (double)c->len_pad * 8.0 / 5.5e6;          // one word at 5.5 TB/s
+    const double launch = 2.0 / (word_us > 1e-3 ? word_us : 1e-3);
+    double u = st.reads + kW * st.writes;
+    if (st.op == OP_CHAIN) {
+        u = 1.15 * (st.reads * kHalo[st.depth < 8 ? st.depth : 7] + kW * st.writes);
+        if (st.depth == 2) u *= 1.25;
+    }
+    return u + launch;
+}
+
+// One way to evaluate stage i (and, as a chain, more): the launches, where the
+// walk stands afterwards, what it cost.
+struct PlanOption {
+    std::vector<PlanStep> steps;
+    int next = 0;
+    bool ready = false, block_done = false, ynew = false, solerr = false;
+    double cost = 0.0;
+};
+
+Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, bool lazy_ok) {
+    const int s = c->s;
+    const double t = 0.0, h = 1.0;             // queries do not depend on them
+    const bool chains = c->rhs_chain && c->rhs_fused && !c->cplx && c->chain_depth >= 2;
+    // ESQ_PLAN_GREEDY=1: the first option in order of preference (round 3's rule:
+    // the longest chain first) instead of the cheapest sequence
+    static const bool greedy = env_uint("ESQ_PLAN_GREEDY", 0) != 0;
+    auto crosses = [&](int lo, int hi) {       // a boundary J with lo < J <= hi
+        for (const auto &b : c->blocks)
+            if (b.J > lo && b.J <= hi) return true;
+        return false;
+    };
+    auto mk = [&](PlanOp op, int i, const Dry &d, int depth = 0, int what = 0,
+                  bool lazy = false, bool from_rows = false, bool skip_out = false) {
+        return PlanStep{(unsigned char)op, (signed char)i, (signed char)depth,
+                        (signed char)what, lazy, from_rows, skip_out, (float)d.reads,
+                        (float)d.writes};
+    };
+    auto refused = [&](const PlanStep &st) { return c->refused.count(step_signature(st)) != 0; };
+    std::map<unsigned long long, std::pair<int, Dry>> asked;     // chain queries, memoised
+    auto ask_chain = [&](int i, int D, int what, bool lazy, bool from_rows, bool skip_out,
+                         Dry &d) {
+        Dry none;
+        const PlanStep st = mk(OP_CHAIN, i, none, D, what, lazy, from_rows, skip_out);
+        if (refused(st)) return false;
+        const unsigned long long sig = step_signature(st);
+        auto it = asked.find(sig);
+        if (it == asked.end()) {
+            Dry q;
+            const int r = sweep_chain(c, i, D, t, h, what, lazy, from_rows, skip_out, &q);
+            it = asked.emplace(sig, std::make_pair(r, q)).first;
+        }
+        d = it->second.second;
+        return it->second.first == 0;
+    };
+    // what a chain of depth D from stage i ends in: -1 = no such chain
+    auto last_kind = [&](int i, int D) {
+        if (i + D == s && i_to == s)
+            return c->fsal ? (may_fuse(c, ESQ_EPI_STAGE) ? 1 : -1)
+                           : (may_fuse(c, ESQ_EPI_SOLERR) ? 2 : -1);
+        return (i + D < i_to && may_fuse(c, ESQ_EPI_STAGE)) ? 0 : -1;
+    };
+    const bool lazy = lazy_ok && c->rhs && i_to == s && (c->chain_caps & ESQ_CHAIN_CAP_SKIP_ROWS);
+    const bool from_cap = c->chain_from_rows && (c->chain_caps & ESQ_CHAIN_CAP_FROM_ROWS);
+    const bool skip_cap = from_cap && (c->chain_caps & ESQ_CHAIN_CAP_SKIP_OUT) && i_to == s;
+    // the argument of stage i by the library's own kernel (after a block sweep that
+    // left only the partial sums: the stage kernel alone)
+    auto argument = [&](int i, bool block_done) {
+        Dry d;
+        const double *init = nullptr;
+        Terms tm;
+        int nnz_all = 0;
+        const int nt = stage_terms(c, i, -1, tm, &init, &nnz_all, nullptr);
+        d.reads = (nt < 0 ? 0 : nt) + 1 + (init ? 1 : 0);
+        d.writes = 1;
+        // (a blocked-accumulation boundary at i: the block kernel's rows and outputs)
+        if (!block_done)
+            if (const esq_ctx::Block *b = block_at(c, i)) {
+                d.reads += (double)b->cols.size();
+                d.writes += (double)b->stages.size();
+            }
+        return mk(block_done ? OP_LINCOMB : OP_ACCUM, i, d);
+    };
+    // ---- every way to go on from stage i, in order of preference
+    auto options = [&](int i, bool ready, bool block_done, bool first) {
+        std::vector<PlanOption> out;
+        const esq_ctx::Block *bnext = block_at(c, i + 1);
+        auto push = [&](std::vector<PlanStep> steps, int next, bool rdy, bool bd = false,
+                        bool yn = false, bool se = false) {
+            PlanOption o;
+            o.steps = std::move(steps);
+            o.next = next; o.ready = rdy; o.block_done = bd; o.ynew = yn; o.solerr = se;
+            for (const PlanStep &st : o.steps) o.cost += step_cost(c, st);
+            out.push_back(std::move(o));
+        };
+        // the first chain of a step can start from the state: stage 1's argument
+        // y + h*a_10*K_0 from the K_0 it reads anyway (one stage more than the
+        // plan's depth, as with the fused end-point stage)
+        const bool first_from = first && i == 1 && !ready && chains && from_cap && i_to == s &&
+                                !block_at(c, 2);
+        if (chains && i + 1 < i_to && !bnext) {
+            const int d_top = first_from && c->chain_depth < ESQ_CHAIN_MAX_DEPTH
+                                  ? c->chain_depth + 1 : c->chain_depth;
+            for (int D = d_top; D >= 2; --D) {
+                if (i + D > i_to || crosses(i, i + D)) continue;
+                const int what = last_kind(i, D);
+                if (what < 0) continue;
+                // a chain that hands over to one that forms its own input need not
+                // write its last target
+                for (int skip = (what == 0 && skip_cap) ? 1 : 0; skip >= 0; --skip) {
+                    // a chain that ends the step, or the first one of a step: its
+                    // input from the rows it reads anyway
+                    Dry d;
+                    if ((what == 2 || first_from) && from_cap &&
+                        ask_chain(i, D, what, lazy, true, skip != 0, d))
+                        push({mk(OP_CHAIN, i, d, D, what, lazy, true, skip != 0)}, i + D,
+                             what == 0 && !skip, false, what >= 1, what == 2);
+                    if (D > c->chain_depth) continue;      // (that depth: from rows only)
+                    if (ask_chain(i, D, what, lazy, false, skip != 0, d)) {
+                        std::vector<PlanStep> st;
+                        if (!ready) st.push_back(argument(i, block_done));
+                        st.push_back(mk(OP_CHAIN, i, d, D, what, lazy, false, skip != 0));
+                        push(std::move(st), i + D, what == 0 && !skip, false, what >= 1,
+                             what == 2);
+                    }
+                }
+            }
+        }
+        // stage 1 from the state (no stage-1 kernel, no argument in memory)
+        if (i == 1 && !ready && i + 1 < i_to && may_use_src(c) && !block_at(c, 2)) {
+            Dry d;
+            const PlanStep st = mk(OP_SRC_STAGE, 1, d);
+            if (!refused(st) && sweep_next_stage(c, 1, t, h, true, &d) == 0) {
+                // (round 3's order: before any chain that does not form its input)
+                push({mk(OP_SRC_STAGE, 1, d)}, 2, true);
+                if (greedy) {
+                    // keep it in front of the plain chains, behind the from-rows ones
+                    std::stable_partition(out.begin(), out.end(), [](const PlanOption &x) {
+                        return x.steps.size() == 1 && (x.steps[0].from_rows ||
+                                                       x.steps[0].op == OP_SRC_STAGE);
+                    });
+                }
+            }
+        }
+        auto with_arg = [&](PlanStep st) {
+            std::vector<PlanStep> v;
+            if (!ready) v.push_back(argument(i, block_done));
+            v.push_back(st);
+            return v;
+        };
+        if (i + 1 < i_to && !bnext && may_fuse(c, ESQ_EPI_STAGE)) {
+            // this stage's RHS sweep also forms the NEXT stage's argument
+            Dry d;
+            if (!refused(mk(OP_STAGE_SWEEP, i, d)) && sweep_next_stage(c, i, t, h, false, &d) == 0)
+                push(with_arg(mk(OP_STAGE_SWEEP, i, d)), i + 1, true);
+        }
+        if (i + 1 < i_to && bnext && may_fuse(c, ESQ_EPI_BLOCK)) {
+            // ... or runs the blocked accumulation at the column boundary
+            Dry d;
+            bool made = false;
+            if (!refused(mk(OP_BLOCK_SWEEP, i, d)) &&
+                sweep_block(c, *bnext, i, t, h, &made, &d) == 0)
+                push(with_arg(mk(OP_BLOCK_SWEEP, i, d)), i + 1, d.made, !d.made);
+        }
+        if (i == s - 1 && i_to == s) {
+            Dry d;
+            if (c->fsal && may_fuse(c, ESQ_EPI_STAGE) && !refused(mk(OP_YNEW_SWEEP, i, d)) &&
+                sweep_ynew(c, i, t, h, &d) == 0)         // FSAL: ... also forms y_new
+                push(with_arg(mk(OP_YNEW_SWEEP, i, d)), i + 1, false, false, true);
+            if (!c->fsal && may_fuse(c, ESQ_EPI_SOLERR) && !refused(mk(OP_SOLERR_SWEEP, i, d)) &&
+                sweep_solerr(c, i, t, h, &d) == 0)       // others: y_new + error sums
+                push(with_arg(mk(OP_SOLERR_SWEEP, i, d)), i + 1, false, false, true, true);
+        }
+        {
+            Dry d;
+            d.reads = 1; d.writes = 1;
+            push(with_arg(mk(OP_RHS, i, d)), i + 1, false);
+        }
+        return out;
+    };
+    // ---- what esq_rk_solution_error still has to do after the last launch
+    auto tail_cost = [&](bool ynew, bool solerr) {
+        if (i_to != s) return 0.0;
+        int nb = 0, ne = 0;
+        for (int j = 0; j < s; ++j) { nb += c->B[j] != 0.0; ne += (c->B[j] != 0.0 || c->E[j] != 0.0); }
+        Dry d;
+        if (c->fsal) { d.reads = ynew ? 0 : nb + 1; d.writes = ynew ? 0 : 1; }
+        else { d.reads = solerr ? 0 : ne + 1; d.writes = solerr ? 0 : 1; }
+        return d.reads > 0 ? step_cost(c, mk(OP_ACCUM, s, d)) : 0.0;
+    };
+    // ---- cheapest sequence from (i, ready, block_done) to the end of the range
+    struct Best { double cost = -1.0; int pick = -1; };
+    std::map<unsigned, Best> memo;
+    std::map<unsigned, std::vector<PlanOption>> opts;
+    auto key_of = [](int i, bool ready, bool bd, bool first) {
+        return (unsigned)i | (ready ? 256u : 0u) | (bd ? 512u : 0u) | (first ? 1024u : 0u);
+    };
+    std::function<double(int, bool, bool, bool, bool, bool)> solve =
+        [&](int i, bool ready, bool bd, bool first, bool yn, bool se) -> double {
+        if (i >= i_to) return tail_cost(yn, se);
+        const unsigned k = key_of(i, ready, bd, first);
+        auto it = memo.find(k);
+        if (it != memo.end()) return it->second.cost;
+        std::vector<PlanOption> &o = opts[k];
+        o = options(i, ready, bd, first);
+        Best best;
+        for (int q = 0; q < (int)o.size(); ++q) {
+            const double cst = o[q].cost +
+                               solve(o[q].next, o[q].ready, o[q].block_done, false, o[q].ynew,
+                                     o[q].solerr);
+            if (greedy) {
+                // round 3's rule: the first option in order of preference; a chain
+                // leaves its last target unwritten only if the launch that follows
+                // is a chain that forms its own input
+                const PlanStep &last = o[q].steps.back();
+                if (last.op == OP_CHAIN && last.skip_out) {
+                    const unsigned kn = key_of(o[q].next, false, false, false);
+                    const bool ok = o[q].next < i_to && memo[kn].pick >= 0 &&
+                                    opts[kn][memo[kn].pick].steps[0].op == OP_CHAIN &&
+                                    opts[kn][memo[kn].pick].steps[0].from_rows;
+                    if (!ok) continue;
+                }
+                best.cost = cst; best.pick = q;
+                break;
+            }
+            if (best.pick < 0 || cst < best.cost) { best.cost = cst; best.pick = q; }
+        }
+        memo[k] = best;
+        return best.cost;
+    };
+    Plan plan;
+    auto walk = [&](int i, bool ready, bool bd, bool first) {
+        while (i < i_to) {
+            const unsigned k = key_of(i, ready, bd, first);
+            const PlanOption &o = opts[k][memo[k].pick];
+            for (const PlanStep &st : o.steps) plan.steps.push_back(st);
+            if (o.ynew) plan.ynew_ready = true;
+            if (o.solerr) plan.solerr_ready = true;
+            i = o.next; ready = o.ready; bd = o.block_done; first = false;
+        }
+    };
+    if (!k0_missing) {
+        solve(i_from, ready0, false, true, false, false);
+        walk(i_from, ready0, false, true);
+        return plan;
+    }
+    // f(t, y) was left to this step (esq_rk_accept): one stage more in front of the
+    // first chain -- stage 0 reads the state itself, its argument never existed,
+    // K[0] is written once and not read back -- or a launch of its own
+    Dry dk;
+    dk.reads = 1; dk.writes = 1;
+    const PlanStep k0 = mk(OP_RHS_K0, 0, dk);
+    double best = step_cost(c, k0) + solve(i_from, false, false, true, false, false);
+    int best_D = 0;
+    Dry best_d;
+    if (i_from == 1 && chains && may_fuse(c, ESQ_EPI_STAGE) &&
+        (c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE)) {
+        for (int D = c->chain_depth; D >= 2; --D) {
+            if (1 + D >= i_to || crosses(1, 1 + D) || D + 1 > ESQ_CHAIN_MAX_DEPTH) continue;
+            Dry d;      // (its successor is never the chain that ends the step: the
+                        // last target is written)
+            if (!ask_chain(0, D + 1, 0, lazy, false, false, d)) { if (greedy) break; continue; }
+            const double cst = step_cost(c, mk(OP_CHAIN, 0, d, D + 1, 0, lazy)) +
+                               solve(D + 1, true, false, false, false, false);
+            if (greedy || cst < best) { best = cst; best_D = D; best_d = d; }
+            if (greedy) break;
+        }
+    }
+    if (best_D) {
+        plan.steps.push_back(mk(OP_CHAIN, 0, best_d, best_D + 1, 0, lazy));
+        walk(best_D + 1, true, false, false);
+    } else {
+        plan.steps.push_back(k0);
+        walk(i_from, false, false, true);
+    }
+    return plan;
+}
+
+const Plan &get_plan(esq_ctx *c, int i_from, int i_to, bool ready, bool k0_missing) {
+    const bool lazy_ok = c->lazy_rows && !c->keep_rows;
+    const unsigned key = plan_key(i_from, i_to, ready, k0_missing, lazy_ok);
+    auto it = c->plans.find(key);
+    if (it == c->plans.end())
+        it = c->plans.emplace(key, build_plan(c, i_from, i_to, ready, k0_missing, lazy_ok)).first;
+    return it->second;
+}
+
+// argument of stage i from the rows in memory (after a block sweep that left only
+// the partial sums): the stage kernel alone
+int lincomb_stage(esq_ctx *c, int i, double h) {
+    const double *init = nullptr;
+    Terms tm;
+    int nnz_all = 0;
+    const int nt = stage_terms(c, i, -1, tm, &init, &nnz_all, nullptr);
+    if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
+    Prof p(c, ESQ_PROF_STAGE, "k_lincomb", nt, 8.0 * (nnz_all + 2) * (double)c->len, false,
+           8.0 * (nt + 2 + (init ? 1 : 0)) * (double)c->len);
+    return launch_lincomb(c, c->ystage, c->y, tm, nt, h, &p, init);
+}
+
+// one entry of a plan; ESQ_ENOTSUP / kNotApplicable: the plugin refused at run time
+int run_step(esq_ctx *c, const PlanStep &st, double t, double h) {
+    const int i = st.i;
+    switch (st.op) {
+        case OP_RHS_K0: {
+            const int r = call_rhs(c, t, c->y, c->krow[c->kmap[0]]);
+            if (r == 0) { ++c->end_plain; c->k0_missing = false; }
+            return r;
+        }
+        case OP_CHAIN: {
+            const int r = sweep_chain(c, i, st.depth, t, h, st.what, st.lazy, st.from_rows,
+                                      st.skip_out);
+            if (r == 0 && i == 0) { ++c->end_fused; c->k0_missing = false; }
+            return r;
+        }
+        case OP_SRC_STAGE: return sweep_next_stage(c, 1, t, h, true);
+        case OP_ACCUM: return esq_rk_stage_accumulate(c, i, h);
+        case OP_LINCOMB: return lincomb_stage(c, i, h);
+        case OP_STAGE_SWEEP: return sweep_next_stage(c, i, t, h);
+        case OP_BLOCK_SWEEP: {
+            bool made = false;
+            const esq_ctx::Block *b = block_at(c, i + 1);
+            return b ? sweep_block(c, *b, i, t, h, &made) : kNotApplicable;
+        }
+        case OP_YNEW_SWEEP: return sweep_ynew(c, i, t, h);
+        case OP_SOLERR_SWEEP: return sweep_solerr(c, i, t, h);
+        default: return call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
+    }
+}
+
 }  // namespace
+
+void esqi::drop_plans(esq_ctx *c) {
+    c->plans.clear();
+    c->refused.clear();
+}
 
 // The rows `missing_rows` of the step in flight (or of the step just accepted) exist
 // only as terms of the sums their own sweep formed.  Re-evaluate
@@ -685,9 +1081,7 @@ extern "C" {
 int esq_replan(esq_ctx *c) {
     if (!c || !c->have_tab) return ESQ_EINVAL;
     const int s = c->s;
-    c->chain_refused.assign((size_t)(s + 1) * 8, 0);
-    c->from_rows.assign((size_t)(s + 1) * 8, 0);
-    c->end_fused_ok = -1;
+    drop_plans(c);
     const bool chained = c->rhs_chain && c->chain_depth >= 2 &&
                          env_uint("ESQ_PLAN_CHAINED", 1) != 0;
     auto cost = [&](const std::vector<int> &bounds) -> double {
@@ -872,7 +1266,7 @@ int esq_rk_eval_rhs(esq_ctx *c, int dst_row, double t, int src_slot, int src_row
 int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     if (!c) return ESQ_EINVAL;
     // YSTAGE may already hold the first stage's argument (esq_rk_accept)
-    bool ready = i_from == 1 && c->pre_valid && c->pre_h == h;
+    const bool ready = i_from == 1 && c->pre_valid && c->pre_h == h;
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (i_from < 1 || i_to > c->s || i_from > i_to)
@@ -882,221 +1276,134 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     c->missing_rows = 0;
     c->ynew_ready = false;
     c->solerr_ready = false;
-    bool block_done = false;   // the block at boundary i already ran in a sweep
-    // marching chain sweeps: ESQ_CHAIN_DEPTH = 1 (off), 2, 3, 4 (default) ...
-    const bool chains = c->rhs_chain && c->rhs_fused && !c->cplx && c->chain_depth >= 2;
-    int i_first = i_from;
-    if (c->k0_missing) {
-        // f(t, y) was left to this step (esq_rk_accept): one stage more in front
-        // of the chain the plan starts with -- stage 0 reads the state itself, its
-        // argument never existed, K[0] is written once and not read back
-        bool fused = false;
-        if (i_from == 1 && chains && c->end_fused_ok != 0 && may_fuse(c, ESQ_EPI_STAGE) &&
-            (c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE)) {
-            int d1 = 0;
-            for (int D = c->chain_depth; D >= 2 && !d1; --D) {
-                if (1 + D >= i_to) continue;
-                bool crosses = false;
-                for (const auto &b : c->blocks) crosses |= (b.J > 1 && b.J <= 1 + D);
-                const size_t slot = (size_t)8 + (size_t)D;
-                if (!crosses && !(slot < c->chain_refused.size() && c->chain_refused[slot]))
-                    d1 = D;
-            }
-            int r = kNotApplicable;
-            if (d1 && d1 + 1 <= ESQ_CHAIN_MAX_DEPTH)
-                r = sweep_chain(c, 0, d1 + 1, t, h, 0,
-                                c->lazy_rows && !c->keep_rows && i_to == c->s &&
-                                    (c->chain_caps & ESQ_CHAIN_CAP_SKIP_ROWS));   // (its
-            // successor is never the chain that ends the step: the output is written)
-            if (r == 0) {
-                fused = true;
-                c->end_fused_ok = 1;
-                ++c->end_fused;
-                i_first = d1 + 1;
-                ready = true;
-            } else if (r == ESQ_ENOTSUP || r == kNotApplicable) {
-                c->end_fused_ok = 0;       // esq_rk_accept evaluates it from now on
-            } else {
-                return r;
-            }
-        }
-        if (!fused) {
-            const int r = call_rhs(c, t, c->y, c->krow[c->kmap[0]]);
-            if (r) return r;
+    const Plan &plan = get_plan(c, i_from, i_to, ready, c->k0_missing);
+    for (const PlanStep &st : plan.steps) {
+        const int r = run_step(c, st, t, h);
+        if (r == 0) continue;
+        if (r != ESQ_ENOTSUP && r != kNotApplicable) return r;
+        // an entry without the query capability refused a launch the plan took for
+        // granted: remember it, finish THIS step the plain way (an accumulate and
+        // an RHS launch per stage; rows left unwritten so far are restored by the
+        // accumulate), and plan again without that launch
+        const PlanStep failed = st;
+        c->plans.clear();
+        c->refused.insert(step_signature(failed));
+        int i0 = failed.i;
+        if (failed.op == OP_CHAIN && failed.i == 0) {
+            const int r0 = call_rhs(c, t, c->y, c->krow[c->kmap[0]]);
+            if (r0) return r0;
             ++c->end_plain;
+            c->k0_missing = false;
+            i0 = 1;
         }
-        c->k0_missing = false;
+        for (int i = i0; i < i_to; ++i) {
+            int rp = esq_rk_stage_accumulate(c, i, h);
+            if (rp) return rp;
+            rp = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
+            if (rp) return rp;
+        }
+        return 0;
     }
-    for (int i = i_first; i < i_to; ++i) {
-        // the first chain of a step can start from the state: stage 1's argument
-        // y + h*a_10*K_0 from the K_0 it reads anyway (one stage more than the plan's
-        // depth, as with the fused end-point stage); tried until the plugin declines
-        bool first_from_rows = false;
-        if (i == 1 && !ready && chains && c->chain_from_rows && i_to == c->s &&
-            (c->chain_caps & ESQ_CHAIN_CAP_FROM_ROWS)) {
-            bool boundary = false;
-            for (const auto &b : c->blocks) boundary |= (b.J == 2);
-            const int d_hi = c->chain_depth < ESQ_CHAIN_MAX_DEPTH ? c->chain_depth + 1
-                                                                  : c->chain_depth;
-            for (int D = d_hi; D >= 2 && !boundary && !first_from_rows; --D) {
-                const size_t slot = (size_t)8 + (size_t)D;
-                first_from_rows = 1 + D <= i_to && slot < c->from_rows.size() &&
-                                  c->from_rows[slot] != 2;
-            }
-        }
-        if (i == 1 && !ready && !first_from_rows && i + 1 < i_to && may_use_src(c)) {
-            // the first sweep forms its own input from y and K[0]: no stage-1
-            // kernel, no stage argument in memory
-            bool boundary = false;
-            for (const auto &b : c->blocks) boundary |= (b.J == 2);
-            if (!boundary) {
-                const int r = sweep_next_stage(c, 1, t, h, /*from_state=*/true);
-                if (r == 0) { ready = true; continue; }
-                if (r == ESQ_ENOTSUP) c->src_declined = true;   // the plugin declined
-                else if (r != kNotApplicable) return r;
-            }
-        }
-        // the chain that starts here forms its own input from the rows it reads
-        // (known from its first launch on): nobody wrote the argument, nobody has to
-        bool arg_missing = false;
-        if (!ready && !block_done && chains &&
-            (first_from_rows || next_forms_its_input(c, i, i_to))) {
-            arg_missing = true;
-            ready = true;
-        }
-        if (!ready) {
-            if (block_done) {
-                // partial sums are in place; only the stage kernel is left
-                const double *init = nullptr;
-                Terms tm;
-                int nnz_all = 0;
-                const int nt = stage_terms(c, i, -1, tm, &init, &nnz_all, nullptr);
-                if (nt < 0) return fail(c, ESQ_EINVAL, "too many terms");
-                Prof p(c, ESQ_PROF_STAGE, "k_lincomb", nt,
-                       8.0 * (nnz_all + 2) * (double)c->len, false,
-                       8.0 * (nt + 2 + (init ? 1 : 0)) * (double)c->len);
-                const int r = launch_lincomb(c, c->ystage, c->y, tm, nt, h, &p, init);
-                if (r) return r;
-            } else {
-                const int r = esq_rk_stage_accumulate(c, i, h);
-                if (r) return r;
-            }
-        }
-        ready = false;
-        block_done = false;
-        const esq_ctx::Block *bnext = nullptr;
-        for (const auto &b : c->blocks)
-            if (b.J == i + 1) bnext = &b;
-        if (chains && i + 1 < i_to && !bnext) {
-            // stages i .. i + D - 1 in ONE marching sweep: the arguments of the
-            // later stages stay in registers.  The longest chain that crosses no
-            // blocked-accumulation boundary and fits the plugin is taken.
-            bool done = false, handed_over = false;
-            const int d_top = first_from_rows && c->chain_depth < ESQ_CHAIN_MAX_DEPTH
-                                  ? c->chain_depth + 1 : c->chain_depth;
-            for (int D = d_top; D >= 2 && !done; --D) {
-                if (i + D > i_to) continue;
-                bool crosses = false;
-                for (const auto &b : c->blocks) crosses |= (b.J > i && b.J <= i + D);
-                if (crosses) continue;
-                int what = -1;
-                if (i + D == c->s && i_to == c->s)
-                    what = c->fsal ? (may_fuse(c, ESQ_EPI_STAGE) ? 1 : -1)
-                                   : (may_fuse(c, ESQ_EPI_SOLERR) ? 2 : -1);
-                else if (i + D < i_to && may_fuse(c, ESQ_EPI_STAGE))
-                    what = 0;
-                if (what < 0) continue;
-                const size_t slot = (size_t)i * 8 + (size_t)D;
-                if (slot < c->chain_refused.size() && c->chain_refused[slot]) continue;
-                // derivatives nothing after their chain reads (all rows of a chain that
-                // ends in the solution/error sums; K_1 of Pr7/8/9) are written only for
-                // a context whose caller keeps asking for them (restore_rows).  Whole
-                // steps only: a caller that runs the stages in pieces (BS5, CFMR7osc)
-                // reads rows with weights the tableau does not show
-                const bool lazy = c->lazy_rows && !c->keep_rows && c->rhs && i_to == c->s &&
-                                  (c->chain_caps & ESQ_CHAIN_CAP_SKIP_ROWS);
-                int r = kNotApplicable;
-                // a chain that ends the step, or the first one of a step: its input
-                // from the rows it reads anyway
-                if ((what == 2 || first_from_rows) && c->chain_from_rows &&
-                    (c->chain_caps & ESQ_CHAIN_CAP_FROM_ROWS) &&
-                    slot < c->from_rows.size() && c->from_rows[slot] != 2) {
-                    const bool skip_out = what == 0 && next_forms_its_input(c, i + D, i_to);
-                    r = sweep_chain(c, i, D, t, h, what, lazy, /*from_rows=*/true, skip_out);
-                    if (r == 0) {
-                        c->from_rows[slot] = 1;
-                        handed_over = skip_out;
-                    } else if (r == ESQ_ENOTSUP || r == kNotApplicable) {
-                        c->from_rows[slot] = 2;
-                    } else {
-                        return r;
-                    }
-                }
-                if (r != 0 && D > c->chain_depth) continue;    // (that depth: from rows only)
-                if (r != 0) {
-                    if (arg_missing) {           // (only if a chain changed its mind)
-                        const int ra = esq_rk_stage_accumulate(c, i, h);
-                        if (ra) return ra;
-                        arg_missing = false;
-                    }
-                    // a chain that hands over to one that forms its own input does
-                    // not write its last target
-                    const bool skip_out = what == 0 && next_forms_its_input(c, i + D, i_to);
-                    r = sweep_chain(c, i, D, t, h, what, lazy, false, skip_out);
-                    if (r == 0 && skip_out) handed_over = true;
-                }
-                if (r == ESQ_ENOTSUP || r == kNotApplicable) {
-                    // a property of the tableau and the grid, not of this step
-                    if (slot < c->chain_refused.size()) c->chain_refused[slot] = 1;
-                    continue;
-                }
-                if (r == 0) {
-                    i += D - 1;                        // those stages are done too
-                    ready = what == 0 && !handed_over;
-                    if (what >= 1) c->ynew_ready = true;
-                    if (what == 2) c->solerr_ready = true;
-                    done = true;
-                } else if (r != ESQ_ENOTSUP && r != kNotApplicable) {
-                    return r;
-                }
-            }
-            if (done) continue;
-        }
-        if (arg_missing) {                       // no chain after all: the plain way
-            const int ra = esq_rk_stage_accumulate(c, i, h);
-            if (ra) return ra;
-        }
-        if (i + 1 < i_to && !bnext && may_fuse(c, ESQ_EPI_STAGE)) {
-            // this stage's RHS sweep also forms the NEXT stage's argument
-            const int r = sweep_next_stage(c, i, t, h);
-            if (r == 0) { ready = true; continue; }
-            if (r != ESQ_ENOTSUP) return r;
-        }
-        if (i + 1 < i_to && bnext && may_fuse(c, ESQ_EPI_BLOCK)) {
-            // ... or runs the blocked accumulation at the column boundary
-            bool made = false;
-            const int r = sweep_block(c, *bnext, i, t, h, &made);
-            if (r == 0) { ready = made; block_done = !made; continue; }
-            if (r != ESQ_ENOTSUP) return r;
-        }
-        if (i == c->s - 1 && i_to == c->s) {
-            if (c->fsal && may_fuse(c, ESQ_EPI_STAGE)) {
-                // FSAL pairs: the LAST stage's sweep also forms y_new
-                const int r = sweep_ynew(c, i, t, h);
-                if (r == 0) { c->ynew_ready = true; continue; }
-                if (r != ESQ_ENOTSUP) return r;
-            }
-            if (!c->fsal && may_fuse(c, ESQ_EPI_SOLERR)) {
-                // others: ... y_new and the error partial sums
-                const int r = sweep_solerr(c, i, t, h);
-                if (r == 0) { c->ynew_ready = c->solerr_ready = true; continue; }
-                if (r != ESQ_ENOTSUP) return r;
-            }
-        }
-        const int r = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
-        if (r) return r;
-    }
+    c->ynew_ready = plan.ynew_ready;
+    c->solerr_ready = plan.solerr_ready;
     return 0;
+}
+
+// ---- the step programs as text, without a GPU (tests/test_step_plans.py) ---------
+// A DETACHED context (no device, no slab: the vectors are distinct fake addresses
+// nothing dereferences) gets the tableau and one of the built-in plugins' entries;
+// the plans are built exactly as esq_rk_stages builds them -- the plugins answer
+// the queries on the host -- and printed one per line:
+//   <key>: <op>[<i>[,<depth>,<what>]][flags] ...  | launches=<n> words=<read>+<written>
+// keys: first = a step that starts from K[0] in memory (the first step, a retry
+// after a rejection), deferred = after an accepted step that left f(t, y) to this
+// one, prelaunched = stage 1's argument formed at accept time.
+int esq_plan_describe(const char *plugin, int N, int s, const double *A, const double *B,
+                      const double *C, const double *E, int fsal, int chain_caps,
+                      int fuse_mask, int lazy_rows, int chain_depth, int src_pays, char *buf,
+                      size_t buflen) {
+    if (!plugin || !A || !B || !C || !E || !buf || buflen < 2 || s < 1 || N < 1) return ESQ_EINVAL;
+    esq_ctx ctx;
+    esq_ctx *c = &ctx;
+    c->detached = true;
+    c->device = -1;
+    void *user = nullptr;
+    size_t n = 0;
+    const std::string name(plugin);
+    if (name == "bruss2d") {
+        if (esq_rhs_bruss2d_create(&user, N, 0.1, 1.0, 3.4)) return ESQ_EINVAL;
+        n = 2 * (size_t)N * N;
+        c->rhs = esq_rhs_bruss2d; c->rhs_fused = esq_rhs_bruss2d_fused;
+        c->rhs_chain = esq_rhs_bruss2d_chain;
+    } else if (name == "heat2d") {
+        if (esq_rhs_heat2d_create(&user, N)) return ESQ_EINVAL;
+        n = (size_t)N * N;
+        c->rhs = esq_rhs_heat2d; c->rhs_fused = esq_rhs_heat2d_fused;
+        c->rhs_chain = esq_rhs_heat2d_chain;
+    } else if (name == "diff3d") {
+        if (esq_rhs_diff3d_create(&user, N)) return ESQ_EINVAL;
+        n = (size_t)N * N * N;
+        c->rhs = esq_rhs_diff3d; c->rhs_fused = esq_rhs_diff3d_fused;
+    } else if (name == "plain") {                 // an esq_rhs_fn-only plugin
+        if (esq_rhs_heat2d_create(&user, N)) return ESQ_EINVAL;
+        n = (size_t)N * N;
+        c->rhs = esq_rhs_heat2d;
+    } else {
+        return ESQ_EINVAL;
+    }
+    c->rhs_user = user;
+    c->n = c->len = n;
+    c->len_pad = ((n + kPadDoubles - 1) / kPadDoubles) * kPadDoubles;
+    c->stride = c->len_pad;
+    c->n_rows = s + 1;
+    double *fake = reinterpret_cast<double *>((uintptr_t)1 << 40);
+    c->krow.resize(c->n_rows);
+    c->kmap.resize(c->n_rows);
+    for (int r = 0; r < c->n_rows; ++r) { c->krow[r] = fake + (size_t)r * c->stride; c->kmap[r] = r; }
+    c->kmap_last = c->kmap;
+    double *base = fake + (size_t)c->n_rows * c->stride;
+    c->y = base; c->ynew = base + c->stride; c->ystage = base + 2 * c->stride;
+    c->atolv = base + 3 * c->stride; c->work = base + 4 * c->stride;
+    c->partials = base + 5 * c->stride;
+    c->fuse_mask = c->rhs_fused ? fuse_mask : 0;
+    c->chain_caps = c->rhs_chain ? chain_caps : 0;
+    c->lazy_rows = lazy_rows != 0;
+    c->lazy_end = true;
+    c->chain_depth = chain_depth;
+    c->src_pays = src_pays != 0;
+    int r = esq_rk_set_tableau(c, s, A, B, C, E, fsal);
+    size_t used = 0;
+    buf[0] = 0;
+    static const char *kOp[] = {"k0", "chain", "src", "accum", "lincomb", "stage", "block",
+                                "ynew", "solerr", "rhs"};
+    const struct { const char *label; bool ready, k0; } keys[] = {
+        {"first", false, false}, {"deferred", false, true}, {"prelaunched", true, false}};
+    for (const auto &k : keys) {
+        if (r) break;
+        if (k.k0 && fsal) continue;
+        const Plan plan = build_plan(c, 1, s, k.ready, k.k0, c->lazy_rows);
+        std::string line = std::string(k.label) + ":";
+        double rd = 0, wr = 0;
+        for (const PlanStep &st : plan.steps) {
+            char tok[64];
+            if (st.op == OP_CHAIN)
+                snprintf(tok, sizeof(tok), " chain[%d,%d,%d]%s%s%s", st.i, st.depth, st.what,
+                         st.lazy ? "L" : "", st.from_rows ? "F" : "", st.skip_out ? "S" : "");
+            else
+                snprintf(tok, sizeof(tok), " %s[%d]", kOp[st.op], st.i);
+            line += tok;
+            rd += st.reads; wr += st.writes;
+        }
+        char tail[96];
+        snprintf(tail, sizeof(tail), " | launches=%zu words=%g+%g%s%s\n", plan.steps.size(), rd,
+                 wr, plan.ynew_ready ? " ynew" : "", plan.solerr_ready ? " solerr" : "");
+        line += tail;
+        if (used + line.size() + 1 > buflen) { r = ESQ_EINVAL; break; }
+        memcpy(buf + used, line.c_str(), line.size() + 1);
+        used += line.size();
+    }
+    esq_rhs_free(user);
+    return r;
 }
 
 int esq_rk_solution(esq_ctx *c, double h) {
@@ -1234,10 +1541,14 @@ int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
                           !(may_use_src(c) && c->s >= 3);
     bool pre_done = false;
     // the end-point derivative can wait for the next step's first chain sweep
-    const bool defer = !c->fsal && with_end_eval && c->lazy_end && c->end_fused_ok != 0 &&
-                       c->rhs && c->rhs_chain && c->rhs_fused && !c->cplx &&
-                       (c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE) &&
-                       c->chain_depth >= 2 && may_fuse(c, ESQ_EPI_STAGE);
+    // (if the next whole step's program starts with that chain: a query, not a guess)
+    bool defer = !c->fsal && with_end_eval && c->lazy_end && c->rhs && c->rhs_chain &&
+                 c->rhs_fused && !c->cplx && (c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE) &&
+                 c->chain_depth >= 2 && may_fuse(c, ESQ_EPI_STAGE);
+    if (defer) {
+        const Plan &next = get_plan(c, 1, c->s, false, true);
+        defer = !next.steps.empty() && next.steps[0].op == OP_CHAIN && next.steps[0].i == 0;
+    }
     if (defer) {
         c->k0_missing = true;
         c->k0_t = t_new;

@@ -229,6 +229,8 @@ class DeviceContext:
                         raise ValueError(f"ESQ_FUSE: unknown epilogue {name!r}")
                     mask |= kinds[name.strip()]
                 mask &= supported
+            # the entry answers the library's side-effect-free queries
+            mask |= _lib.FUSE_QUERY if rhs._fuse_query else 0
             self._chk(self.lib.esq_set_rhs_fused(self.handle,
                                                  C.cast(fused, C.c_void_p), mask),
                       "esq_set_rhs_fused")
@@ -333,6 +335,7 @@ class DeviceRHS:
     _fuse_default = False      # use the fused entry unless ESQ_CHAIN says otherwise
     _fuse_src = False          # the fused entry accepts the on-the-fly first-stage input
     _fuse_mask = None          # epilogue kinds the fused entry implements (None: all)
+    _fuse_query = False        # the fused entry honours esq_epilogue.dry_run
 
     def __init__(self):
         self._bound = {}       # device -> (fn, user)
@@ -414,7 +417,8 @@ class _Builtin(DeviceRHS):
     _symbol_chain = None
     _symbol_rkc_chain = None
     _rkc_chain_depth = int(os.environ.get("ESQ_RKC_MAXDEPTH", "4"))
-    _chain_caps = 15                  # the built-in sweeps handle every form
+    _chain_caps = 31                  # the built-in sweeps handle every form and
+    _fuse_query = True                # answer the planner's queries
 
     def _rkc_chain_entry(self, lib):
         if not self._symbol_rkc_chain:

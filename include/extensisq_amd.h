@@ -150,6 +150,12 @@ typedef struct esq_epilogue {
      * kinds differ (|.| is the complex modulus, n_valid counts complex
      * elements); a plugin for real states returns ESQ_ENOTSUP for them. */
     int is_complex;
+    /* QUERY: decide exactly as for a launch -- return 0, ESQ_ENOTSUP or an error --
+     * but enqueue nothing and write nothing (*partials_used included).  The library
+     * builds its launch plan of a step from such queries (esq_rk_stages) instead of
+     * learning from refused launches; asked only of entries registered with
+     * ESQ_FUSE_QUERY.  esq::dispatch_epilogue (csrc/esq_plugin.hpp) implements it. */
+    int dry_run;
 } esq_epilogue;
 typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
                                 double *f_dev, const esq_epilogue *epi, size_t n,
@@ -228,6 +234,9 @@ typedef struct esq_chain {
      * multiplies the bytes READ (halo rows and columns are loaded by two tiles);
      * the library books it in the launch's designed traffic (esq_profile_*) */
     double *read_amplification;
+    /* QUERY (see esq_epilogue.dry_run): asked only of entries registered with
+     * ESQ_CHAIN_CAP_QUERY; esq::dispatch_chain implements it. */
+    int dry_run;
 } esq_chain;
 typedef int (*esq_rhs_chain_fn)(void *user, const double *y_in,
                                 const esq_chain *chain, size_t n, void *hip_stream,
@@ -335,6 +344,7 @@ int  esq_set_rhs(esq_ctx *ctx, esq_rhs_fn fn, void *user);
  * unfused sequence and can be switched off for A/B tests. */
 #define ESQ_FUSE_ALL 0x5e
 #define ESQ_FUSE_SRC 0x20    /* the entry also accepts the on-the-fly input    */
+#define ESQ_FUSE_QUERY 0x80  /* the entry honours esq_epilogue.dry_run         */
 int  esq_set_rhs_fused(esq_ctx *ctx, esq_rhs_fused_fn fn, int fuse_mask);
 /* register (or clear) the optional chain entry: esq_rk_stages then runs up to
  * ESQ_CHAIN_DEPTH (default 4) stages per launch wherever plain stage sweeps (and
@@ -354,6 +364,10 @@ int  esq_set_rhs_fused(esq_ctx *ctx, esq_rhs_fused_fn fn, int fuse_mask);
 #define ESQ_CHAIN_CAP_FROM_ROWS  4
 #define ESQ_CHAIN_CAP_SKIP_OUT   8
 #define ESQ_CHAIN_CAP_ALL        15
+/*   QUERY       the entry honours chain->dry_run (side-effect-free "would you take
+ *               this chain?"): the library then plans a step from the answers; without
+ *               it a refused launch is remembered and the step finished the plain way */
+#define ESQ_CHAIN_CAP_QUERY      16
 int  esq_set_rhs_chain(esq_ctx *ctx, esq_rhs_chain_fn fn, int caps);
 /* register (or clear) the optional RKC entry: esq_rkc_stages then issues ONE
  * kernel per Chebyshev stage (RHS + recursion) instead of two */
@@ -433,6 +447,18 @@ int  esq_rk_error_vector(esq_ctx *ctx, double h, int last_step);
 int  esq_rk_row_id(esq_ctx *ctx, int logical_row, int last_step);
 /* logical->physical row of K for the step just accepted (for solver.K) */
 int  esq_rk_download_last_K(esq_ctx *ctx, int row, double *host);
+/* The launch plans ("step programs") esq_rk_stages would run for a method on one
+ * of the built-in plugins ("bruss2d", "heat2d", "diff3d", "plain" = esq_rhs_fn
+ * only) with the given entry capabilities, as text -- built exactly as on a
+ * device, but on a detached context: no GPU is touched (the plugins answer the
+ * library's queries on the host).  One line per starting state of a step:
+ *   first / deferred / prelaunched: <launch> ... | launches=<n> words=<r>+<w>
+ * (designed 8-byte words per element read + written, halo re-reads not counted).
+ * tests/test_step_plans.py pins the plans of every tableau with it. */
+int  esq_plan_describe(const char *plugin, int N, int s, const double *A,
+                       const double *B, const double *C, const double *E, int fsal,
+                       int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
+                       int src_pays, char *buf, size_t buflen);
 /* Rows of K that only the solution / error sums of their own sweep read (the
  * stages of a step's last chain sweep, non-FSAL pairs: `self.K[s] = f` of
  * common.py:355 for rows nothing in `_step_impl` reads again) are NOT written

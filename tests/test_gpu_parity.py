@@ -2010,9 +2010,9 @@ def test_last_chain_forms_its_own_input(monkeypatch, name, plugin, N, rows):
     and error sums anyway; where the argument of its first stage needs no other row
     it forms that argument itself, T_0 = y + h * a_i . K (`esq_chain.from_rows`), and
     the chain before it does not write it (`out = NULL`): one vector less written,
-    one less read.  From the second step on (the library learns it from the first
-    launch); states and K rows equal ESQ_CHAIN_FROM_ROWS=0 bit for bit, the bytes
-    the launches are designed to move do not."""
+    one less read.  The plan is made from the plugin's answers to the library's
+    queries (no learning step); states and K rows equal ESQ_CHAIN_FROM_ROWS=0 bit for
+    bit, the bytes the launches are designed to move do not."""
     mk, y0, rho = _plugin(plugin, N)
     h = 0.4 / rho
     kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
@@ -2023,7 +2023,7 @@ def test_last_chain_forms_its_own_input(monkeypatch, name, plugin, N, rows):
     b = cls(mk(), 0.0, y0, 1.0, **kw)
     monkeypatch.delenv("ESQ_CHAIN_FROM_ROWS")
     for s in (a, b):
-        assert s.step() is None                       # the step that learns
+        assert s.step() is None                       # the first step starts from K[0]
         s._dev.profile_reset()
         s._dev.profile_enable([0, 1, 2])
     for _ in range(4):
@@ -2033,14 +2033,18 @@ def test_last_chain_forms_its_own_input(monkeypatch, name, plugin, N, rows):
     assert_equal(a.y, b.y)
     assert_equal(a.K, b.K)
     assert a.nfev == b.nfev
-    moved = [sum(r[5] for r in s._dev.profile_kernels() if r[0].startswith("chain"))
-             for s in (a, b)]
+    moved = [sum(r[5] for r in s._dev.profile_kernels()) for s in (a, b)]
     labels = [r[0] for r in a._dev.profile_kernels()]
     if any("+solerr" in lab and lab.startswith("chain") for lab in labels):
         # one vector less written and read per step, two more halo rows of the other
         # rows: a clear saving on tall tiles, a small one on short tiles
         vec = 8.0 * y0.size * 4
-        assert moved[0] < moved[1] - (1.0 if rows >= 16 else 0.0) * vec, (moved, labels)
+        # (the planner may use the form to restructure the whole step -- Pr7: a plain
+        # RHS launch between the chains -- so the saving is asserted as such, and as
+        # "one vector less each way" where both plans have the same launches)
+        same = sorted(r[0] for r in a._dev.profile_kernels()) == \
+            sorted(r[0] for r in b._dev.profile_kernels())
+        assert moved[0] < moved[1] - (1.0 if rows >= 16 and same else 0.0) * vec, (moved, labels)
     else:
         assert moved[0] == moved[1]
 

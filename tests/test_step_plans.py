@@ -1,0 +1,141 @@
+"""The step as a program (csrc/esq_step.hip: build_plan / run_plan), checked on the
+CPU: `esq_plan_describe` builds the launch plans of a method on a built-in plugin
+exactly as esq_rk_stages does on a device -- the plugins answer the library's
+side-effect-free queries on the host -- on a detached context that touches no GPU.
+
+* every plan of the 9 tableaux x plugins x chain capabilities 0...15 x lazy rows on /
+  off is pinned (launch sequence and designed words per element) in
+  tests/golden/step_plans.json (tools/gen_step_plans.py);
+* structural invariants hold for every plan: each stage is evaluated exactly once
+  and in order, a capability that was not declared is never used, a step that
+  leaves K[0] to the next one starts with it;
+* the plans of the BASELINE.json configurations are spelled out here.
+"""
+import json
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_step_plans as gsp  # noqa: E402
+
+CAP_FROM_STATE, CAP_SKIP_ROWS, CAP_FROM_ROWS, CAP_SKIP_OUT = 1, 2, 4, 8
+
+
+@pytest.fixture(scope="module")
+def plans():
+    return gsp.table()
+
+
+def test_plans_match_the_pinned_table(plans, golden_dir):
+    with open(os.path.join(golden_dir, "step_plans.json")) as fh:
+        want = json.load(fh)
+    assert sorted(plans) == sorted(want)
+    bad = [k for k in plans if plans[k] != want[k]]
+    assert not bad, (bad[:5], plans[bad[0]], want[bad[0]])
+
+
+TOKEN = re.compile(r"(\w+)\[(\d+)(?:,(\d+),(\d+))?\]([LFS]*)")
+
+
+def _parse(line):
+    label, rest = line.split(":", 1)
+    body, tail = rest.split("|")
+    steps = [(m.group(1), int(m.group(2)), int(m.group(3) or 0), int(m.group(4) or 0),
+              m.group(5)) for m in TOKEN.finditer(body)]
+    launches = int(re.search(r"launches=(\d+)", tail).group(1))
+    return label.strip(), steps, launches, tail
+
+
+def test_every_plan_evaluates_each_stage_once_and_uses_only_declared_forms(plans):
+    import extensisq_amd as esq
+    stages = {m: getattr(esq, m).n_stages for m in gsp.METHODS}
+    stages["Heun"] = 2
+    for key, lines in plans.items():
+        name, plugin, caps, lazy = key.split("/")
+        caps, lazy, s = int(caps[4:]), int(lazy[4:]), stages[name]
+        for line in lines:
+            label, steps, launches, tail = _parse(line)
+            assert launches == len(steps)
+            done = []                     # stages whose derivative this plan evaluates
+            have_arg = label == "prelaunched"
+            for op, i, depth, what, flags in steps:
+                if op == "chain":
+                    done += list(range(i, i + depth))
+                    if i == 0:
+                        assert label == "deferred" and caps & CAP_FROM_STATE, (key, line)
+                    if "L" in flags:
+                        assert lazy and caps & CAP_SKIP_ROWS, (key, line)
+                    if "F" in flags:
+                        assert caps & CAP_FROM_ROWS, (key, line)
+                    if "S" in flags:
+                        assert caps & CAP_SKIP_OUT and caps & CAP_FROM_ROWS, (key, line)
+                    # an argument must exist unless the chain makes it itself
+                    assert have_arg or "F" in flags or i == 0, (key, line)
+                    have_arg = what == 0 and "S" not in flags
+                elif op == "k0":
+                    assert label == "deferred" and i == 0
+                    done.append(0)
+                elif op in ("accum", "lincomb"):
+                    assert not have_arg, (key, line)
+                    have_arg = True
+                elif op == "src":
+                    assert i == 1 and not have_arg
+                    done.append(1)
+                    have_arg = True
+                else:                     # stage / block / ynew / solerr / rhs
+                    assert have_arg, (key, line)
+                    done.append(i)
+                    have_arg = op == "stage" or (op == "block" and False)
+                    if op == "block":     # the block sweep may or may not form the argument
+                        have_arg = None
+                if have_arg is None:      # resolved by what follows
+                    nxt = steps[steps.index((op, i, depth, what, flags)) + 1][0]
+                    have_arg = nxt not in ("lincomb", "accum")
+            first = 0 if label == "deferred" else 1
+            assert done == list(range(first, s)), (key, line, done)
+            # the last launch of a whole step forms y_new where the plugin fuses
+            if plugin.startswith(("bruss2d", "heat2d", "diff3d")):
+                assert " ynew" in tail, (key, line)
+
+
+def test_baseline_configuration_plans(plans):
+    """the launch sequences bench.py times (BASELINE.json configs 2, 3, 5), spelled out"""
+    pr8 = plans["Pr8/bruss2d2236/caps15/lazy1"]
+    assert pr8[1] == ("deferred: chain[0,5,0]L chain[5,4,0]LS chain[9,4,2]LF "
+                      "| launches=3 words=16+10 ynew solerr")
+    assert pr8[0].startswith("first: chain[1,4,0]LF chain[5,4,0]LS chain[9,4,2]LF ")
+    ts5 = plans["Ts5/heat2d1000/caps15/lazy1"]
+    assert ts5[0] == "first: chain[1,5,1]LF | launches=1 words=2+6 ynew"
+    pr9 = plans["Pr9/heat2d2236/caps15/lazy1"]
+    assert pr9[1].startswith("deferred: chain[0,5,0]L chain[5,3,0]L block[8] chain[9,3,0]L "
+                             "chain[12,4,0]L solerr[16] | launches=6 ")
+    # Pr7: the cheapest sequence is not the longest chains first (30 -> 15 words)
+    pr7 = plans["Pr7/bruss2d2236/caps15/lazy1"]
+    assert pr7[1] == ("deferred: chain[0,5,0]L rhs[5] chain[6,4,2]LF "
+                      "| launches=3 words=8+7 ynew solerr")
+    # a plugin with esq_rhs_fn only: one library kernel + one RHS launch per stage
+    plain = plans["Pr8/plain100/caps0/lazy1"]
+    assert plain[0].count("accum[") == 12 and plain[0].count("rhs[") == 12
+    # the 3-D plugin fuses every stage but has no chain entry
+    d3 = plans["Pr8/diff3d159/caps0/lazy1"]
+    assert "chain" not in d3[0] and d3[0].count("stage[") == 10 and "solerr[12]" in d3[0]
+
+
+def test_fewer_capabilities_never_mean_fewer_words(plans):
+    """the optional chain forms only ever remove traffic: the plan with every
+    capability moves no more words than any plan with a subset"""
+    def words(line):
+        m = re.search(r"words=([\d.]+)\+([\d.]+)", line)
+        return float(m.group(1)) + float(m.group(2))
+    for key, lines in plans.items():
+        if "/caps15/" not in key:
+            continue
+        for caps in range(15):
+            other = plans[key.replace("/caps15/", f"/caps{caps}/")]
+            for a, b in zip(lines, other):
+                if a.split(":")[0] == b.split(":")[0]:
+                    assert words(a) <= words(b) + 1e-9, (key, caps, a, b)
