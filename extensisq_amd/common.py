@@ -388,6 +388,16 @@ class RungeKutta(OdeSolver):
         self._dev.set_tableau(self.A, self.B, self.C, self.E, self.FSAL)
         self._dev.set_tol(self.rtol, self.atol)
         self._dev.upload(SLOT_Y, 0, y_host)
+        # classes that take WHOLE steps (the generic `_step_impl`: every accepted
+        # step is followed by stages 1 .. s) let the library enqueue the next step's
+        # first launch ahead of time; BS5 / CFMR7osc / CKdisc run their stages in
+        # pieces and would only repeat it
+        self._launch_ahead = (self._device_rhs is not None
+                              and type(self)._step_impl is RungeKutta._step_impl
+                              and os.environ.get("ESQ_LAUNCH_AHEAD", "1") != "0")
+        self._dev._chk(self._lib.esq_rk_set_launch_ahead(self._ctx,
+                                                         int(self._launch_ahead)),
+                       "esq_rk_set_launch_ahead")
         self._lockstep = lockstep
         self._n_norm = self.n
         if lockstep is not None:
@@ -738,11 +748,12 @@ class RungeKutta(OdeSolver):
             y_stage = self._dev.download(SLOT_YSTAGE)
             self._dev.upload(SLOT_K, i, self.fun(t + self.C[i] * h, y_stage))
 
-    def _solution_and_error(self, t, h):
+    def _solution_and_error(self, t, h, h_next=0.0):
         """`_comp_sol_err` (ref common.py:341-351): returns the error norm,
-        leaves y_new in the YNEW slot"""
+        leaves y_new in the YNEW slot.  `h_next`: the next step size if this
+        attempt is accepted, where the caller knows it already (`_step_impl`)"""
         if self._device_rhs is not None:
-            sumsq = self._dev.rk_solution_error_sumsq(t, h)
+            sumsq = self._dev.rk_solution_error_sumsq(t, h, h_next)
             self.nfev += self.FSAL
         elif self.FSAL:
             self._chk(self._lib.esq_rk_solution(self._ctx, h), "esq_rk_solution")
@@ -779,6 +790,18 @@ class RungeKutta(OdeSolver):
                   "esq_rk_accept")
         self._invalidate_mirrors()
 
+    def _guess_next_step(self, t_new, h_abs):
+        """The next step size, known BEFORE the error norm of this attempt: a run
+        that sits at `max_step` keeps its step when the attempt is accepted with a
+        factor >= 1 (the usual case there) -- the library then enqueues the next
+        step's first launch behind the error norm instead of after the host has
+        digested it (esq_rk_solution_error_ahead).  A wrong guess (a rejection, a
+        factor < 1) costs one discarded launch; 0.0: no guess."""
+        if not self._launch_ahead or h_abs < self.max_step:
+            return 0.0
+        h_lim, min_step, _ = self._limit_step(t_new, h_abs)
+        return h_lim * self.direction if h_lim >= min_step else 0.0
+
     # ----------------------------------------------------------------- step
     def _step_impl(self):
         t = self.t
@@ -792,7 +815,7 @@ class RungeKutta(OdeSolver):
             if self._lockstep is not None:
                 self._lockstep.check_identical(self._dev, "(t, h)", (t, h))
             self._run_stages(1, self.n_stages, t, h)
-            error_norm = self._solution_and_error(t, h)
+            error_norm = self._solution_and_error(t, h, self._guess_next_step(t_new, h_abs))
             if error_norm < 1:
                 h_abs *= self._accept_factor(error_norm, h, rejected)
                 break

@@ -250,6 +250,9 @@ int finish_reduction(esq_ctx *c, double *out, bool take_min, const double *parti
                            c->d_result, rs);
         HIPCHK(c, hipGetLastError());
     }
+    // the next step's first launch goes in behind the reduction, BEFORE the host
+    // waits for it (only if the caller asked: esq_rk_solution_error_ahead)
+    launch_ahead_if_asked(c);
     int w = wait_slot(c, rs.seq, c->comm ? c->comm_timeout_s : 0.0);
     if (w == ESQ_ETIMEOUT) {
         // a peer never reached the collective
@@ -458,6 +461,7 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     c->epi_nt = env_uint("ESQ_EPI_NT", three_fit ? 0x3 : 0xf);
     c->lazy_rows = env_uint("ESQ_LAZY_ROWS", 1) != 0;
     c->lazy_end = env_uint("ESQ_LAZY_END", 1) != 0;
+    c->ahead_on = false;           // esq_rk_set_launch_ahead: callers that take whole steps
     c->chain_from_rows = env_uint("ESQ_CHAIN_FROM_ROWS", 1) != 0;
     if (const char *e = getenv("ESQ_CHAIN_LDNT")) {          // "first,middle,last" bit masks
         unsigned a = 4, b = 4, d = 4;

@@ -160,6 +160,34 @@ struct esq_ctx {
     // first stage argument of the NEXT step, formed at accept time
     bool pre_valid = false;
     double pre_h = 0.0;
+    // THE NEXT STEP'S FIRST LAUNCH, AHEAD OF TIME (esqi::launch_ahead): where a
+    // whole step's program starts with a chain sweep, that sweep is enqueued behind
+    // the error norm of the step in flight -- before the host has even seen the
+    // norm, if the caller could name the next step size (a run at max_step), else
+    // when the step is accepted -- so the GPU does not idle while the result
+    // travels to the host, the controller runs and the next launch is enqueued.
+    // The sweep's K rows go to SPARE physical rows (the rows of the step in flight
+    // stay readable: dense output, solver.K); accepting the step with that step
+    // size swaps them in (`ahead.committed`), anything else drops them.
+    bool ahead_on = true;                 // ESQ_LAUNCH_AHEAD=0: never
+    std::vector<int> spare_rows;          // physical rows nobody's map points at
+    double *spare_vec = nullptr;          // ... and a spare state vector: a chain that
+                                          // ends in y_new writes the NEXT step's there
+    double ahead_ask_t = 0.0, ahead_ask_h = 0.0;   // request of esq_rk_solution_error_ahead
+    struct Ahead {
+        bool valid = false;               // launched for (t, h), not yet accepted
+        bool committed = false;           // accepted: esq_rk_stages(1, s, t, h) skips it
+        double t = 0.0, h = 0.0;
+        unsigned key = 0;                 // plan it is the first entry of
+        std::vector<int> kmap;            // the next step's row map (spares swapped in)
+        std::vector<int> spares;          // the spare rows once it is accepted
+        double *ystage = nullptr, *work = nullptr;
+        bool wrote_ynew = false;          // its last target was y_new (into spare_vec)
+        bool tail_missing = false;        // rows the sweep left unwritten (lazy rows)
+        unsigned long long missing_rows = 0;
+        bool k0_done = false;             // it evaluated f(t, y) of the new state
+    } ahead;
+    long ahead_used = 0, ahead_dropped = 0;
     // which sweeps stream the fresh derivative out with non-temporal stores
     // (ESQ_EPI_NT bits: 0 stage, 1 block, 2 solerr, 3 end-point, 4 FSAL errnorm)
     unsigned epi_nt = 0x3;
@@ -254,6 +282,8 @@ double *slot_ptr(esq_ctx *c, int slot, int row, bool logical = true);
         (c)->pre_valid = false;              \
         (c)->idle = false;                   \
         (c)->self_valid = false;             \
+        (c)->ahead.valid = false;            \
+        (c)->ahead.committed = false;        \
     } while (0)
 
 // ---- profiling -------------------------------------------------------------
@@ -293,6 +323,9 @@ int build_row_terms2(esq_ctx *c, const double *b, int nb, const double *e, int n
 int restore_rows(esq_ctx *c);
 // forget the step programs (the tableau, a plugin entry or a tuning knob changed)
 void drop_plans(esq_ctx *c);
+// the next step's first launch behind the reduction just enqueued (finish_reduction
+// calls it before it waits, if esq_rk_solution_error_ahead asked for it)
+void launch_ahead_if_asked(esq_ctx *c);
 // ---- esq_core.hip ------------------------------------------------------------
 // sink of the next reduction / completion signal (bumps red_seq)
 ResultSink next_sink(esq_ctx *c, bool to_host_value);

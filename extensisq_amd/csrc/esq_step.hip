@@ -1024,11 +1024,114 @@ int run_step(esq_ctx *c, const PlanStep &st, double t, double h) {
     }
 }
 
+// would esq_rk_accept leave f(t_new, y_new) to the next step's first chain?
+bool defers_end_point(esq_ctx *c) {
+    if (c->fsal || !c->lazy_end || !c->rhs || !c->rhs_chain || !c->rhs_fused || c->cplx ||
+        !(c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE) || c->chain_depth < 2 ||
+        !may_fuse(c, ESQ_EPI_STAGE))
+        return false;
+    const Plan &next = get_plan(c, 1, c->s, false, true);
+    return !next.steps.empty() && next.steps[0].op == OP_CHAIN && next.steps[0].i == 0;
+}
+
+// The first launch of the step that FOLLOWS the one in flight, enqueued now: the
+// context is put into the state esq_rk_accept would leave it in (y <-> y_new, the
+// row map rotated, the rows the sweep writes mapped to spare physical rows), the
+// first entry of that step's program runs, and the context is put back.  What
+// the launch produced is remembered in c->ahead; esq_rk_accept(t_new, ., h) with
+// the same (t_new, h) makes it real.  Only a chain sweep is launched ahead (it
+// writes nothing but its own K rows and the stage-argument buffer).
+void launch_ahead(esq_ctx *c, double t_new, double h) {
+    c->ahead.valid = c->ahead.committed = false;
+    if (!c->ahead_on || !c->have_tab || !c->rhs || c->cplx || c->host_slab || h == 0.0) return;
+    const bool k0_next = defers_end_point(c);
+    // (a pair that is not FSAL and does not leave f(t_new, y_new) to the chain has
+    // that derivative evaluated by esq_rk_accept: nothing can run ahead of it)
+    if (!c->fsal && !k0_next) return;
+    const bool lazy_ok = c->lazy_rows && !c->keep_rows;
+    const Plan &plan = get_plan(c, 1, c->s, false, k0_next);
+    // a chain sweep, or stage 1 from the state: launches that write nothing but K
+    // rows of the new step and the stage-argument buffer
+    if (plan.steps.empty() ||
+        (plan.steps[0].op != OP_CHAIN && plan.steps[0].op != OP_SRC_STAGE))
+        return;
+    const PlanStep st = plan.steps[0];
+    const int n_cols = st.op == OP_CHAIN ? st.depth : 1;
+    if ((int)c->spare_rows.size() < ESQ_CHAIN_MAX_DEPTH || !c->spare_vec) {
+        int first = 0;
+        if (esq_aux_rows(c, ESQ_CHAIN_MAX_DEPTH + 1, &first) != 0) return;
+        c->spare_rows.clear();
+        for (int k = 0; k < ESQ_CHAIN_MAX_DEPTH; ++k) c->spare_rows.push_back(first + k);
+        c->spare_vec = c->krow[first + ESQ_CHAIN_MAX_DEPTH];
+        c->ahead.valid = c->ahead.committed = false;        // (esq_aux_rows went through ENTER)
+    }
+    // ---- the state after an accept
+    esq_ctx::Ahead &a = c->ahead;
+    const std::vector<int> kmap_now = c->kmap;
+    a.kmap = c->kmap;
+    std::swap(a.kmap[0], a.kmap[c->s]);
+    a.spares.clear();
+    int used = 0;
+    for (int k = 0; k < n_cols; ++k) {
+        const int col = st.i + k;
+        if (col == 0) continue;              // K[0] of the new step: the free K[s] slot
+        a.spares.push_back(a.kmap[col]);     // (this step's row: a spare once accepted)
+        a.kmap[col] = c->spare_rows[used++];
+    }
+    for (size_t q = (size_t)used; q < c->spare_rows.size(); ++q) a.spares.push_back(c->spare_rows[q]);
+    struct Saved {
+        double *y, *ynew, *ystage, *work;
+        bool tail_missing, tail_accepted, k0_missing, ynew_ready, solerr_ready;
+        unsigned long long missing_rows;
+        double tail_t, tail_h;
+        long end_fused;
+    } sv{c->y, c->ynew, c->ystage, c->work, c->tail_missing, c->tail_accepted, c->k0_missing,
+         c->ynew_ready, c->solerr_ready, c->missing_rows, c->tail_t, c->tail_h, c->end_fused};
+    c->kmap = a.kmap;
+    // (the new step's y_new buffer: NOT the old state -- the attempt may be rejected,
+    // and after an accept the old state is what the interpolant starts from)
+    c->y = sv.ynew;
+    c->ynew = c->spare_vec;
+    c->tail_missing = false;
+    c->missing_rows = 0;
+    c->k0_missing = k0_next;
+    const int r = run_step(c, st, t_new, h);
+    // ---- what it left behind, and the context as it was
+    a.ystage = c->ystage; a.work = c->work;
+    a.tail_missing = c->tail_missing; a.missing_rows = c->missing_rows;
+    a.k0_done = k0_next && !c->k0_missing;
+    a.wrote_ynew = st.op == OP_CHAIN && st.what >= 1;
+    c->kmap = kmap_now;
+    c->y = sv.y; c->ynew = sv.ynew; c->ystage = sv.ystage; c->work = sv.work;
+    c->tail_missing = sv.tail_missing; c->tail_accepted = sv.tail_accepted;
+    c->missing_rows = sv.missing_rows; c->tail_t = sv.tail_t; c->tail_h = sv.tail_h;
+    c->k0_missing = sv.k0_missing;
+    c->ynew_ready = sv.ynew_ready; c->solerr_ready = sv.solerr_ready;
+    c->end_fused = sv.end_fused;
+    if (r != 0) {                        // refused at run time: the plans learn it
+        if (r == ESQ_ENOTSUP || r == kNotApplicable) {
+            c->refused.insert(step_signature(st));
+            c->plans.clear();
+        }
+        return;
+    }
+    a.valid = true;
+    a.t = t_new; a.h = h;
+    a.key = plan_key(1, c->s, false, k0_next, lazy_ok);
+}
+
 }  // namespace
 
 void esqi::drop_plans(esq_ctx *c) {
     c->plans.clear();
     c->refused.clear();
+    c->ahead.valid = c->ahead.committed = false;
+}
+
+void esqi::launch_ahead_if_asked(esq_ctx *c) {
+    const double h = c->ahead_ask_h, t = c->ahead_ask_t;
+    c->ahead_ask_h = 0.0;
+    if (h != 0.0) launch_ahead(c, t, h);
 }
 
 // The rows `missing_rows` of the step in flight (or of the step just accepted) exist
@@ -1042,6 +1145,9 @@ int esqi::restore_rows(esq_ctx *c) {
     (void)hipSetDevice(c->device);
     c->idle = false;
     c->self_valid = false;
+    // (WORK is scratch below: a first launch made ahead of time has its result there)
+    if (c->ahead.valid || c->ahead.committed) ++c->ahead_dropped;
+    c->ahead.valid = c->ahead.committed = false;
     // (a flag is cleared only once its rows are in memory: after a failure the
     // next reader tries again instead of reading what is not there)
     if (c->k0_missing) {
@@ -1267,6 +1373,14 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     if (!c) return ESQ_EINVAL;
     // YSTAGE may already hold the first stage's argument (esq_rk_accept)
     const bool ready = i_from == 1 && c->pre_valid && c->pre_h == h;
+    // ... or the whole first launch of this step may have run already (launch_ahead)
+    struct { bool committed, tail_missing; double t, h; unsigned key;
+             unsigned long long missing_rows; } ahead{c->ahead.committed, c->ahead.tail_missing,
+                                                     c->ahead.t, c->ahead.h, c->ahead.key,
+                                                     c->ahead.missing_rows};
+    bool skip_first = ahead.committed && i_from == 1 && i_to == c->s && ahead.t == t &&
+                      ahead.h == h;
+    if (c->ahead.valid) ++c->ahead_dropped;     // launched for an attempt that was rejected
     ENTER(c);
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
     if (i_from < 1 || i_to > c->s || i_from > i_to)
@@ -1276,8 +1390,28 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     c->missing_rows = 0;
     c->ynew_ready = false;
     c->solerr_ready = false;
-    const Plan &plan = get_plan(c, i_from, i_to, ready, c->k0_missing);
-    for (const PlanStep &st : plan.steps) {
+    // (the key of the plan that launch belongs to: K[0] was still to come then)
+    const bool k0_then = skip_first ? ((ahead.key >> 17) & 1u) != 0 : c->k0_missing;
+    if (skip_first && plan_key(i_from, i_to, false, k0_then, c->lazy_rows && !c->keep_rows) !=
+                          ahead.key)
+        skip_first = false;
+    const Plan &plan = get_plan(c, i_from, i_to, skip_first ? false : ready,
+                                skip_first ? k0_then : c->k0_missing);
+    if (skip_first) {
+        c->tail_missing = ahead.tail_missing;
+        c->missing_rows = ahead.missing_rows;
+        c->tail_accepted = false;
+        c->tail_t = t;
+        c->tail_h = h;
+        // the launch ended in y_new: that buffer is this step's YNEW now (the old one
+        // -- the state before the last step, dead from here on -- is the spare)
+        if (c->ahead.wrote_ynew) std::swap(c->ynew, c->spare_vec);
+        ++c->ahead_used;
+    } else if (ahead.committed) {
+        ++c->ahead_dropped;
+    }
+    for (size_t q = skip_first ? 1 : 0; q < plan.steps.size(); ++q) {
+        const PlanStep &st = plan.steps[q];
         const int r = run_step(c, st, t, h);
         if (r == 0) continue;
         if (r != ESQ_ENOTSUP && r != kNotApplicable) return r;
@@ -1435,6 +1569,17 @@ int esq_rk_error_norm(esq_ctx *c, double h, double *sumsq_out) {
     return finish_reduction(c, sumsq_out);
 }
 
+int esq_rk_solution_error_ahead(esq_ctx *c, double t, double h, double h_next,
+                                 double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    // the request is taken up by finish_reduction, between the enqueue of the final
+    // sum and the wait for it
+    c->ahead_ask_t = t + h;
+    c->ahead_ask_h = h_next;
+    const int r = esq_rk_solution_error(c, t, h, sumsq_out);
+    c->ahead_ask_h = 0.0;
+    return r;
+}
 int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
     const bool ynew_ready = c->ynew_ready, solerr_ready = c->solerr_ready;
@@ -1533,23 +1678,31 @@ int esq_rk_custom_sol_err(esq_ctx *c, double h, const double *b, const double *e
 
 int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
     if (!c) return ESQ_EINVAL;
-    ENTER(c);
+    // the next step's first launch may be in the queue already (launch_ahead, asked
+    // for by esq_rk_solution_error_ahead): it is this accept that makes it real
+    bool commit = c->ahead.valid && h_next != 0.0 && c->ahead.h == h_next &&
+                  c->ahead.t == t_new && c->have_tab && (with_end_eval || c->fsal);
+    if (c->ahead.valid && !commit) ++c->ahead_dropped;
+    ENTER(c);                      // (clears the flags of c->ahead, not what it holds)
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    // ... or is made now that the step size is known: it runs while the host
+    // returns from this step and enters the next
+    if (!commit && h_next != 0.0 && (with_end_eval || c->fsal)) {
+        launch_ahead(c, t_new, h_next);
+        commit = c->ahead.valid;
+        c->ahead.valid = false;
+    }
     // the next step's first stage argument can be formed now: stage 1 reads
     // nothing but y and K[0]
-    const bool want_pre = h_next != 0.0 && c->s >= 2 && c->rhs != nullptr &&
+    const bool want_pre = !commit && h_next != 0.0 && c->s >= 2 && c->rhs != nullptr &&
                           !(may_use_src(c) && c->s >= 3);
     bool pre_done = false;
-    // the end-point derivative can wait for the next step's first chain sweep
-    // (if the next whole step's program starts with that chain: a query, not a guess)
-    bool defer = !c->fsal && with_end_eval && c->lazy_end && c->rhs && c->rhs_chain &&
-                 c->rhs_fused && !c->cplx && (c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE) &&
-                 c->chain_depth >= 2 && may_fuse(c, ESQ_EPI_STAGE);
-    if (defer) {
-        const Plan &next = get_plan(c, 1, c->s, false, true);
-        defer = !next.steps.empty() && next.steps[0].op == OP_CHAIN && next.steps[0].i == 0;
-    }
-    if (defer) {
+    // the end-point derivative can wait for the next step's first chain sweep (if
+    // the next whole step's program starts with that chain: a query, not a guess)
+    const bool defer = !commit && with_end_eval && defers_end_point(c);
+    if (commit) {
+        // (the launch ahead evaluated f(t_new, y_new) as its stage 0, or the pair is FSAL)
+    } else if (defer) {
         c->k0_missing = true;
         c->k0_t = t_new;
     } else if (!c->fsal && with_end_eval) {
@@ -1580,8 +1733,21 @@ int esq_rk_accept(esq_ctx *c, double t_new, int with_end_eval, double h_next) {
     c->kmap_last = c->kmap;
     c->tail_accepted = true;       // a restore now works from kmap_last and YNEW
     ++c->accepted_steps;
-    std::swap(c->kmap[0], c->kmap[c->s]);
     std::swap(c->y, c->ynew);
+    if (commit) {
+        // the rows the launch wrote take the place of those logical rows; the
+        // physical rows they replace (still this step's, for its readers) are the
+        // spares of the next launch ahead
+        c->kmap = c->ahead.kmap;
+        c->spare_rows = c->ahead.spares;
+        c->ystage = c->ahead.ystage;
+        c->work = c->ahead.work;
+        c->k0_missing = false;
+        if (c->ahead.k0_done) ++c->end_fused;
+        c->ahead.committed = true;
+        return 0;
+    }
+    std::swap(c->kmap[0], c->kmap[c->s]);
     if (want_pre && !pre_done && !defer) {
         // stage 1's accumulate, launched now: it runs while the host controller
         // is between steps
@@ -1633,6 +1799,19 @@ int esq_rk_lazy_rows(esq_ctx *c, int *missing_out, int *keeps_out, long *restore
     if (restores_out) *restores_out = c->restores;
     if (end_fused_out) *end_fused_out = c->end_fused;
     if (end_plain_out) *end_plain_out = c->end_plain;
+    return 0;
+}
+
+int esq_rk_set_launch_ahead(esq_ctx *c, int on) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    c->ahead_on = on != 0;
+    return 0;
+}
+int esq_rk_launch_ahead_stats(esq_ctx *c, long *used_out, long *dropped_out) {
+    if (!c) return ESQ_EINVAL;
+    if (used_out) *used_out = c->ahead_used;
+    if (dropped_out) *dropped_out = c->ahead_dropped;
     return 0;
 }
 

@@ -265,7 +265,13 @@ class DeviceContext:
     def rk_error_norm_sumsq(self, h):
         return self._scalar(self.lib.esq_rk_error_norm, "esq_rk_error_norm", h)
 
-    def rk_solution_error_sumsq(self, t, h):
+    def rk_solution_error_sumsq(self, t, h, h_next=0.0):
+        """h_next != 0: the step size of the next step IF this attempt is accepted --
+        its first launch then goes into the queue behind the error norm
+        (esq_rk_solution_error_ahead)"""
+        if h_next:
+            return self._scalar(self.lib.esq_rk_solution_error_ahead,
+                                "esq_rk_solution_error_ahead", t, h, h_next)
         return self._scalar(self.lib.esq_rk_solution_error,
                             "esq_rk_solution_error", t, h)
 

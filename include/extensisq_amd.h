@@ -415,6 +415,18 @@ int  esq_rk_error_norm(esq_ctx *ctx, double h, double *sumsq_out);
  * Non-FSAL tableaux use ONE fused pass (solution + scale + error).
  * Synchronises. */
 int  esq_rk_solution_error(esq_ctx *ctx, double t, double h, double *sumsq_out);
+/* The same, and -- h_next != 0: the step size the caller will use next IF this
+ * attempt is accepted (a run at max_step knows it before it knows the error norm)
+ * -- the NEXT step's first launch goes into the queue right behind the error norm,
+ * before the host waits for it, where that step's program starts with a chain
+ * sweep.  The sweep writes spare rows: the K rows of the attempt stay readable.
+ * esq_rk_accept(t + h, ., h_next) with exactly that step size makes it real (the
+ * next esq_rk_stages(1, s, t + h, h_next) skips its first launch); a rejected
+ * attempt, another step size or any call that may write a vector drops it.  The
+ * GPU then does not idle while the norm travels to the host, the controller runs
+ * and the first launch is enqueued (~17 us per step).  Needs esq_rk_set_launch_ahead. */
+int  esq_rk_solution_error_ahead(esq_ctx *ctx, double t, double h, double h_next,
+                                 double *sumsq_out);
 /* BS5's early estimate (bogacki.py:340-346) over K[0..rows): YSTAGE-free,
  * y_pre = Y + h*sum b_scale_pre[j] K[j] is formed in registers only.
  * Synchronises. */
@@ -479,6 +491,15 @@ int  esq_plan_describe(const char *plugin, int N, int s, const double *A,
  * reader, or where no chain sweep fits).  Any pointer may be NULL. */
 int  esq_rk_lazy_rows(esq_ctx *ctx, int *missing_out, int *keeps_out,
                       long *restores_out, long *end_fused_out, long *end_plain_out);
+/* on != 0: the caller takes WHOLE steps -- every accepted step is followed by
+ * esq_rk_stages(1, s, ...) -- so esq_rk_accept(t_new, ., h_next != 0) may enqueue
+ * the next step's first launch right away and esq_rk_solution_error_ahead may be
+ * used (default off: callers that run the stages in pieces would pay for a launch
+ * they then repeat).  The Python classes switch it on unless ESQ_LAUNCH_AHEAD=0. */
+int  esq_rk_set_launch_ahead(esq_ctx *ctx, int on);
+/* first launches made ahead of time (esq_rk_solution_error_ahead / esq_rk_accept)
+ * that the next step used / that were dropped; either pointer may be NULL */
+int  esq_rk_launch_ahead_stats(esq_ctx *ctx, long *used_out, long *dropped_out);
 
 /* ---- dense output (common.py:358-368, 766-790) --------------------------- */
 /* Device-resident interpolant (ref HornerDenseOutput, common.py:766-790): an

@@ -63,6 +63,7 @@ REQUIRED = {
     "test_gpu_parity.py::test_lazy_rows_solve_ivp_with_dense_output": 2,
     "test_gpu_parity.py::test_end_point_derivative_as_stage_zero_of_the_next_step": 7,
     "test_gpu_parity.py::test_last_chain_forms_its_own_input": 4,
+    "test_gpu_parity.py::test_first_launch_ahead_of_time": 7,
     "test_gpu_parity.py::test_chain_entry_without_declared_capabilities": 1,
     "test_gpu_rkc.py::test_rkc_fused_tail_matches_unfused": 5,
     "test_gpu_parity.py::test_host_slab_mode_is_bit_identical": 10,

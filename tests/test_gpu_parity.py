@@ -1952,6 +1952,9 @@ def test_end_point_derivative_as_stage_zero_of_the_next_step(monkeypatch, name, 
     kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
     cls = getattr(esq, name)
     monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    # (the counts below are those of a context that launches nothing ahead of time:
+    # test_first_launch_ahead_of_time has the other half)
+    monkeypatch.setenv("ESQ_LAUNCH_AHEAD", "0")
     lazy = cls(mk(), 0.0, y0, 1.0, **kw)
     monkeypatch.setenv("ESQ_LAZY_END", "0")
     eager = cls(mk(), 0.0, y0, 1.0, **kw)
@@ -2000,6 +2003,80 @@ def test_end_point_derivative_as_stage_zero_of_the_next_step(monkeypatch, name, 
     assert_allclose(a.y, b.y, rtol=1e-9, atol=1e-12)
     assert a.nfev == b.nfev
     assert int(esq.NFS[()]) > nfs0
+
+
+def _ahead_stats(solver):
+    import ctypes
+    used, dropped = ctypes.c_long(), ctypes.c_long()
+    solver._chk(solver._lib.esq_rk_launch_ahead_stats(solver._ctx, ctypes.byref(used),
+                                                      ctypes.byref(dropped)),
+                "esq_rk_launch_ahead_stats")
+    return used.value, dropped.value
+
+
+@pytest.mark.parametrize("name,plugin,N,rows", [
+    ("Pr8", "bruss", 124, 30), ("Pr8", "heat", 130, 30), ("Pr7", "bruss", 64, 16),
+    ("Pr9", "heat", 96, 12), ("Ts5", "heat", 96, 8), ("Ts5", "bruss", 64, 12),
+    ("CK5", "bruss", 64, 16)])
+def test_first_launch_ahead_of_time(monkeypatch, name, plugin, N, rows):
+    """The first launch of the NEXT step goes into the queue behind the error norm of
+    the step in flight (before the host has seen the norm where the run sits at
+    max_step, else when the step is accepted); its K rows land in spare physical rows
+    and the y_new of a whole-step chain in a spare state vector, so everything a
+    caller may read after `step()` -- y, f, K, the dense output, the old state -- is
+    what a context that launches nothing ahead (ESQ_LAUNCH_AHEAD=0) holds, bit for
+    bit; readers in between, a rejected attempt and a changed step size drop the
+    launch and the step is taken again in full."""
+    mk, y0, rho = _plugin(plugin, N)
+    h = 0.4 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7)
+    cls = getattr(esq, name)
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    a = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_LAUNCH_AHEAD", "0")
+    b = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_LAUNCH_AHEAD")
+    assert a._launch_ahead and not b._launch_ahead
+    for _ in range(5):                     # nobody looks: every launch ahead is used
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t and a.error_norm_old == b.error_norm_old
+    used, dropped = _ahead_stats(a)
+    # (CK5: the cheapest program evaluates f(t, y) by a launch of its own at accept
+    # time and runs the whole step as ONE chain: nothing to launch ahead)
+    every = 0 if name == "CK5" else 1
+    assert used == 4 * every and dropped == 0, (used, dropped)
+    assert _ahead_stats(b) == (0, 0)
+    assert_equal(a.y, b.y)                 # (reading y drops nothing)
+    assert a.step() is None and b.step() is None
+    assert _ahead_stats(a) == (5 * every, 0)
+    # readers after a step: the accepted step's rows, not the next step's
+    assert_equal(a.K, b.K)
+    assert_equal(a.f, b.f)
+    sa, sb = a.dense_output(), b.dense_output()
+    tc = np.linspace(b.t_old, b.t, 5)
+    assert_equal(sa(tc), sb(tc))
+    for _ in range(3):                     # ... and the run goes on, bit for bit
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t
+    assert_equal(a.y, b.y)
+    assert_equal(a.K, b.K)
+    assert a.nfev == b.nfev
+    # a step size the guess did not foresee (the controller shrinks it: the attempt
+    # from 40 h is rejected, the retries grow back): launches are dropped, never wrong
+    kw2 = dict(first_step=40 * h, max_step=40 * h, rtol=1e-6, atol=1e-9)
+    c = cls(mk(), 0.0, y0, 1.0, **kw2)
+    monkeypatch.setenv("ESQ_LAUNCH_AHEAD", "0")
+    d = cls(mk(), 0.0, y0, 1.0, **kw2)
+    monkeypatch.delenv("ESQ_LAUNCH_AHEAD")
+    nfs0 = int(esq.NFS[()])
+    for _ in range(6):
+        assert c.step() is None and d.step() is None
+        assert c.t == d.t and c.h_abs == d.h_abs
+    assert int(esq.NFS[()]) > nfs0
+    assert_equal(c.y, d.y)
+    assert_equal(c.K, d.K)
+    assert c.nfev == d.nfev
+    assert _ahead_stats(c)[1] >= every
 
 
 @pytest.mark.parametrize("name,plugin,N,rows", [
