@@ -234,13 +234,24 @@ int dispatch_chain(const esq_chain *c, Launch &&launch) {
     if (c->kind_last == ESQ_EPI_SOLERR && (!c->partials || !c->y)) return ESQ_EINVAL;
     if (c->kind_last != ESQ_EPI_STAGE && c->kind_last != ESQ_EPI_SOLERR)
         return ESQ_ENOTSUP;
-    /* the from-rows form is instantiated for the solution/error kind, depth >= 3
-     * and 4+ memory rows (where a late stage's argument can be a subset of them),
-     * and for either kind with 1..3 memory rows (the first chain of a step) */ \
+    /* the from-rows form is instantiated for either kind with 1..6 memory rows (the
+     * first chain of a step; depth >= 3 from 4 rows on: a chain in the middle) and
+     * for the solution/error kind with 7+ rows (the chain that ends a step) */ \
 #define ESQ_CHAIN_CASE_(DD, K)                                                     \
     case K:                                                                        \
         if (c->from_rows) {                                                        \
-            if constexpr (DD >= 3 && K >= 4) {                                     \
+            if constexpr (DD >= 3 && K >= 4 && K <= 6) {                           \
+                /* a chain in the MIDDLE of a step too (round 4): the chain before */ \
+                /* it then leaves its last target unwritten                        */ \
+                if (c->dry_run) return 0;                                          \
+                if (c->kind_last == ESQ_EPI_STAGE)                                 \
+                    launch(make_chain_args<DD, K>(c),                              \
+                           std::integral_constant<int, ESQ_EPI_STAGE>{}, std::true_type{}); \
+                else                                                               \
+                    launch(make_chain_args<DD, K>(c),                              \
+                           std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::true_type{}); \
+                return 0;                                                          \
+            } else if constexpr (DD >= 3 && K >= 7) {                              \
                 if (c->kind_last != ESQ_EPI_SOLERR) return ESQ_ENOTSUP;            \
                 if (c->dry_run) return 0;                                          \
                 launch(make_chain_args<DD, K>(c),                                  \

@@ -371,6 +371,13 @@ struct Stencil2D {
             return ESQ_ENOTSUP;
         // (several fields in one wave: no kernel forms its own input)
         if (chain->from_rows && !(split || NF == 1)) return ESQ_ENOTSUP;
+        // a chain in the MIDDLE of a step that forms its own input (stage kind, 4+
+        // memory rows) pays only where a wave carries one field of several: the
+        // one-field heat sweep of that form moves its words at 3.5 TB/s against
+        // 5.4 for the plain chain (Pr9, N = 2236: 0.546 vs 0.519 ms/step), the
+        // Brusselator's gains (Pr9 1.074 vs 1.158, Ts5 0.302 vs 0.317)
+        if (chain->from_rows && chain->kind_last == ESQ_EPI_STAGE && chain->nu >= 4 && !split)
+            return ESQ_ENOTSUP;
         int rc_launch = 0;
         auto body = [&](auto ca, auto kind, auto split_c, auto from_c) {
             using CA = decltype(ca);

@@ -744,6 +744,11 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
         if (it == asked.end()) {
             Dry q;
             const int r = sweep_chain(c, i, D, t, h, what, lazy, from_rows, skip_out, &q);
+            static const bool dbg = getenv("ESQ_PLAN_DEBUG") != nullptr;
+            if (dbg)
+                fprintf(stderr, "[esq plan] chain(i=%d, D=%d, what=%d%s%s%s) -> %d  words %g+%g\n",
+                        i, D, what, lazy ? ", lazy" : "", from_rows ? ", from rows" : "",
+                        skip_out ? ", no out" : "", r, q.reads, q.writes);
             it = asked.emplace(sig, std::make_pair(r, q)).first;
         }
         d = it->second.second;
@@ -759,6 +764,8 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
     const bool lazy = lazy_ok && c->rhs && i_to == s && (c->chain_caps & ESQ_CHAIN_CAP_SKIP_ROWS);
     const bool from_cap = c->chain_from_rows && (c->chain_caps & ESQ_CHAIN_CAP_FROM_ROWS);
     const bool skip_cap = from_cap && (c->chain_caps & ESQ_CHAIN_CAP_SKIP_OUT) && i_to == s;
+    // ESQ_CHAIN_FROM_ROWS=2: only the chains that end or start a step (round 3)
+    static const bool from_anywhere = env_uint("ESQ_CHAIN_FROM_ROWS", 1) != 2;
     // the argument of stage i by the library's own kernel (after a block sweep that
     // left only the partial sums: the stage kernel alone)
     auto argument = [&](int i, bool block_done) {
@@ -806,8 +813,12 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
                 for (int skip = (what == 0 && skip_cap) ? 1 : 0; skip >= 0; --skip) {
                     // a chain that ends the step, or the first one of a step: its
                     // input from the rows it reads anyway
+                    // ... any chain whose first argument is a combination of rows it
+                    // reads anyway (sweep_chain decides; the launch before it can then
+                    // leave that argument unwritten)
                     Dry d;
-                    if ((what == 2 || first_from) && from_cap &&
+                    if (from_cap && (i_to == s || first_from) &&
+                        (from_anywhere || what == 2 || first_from) &&
                         ask_chain(i, D, what, lazy, true, skip != 0, d))
                         push({mk(OP_CHAIN, i, d, D, what, lazy, true, skip != 0)}, i + D,
                              what == 0 && !skip, false, what >= 1, what == 2);
@@ -948,23 +959,26 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
     const PlanStep k0 = mk(OP_RHS_K0, 0, dk);
     double best = step_cost(c, k0) + solve(i_from, false, false, true, false, false);
     int best_D = 0;
+    bool best_skip = false;
     Dry best_d;
     if (i_from == 1 && chains && may_fuse(c, ESQ_EPI_STAGE) &&
         (c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE)) {
         for (int D = c->chain_depth; D >= 2; --D) {
             if (1 + D >= i_to || crosses(1, 1 + D) || D + 1 > ESQ_CHAIN_MAX_DEPTH) continue;
-            Dry d;      // (its successor is never the chain that ends the step: the
-                        // last target is written)
-            if (!ask_chain(0, D + 1, 0, lazy, false, false, d)) { if (greedy) break; continue; }
-            const double cst = step_cost(c, mk(OP_CHAIN, 0, d, D + 1, 0, lazy)) +
-                               solve(D + 1, true, false, false, false, false);
-            if (greedy || cst < best) { best = cst; best_D = D; best_d = d; }
+            // (its last target unwritten where the chain behind it forms its own input)
+            for (int skip = (skip_cap && !greedy) ? 1 : 0; skip >= 0; --skip) {
+                Dry d;
+                if (!ask_chain(0, D + 1, 0, lazy, false, skip != 0, d)) continue;
+                const double cst = step_cost(c, mk(OP_CHAIN, 0, d, D + 1, 0, lazy, false, skip != 0)) +
+                                   solve(D + 1, !skip, false, false, false, false);
+                if (greedy || cst < best) { best = cst; best_D = D; best_d = d; best_skip = skip != 0; }
+            }
             if (greedy) break;
         }
     }
     if (best_D) {
-        plan.steps.push_back(mk(OP_CHAIN, 0, best_d, best_D + 1, 0, lazy));
-        walk(best_D + 1, true, false, false);
+        plan.steps.push_back(mk(OP_CHAIN, 0, best_d, best_D + 1, 0, lazy, false, best_skip));
+        walk(best_D + 1, !best_skip, false, false);
     } else {
         plan.steps.push_back(k0);
         walk(i_from, false, false, true);
@@ -1517,7 +1531,7 @@ int esq_plan_describe(const char *plugin, int N, int s, const double *A, const d
         if (k.k0 && fsal) continue;
         const Plan plan = build_plan(c, 1, s, k.ready, k.k0, c->lazy_rows);
         std::string line = std::string(k.label) + ":";
-        double rd = 0, wr = 0;
+        double rd = 0, wr = 0, cost = 0;
         for (const PlanStep &st : plan.steps) {
             char tok[64];
             if (st.op == OP_CHAIN)
@@ -1527,10 +1541,12 @@ int esq_plan_describe(const char *plugin, int N, int s, const double *A, const d
                 snprintf(tok, sizeof(tok), " %s[%d]", kOp[st.op], st.i);
             line += tok;
             rd += st.reads; wr += st.writes;
+            cost += step_cost(c, st);
         }
-        char tail[96];
-        snprintf(tail, sizeof(tail), " | launches=%zu words=%g+%g%s%s\n", plan.steps.size(), rd,
-                 wr, plan.ynew_ready ? " ynew" : "", plan.solerr_ready ? " solerr" : "");
+        char tail[128];
+        snprintf(tail, sizeof(tail), " | launches=%zu words=%g+%g cost=%.2f%s%s\n",
+                 plan.steps.size(), rd, wr, cost, plan.ynew_ready ? " ynew" : "",
+                 plan.solerr_ready ? " solerr" : "");
         line += tail;
         if (used + line.size() + 1 > buflen) { r = ESQ_EINVAL; break; }
         memcpy(buf + used, line.c_str(), line.size() + 1);

@@ -464,8 +464,9 @@ int  esq_rk_download_last_K(esq_ctx *ctx, int row, double *host);
  * only) with the given entry capabilities, as text -- built exactly as on a
  * device, but on a detached context: no GPU is touched (the plugins answer the
  * library's queries on the host).  One line per starting state of a step:
- *   first / deferred / prelaunched: <launch> ... | launches=<n> words=<r>+<w>
- * (designed 8-byte words per element read + written, halo re-reads not counted).
+ *   first / deferred / prelaunched: <launch> ... | launches=<n> words=<r>+<w> cost=<c>
+ * (designed 8-byte words per element read + written, halo re-reads not counted; the
+ * planner's cost of the sequence, which it minimises).
  * tests/test_step_plans.py pins the plans of every tableau with it. */
 int  esq_plan_describe(const char *plugin, int N, int s, const double *A,
                        const double *B, const double *C, const double *E, int fsal,

@@ -1937,7 +1937,7 @@ def test_lazy_rows_solve_ivp_with_dense_output(monkeypatch, name):
 
 @pytest.mark.parametrize("name,plugin,N,rows,first", [
     ("Pr8", "bruss", 50, 9, "chain5<0>"), ("Pr8", "bruss", 124, 30, "chain5<0>"),
-    ("Pr7", "bruss", 64, 16, "chain"), ("Pr9", "bruss", 64, 16, "chain5<0>"),
+    ("Pr7", "bruss", 64, 16, "chain"), ("Pr9", "bruss", 64, 16, "chain"),
     ("Pr8", "heat", 130, 30, ""), ("CK5", "bruss", 64, 16, ""), ("Me4", "heat", 100, 12, "")])
 def test_end_point_derivative_as_stage_zero_of_the_next_step(monkeypatch, name, plugin, N,
                                                              rows, first):
