@@ -288,7 +288,9 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             }                                                                      \
             const double2 t0_ = make_double2(__dadd_rn(Y_[f].x, __dmul_rn(ca.h, s0_.x)), \
                                              __dadd_rn(Y_[f].y, __dmul_rn(ca.h, s0_.y))); \
-            DST[f] = act_ ? t0_ : zero;                                            \
+            /* componentwise: `c ? a : b` on two double2 lvalues selects an        \
+               ADDRESS and loads through it -- a round trip through scratch */     \
+            DST[f] = make_double2(act_ ? t0_.x : 0.0, act_ ? t0_.y : 0.0);         \
         }                                                                          \
     }
         // the D targets' sums over a row set (leading partial + memory rows)
@@ -458,7 +460,8 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                             make_double2(__dadd_rn(yf[k][f].x, __dmul_rn(ca.h, s.x)),
                                          __dadd_rn(yf[k][f].y, __dmul_rn(ca.h, s.y)));
                         if (k + 1 < D) {
-                            wp[k + 1 < D ? k + 1 : k][f] = actk ? t : zero;
+                            wp[k + 1 < D ? k + 1 : k][f] =
+                                make_double2(actk ? t.x : 0.0, actk ? t.y : 0.0);
                         } else if (own && store_ok) {
                             if (SOLERR || ca.out) st2(ca.out, k2, t);
                             if (SOLERR) {

@@ -1,13 +1,14 @@
 #!/bin/bash
-# same-box interleaved A/B of two builds of the library (make VARIANT=... in csrc/):
-#   tools/ab_lib.sh <variant> <rounds> <config> [config ...]
-# A = the default libextensisq_amd.so, B = libextensisq_amd_<variant>.so
-VAR=$1; ROUNDS=$2; shift; shift
+# same-box interleaved A/B of builds of the library (make VARIANT=... in csrc/):
+#   tools/ab_lib.sh <variant[,variant...]> <rounds> <config> [config ...]
+# A = the default libextensisq_amd.so, then libextensisq_amd_<variant>.so for each
+# variant, round by round
+VARS=$1; ROUNDS=$2; shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for cfg in "$@"; do
   for r in $(seq 1 $ROUNDS); do
-    for side in A B; do
-      if [ $side = B ]; then export ESQ_LIB=$ROOT/extensisq_amd/libextensisq_amd_$VAR.so; else unset ESQ_LIB; fi
+    for side in A ${VARS//,/ }; do
+      if [ $side = A ]; then unset ESQ_LIB; else export ESQ_LIB=$ROOT/extensisq_amd/libextensisq_amd_$side.so; fi
       python3 $ROOT/bench.py --config $cfg --steps ${ESQ_AB_STEPS:-60} --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras \
           > $ROOT/gpurun_out/ab_lib_${cfg}_${side}_$r.json 2> $ROOT/gpurun_out/ab_lib.err
       python3 -c "
