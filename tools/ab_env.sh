@@ -1,17 +1,18 @@
 #!/bin/bash
-# same-box interleaved A/B of environment settings on a bench config:
-#   tools/ab_env.sh <config> "VAR=a VAR2=b" "VAR=c" ...     ("" = defaults)
+# same-box interleaved A/B of one environment switch of the library:
+#   tools/ab_env.sh <VAR>=<value-B> <rounds> <config> [config ...]     (A = unset)
+KV=$1; ROUNDS=$2; shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-CFG=${1:-pr8}; shift
-python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras > /dev/null 2>&1
-for round in 1 2 3; do
-  for SET in "$@"; do
-    env $SET python3 $ROOT/bench.py --config $CFG --steps 60 --warmup 10 --no-cpu-baseline --no-solve-ivp --no-extras > /tmp/ab_env.json 2>/dev/null
-    python3 - <<PY
+for cfg in "$@"; do
+  for r in $(seq 1 $ROUNDS); do
+    for side in A B; do
+      if [ $side = B ]; then export "$KV"; else unset ${KV%%=*}; fi
+      python3 $ROOT/bench.py --config $cfg --steps ${ESQ_AB_STEPS:-60} --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras \
+          > $ROOT/gpurun_out/ab_env_${cfg}_${side}_$r.json 2> $ROOT/gpurun_out/ab_env.err
+      python3 -c "
 import json
-d=json.load(open("/tmp/ab_env.json"))
-ks=d["roofline"]["kernels"]
-print("$CFG [%s] round=$round ms/step=%.4f sum=%.4f  "%("$SET", d["ms_per_step"], sum(v["avg_us"]*v["launches"] for v in ks.values())/d["steps"]/1e3) + " ".join("%s=%.0f"%(k,v["avg_us"]) for k,v in sorted(ks.items())))
-PY
+b=json.loads(open('$ROOT/gpurun_out/ab_env_${cfg}_${side}_$r.json').read().strip().splitlines()[-1])
+print('$cfg $side round $r: %.4f ms/step  ' % b['ms_per_step'] + '  '.join('%s %.1f' % (k, v['avg_us']) for k, v in b['roofline']['kernels'].items()))"
+    done
   done
 done
