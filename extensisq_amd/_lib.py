@@ -13,13 +13,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # `make VARIANT=...` in csrc/); must sit next to the package like the default one
 LIB_PATH = os.environ.get("ESQ_LIB") or os.path.join(_HERE, "libextensisq_amd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
 EPI_RKCERR = 6
 FUSE_ALL = 0x5e
 FUSE_SRC = 0x20
 FUSE_QUERY = 0x80
+RKC_CHAIN_FIRST = 0x100
 CHAIN_CAP_ALL, CHAIN_CAP_QUERY = 15, 16
 CREATE_HOST_SLAB = 1
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)

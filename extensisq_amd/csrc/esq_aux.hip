@@ -179,10 +179,17 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
     ENTER(c);
     // rotation instead of the reference's two full copies per stage:
     //   jm1 = first-stage result, jm2 = yn; every stage writes into a free row
-    int r = esq_rkc_first_stage(c, w0, yn, fn, hmus1);
-    if (r) return r;
     const int work[4] = {w0, w1, w2, w3};
     const int nwork = w3 == ESQ_VEC_NONE ? 3 : 4;
+    // the first iterate y_1 = yn + hmus1*fn: a sweep of its own, unless the chain
+    // that opens the step forms it on the fly (FIRST; at least two more stages)
+    bool first_pending = c->rhs_rkc_chain && c->rkc_first && !c->rkc_first_refused &&
+                         nwork == 4 && c->rkc_depth >= 2 && m >= 3;
+    int r = 0;
+    if (!first_pending) {
+        r = esq_rkc_first_stage(c, w0, yn, fn, hmus1);
+        if (r) return r;
+    }
     for (int a = 0; a < nwork; ++a) {
         if (!ROW(c, work[a]) || work[a] == yn || work[a] == fn)
             return fail(c, ESQ_EINVAL, "bad work row");
@@ -212,7 +219,9 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                 esq_rkc_chain ch;
                 memset(&ch, 0, sizeof(ch));
                 ch.depth = d;
-                ch.yjm1 = ROW(c, jm1); ch.yjm2 = ROW(c, jm2);
+                ch.yjm1 = first_pending ? nullptr : ROW(c, jm1);
+                ch.hmus_first = first_pending ? hmus1 : 0.0;
+                ch.yjm2 = ROW(c, jm2);
                 ch.yn = ROW(c, yn); ch.fn = ROW(c, fn);
                 for (int k = 0; k < d; ++k) {
                     const double *s5 = sc + 5 * (size_t)k;
@@ -228,7 +237,8 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                 if (o1 == ESQ_VEC_NONE || o2 == ESQ_VEC_NONE || !ch.out)
                     return fail(c, ESQ_EINVAL, "bad row");
                 char label[24];
-                snprintf(label, sizeof(label), "rkc_chain%d%s", d, last ? "-last" : "");
+                snprintf(label, sizeof(label), "rkc_chain%d%s", d,
+                         first_pending ? "-first" : last ? "-last" : "");
                 // booked: d x (RHS 16 B + recursion 48 B); moved: 4 inputs (x halo
                 // factor, filled in by the plugin) + 2 (1) outputs
                 Prof p(c, ESQ_PROF_RKC, label, -1, 64.0 * d * (double)c->len, false,
@@ -237,8 +247,10 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                 r = c->rhs_rkc_chain(c->rhs_user, &ch, c->len, (void *)c->stream,
                                      (void *)p.start(), (void *)p.stop());
                 if (r == 0) {
-                    p.ev.moved = (4.0 * amp + (last ? 1.0 : 2.0)) * 8.0 * (double)c->len;
-                    p.ev.floor = (4.0 + (last ? 1.0 : 2.0)) * 8.0 * (double)c->len;
+                    const double in = first_pending ? 2.0 : 4.0;
+                    p.ev.moved = (in * amp + (last ? 1.0 : 2.0)) * 8.0 * (double)c->len;
+                    p.ev.floor = (in + (last ? 1.0 : 2.0)) * 8.0 * (double)c->len;
+                    first_pending = false;
                     jm2 = last ? jm1 : o2;
                     jm1 = o1;
                     j += d;
@@ -247,9 +259,22 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                 p.cancel();
                 if (r != ESQ_ENOTSUP)
                     return fail(c, ESQ_ERHS, "RKC chain entry returned %d", r);
+                if (first_pending) {
+                    // declined in this form: y_1 the plain way, then the same chain
+                    c->rkc_first_refused = true;
+                    first_pending = false;
+                    r = esq_rkc_first_stage(c, w0, yn, fn, hmus1);
+                    if (r) return r;
+                    continue;
+                }
                 c->rkc_refused |= 1u << d;
                 continue;                                  // a shorter chain, or one stage
             }
+        }
+        if (first_pending) {                               // no chain took the form
+            first_pending = false;
+            r = esq_rkc_first_stage(c, w0, yn, fn, hmus1);
+            if (r) return r;
         }
         const int dst = free_row(jm1, jm2, ESQ_VEC_NONE);
         bool done = false;

@@ -140,6 +140,8 @@ struct esq_ctx {
     esq_rhs_rkc_fn rhs_rkc = nullptr;       // optional RHS + Chebyshev recursion entry
     esq_rhs_rkc_chain_fn rhs_rkc_chain = nullptr;   // optional multi-stage RKC sweep
     int rkc_depth = 1;                      // stages per RKC launch (1: one each)
+    bool rkc_first = false;                 // the chain entry forms y_1 itself (FIRST)
+    bool rkc_first_refused = false;
     unsigned rkc_refused = 0;               // bit D: the plugin declined depth D
     esq_rhs_chain_fn rhs_chain = nullptr;   // optional multi-stage marching sweep
     int chain_depth = 4;                    // ESQ_CHAIN_DEPTH: 1 off, up to 4 stages per sweep

@@ -212,10 +212,10 @@ struct Diff3dSt {
 // delay lines and one plane of operands in flight are (4 D + 7) JT doubles per
 // thread.  ESQ_RKC_CFG="JT,NW" (read when the plugin object is made) picks another
 // instantiated shape (tuning).
-template <int D, int JT, int NW>
+template <int D, int JT, int NW, bool FIRST = false>
 int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
                  hipEvent_t e0, hipEvent_t e1) {
-    auto kern = esq::k_rkc3d_chain<D, JT, NW, Diff3dSt>;
+    auto kern = esq::k_rkc3d_chain<D, JT, NW, Diff3dSt, FIRST>;
     static int slots = 0;                    // workgroups resident on the chip
     if (slots == 0) {
         int per_cu = 0;
@@ -229,10 +229,12 @@ int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
     esq::Rkc3dArgs<D> a;
     a.a = ch->yjm1; a.b = ch->yjm2; a.yn = ch->yn; a.fn = ch->fn;
     a.out = ch->out; a.outp = ch->out_prev;
+    a.hmus1 = ch->hmus_first;
     for (int k = 0; k < D; ++k) {
         a.mu[k] = ch->mu[k]; a.nu[k] = ch->nu[k]; a.omn[k] = ch->omn[k];
         a.hmus[k] = ch->hmus[k]; a.ajm1[k] = ch->ajm1[k];
     }
+    // (FIRST: two vectors, both on the first input's wider plane range)
     if (ch->read_amplification) *ch->read_amplification = esq::amp_rkc3d(g, D);
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
     hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(64 * NW), 0, stream, e0, e1, 0, a,
@@ -241,6 +243,13 @@ int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
 }
 #define ESQ_RKC_SHAPE(DD, JJ, WW) \
     if (jt == JJ && nw == WW) return launch_rkc3d<DD, JJ, WW>(r, ch, stream, e0, e1);
+// the form that opens a step (ch->yjm1 == NULL) exists on each depth's default shape
+#define ESQ_RKC_SHAPE_FIRST(DD, JJ, WW)                                               \
+    if (!ch->yjm1) {                                                                  \
+        if (jt == JJ && nw == WW)                                                     \
+            return launch_rkc3d<DD, JJ, WW, true>(r, ch, stream, e0, e1);             \
+        return ESQ_ENOTSUP;                                                           \
+    }
 template <int D>
 int launch_rkc3d_d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
                    hipEvent_t e0, hipEvent_t e1) {
@@ -250,6 +259,7 @@ int launch_rkc3d_d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
     constexpr int djt = D == 2 ? 4 : D == 3 ? 5 : D == 4 ? 2 : D == 5 ? 4 : 3;
     constexpr int dnw = D == 4 ? 16 : 8;
     const int jt = r->rkc_jt > 0 ? r->rkc_jt : djt, nw = r->rkc_nw > 0 ? r->rkc_nw : dnw;
+    ESQ_RKC_SHAPE_FIRST(D, djt, dnw)
     if constexpr (D == 2) {
         ESQ_RKC_SHAPE(2, 6, 8) ESQ_RKC_SHAPE(2, 3, 16) ESQ_RKC_SHAPE(2, 4, 8)
     } else if constexpr (D == 3) {
@@ -264,6 +274,7 @@ int launch_rkc3d_d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
     return ESQ_ENOTSUP;
 }
 #undef ESQ_RKC_SHAPE
+#undef ESQ_RKC_SHAPE_FIRST
 
 }  // namespace
 
@@ -276,7 +287,8 @@ int esq_rhs_diff3d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void
                              void *start_event, void *stop_event) {
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != DIFF3D || n != r->n || !ch) return ESQ_EINVAL;
-    if (!ch->yjm1 || !ch->yjm2 || !ch->yn || !ch->fn || !ch->out) return ESQ_EINVAL;
+    if (!ch->yjm2 || !ch->yn || !ch->fn || !ch->out) return ESQ_EINVAL;
+    if (!ch->yjm1 && ch->yjm2 != ch->yn) return ESQ_EINVAL;       // FIRST: y_{j-2} = y_n
     if (r->N < 2 || (r->N < 48 && !r->rkc_force)) return ESQ_ENOTSUP;
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;

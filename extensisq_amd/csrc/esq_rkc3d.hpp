@@ -45,6 +45,7 @@ struct Rkc3dArgs {
     const double *a, *b, *yn, *fn;          // y_{j-1}, y_{j-2}, y_n, f_n
     double *out, *outp;                     // Y_D, Y_{D-1} (outp may be null)
     double mu[D], nu[D], omn[D], hmus[D], ajm1[D];
+    double hmus1;                           // FIRST: a = y_n + hmus1 * f_n, b = y_n
 };
 
 // tiles: TL x TJ patches per plane, each VL x VJ stored points, R planes deep
@@ -123,7 +124,12 @@ __device__ __forceinline__ void buf_st(rsrc_t r, unsigned voff, unsigned soff, d
 // St::eval(below, above, up, down, left, right, centre) -> derivative at the point
 // (i-1, i+1; j-1, j+1; l-1, l+1); autonomous stencils only (t is not passed).
 // Vectors of at most 4 GiB - 16 B (the offsets are 32-bit).
-template <int D, int JT, int NW, class St>
+// FIRST: the chain opens a step -- its first input is the first Chebyshev iterate
+// y_1 = y_n + hmus1 * f_n (sommeijer.py:289), formed where the window needs it from
+// the two vectors the sweep reads anyway (one plane earlier than before), and
+// y_{j-2} = y_n: two loads per point and plane instead of four, and no sweep that
+// writes y_1.
+template <int D, int JT, int NW, class St, bool FIRST = false>
 __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st, Geo3d g) {
     // edge rows of the D centre planes: slot w + 1 belongs to wave w, slots 0 and
     // NW + 1 stay zero (outside the patch), two buffers by iteration parity
@@ -192,10 +198,24 @@ __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st,
 #pragma unroll
         for (int r = 0; r < JT; ++r) wm[k][r] = wc[k][r] = dy[k][r] = df[k][r] = 0.0;
     const int ibase = i_lo - (D - 1);                 // stage 0's first centre plane
+    auto first = [&](double y, double f) -> double {          // k_rkc_first's rounding
+        return __dadd_rn(y, __dmul_rn(ca.hmus1, f));
+    };
+    // FIRST: y_n, f_n at stage 0's centre plane (loaded as the plane AFTER the
+    // centre one iteration earlier)
+    double cy[JT], cf[JT];
 #pragma unroll
     for (int r = 0; r < JT; ++r) {
-        wm[0][r] = ld(ra, ibase - 1, r);
-        wc[0][r] = ld(ra, ibase, r);
+        if constexpr (FIRST) {
+            wm[0][r] = first(ld(ry, ibase - 1, r), ld(rf, ibase - 1, r));
+            cy[r] = ld(ry, ibase, r);
+            cf[r] = ld(rf, ibase, r);
+            wc[0][r] = first(cy[r], cf[r]);
+        } else {
+            wm[0][r] = ld(ra, ibase - 1, r);
+            wc[0][r] = ld(ra, ibase, r);
+            cy[r] = cf[r] = 0.0;
+        }
     }
     // operands of stage 0's plane, requested ONE ITERATION AHEAD (beyond the last
     // iteration: one more plane is requested and never used)
@@ -204,10 +224,15 @@ __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st,
     {                                                                       \
         const int i_ = ibase + (IT);                                        \
         _Pragma("unroll") for (int r = 0; r < JT; ++r) {                    \
-            pa[r] = ld(ra, i_ + 1, r);                                      \
-            pb[r] = ld(rb, i_, r);                                          \
-            py[r] = ld(ry, i_, r);                                          \
-            pf[r] = ld(rf, i_, r);                                          \
+            if constexpr (FIRST) {                                          \
+                py[r] = ld(ry, i_ + 1, r);                                  \
+                pf[r] = ld(rf, i_ + 1, r);                                  \
+            } else {                                                        \
+                pa[r] = ld(ra, i_ + 1, r);                                  \
+                pb[r] = ld(rb, i_, r);                                      \
+                py[r] = ld(ry, i_, r);                                      \
+                pf[r] = ld(rf, i_, r);                                      \
+            }                                                               \
         }                                                                   \
     }
     ESQ_RKC3D_LOAD(0)
@@ -217,10 +242,19 @@ __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st,
         double wp[JT], ykm1[JT];
 #pragma unroll
         for (int r = 0; r < JT; ++r) {
-            wp[r] = pa[r];
-            ykm1[r] = pb[r];
-            dy[0][r] = py[r];
-            df[0][r] = pf[r];
+            if constexpr (FIRST) {
+                wp[r] = first(py[r], pf[r]);
+                ykm1[r] = cy[r];
+                dy[0][r] = cy[r];
+                df[0][r] = cf[r];
+                cy[r] = py[r];
+                cf[r] = pf[r];
+            } else {
+                wp[r] = pa[r];
+                ykm1[r] = pb[r];
+                dy[0][r] = py[r];
+                df[0][r] = pf[r];
+            }
         }
         ESQ_RKC3D_LOAD(it + 1)
         // the slices' edge rows of all D centre planes change hands

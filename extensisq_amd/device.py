@@ -429,7 +429,9 @@ class _Builtin(DeviceRHS):
     def _rkc_chain_entry(self, lib):
         if not self._symbol_rkc_chain:
             return None
-        return getattr(lib, self._symbol_rkc_chain), self._rkc_chain_depth
+        # (the built-in chain sweep also opens a step: ESQ_RKC_CHAIN_FIRST)
+        return (getattr(lib, self._symbol_rkc_chain),
+                self._rkc_chain_depth | _lib.RKC_CHAIN_FIRST)
 
     def _rkc_entry(self, lib):
         return getattr(lib, self._symbol_rkc) if self._symbol_rkc else None

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ESQ_ABI_VERSION 4
+#define ESQ_ABI_VERSION 5
 
 /* error codes (negative = misuse) */
 #define ESQ_EINVAL   (-1)   /* bad argument (row/slot out of range, NULL, ...) */
@@ -283,6 +283,12 @@ typedef struct esq_rkc_chain {
     double hmus[ESQ_RKC_CHAIN_MAX_DEPTH], ajm1[ESQ_RKC_CHAIN_MAX_DEPTH];
     double t[ESQ_RKC_CHAIN_MAX_DEPTH];       /* t + h*theta_{j-1} of each stage */
     double *out, *out_prev;
+    /* FIRST (ABI v5; asked only of entries registered with ESQ_RKC_CHAIN_FIRST): the
+     * chain opens a step -- yjm1 == NULL, and the chain's first input is the first
+     * Chebyshev iterate  y_1 = yn + hmus_first * fn  (sommeijer.py:289; product and sum
+     * rounded separately), formed where the sweep needs it; yjm2 == yn.  No sweep
+     * writes y_1, the chain reads two vectors instead of four. */
+    double hmus_first;
     /* out (may be NULL): bytes read per byte of the four inputs (halo points are
      * loaded by several tiles); booked in the launch's designed traffic */
     double *read_amplification;
@@ -376,6 +382,7 @@ int  esq_set_rhs_rkc(esq_ctx *ctx, esq_rhs_rkc_fn fn);
  * to max_depth (<= ESQ_RKC_CHAIN_MAX_DEPTH; ESQ_RKC_DEPTH in the environment
  * lowers it, 1 = one launch per stage) stages per launch when it is given four
  * work rows.  Needs the one-stage RKC entry too (remainders, refused chains). */
+#define ESQ_RKC_CHAIN_FIRST 0x100   /* or-ed into max_depth: the entry takes the FIRST form */
 int  esq_set_rhs_rkc_chain(esq_ctx *ctx, esq_rhs_rkc_chain_fn fn, int max_depth);
 
 /* ---- explicit RK launches ----------------------------------------------- */

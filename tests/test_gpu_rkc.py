@@ -221,6 +221,14 @@ def test_rkc_chain_sweeps_are_bit_identical(monkeypatch, N, planes, depth):
         names = [k[0] for k in _profiled_kernels(s2, m)]
         if m - 1 >= 2:
             assert any(k.startswith("rkc_chain") for k in names), names
+            # the chain that opens the step forms the first iterate itself ...
+            assert names.count("k_rkc_first") == 0 and any("-first" in k for k in names), names
+            # ... or reads it from the sweep that wrote it: the same bits
+            monkeypatch.setenv("ESQ_RKC_FIRST", "0")
+            got0, s3 = _stage_run(N, m)
+            monkeypatch.delenv("ESQ_RKC_FIRST")
+            np.testing.assert_array_equal(got0, ref, err_msg=f"m = {m}, ESQ_RKC_FIRST=0")
+            assert "k_rkc_first" in [k[0] for k in _profiled_kernels(s3, m)]
 
 
 def _profiled_kernels(s, m):
@@ -256,9 +264,9 @@ def test_rkc_chain_plan_and_whole_steps(monkeypatch):
         np.testing.assert_array_equal(a.y, b.y)
     assert a.nfev == b.nfev and int(dev_rkc.maxm[()]) == 100
     tab = {k[0]: k[2] for k in _profiled_kernels(a, 100)}
-    assert tab == {"k_rkc_first": 1, "rkc_chain4": 24, "rkc_chain3-last": 1}, tab
+    assert tab == {"rkc_chain4-first": 1, "rkc_chain4": 23, "rkc_chain3-last": 1}, tab
     tab = {k[0]: k[2] for k in _profiled_kernels(a, 6)}       # 5 = 3 + 2
-    assert tab == {"k_rkc_first": 1, "rkc_chain3": 1, "rkc_chain2-last": 1}, tab
+    assert tab == {"rkc_chain3-first": 1, "rkc_chain2-last": 1}, tab
     tab = {k[0]: k[2] for k in _profiled_kernels(b, 6)}
     assert tab == {"k_rkc_first": 1, "rhs_rkc": 5}, tab
 
