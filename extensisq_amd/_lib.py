@@ -20,7 +20,7 @@ EPI_RKCERR = 6
 FUSE_ALL = 0x5e
 FUSE_SRC = 0x20
 FUSE_QUERY = 0x80
-RKC_CHAIN_FIRST = 0x100
+RKC_CHAIN_FIRST, RKC_CHAIN_LAST = 0x100, 0x200
 CHAIN_CAP_ALL, CHAIN_CAP_QUERY = 15, 16
 CREATE_HOST_SLAB = 1
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
@@ -89,6 +89,8 @@ SIGNATURES = {
     "esq_rkc_stages": (C.c_int, [_vp] + [C.c_int] * 6 + [C.c_double, C.c_int, _vp,
                                                          C.POINTER(C.c_int)]),
     "esq_rkc_error_norm": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, _dp]),
+    "esq_rkc_stages_end": (C.c_int, [_vp] + [C.c_int] * 6 + [C.c_double, C.c_int, _vp,
+                                    C.c_double, C.c_double, _vp, _vp, _vp]),
     "esq_rkc_end_error": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, C.c_double,
                                                             _dp]),
     "esq_rkc_eval_rhs": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),

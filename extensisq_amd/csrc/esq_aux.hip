@@ -173,10 +173,51 @@ int esq_rkc_eval_rhs(esq_ctx *c, int dst, double t, int src) {
     if (!d || !s) return fail(c, ESQ_EINVAL, "bad row");
     return call_rhs(c, t, s, d);
 }
+namespace {
+// the end of the step, wanted with the stages (esq_rkc_stages_end): f(t_end, y_{n+1})
+// into a work row and the error estimate's sum of squares
+struct RkcTail {
+    double t_end, h;
+    int fy_row = ESQ_VEC_NONE;
+    double sumsq = 0.0;
+    bool done = false;         // the last chain sweep took it along (LAST form)
+};
+int rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3, double hmus1,
+               int m, const double *scalars, int *y_row_out, RkcTail *tail);
+}  // namespace
 int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                    double hmus1, int m, const double *scalars, int *y_row_out) {
     if (!c || !y_row_out || m < 1 || (m > 1 && !scalars)) return ESQ_EINVAL;
     ENTER(c);
+    return rkc_stages(c, yn, fn, w0, w1, w2, w3, hmus1, m, scalars, y_row_out, nullptr);
+}
+int esq_rkc_stages_end(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
+                       double hmus1, int m, const double *scalars, double t_end, double h,
+                       int *y_row_out, int *fy_row_out, double *sumsq_out) {
+    if (!c || !y_row_out || !fy_row_out || !sumsq_out || m < 1 || (m > 1 && !scalars))
+        return ESQ_EINVAL;
+    ENTER(c);
+    RkcTail tail;
+    tail.t_end = t_end;
+    tail.h = h;
+    int r = rkc_stages(c, yn, fn, w0, w1, w2, w3, hmus1, m, scalars, y_row_out, &tail);
+    if (r) return r;
+    if (!tail.done) {
+        // f(t_end, y) into a work row that does not hold y, and the estimate
+        const int work[4] = {w0, w1, w2, w3};
+        tail.fy_row = ESQ_VEC_NONE;
+        for (int a = 0; a < 4 && tail.fy_row == ESQ_VEC_NONE; ++a)
+            if (work[a] != ESQ_VEC_NONE && work[a] != *y_row_out) tail.fy_row = work[a];
+        r = esq_rkc_end_error(c, *y_row_out, yn, fn, tail.fy_row, t_end, h, &tail.sumsq);
+        if (r) return r;
+    }
+    *fy_row_out = tail.fy_row;
+    *sumsq_out = tail.sumsq;
+    return 0;
+}
+namespace {
+int rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3, double hmus1,
+               int m, const double *scalars, int *y_row_out, RkcTail *tail) {
     // rotation instead of the reference's two full copies per stage:
     //   jm1 = first-stage result, jm2 = yn; every stage writes into a free row
     const int work[4] = {w0, w1, w2, w3};
@@ -232,13 +273,29 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                 const bool last = j + d > m;              // nothing reads y_{m-1}
                 ch.out = ROW(c, o1);
                 ch.out_prev = last ? nullptr : ROW(c, o2);
+                // the chain that ends the step takes f(t_end, y) and the error
+                // estimate along (LAST; d + 1 stage slots)
+                const bool with_end = last && tail && c->rkc_last && !c->rkc_last_refused &&
+                                      !first_pending && d + 1 <= 5 && !c->cplx;
+                if (with_end) {
+                    ch.fy_out = ROW(c, o2);
+                    ch.t_end = tail->t_end;
+                    ch.h = tail->h;
+                    ch.atol_vec = c->atol_is_vec ? c->atolv : nullptr;
+                    ch.atol_s = c->atol_s;
+                    ch.rtol = c->rtol;
+                    ch.n_valid = c->n;
+                    ch.partials = c->partials;
+                    ch.partials_cap = kPartialsCap;
+                    ch.partials_used = &c->red_count;
+                }
                 double amp = 1.0;
                 ch.read_amplification = &amp;
                 if (o1 == ESQ_VEC_NONE || o2 == ESQ_VEC_NONE || !ch.out)
                     return fail(c, ESQ_EINVAL, "bad row");
                 char label[24];
                 snprintf(label, sizeof(label), "rkc_chain%d%s", d,
-                         first_pending ? "-first" : last ? "-last" : "");
+                         first_pending ? "-first" : with_end ? "-end" : last ? "-last" : "");
                 // booked: d x (RHS 16 B + recursion 48 B); moved: 4 inputs (x halo
                 // factor, filled in by the plugin) + 2 (1) outputs
                 Prof p(c, ESQ_PROF_RKC, label, -1, 64.0 * d * (double)c->len, false,
@@ -248,9 +305,17 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                                      (void *)p.start(), (void *)p.stop());
                 if (r == 0) {
                     const double in = first_pending ? 2.0 : 4.0;
-                    p.ev.moved = (in * amp + (last ? 1.0 : 2.0)) * 8.0 * (double)c->len;
-                    p.ev.floor = (in + (last ? 1.0 : 2.0)) * 8.0 * (double)c->len;
+                    const double outw = (last && !with_end) ? 1.0 : 2.0;    // -end: y and f(y)
+                    p.ev.moved = (in * amp + outw) * 8.0 * (double)c->len;
+                    p.ev.floor = (in + outw) * 8.0 * (double)c->len;
                     first_pending = false;
+                    if (with_end) {
+                        tail->done = true;
+                        tail->fy_row = o2;
+                        *y_row_out = o1;
+                        return finish_reduction(c, &tail->sumsq, false, c->partials,
+                                                c->red_count);
+                    }
                     jm2 = last ? jm1 : o2;
                     jm1 = o1;
                     j += d;
@@ -259,6 +324,10 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                 p.cancel();
                 if (r != ESQ_ENOTSUP)
                     return fail(c, ESQ_ERHS, "RKC chain entry returned %d", r);
+                if (with_end) {                            // declined in this form
+                    c->rkc_last_refused = true;
+                    continue;
+                }
                 if (first_pending) {
                     // declined in this form: y_1 the plain way, then the same chain
                     c->rkc_first_refused = true;
@@ -311,6 +380,7 @@ int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
     *y_row_out = jm1;
     return 0;
 }
+}  // namespace
 int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
                        double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;

@@ -212,10 +212,11 @@ struct Diff3dSt {
 // delay lines and one plane of operands in flight are (4 D + 7) JT doubles per
 // thread.  ESQ_RKC_CFG="JT,NW" (read when the plugin object is made) picks another
 // instantiated shape (tuning).
-template <int D, int JT, int NW, bool FIRST = false>
+// D: stage slots of the sweep (LAST: the chain's depth + 1)
+template <int D, int JT, int NW, bool FIRST = false, bool LAST = false>
 int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
                  hipEvent_t e0, hipEvent_t e1) {
-    auto kern = esq::k_rkc3d_chain<D, JT, NW, Diff3dSt, FIRST>;
+    auto kern = esq::k_rkc3d_chain<D, JT, NW, Diff3dSt, FIRST, LAST>;
     static int slots = 0;                    // workgroups resident on the chip
     if (slots == 0) {
         int per_cu = 0;
@@ -230,9 +231,22 @@ int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
     a.a = ch->yjm1; a.b = ch->yjm2; a.yn = ch->yn; a.fn = ch->fn;
     a.out = ch->out; a.outp = ch->out_prev;
     a.hmus1 = ch->hmus_first;
+    a.h04 = 0.0;
+    a.red = esq::RedArgs{};
     for (int k = 0; k < D; ++k) {
-        a.mu[k] = ch->mu[k]; a.nu[k] = ch->nu[k]; a.omn[k] = ch->omn[k];
-        a.hmus[k] = ch->hmus[k]; a.ajm1[k] = ch->ajm1[k];
+        const bool stage = k < ch->depth;                  // (LAST: slot D - 1 is the end)
+        a.mu[k] = stage ? ch->mu[k] : 0.0; a.nu[k] = stage ? ch->nu[k] : 0.0;
+        a.omn[k] = stage ? ch->omn[k] : 0.0; a.hmus[k] = stage ? ch->hmus[k] : 0.0;
+        a.ajm1[k] = stage ? ch->ajm1[k] : 0.0;
+    }
+    if constexpr (LAST) {
+        if ((int)g.grid > ch->partials_cap) return ESQ_ENOTSUP;
+        if (ch->partials_used) *ch->partials_used = (int)g.grid;
+        a.out = ch->fy_out;                                // the slot's "result" ...
+        a.outp = ch->out;                                  // ... and its input: y_{n+1}
+        a.h04 = 0.4 * ch->h;
+        a.red.atol_vec = ch->atol_vec; a.red.atol_s = ch->atol_s; a.red.rtol = ch->rtol;
+        a.red.n_valid = ch->n_valid; a.red.partials = ch->partials;
     }
     // (FIRST: two vectors, both on the first input's wider plane range)
     if (ch->read_amplification) *ch->read_amplification = esq::amp_rkc3d(g, D);
@@ -246,8 +260,15 @@ int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
 // the form that opens a step (ch->yjm1 == NULL) exists on each depth's default shape
 #define ESQ_RKC_SHAPE_FIRST(DD, JJ, WW)                                               \
     if (!ch->yjm1) {                                                                  \
-        if (jt == JJ && nw == WW)                                                     \
+        if (jt == JJ && nw == WW && !ch->fy_out)                                      \
             return launch_rkc3d<DD, JJ, WW, true>(r, ch, stream, e0, e1);             \
+        return ESQ_ENOTSUP;                                                           \
+    }                                                                                 \
+    if (ch->fy_out) {                     /* LAST: DD = the chain's depth + 1 */      \
+        if constexpr (DD >= 3 && DD <= 5) {                                           \
+            if (jt == JJ && nw == WW)                                                 \
+                return launch_rkc3d<DD, JJ, WW, false, true>(r, ch, stream, e0, e1);  \
+        }                                                                             \
         return ESQ_ENOTSUP;                                                           \
     }
 template <int D>
@@ -289,10 +310,11 @@ int esq_rhs_diff3d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void
     if (!r || r->kind != DIFF3D || n != r->n || !ch) return ESQ_EINVAL;
     if (!ch->yjm2 || !ch->yn || !ch->fn || !ch->out) return ESQ_EINVAL;
     if (!ch->yjm1 && ch->yjm2 != ch->yn) return ESQ_EINVAL;       // FIRST: y_{j-2} = y_n
+    if (ch->fy_out && (ch->out_prev || !ch->partials)) return ESQ_EINVAL;
     if (r->N < 2 || (r->N < 48 && !r->rkc_force)) return ESQ_ENOTSUP;
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;
-    switch (ch->depth) {
+    switch (ch->depth + (ch->fy_out ? 1 : 0)) {           // stage slots of the sweep
         case 2: return launch_rkc3d_d<2>(r, ch, s, e0, e1);
         case 3: return launch_rkc3d_d<3>(r, ch, s, e0, e1);
         case 4: return launch_rkc3d_d<4>(r, ch, s, e0, e1);

@@ -36,6 +36,7 @@
 #include <stdlib.h>
 
 #include "../../include/extensisq_amd.h"
+#include "esq_epilogue.hpp"
 #include "esq_terms.hpp"
 
 namespace esq {
@@ -46,6 +47,11 @@ struct Rkc3dArgs {
     double *out, *outp;                     // Y_D, Y_{D-1} (outp may be null)
     double mu[D], nu[D], omn[D], hmus[D], ajm1[D];
     double hmus1;                           // FIRST: a = y_n + hmus1 * f_n, b = y_n
+    // LAST: the last of the D stage slots is not a Chebyshev stage but the end of the
+    // step: f = St(Y_{D-1}) -> out, Y_{D-1} -> outp, and the partial sums of the error
+    // estimate 0.8 (y_n - y) + 0.4 h (f_n + f)  (ESQ_EPI_RKCERR, sommeijer.py:214-220)
+    double h04;
+    RedArgs red;
 };
 
 // tiles: TL x TJ patches per plane, each VL x VJ stored points, R planes deep
@@ -129,7 +135,11 @@ __device__ __forceinline__ void buf_st(rsrc_t r, unsigned voff, unsigned soff, d
 // the two vectors the sweep reads anyway (one plane earlier than before), and
 // y_{j-2} = y_n: two loads per point and plane instead of four, and no sweep that
 // writes y_1.
-template <int D, int JT, int NW, class St, bool FIRST = false>
+// LAST: the chain ends a step (Rkc3dArgs::h04): D - 1 Chebyshev stages and the sweep
+// that evaluates f(t + h, y_{n+1}) with the error estimate as stage slot D - 1 -- the
+// final iterate is still in the window registers, y_n and f_n arrive down the delay
+// lines the stages use anyway.
+template <int D, int JT, int NW, class St, bool FIRST = false, bool LAST = false>
 __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st, Geo3d g) {
     // edge rows of the D centre planes: slot w + 1 belongs to wave w, slots 0 and
     // NW + 1 stay zero (outside the patch), two buffers by iteration parity
@@ -138,7 +148,11 @@ __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st,
     // neighbouring patches and plane ranges meet in that XCD's L2
     const unsigned per = g.grid / 8u;
     const unsigned lb = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
-    if (lb >= g.ntiles) return;                                  // workgroup-uniform
+    if (lb >= g.ntiles) {                                        // workgroup-uniform
+        if constexpr (LAST) block_partial_w<NW>(0.0, ca.red.partials);
+        return;
+    }
+    double local = 0.0;                                          // LAST: error sum
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int N = g.N;
@@ -283,8 +297,20 @@ __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st,
                     const double lf = lane_left(wc[k][r]);
                     const double rt = lane_right(wc[k][r]);
                     const double fy = st.eval(wm[k][r], wp[r], up, dn, lf, rt, wc[k][r]);
-                    const double v = one(k, wc[k][r], ykm1[r], dy[k][r], df[k][r], fy);
-                    nw[r] = (pl_ok && in[r]) ? v : 0.0;
+                    if (LAST && k == D - 1) {
+                        nw[r] = (pl_ok && in[r]) ? fy : 0.0;
+                        if (so[r] != 0xffffffffu) {              // a point this tile stores
+                            const double er =
+                                __dadd_rn(__dmul_rn(0.8, __dsub_rn(dy[k][r], wc[k][r])),
+                                          __dmul_rn(ca.h04, __dadd_rn(df[k][r], fy)));
+                            const size_t e = (size_t)ik * (size_t)N * (size_t)N + so[r] / 8u;
+                            local += ratio_sq1(er, wc[k][r], dy[k][r], ca.red.atol_vec,
+                                               ca.red.atol_s, ca.red.rtol, e, ca.red.n_valid);
+                        }
+                    } else {
+                        const double v = one(k, wc[k][r], ykm1[r], dy[k][r], df[k][r], fy);
+                        nw[r] = (pl_ok && in[r]) ? v : 0.0;
+                    }
                 }
                 if (k == D - 1) {
                     // the last stage is only ever at planes [i_lo, i_hi)
@@ -320,6 +346,7 @@ __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st,
             }
     }
 #undef ESQ_RKC3D_LOAD
+    if constexpr (LAST) block_partial_w<NW>(local, ca.red.partials);
 }
 
 }  // namespace esq

@@ -429,9 +429,9 @@ class _Builtin(DeviceRHS):
     def _rkc_chain_entry(self, lib):
         if not self._symbol_rkc_chain:
             return None
-        # (the built-in chain sweep also opens a step: ESQ_RKC_CHAIN_FIRST)
+        # (the built-in chain sweep also opens and ends a step: ESQ_RKC_CHAIN_FIRST / _LAST)
         return (getattr(lib, self._symbol_rkc_chain),
-                self._rkc_chain_depth | _lib.RKC_CHAIN_FIRST)
+                self._rkc_chain_depth | _lib.RKC_CHAIN_FIRST | _lib.RKC_CHAIN_LAST)
 
     def _rkc_entry(self, lib):
         return getattr(lib, self._symbol_rkc) if self._symbol_rkc else None

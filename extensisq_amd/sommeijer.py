@@ -252,6 +252,22 @@ class SSV2stab(OdeSolver):
             jm2, jm1 = jm1, free
         return jm1
 
+    def _stages_end(self, t, h, m, out):
+        """device RHS: all m stages, f(t + h, y_{n+1}) and the sum of squares of the
+        weighted error estimate (into `out`); returns the rows of y_{n+1} and of
+        its derivative"""
+        r = self._r
+        hmus1, table = chebyshev_scalars(m, t, h)
+        w = r["w"]
+        yrow, fyrow = C.c_int(), C.c_int()
+        tab = np.ascontiguousarray(table)
+        self._chk(self._lib.esq_rkc_stages_end(
+            self._ctx, r["yn"], r["fn"], w[0], w[1], w[2], w[3], hmus1, m, as_ptr(tab),
+            float(t + h), h, C.byref(yrow), C.byref(fyrow), C.byref(out)),
+            "esq_rkc_stages_end")
+        self.nfev += m
+        return yrow.value, fyrow.value
+
     # ------------------------------------------------------ spectral radius
     def _rho(self, t):
         """nonlinear power iteration for the spectral radius
@@ -355,17 +371,15 @@ class SSV2stab(OdeSolver):
                        13.3 * self.uround * (abs(t) + absh) * (m ** 2 - 1))
             if self._lockstep is not None:
                 self._lockstep.check_identical(self._dev, "(t, h, m)", (t, h, m))
-            yrow = self._stages(t, h, m)
-            fyrow = next(w for w in r["w"] if w != yrow)
             out = C.c_double()
             if self._device_rhs is not None:
-                # f(t + h, y) and the error estimate (ref sommeijer.py:214-220)
-                # in one call: one sweep + final sum with a fused plugin entry
-                self._chk(self._lib.esq_rkc_end_error(
-                    self._ctx, yrow, r["yn"], r["fn"], fyrow, float(t + h), h,
-                    C.byref(out)), "esq_rkc_end_error")
-                self.nfev += 1
+                # the stages, f(t + h, y) and the error estimate (ref
+                # sommeijer.py:273-329, 214-220) in one call: with a chain entry the
+                # end of the step rides in the last chain sweep
+                yrow, fyrow = self._stages_end(t, h, m, out)
             else:
+                yrow = self._stages(t, h, m)
+                fyrow = next(w for w in r["w"] if w != yrow)
                 self._eval_rhs(fyrow, t + h, yrow)
                 self._chk(self._lib.esq_rkc_error_norm(
                     self._ctx, yrow, r["yn"], r["fn"], fyrow, h, C.byref(out)),

@@ -289,6 +289,22 @@ typedef struct esq_rkc_chain {
      * rounded separately), formed where the sweep needs it; yjm2 == yn.  No sweep
      * writes y_1, the chain reads two vectors instead of four. */
     double hmus_first;
+    /* LAST (ABI v5; asked only of entries registered with ESQ_RKC_CHAIN_LAST): the
+     * chain ends a step -- fy_out != NULL (and out_prev == NULL): after the `depth`
+     * stages, in the same sweep,  fy_out = fun(t_end, out)  and the partial sums of the
+     * error estimate exactly as ESQ_EPI_RKCERR forms them from (out, yn, fn, fy_out, h)
+     * with the tolerances below: one partial per workgroup in partials[blockIdx.x],
+     * the workgroup count in *partials_used (> partials_cap: return ESQ_ENOTSUP).
+     * The sweep `f(t + h, y_{n+1})` + error estimate of sommeijer.py:214-220 and its
+     * launch disappear; y_{n+1} is never read back. */
+    double *fy_out;
+    double t_end, h;
+    const double *atol_vec;
+    double atol_s, rtol;
+    size_t n_valid;
+    double *partials;
+    int partials_cap;
+    int *partials_used;
     /* out (may be NULL): bytes read per byte of the four inputs (halo points are
      * loaded by several tiles); booked in the launch's designed traffic */
     double *read_amplification;
@@ -383,6 +399,7 @@ int  esq_set_rhs_rkc(esq_ctx *ctx, esq_rhs_rkc_fn fn);
  * lowers it, 1 = one launch per stage) stages per launch when it is given four
  * work rows.  Needs the one-stage RKC entry too (remainders, refused chains). */
 #define ESQ_RKC_CHAIN_FIRST 0x100   /* or-ed into max_depth: the entry takes the FIRST form */
+#define ESQ_RKC_CHAIN_LAST  0x200   /* ... and the LAST form                              */
 int  esq_set_rhs_rkc_chain(esq_ctx *ctx, esq_rhs_rkc_chain_fn fn, int max_depth);
 
 /* ---- explicit RK launches ----------------------------------------------- */
@@ -565,6 +582,13 @@ int  esq_rkc_error_norm(esq_ctx *ctx, int y, int yn, int fn, int fy, double h,
  *   fy = rhs(t_end, y);  then the error sum of squares as esq_rkc_error_norm.
  * With a plugin whose fused entry takes ESQ_EPI_RKCERR this is ONE sweep + the
  * final sum (instead of RHS, error kernel, final sum).  Synchronises. */
+/* esq_rkc_stages + esq_rkc_end_error in one call: all stages, f(t_end, y_{n+1}) and
+ * the error estimate; rows of y_{n+1} and of its derivative in *y_row_out /
+ * *fy_row_out (two of the work rows).  With a chain entry that takes the LAST form the
+ * end of the step rides in the step's last chain sweep. */
+int  esq_rkc_stages_end(esq_ctx *ctx, int yn, int fn, int w0, int w1, int w2, int w3,
+                        double hmus1, int m, const double *scalars, double t_end,
+                        double h, int *y_row_out, int *fy_row_out, double *sumsq_out);
 int  esq_rkc_end_error(esq_ctx *ctx, int y, int yn, int fn, int fy, double t_end,
                        double h, double *sumsq_out);
 /* generic K[dst] = rhs(t, K[src]) on physical rows   sommeijer.py:214, 311    */

@@ -231,6 +231,53 @@ def test_rkc_chain_sweeps_are_bit_identical(monkeypatch, N, planes, depth):
             assert "k_rkc_first" in [k[0] for k in _profiled_kernels(s3, m)]
 
 
+def _end_run(N, m):
+    """all stages + the end of the step (esq_rkc_stages_end) from a fixed state:
+    y_{n+1}, f(t + h, y_{n+1}), the error estimate's sum of squares, kernel labels"""
+    import ctypes as C
+    from extensisq_amd._lib import PROF_RKC
+    rhs = esq.Diffusion3D(N)
+    rho = rhs.spectral_radius()
+    rng = np.random.default_rng(11 + N)
+    y0 = pb.diff3d_y0(N) + 0.1 * rng.standard_normal(N ** 3)
+    s = esq.SSV2stab(rhs, 0.0, y0, 1.0, rtol=1e-3, atol=1e-3, const_jac=True,
+                     first_step=1e-6, rho_jac=lambda t, y: rho)
+    h = (m * m - 1) / (1.54 * rho)
+    out = C.c_double()
+    s._dev.profile_reset()
+    s._dev.profile_enable([PROF_RKC])
+    yrow, fyrow = s._stages_end(0.0, h, m, out)
+    s._dev.profile_enable(None)
+    names = [k[0] for k in s._dev.profile_kernels()]
+    return s._dev.download(SLOT_K, yrow), s._dev.download(SLOT_K, fyrow), out.value, names
+
+
+@pytest.mark.parametrize("N", [13, 24, 41, 57, 64])
+def test_rkc_chain_takes_the_end_of_the_step_along(monkeypatch, N):
+    """the chain sweep that ends a step also evaluates f(t + h, y_{n+1}) and the error
+    estimate (LAST form of esq_rhs_rkc_chain_fn): y_{n+1} and its derivative bit for
+    bit those of one launch per stage + the fused end sweep, the sum of squares (other
+    workgroups, another summation tree) to 1e-13; chains of every length at the end,
+    and the step that is one chain from start to end (FIRST wins, the end separate)"""
+    monkeypatch.setenv("ESQ_RKC_FORCE", "1")
+    for m in (2, 3, 4, 5, 6, 7, 8, 10, 23):
+        monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+        y1, f1, e1, n1 = _end_run(N, m)
+        monkeypatch.delenv("ESQ_RKC_DEPTH")
+        y2, f2, e2, n2 = _end_run(N, m)
+        monkeypatch.setenv("ESQ_RKC_LAST", "0")
+        y3, f3, e3, n3 = _end_run(N, m)
+        monkeypatch.delenv("ESQ_RKC_LAST")
+        assert np.isfinite(y1).all() and np.isfinite(f1).all() and e1 > 0.0
+        for y, f, e, tag in ((y2, f2, e2, "LAST"), (y3, f3, e3, "ESQ_RKC_LAST=0")):
+            np.testing.assert_array_equal(y, y1, err_msg=f"m = {m}, {tag}")
+            np.testing.assert_array_equal(f, f1, err_msg=f"m = {m}, {tag}")
+            assert abs(e - e1) <= 1e-13 * e1, (m, tag, e, e1)
+        assert not any(k.endswith("-end") for k in n1 + n3), (n1, n3)
+        if m >= 7:                       # a last chain that is not the first one
+            assert any(k.endswith("-end") for k in n2), n2
+
+
 def _profiled_kernels(s, m):
     """kernel labels of one more run of the stages (the launch plan, by name)"""
     from extensisq_amd._lib import PROF_RKC
@@ -260,9 +307,24 @@ def test_rkc_chain_plan_and_whole_steps(monkeypatch):
     monkeypatch.delenv("ESQ_RKC_DEPTH")
     for _ in range(3):
         assert a.step() is None and b.step() is None
-        assert a.t == b.t and a.errold == b.errold and a.absh == b.absh
-        np.testing.assert_array_equal(a.y, b.y)
+        # (the end of the step in the last chain sweep sums the error estimate over
+        # other workgroups than the separate sweep: equal to rounding, and so the
+        # step sizes the controller derives from it)
+        assert abs(a.errold - b.errold) <= 1e-13 * b.errold
+        assert abs(a.t - b.t) <= 1e-13 * b.t and abs(a.absh - b.absh) <= 1e-13 * b.absh
+        np.testing.assert_allclose(a.y, b.y, rtol=1e-11, atol=1e-13)
     assert a.nfev == b.nfev and int(dev_rkc.maxm[()]) == 100
+    # ... and bit for bit with that form switched off
+    monkeypatch.setenv("ESQ_RKC_LAST", "0")
+    a0 = esq.SSV2stab(esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_RKC_LAST")
+    monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+    b0 = esq.SSV2stab(esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_RKC_DEPTH")
+    for _ in range(3):
+        assert a0.step() is None and b0.step() is None
+        assert a0.t == b0.t and a0.errold == b0.errold and a0.absh == b0.absh
+        np.testing.assert_array_equal(a0.y, b0.y)
     tab = {k[0]: k[2] for k in _profiled_kernels(a, 100)}
     assert tab == {"rkc_chain4-first": 1, "rkc_chain4": 23, "rkc_chain3-last": 1}, tab
     tab = {k[0]: k[2] for k in _profiled_kernels(a, 6)}       # 5 = 3 + 2
