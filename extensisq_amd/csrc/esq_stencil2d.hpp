@@ -268,9 +268,19 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
         // ONE wave per SIMD already gives tiles of 24..48 rows the launch is
         // bandwidth-bound and the fewer halo rows win (heat Pr9 at N = 2236:
         // R = 44 0.587 ms/step, R = 15 at three waves per SIMD 0.62)
+        // ... and where TWO waves per SIMD give tiles of 20+ rows, those: half as many
+        // marching steps per wave and a second wave to fill the first one's issue gaps
+        // (Pr9 at N = 2236, tools/chain_rows_sweep.sh: R = 22 0.5235 ms/step with
+        // chain5<0> 50 us, R = 44 0.540 with 65 us; R = 15, 18, 26 .. 36 -- three waves,
+        // or a partial second round -- 0.549 .. 0.600)
         if (tall_if_one_round) {
-            const int cand = rows_for((size_t)256 * 4);
-            if (cand >= 24 && cand <= 48) R = cand;
+            static const int tall_waves = getenv("ESQ_CHAIN_TALL_WAVES")
+                                              ? atoi(getenv("ESQ_CHAIN_TALL_WAVES")) : 2;
+            for (int w = tall_waves < waves_per_cu / 4 ? tall_waves : waves_per_cu / 4;
+                 w >= 1 && R <= 0; --w) {
+                const int cand = rows_for((size_t)256 * 4 * (size_t)w);
+                if (cand >= (w == 1 ? 24 : 20) && cand <= 48) R = cand;
+            }
         }
         size_t rounds = 1;
         if (R <= 0) R = rows_for((size_t)256 * (size_t)waves_per_cu);
