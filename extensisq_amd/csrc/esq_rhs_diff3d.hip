@@ -311,6 +311,8 @@ int esq_rhs_diff3d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void
     if (!ch->yjm2 || !ch->yn || !ch->fn || !ch->out) return ESQ_EINVAL;
     if (!ch->yjm1 && ch->yjm2 != ch->yn) return ESQ_EINVAL;       // FIRST: y_{j-2} = y_n
     if (ch->fy_out && (ch->out_prev || !ch->partials)) return ESQ_EINVAL;
+    // (32-bit byte offsets into a vector: esq_rkc3d.hpp)
+    if ((unsigned long long)n * 8ull > 0xffffffffull - 16ull) return ESQ_ENOTSUP;
     if (r->N < 2 || (r->N < 48 && !r->rkc_force)) return ESQ_ENOTSUP;
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = (hipEvent_t)start_event, e1 = (hipEvent_t)stop_event;

@@ -2,8 +2,15 @@ import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import extensisq_amd as esq
 from extensisq_amd import workloads as wl
+# kernel table of one method:  python tools/method_profile.py <method> [bruss2d|heat2d] [N]
 name = sys.argv[1]
-rhs = esq.Brusselator2D(2236); y0 = wl.bruss2d_y0(2236); h = 1.0 / rhs.spectral_radius()
+plugin = sys.argv[2] if len(sys.argv) > 2 else "bruss2d"
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 2236
+if plugin == "heat2d":
+    rhs = esq.Heat2D(N); y0 = wl.heat2d_y0(N)
+else:
+    rhs = esq.Brusselator2D(N); y0 = wl.bruss2d_y0(N)
+h = 1.0 / rhs.spectral_radius()
 s = getattr(esq, name)(rhs, 0.0, y0, 1e9, first_step=h, max_step=h, rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
 for _ in range(8): assert s.step() is None
 nfs0 = int(esq.NFS[()]); nf0 = s.nfev
