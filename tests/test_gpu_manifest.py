@@ -11,6 +11,7 @@ ROOT = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
 # test function -> minimum number of collected parametrisations
 REQUIRED = {
     # golden vectors of the real reference
+    "test_gpu_smoke.py::test_smoke_entry_point": 1,
     "test_gpu_parity.py::test_single_step_golden": 80,
     "test_gpu_parity.py::test_trajectory_golden": 56,
     "test_gpu_parity.py::test_published_known_answers": 1,
