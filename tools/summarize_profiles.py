@@ -48,6 +48,19 @@ def label(name):
         return "rhs+rkcerr"
     if re.search(r"_sweep<.*EpiRkc\b", name):
         return "rhs_rkc"
+    # one-stage sweeps of the 2-D stencil plugins (round 4: esq_stencil2d.hpp) and the
+    # 3-D pair / row sweeps: k_stencil2d_sweep<NF, PERIODIC, Fn, Epi...<NT>, Src>
+    m = re.search(r"k_(?:stencil2d_sweep|diff3d_pairs|diff3d_sweep)<.*?Epi(\w+?)(?:<(\d+)|[,>])", name)
+    if m:
+        kind = m.group(1).lower()
+        if kind == "none":
+            return "rhs_plugin"
+        if kind == "rkcerr":
+            return "rhs+rkcerr"
+        if kind == "rkc":
+            return "rhs_rkc"
+        first = "1" if "SrcAxpy" in name else ""
+        return f"rhs{first}+{kind}<{m.group(2)}>" if m.group(2) else f"rhs{first}+{kind}"
     m = re.search(r"k_(bruss2d|heat2d|diff3d|diag)_sweep<.*Epi(\w+)<(\d+)", name)
     if m:                                   # fused sweeps (round 2)
         first = "1" if "SrcAxpy" in name else ""
