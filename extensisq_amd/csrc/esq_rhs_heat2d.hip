@@ -83,6 +83,14 @@ int esq_rhs_heat2d_rkc(void *user, double t, const double *yjm1, const double *y
                      stream, start_event, stop_event);
 }
 
+// D Chebyshev stages per launch (esq_rhs_rkc_chain_fn, csrc/esq_rkc2d.hpp)
+int esq_rhs_heat2d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void *stream,
+                             void *start_event, void *stop_event) {
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != HEAT2D || n != r->n || !ch) return ESQ_EINVAL;
+    return Heat::rkc_chain(fn_of(r), r->N, ch, stream, start_event, stop_event);
+}
+
 // the one-field rows are light: tall tiles where one wave per SIMD fills the chip,
 // tiles down to `depth` rows (esq_stencil2d.hpp, geo_chain)
 int esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,

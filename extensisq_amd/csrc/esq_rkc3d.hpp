@@ -107,26 +107,9 @@ inline double amp_rkc3d(const Geo3d &g, int D) {
     return plane * (cover(g.R, D) + 3.0 * cover(g.R, D - 1)) / 4.0;
 }
 
-// Buffer addressing (raw buffer resources over the whole vector): a lane that is
-// masked out gets the offset 0xffffffff, which the hardware's range check turns
-// into "load returns 0, store is dropped" with no memory traffic -- so every
-// load and store of the marching loop is UNCONDITIONAL: no branch around it (the
-// compiler otherwise wraps each load in a branch with an `s_waitcnt vmcnt(0)`
-// behind it: sixteen exposed latencies per plane), and the compiler can count the
-// stores that are younger than the prefetched plane.  The plane offset travels
-// in the scalar offset (not range-checked; always a valid plane).
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void *p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(unsigned)bytes, 0x00020000);
-}
-__device__ __forceinline__ double buf_ld(rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ void buf_st(rsrc_t r, unsigned voff, unsigned soff, double v) {
-    using v2u = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)voff, (int)soff, 0);
-}
-
+// Buffer addressing (esq_terms.hpp: raw buffer resources over the whole vector,
+// masked lanes at offset 0xffffffff): every load and store of the marching loop is
+// unconditional; the plane offset travels in the scalar offset.
 // St::eval(below, above, up, down, left, right, centre) -> derivative at the point
 // (i-1, i+1; j-1, j+1; l-1, l+1); autonomous stencils only (t is not passed).
 // Vectors of at most 4 GiB - 16 B (the offsets are 32-bit).

@@ -40,6 +40,7 @@
 #include "../../include/extensisq_amd.h"
 #include "esq_epilogue.hpp"
 #include "esq_plugin.hpp"
+#include "esq_rkc2d.hpp"
 #include "esq_terms.hpp"
 
 namespace esq {
@@ -364,6 +365,62 @@ struct Stencil2D {
                               (hipEvent_t)start_event, (hipEvent_t)stop_event, 0,
                               SrcPlain{yjm1}, (double *)nullptr, epi, fn, N, g.grid, g.wpr);
         return (int)hipGetLastError();
+    }
+
+    // `depth` consecutive Chebyshev stages in one marching sweep (esq_rhs_rkc_chain_fn;
+    // one-field plugins; the FIRST form -- the chain opens a step -- included, the
+    // LAST form not: declare ESQ_RKC_CHAIN_FIRST only).  Depth 2 .. 6.
+    static int rkc_chain(const Fn &fn, int N, const esq_rkc_chain *ch, void *stream,
+                         void *start_event, void *stop_event) {
+        if (!ch || !ch->yjm2 || !ch->yn || !ch->fn || !ch->out) return ESQ_EINVAL;
+        if (!ch->yjm1 && ch->yjm2 != ch->yn) return ESQ_EINVAL;     // FIRST: y_{j-2} = y_n
+        if constexpr (NF != 1) {
+            return ESQ_ENOTSUP;
+        } else {
+            if (ch->fy_out || N % 2 != 0 || N < 16) return ESQ_ENOTSUP;
+            if (ch->depth < 2 || ch->depth > 6) return ESQ_ENOTSUP;
+            if (!chain_fits_grid(N, ch->depth + 1)) return ESQ_ENOTSUP;
+            if ((unsigned long long)N * N * 8ull > 0xffffffffull - 16ull) return ESQ_ENOTSUP;
+            int rc = ESQ_ENOTSUP;
+            auto launch = [&](auto depth_c, auto first_c) {
+                constexpr int DD = decltype(depth_c)::value;
+                constexpr bool kFirst = decltype(first_c)::value;
+                auto kern = k_rkc2d_chain<PERIODIC, DD, Fn, kFirst>;
+                static const int wpc = chain_waves_per_cu(kern, (unsigned)kBlock);
+                // (tile width: 64 - 2*ceil(D/2) pairs = geo_chain's rule for depth
+                // ceil(D/2) + 1; D - 1 run-in rows per side)
+                const GeoChain g = geo_chain(N, (DD + 1) / 2 + 1, wpc, kBlock / 64, 1,
+                                             /*tall_if_one_round=*/true, /*min_rows=*/DD);
+                Rkc2dArgs<DD> a;
+                a.a = ch->yjm1; a.b = ch->yjm2; a.yn = ch->yn; a.fn = ch->fn;
+                a.out = ch->out; a.outp = ch->out_prev;
+                a.hmus1 = ch->hmus_first;
+                for (int k = 0; k < DD; ++k) {
+                    a.mu[k] = ch->mu[k]; a.nu[k] = ch->nu[k]; a.omn[k] = ch->omn[k];
+                    a.hmus[k] = ch->hmus[k]; a.ajm1[k] = ch->ajm1[k];
+                }
+                if (ch->read_amplification)
+                    *ch->read_amplification = (double)(g.R + 2 * (DD - 1)) / g.R * 64.0 /
+                                              (64 - 2 * ((DD + 1) / 2));
+                hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(kBlock), 0, (hipStream_t)stream,
+                                      (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, a, fn,
+                                      N, g.R, g.tpr, g.ntiles, g.nblocks, (unsigned)kXcd);
+                rc = (int)hipGetLastError();
+            };
+            auto by_form = [&](auto depth_c) {
+                if (ch->yjm1) launch(depth_c, std::false_type{});
+                else launch(depth_c, std::true_type{});
+            };
+            switch (ch->depth) {
+                case 2: by_form(std::integral_constant<int, 2>{}); break;
+                case 3: by_form(std::integral_constant<int, 3>{}); break;
+                case 4: by_form(std::integral_constant<int, 4>{}); break;
+                case 5: by_form(std::integral_constant<int, 5>{}); break;
+                case 6: by_form(std::integral_constant<int, 6>{}); break;
+                default: break;
+            }
+            return rc;
+        }
     }
 
     // `depth` consecutive stages in one marching sweep          (esq_rhs_chain_fn)

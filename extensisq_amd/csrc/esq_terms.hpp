@@ -43,6 +43,26 @@ __device__ __forceinline__ void st2_nt(double *p, size_t i, double2 v) {
     __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(p) + i);
 }
 
+// Raw buffer resources (the whole vector as one buffer, 32-bit byte offsets): a lane
+// that is masked out gets an out-of-range offset -- or the whole access a resource
+// of zero bytes -- which the hardware's range check turns into "load returns 0,
+// store is dropped" with no memory traffic.  Loads and stores of a marching loop
+// can then be UNCONDITIONAL: no branch around them (the compiler otherwise wraps
+// each load in a branch with an `s_waitcnt vmcnt(0)` behind it), and it counts the
+// younger accesses it may leave in flight.  The scalar offset is not range-checked:
+// always a valid row / plane.  Vectors of at most 4 GiB - 16 B.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ double buf_ld(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_st(rsrc_t r, unsigned voff, unsigned soff, double v) {
+    using v2u = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)voff, (int)soff, 0);
+}
+
 // The neighbouring lane's value: lane l <- lane l - 1 (lane 0 gets 0.0) / lane
 // l + 1 (lane 63 gets 0.0) -- one `v_mov_b32_dpp wave_shr:1 / wave_shl:1` per
 // half and nothing else.  `__shfl_up / __shfl_down(v, 1, 64)` compile to two

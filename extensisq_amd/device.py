@@ -422,16 +422,17 @@ class _Builtin(DeviceRHS):
     _symbol_rkc = None
     _symbol_chain = None
     _symbol_rkc_chain = None
-    _rkc_chain_depth = int(os.environ.get("ESQ_RKC_MAXDEPTH", "4"))
+    _rkc_chain_depth = 4              # Chebyshev stages per chain sweep (ESQ_RKC_MAXDEPTH)
+    _rkc_chain_forms = _lib.RKC_CHAIN_FIRST | _lib.RKC_CHAIN_LAST
     _chain_caps = 31                  # the built-in sweeps handle every form and
     _fuse_query = True                # answer the planner's queries
 
     def _rkc_chain_entry(self, lib):
         if not self._symbol_rkc_chain:
             return None
-        # (the built-in chain sweep also opens and ends a step: ESQ_RKC_CHAIN_FIRST / _LAST)
-        return (getattr(lib, self._symbol_rkc_chain),
-                self._rkc_chain_depth | _lib.RKC_CHAIN_FIRST | _lib.RKC_CHAIN_LAST)
+        # (the forms the built-in chain sweep takes: opening / ending a step)
+        depth = int(os.environ.get("ESQ_RKC_MAXDEPTH", self._rkc_chain_depth))
+        return getattr(lib, self._symbol_rkc_chain), depth | self._rkc_chain_forms
 
     def _rkc_entry(self, lib):
         return getattr(lib, self._symbol_rkc) if self._symbol_rkc else None
@@ -488,6 +489,12 @@ class Heat2D(_Builtin):
     _symbol = "esq_rhs_heat2d"
     _symbol_fused = "esq_rhs_heat2d_fused"
     _symbol_rkc = "esq_rhs_heat2d_rkc"
+    _symbol_rkc_chain = "esq_rhs_heat2d_rkc_chain"
+    _rkc_chain_forms = _lib.RKC_CHAIN_FIRST           # (the end of the step: its own sweep)
+    # (in 2-D the recomputed halo is cheap; tools/rkc2d_bench.py, ms/step by depth
+    # 1 .. 6 at N = 2236: 0.716 0.520 0.393 0.322 0.288 0.268; at N = 1000 depth 5
+    # 0.118, 6 0.124)
+    _rkc_chain_depth = 5
     _symbol_chain = "esq_rhs_heat2d_chain"
     _fuse_default = True
 
@@ -495,6 +502,8 @@ class Heat2D(_Builtin):
         super().__init__()
         self.N = int(N)
         self.n = self.N * self.N
+        if self.N >= 1500:
+            self._rkc_chain_depth = 6
 
     def _make_user(self, lib, device):
         user = C.c_void_p()
@@ -548,7 +557,7 @@ class Diffusion3D(_Builtin):
         # Chebyshev stages per chain sweep: four while the sweep's vectors live in the
         # Infinity Cache (more stages = more recomputed halo points, fewer bytes: a tie
         # there), five beyond it (SSV2stab at N = 400: 19.6 instead of 20.0 ms/step)
-        if "ESQ_RKC_MAXDEPTH" not in os.environ and 6 * 8 * self.n > (256 << 20):
+        if 6 * 8 * self.n > (256 << 20):
             self._rkc_chain_depth = 5
 
     def _make_user(self, lib, device):

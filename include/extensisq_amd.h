@@ -698,6 +698,8 @@ int  esq_rhs_diff3d_rkc(void *user, double t, const double *yjm1,
                         double *y_out, size_t n, void *stream, void *start_event,
                         void *stop_event);
 /* RKC chain entry (esq_rhs_rkc_chain_fn) */
+int  esq_rhs_heat2d_rkc_chain(void *user, const esq_rkc_chain *chain, size_t n,
+                              void *hip_stream, void *start_event, void *stop_event);
 int  esq_rhs_diff3d_rkc_chain(void *user, const esq_rkc_chain *chain, size_t n,
                               void *stream, void *start_event, void *stop_event);
 /* fused entries (esq_rhs_fused_fn) */

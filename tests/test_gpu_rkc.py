@@ -231,6 +231,73 @@ def test_rkc_chain_sweeps_are_bit_identical(monkeypatch, N, planes, depth):
             assert "k_rkc_first" in [k[0] for k in _profiled_kernels(s3, m)]
 
 
+def _stage_run_heat(N, m):
+    """all m stages of one Chebyshev step on the 2-D heat plugin from a non-smooth state"""
+    rhs = esq.Heat2D(N)
+    rho = rhs.spectral_radius()
+    rng = np.random.default_rng(3 + N)
+    y0 = pb.heat2d_y0(N) + 0.1 * rng.standard_normal(N * N)
+    s = esq.SSV2stab(rhs, 0.0, y0, 1.0, rtol=1e-3, atol=1e-3, const_jac=True,
+                     first_step=1e-6, rho_jac=lambda t, y: rho)
+    h = (m * m - 1) / (1.54 * rho)
+    yrow = s._stages(0.0, h, m)
+    return s._dev.download(SLOT_K, yrow), s
+
+
+@pytest.mark.parametrize("N,rows", [(16, 3), (40, 5), (130, 12), (250, 9), (512, 0)])
+@pytest.mark.parametrize("depth", [2, 3, 4, 5, 6])
+def test_rkc_chain_sweeps_2d_are_bit_identical(monkeypatch, N, rows, depth):
+    """the 2-D sibling (csrc/esq_rkc2d.hpp, the heat plugin's esq_rhs_rkc_chain_fn):
+    ESQ_RKC_DEPTH stages per marching sweep against one launch per stage, the final
+    iterate of m stages bit for bit -- tiles of forced heights (several tiles per
+    grid row and column, ragged last tiles), chains of every length at the end of a
+    step, the chain that opens a step forming the first iterate or reading it"""
+    if rows:
+        monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))       # (also lifts the small-grid rule)
+    monkeypatch.setenv("ESQ_RKC_MAXDEPTH", "6")
+    for m in (2, 3, 4, 5, 6, 7, 8, 10, 23):
+        monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+        ref, s1 = _stage_run_heat(N, m)
+        monkeypatch.setenv("ESQ_RKC_DEPTH", str(depth))
+        got, s2 = _stage_run_heat(N, m)
+        assert np.isfinite(ref).all()
+        np.testing.assert_array_equal(got, ref, err_msg=f"m = {m}")
+        assert s1.nfev == s2.nfev
+        names = [k[0] for k in _profiled_kernels(s2, m)]
+        if m - 1 >= 2:
+            assert any(k.startswith("rkc_chain") for k in names), names
+            assert names.count("k_rkc_first") == 0 and any("-first" in k for k in names), names
+            monkeypatch.setenv("ESQ_RKC_FIRST", "0")
+            got0, s3 = _stage_run_heat(N, m)
+            monkeypatch.delenv("ESQ_RKC_FIRST")
+            np.testing.assert_array_equal(got0, ref, err_msg=f"m = {m}, ESQ_RKC_FIRST=0")
+            assert "k_rkc_first" in [k[0] for k in _profiled_kernels(s3, m)]
+
+
+def test_rkc_chain_2d_whole_steps(monkeypatch):
+    """whole adaptive SSV2stab steps on the 2-D heat plugin at a size where the chain
+    sweeps run by themselves (N = 512: first iterate inside the first chain, chains of
+    five, the end of the step its own sweep) against one launch per stage: identical
+    t, y, error norms and counters"""
+    N = 512
+    rho = esq.Heat2D(N).spectral_radius()
+    h0 = (40 ** 2 - 1) / (1.54 * rho) * 0.999
+    kw = dict(rtol=1e-2, atol=1e-2, const_jac=True, first_step=h0, rho_jac=lambda t, y: rho)
+    y0 = pb.heat2d_y0(N)
+    a = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+    b = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_RKC_DEPTH")
+    for _ in range(4):
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t and a.errold == b.errold and a.absh == b.absh
+        np.testing.assert_array_equal(a.y, b.y)
+    assert a.nfev == b.nfev
+    m = int(dev_rkc.maxm[()])
+    names = {k[0] for k in _profiled_kernels(a, m)}
+    assert any(k.startswith("rkc_chain5") for k in names) and "k_rkc_first" not in names, names
+
+
 def _end_run(N, m):
     """all stages + the end of the step (esq_rkc_stages_end) from a fixed state:
     y_{n+1}, f(t + h, y_{n+1}), the error estimate's sum of squares, kernel labels"""
