@@ -275,8 +275,9 @@ int rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3, doubl
                 ch.out_prev = last ? nullptr : ROW(c, o2);
                 // the chain that ends the step takes f(t_end, y) and the error
                 // estimate along (LAST; d + 1 stage slots)
-                const bool with_end = last && tail && c->rkc_last && !c->rkc_last_refused &&
-                                      !first_pending && d + 1 <= 5 && !c->cplx;
+                const bool with_end = last && tail && c->rkc_last &&
+                                      !((c->rkc_last_refused >> d) & 1u) && !first_pending &&
+                                      d + 1 <= ESQ_RKC_CHAIN_MAX_DEPTH && !c->cplx;
                 if (with_end) {
                     ch.fy_out = ROW(c, o2);
                     ch.t_end = tail->t_end;
@@ -325,7 +326,7 @@ int rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3, doubl
                 if (r != ESQ_ENOTSUP)
                     return fail(c, ESQ_ERHS, "RKC chain entry returned %d", r);
                 if (with_end) {                            // declined in this form
-                    c->rkc_last_refused = true;
+                    c->rkc_last_refused |= 1u << d;
                     continue;
                 }
                 if (first_pending) {

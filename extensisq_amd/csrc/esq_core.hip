@@ -622,7 +622,7 @@ int esq_set_rhs_rkc_chain(esq_ctx *c, esq_rhs_rkc_chain_fn fn, int max_depth) {
     c->rkc_first = fn && (max_depth & ESQ_RKC_CHAIN_FIRST) && env_uint("ESQ_RKC_FIRST", 1) != 0;
     c->rkc_first_refused = false;
     c->rkc_last = fn && (max_depth & ESQ_RKC_CHAIN_LAST) && env_uint("ESQ_RKC_LAST", 1) != 0;
-    c->rkc_last_refused = false;
+    c->rkc_last_refused = 0;
     max_depth &= 0xff;
     int d = fn ? max_depth : 1;
     const int env = (int)env_uint("ESQ_RKC_DEPTH", 0);        // 0: the plugin's own

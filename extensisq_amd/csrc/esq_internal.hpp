@@ -143,7 +143,7 @@ struct esq_ctx {
     bool rkc_first = false;                 // the chain entry forms y_1 itself (FIRST)
     bool rkc_first_refused = false;
     bool rkc_last = false;                  // ... and ends the step itself (LAST)
-    bool rkc_last_refused = false;
+    unsigned rkc_last_refused = 0;          // bit d: declined with d stages before the end
     unsigned rkc_refused = 0;               // bit D: the plugin declined depth D
     esq_rhs_chain_fn rhs_chain = nullptr;   // optional multi-stage marching sweep
     int chain_depth = 4;                    // ESQ_CHAIN_DEPTH: 1 off, up to 4 stages per sweep

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/extensisq_amd.h"
+#include "esq_epilogue.hpp"
 #include "esq_terms.hpp"
 
 namespace esq {
@@ -38,6 +39,10 @@ struct Rkc2dArgs {
     double *out, *outp;                     // Y_D, Y_{D-1} (outp may be null)
     double mu[D], nu[D], omn[D], hmus[D], ajm1[D];
     double hmus1;                           // FIRST: a = y_n + hmus1 * f_n, b = y_n
+    // LAST: stage slot D - 1 is the end of the step (esq_rkc3d.hpp): f = Fn(Y_{D-1}) ->
+    // out, Y_{D-1} -> outp, partial sums of the error estimate (ESQ_EPI_RKCERR)
+    double h04;
+    RedArgs red;
 };
 
 // 16-byte buffer accesses (rsrc_t, make_rsrc: esq_terms.hpp)
@@ -63,7 +68,9 @@ __device__ __forceinline__ void buf_st2(rsrc_t r, unsigned voff, unsigned soff, 
 // Fn::eval(centres, laplacians) -> derivatives (esq_stencil2d.hpp), one field.
 // FIRST: the chain opens a step -- its first input is y_1 = y_n + hmus1 * f_n, formed
 // where the window needs it; y_{j-2} = y_n (esq_rkc3d.hpp).
-template <bool PERIODIC, int D, class Fn, bool FIRST = false>
+// LAST: the chain ends a step -- D - 1 Chebyshev stages, then f(t + h, y_{n+1}) and the
+// error estimate 0.8 (y_n - y) + 0.4 h (f_n + f) as stage slot D - 1 (sommeijer.py:214-220).
+template <bool PERIODIC, int D, class Fn, bool FIRST = false, bool LAST = false>
 __global__ __launch_bounds__(kBlock) void k_rkc2d_chain(Rkc2dArgs<D> ca, Fn fn, int N, int R,
                                                        unsigned tpr, unsigned ntiles,
                                                        unsigned nblocks, unsigned xcd) {
@@ -73,7 +80,11 @@ __global__ __launch_bounds__(kBlock) void k_rkc2d_chain(Rkc2dArgs<D> ca, Fn fn, 
     const unsigned lb = (blockIdx.x % xcd) * per + blockIdx.x / xcd;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned tile = lb * (kBlock / 64) + wave;
-    if (lb >= nblocks || tile >= ntiles) return;                     // wave-uniform
+    double local = 0.0;                                              // LAST: error sum
+    if (lb >= nblocks || tile >= ntiles) {                           // wave-uniform
+        if constexpr (LAST) block_partial(local, ca.red.partials);   // (every wave of the block)
+        return;
+    }
     const int npairs = N / 2;
     const int lane = threadIdx.x & 63;
     const int pc = W * (int)(tile % tpr) - H + lane;
@@ -170,9 +181,23 @@ __global__ __launch_bounds__(kBlock) void k_rkc2d_chain(Rkc2dArgs<D> ca, Fn fn, 
                 lap[0].x = ((wm[k].x + wp.x) + (lf + wc[k].y)) - 4.0 * wc[k].x;
                 lap[0].y = ((wm[k].y + wp.y) + (wc[k].x + rt)) - 4.0 * wc[k].y;
                 fn.eval(cc, lap, fy);
-                const double vx = one(k, wc[k].x, ykm1.x, dy[k].x, df[k].x, fy[0].x);
-                const double vy = one(k, wc[k].y, ykm1.y, dy[k].y, df[k].y, fy[0].y);
-                nw = make_double2(ok ? vx : 0.0, ok ? vy : 0.0);
+                if (LAST && k == D - 1) {
+                    nw = make_double2(ok ? fy[0].x : 0.0, ok ? fy[0].y : 0.0);
+                    if (store_ok) {                                  // a pair this tile stores
+                        const double2 er = make_double2(
+                            __dadd_rn(__dmul_rn(0.8, __dsub_rn(dy[k].x, wc[k].x)),
+                                      __dmul_rn(ca.h04, __dadd_rn(df[k].x, fy[0].x))),
+                            __dadd_rn(__dmul_rn(0.8, __dsub_rn(dy[k].y, wc[k].y)),
+                                      __dmul_rn(ca.h04, __dadd_rn(df[k].y, fy[0].y))));
+                        const size_t i2 = (size_t)wrap(ik) * (size_t)npairs + (size_t)pw;
+                        local += ratio_sq<false>(er, wc[k], dy[k], ca.red.atol_vec, ca.red.atol_s,
+                                                 ca.red.rtol, i2, ca.red.n_valid);
+                    }
+                } else {
+                    const double vx = one(k, wc[k].x, ykm1.x, dy[k].x, df[k].x, fy[0].x);
+                    const double vy = one(k, wc[k].y, ykm1.y, dy[k].y, df[k].y, fy[0].y);
+                    nw = make_double2(ok ? vx : 0.0, ok ? vy : 0.0);
+                }
             }
             if (k == D - 1) {
                 // the last stage is only ever at rows [r0, r0 + Re); before it has
@@ -196,6 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_rkc2d_chain(Rkc2dArgs<D> ca, Fn fn, 
         }
     }
 #undef ESQ_RKC2D_LOAD
+    if constexpr (LAST) block_partial(local, ca.red.partials);
 }
 
 }  // namespace esq

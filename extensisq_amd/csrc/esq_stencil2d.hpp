@@ -368,8 +368,9 @@ struct Stencil2D {
     }
 
     // `depth` consecutive Chebyshev stages in one marching sweep (esq_rhs_rkc_chain_fn;
-    // one-field plugins; the FIRST form -- the chain opens a step -- included, the
-    // LAST form not: declare ESQ_RKC_CHAIN_FIRST only).  Depth 2 .. 6.
+    // one-field plugins; the FIRST form -- the chain opens a step -- and the LAST
+    // form -- it ends one: f(t_end, y) and the error estimate as one more stage slot --
+    // included).  Depth 2 .. 6 (LAST: 2 .. 5).
     static int rkc_chain(const Fn &fn, int N, const esq_rkc_chain *ch, void *stream,
                          void *start_event, void *stop_event) {
         if (!ch || !ch->yjm2 || !ch->yn || !ch->fn || !ch->out) return ESQ_EINVAL;
@@ -377,15 +378,18 @@ struct Stencil2D {
         if constexpr (NF != 1) {
             return ESQ_ENOTSUP;
         } else {
-            if (ch->fy_out || N % 2 != 0 || N < 16) return ESQ_ENOTSUP;
-            if (ch->depth < 2 || ch->depth > 6) return ESQ_ENOTSUP;
+            if (N % 2 != 0 || N < 16) return ESQ_ENOTSUP;
+            if (ch->fy_out && (ch->out_prev || !ch->partials || !ch->yjm1)) return ESQ_EINVAL;
+            const int slots = ch->depth + (ch->fy_out ? 1 : 0);
+            if (ch->depth < 2 || slots > 6) return ESQ_ENOTSUP;
             if (!chain_fits_grid(N, ch->depth + 1)) return ESQ_ENOTSUP;
             if ((unsigned long long)N * N * 8ull > 0xffffffffull - 16ull) return ESQ_ENOTSUP;
             int rc = ESQ_ENOTSUP;
-            auto launch = [&](auto depth_c, auto first_c) {
-                constexpr int DD = decltype(depth_c)::value;
+            auto launch = [&](auto depth_c, auto first_c, auto last_c) {
+                constexpr int DD = decltype(depth_c)::value;           // stage slots
                 constexpr bool kFirst = decltype(first_c)::value;
-                auto kern = k_rkc2d_chain<PERIODIC, DD, Fn, kFirst>;
+                constexpr bool kLast = decltype(last_c)::value;
+                auto kern = k_rkc2d_chain<PERIODIC, DD, Fn, kFirst, kLast>;
                 static const int wpc = chain_waves_per_cu(kern, (unsigned)kBlock);
                 // (tile width: 64 - 2*ceil(D/2) pairs = geo_chain's rule for depth
                 // ceil(D/2) + 1; D - 1 run-in rows per side)
@@ -395,9 +399,23 @@ struct Stencil2D {
                 a.a = ch->yjm1; a.b = ch->yjm2; a.yn = ch->yn; a.fn = ch->fn;
                 a.out = ch->out; a.outp = ch->out_prev;
                 a.hmus1 = ch->hmus_first;
+                a.h04 = 0.0;
+                a.red = RedArgs{};
                 for (int k = 0; k < DD; ++k) {
-                    a.mu[k] = ch->mu[k]; a.nu[k] = ch->nu[k]; a.omn[k] = ch->omn[k];
-                    a.hmus[k] = ch->hmus[k]; a.ajm1[k] = ch->ajm1[k];
+                    const bool stage = k < ch->depth;      // (LAST: slot DD - 1 is the end)
+                    a.mu[k] = stage ? ch->mu[k] : 0.0; a.nu[k] = stage ? ch->nu[k] : 0.0;
+                    a.omn[k] = stage ? ch->omn[k] : 0.0; a.hmus[k] = stage ? ch->hmus[k] : 0.0;
+                    a.ajm1[k] = stage ? ch->ajm1[k] : 0.0;
+                }
+                if constexpr (kLast) {
+                    if ((int)g.grid > ch->partials_cap) { rc = ESQ_ENOTSUP; return; }
+                    if (ch->partials_used) *ch->partials_used = (int)g.grid;
+                    a.out = ch->fy_out;                    // the slot's "result" ...
+                    a.outp = ch->out;                      // ... and its input: y_{n+1}
+                    a.h04 = 0.4 * ch->h;
+                    a.red.atol_vec = ch->atol_vec; a.red.atol_s = ch->atol_s;
+                    a.red.rtol = ch->rtol; a.red.n_valid = ch->n_valid;
+                    a.red.partials = ch->partials;
                 }
                 if (ch->read_amplification)
                     *ch->read_amplification = (double)(g.R + 2 * (DD - 1)) / g.R * 64.0 /
@@ -408,10 +426,11 @@ struct Stencil2D {
                 rc = (int)hipGetLastError();
             };
             auto by_form = [&](auto depth_c) {
-                if (ch->yjm1) launch(depth_c, std::false_type{});
-                else launch(depth_c, std::true_type{});
+                if (ch->fy_out) launch(depth_c, std::false_type{}, std::true_type{});
+                else if (ch->yjm1) launch(depth_c, std::false_type{}, std::false_type{});
+                else launch(depth_c, std::true_type{}, std::false_type{});
             };
-            switch (ch->depth) {
+            switch (slots) {
                 case 2: by_form(std::integral_constant<int, 2>{}); break;
                 case 3: by_form(std::integral_constant<int, 3>{}); break;
                 case 4: by_form(std::integral_constant<int, 4>{}); break;

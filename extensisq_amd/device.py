@@ -490,7 +490,7 @@ class Heat2D(_Builtin):
     _symbol_fused = "esq_rhs_heat2d_fused"
     _symbol_rkc = "esq_rhs_heat2d_rkc"
     _symbol_rkc_chain = "esq_rhs_heat2d_rkc_chain"
-    _rkc_chain_forms = _lib.RKC_CHAIN_FIRST           # (the end of the step: its own sweep)
+    _rkc_chain_forms = _lib.RKC_CHAIN_FIRST | _lib.RKC_CHAIN_LAST
     # (in 2-D the recomputed halo is cheap; tools/rkc2d_bench.py, ms/step by depth
     # 1 .. 6 at N = 2236: 0.716 0.520 0.393 0.322 0.288 0.268; at N = 1000 depth 5
     # 0.118, 6 0.124)

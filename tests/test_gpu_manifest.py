@@ -61,6 +61,7 @@ REQUIRED = {
     "test_gpu_rkc.py::test_rkc_chain_plan_and_whole_steps": 1,
     "test_gpu_rkc.py::test_rkc_chain_sweeps_2d_are_bit_identical": 25,
     "test_gpu_rkc.py::test_rkc_chain_2d_whole_steps": 1,
+    "test_gpu_rkc.py::test_rkc_chain_2d_takes_the_end_of_the_step_along": 3,
     "test_gpu_rkc.py::test_rkc_chain_takes_the_end_of_the_step_along": 5,
     "test_gpu_parity.py::test_chained_stage_sweeps_are_bit_identical": 160,
     "test_gpu_parity.py::test_rows_only_their_sweep_reads_are_restored_on_demand": 5,

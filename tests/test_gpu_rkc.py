@@ -290,23 +290,38 @@ def test_rkc_chain_2d_whole_steps(monkeypatch):
     monkeypatch.delenv("ESQ_RKC_DEPTH")
     for _ in range(4):
         assert a.step() is None and b.step() is None
-        assert a.t == b.t and a.errold == b.errold and a.absh == b.absh
-        np.testing.assert_array_equal(a.y, b.y)
+        # (the end of the step inside the last chain sweep: the error estimate summed
+        # over other workgroups -- equal to rounding, and the step sizes with it)
+        assert abs(a.errold - b.errold) <= 1e-13 * b.errold
+        assert abs(a.t - b.t) <= 1e-13 * b.t and abs(a.absh - b.absh) <= 1e-13 * b.absh
+        np.testing.assert_allclose(a.y, b.y, rtol=1e-11, atol=1e-13)
     assert a.nfev == b.nfev
+    # ... and bit for bit with that form switched off
+    monkeypatch.setenv("ESQ_RKC_LAST", "0")
+    a0 = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_RKC_LAST")
+    monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+    b0 = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_RKC_DEPTH")
+    for _ in range(4):
+        assert a0.step() is None and b0.step() is None
+        assert a0.t == b0.t and a0.errold == b0.errold and a0.absh == b0.absh
+        np.testing.assert_array_equal(a0.y, b0.y)
     m = int(dev_rkc.maxm[()])
     names = {k[0] for k in _profiled_kernels(a, m)}
     assert any(k.startswith("rkc_chain5") for k in names) and "k_rkc_first" not in names, names
 
 
-def _end_run(N, m):
+def _end_run(N, m, heat=False):
     """all stages + the end of the step (esq_rkc_stages_end) from a fixed state:
     y_{n+1}, f(t + h, y_{n+1}), the error estimate's sum of squares, kernel labels"""
     import ctypes as C
     from extensisq_amd._lib import PROF_RKC
-    rhs = esq.Diffusion3D(N)
+    rhs = esq.Heat2D(N) if heat else esq.Diffusion3D(N)
     rho = rhs.spectral_radius()
     rng = np.random.default_rng(11 + N)
-    y0 = pb.diff3d_y0(N) + 0.1 * rng.standard_normal(N ** 3)
+    y0 = (pb.heat2d_y0(N) + 0.1 * rng.standard_normal(N * N) if heat else
+          pb.diff3d_y0(N) + 0.1 * rng.standard_normal(N ** 3))
     s = esq.SSV2stab(rhs, 0.0, y0, 1.0, rtol=1e-3, atol=1e-3, const_jac=True,
                      first_step=1e-6, rho_jac=lambda t, y: rho)
     h = (m * m - 1) / (1.54 * rho)
@@ -343,6 +358,30 @@ def test_rkc_chain_takes_the_end_of_the_step_along(monkeypatch, N):
         assert not any(k.endswith("-end") for k in n1 + n3), (n1, n3)
         if m >= 7:                       # a last chain that is not the first one
             assert any(k.endswith("-end") for k in n2), n2
+
+
+@pytest.mark.parametrize("N,rows", [(40, 5), (130, 12), (512, 0)])
+def test_rkc_chain_2d_takes_the_end_of_the_step_along(monkeypatch, N, rows):
+    """the same on the 2-D heat plugin (csrc/esq_rkc2d.hpp, LAST form): y_{n+1} and
+    its derivative bit for bit, the sum of squares to 1e-13"""
+    if rows:
+        monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    for m in (2, 3, 4, 5, 6, 7, 8, 10, 12, 23):
+        monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+        y1, f1, e1, n1 = _end_run(N, m, heat=True)
+        monkeypatch.delenv("ESQ_RKC_DEPTH")
+        y2, f2, e2, n2 = _end_run(N, m, heat=True)
+        monkeypatch.setenv("ESQ_RKC_LAST", "0")
+        y3, f3, e3, n3 = _end_run(N, m, heat=True)
+        monkeypatch.delenv("ESQ_RKC_LAST")
+        assert np.isfinite(y1).all() and np.isfinite(f1).all() and e1 > 0.0
+        for y, f, e, tag in ((y2, f2, e2, "LAST"), (y3, f3, e3, "ESQ_RKC_LAST=0")):
+            np.testing.assert_array_equal(y, y1, err_msg=f"m = {m}, {tag}")
+            np.testing.assert_array_equal(f, f1, err_msg=f"m = {m}, {tag}")
+            assert abs(e - e1) <= 1e-13 * e1, (m, tag, e, e1)
+        assert not any(k.endswith("-end") for k in n1 + n3), (n1, n3)
+        if m in (8, 10, 12):             # (a last chain of 2 .. 5 stages behind the first one)
+            assert any(k.endswith("-end") for k in n2), (m, n2)
 
 
 def _profiled_kernels(s, m):
