@@ -307,8 +307,9 @@ def workload_meta(name, N, plugin=None):
                 metric="accepted RKC steps/s x state-dim (fp64), SSV2stab n=4e6",
                 bytes_per_elt_step=None, klass=PROF_RKC,
                 kernel="RKC stage class: rkc_chain<D> (D consecutive Chebyshev stages "
-                       "in one marching sweep of the 3-D plugin) / rhs_rkc (one stage: "
-                       "stencil sweep + three-term recursion) / k_rkc_first")
+                       "in one marching sweep of the 3-D plugin; -first forms the first "
+                       "iterate, -end also evaluates f(t+h, y) and the error estimate) / "
+                       "rhs_rkc (one stage: stencil sweep + three-term recursion)")
 
 
 def make_workload(name, N, rank, plugin=None):
@@ -374,8 +375,9 @@ def make_workload(name, N, rank, plugin=None):
         cpu_problem=("diff3d_rhs", "diff3d_y0"),
         bytes_per_elt_step=None, klass=PROF_RKC,
         kernel="RKC stage class: rkc_chain<D> (D consecutive Chebyshev stages in one "
-               "marching sweep of the 3-D plugin) / rhs_rkc (one stage: stencil sweep + "
-               "three-term recursion) / k_rkc_first")
+               "marching sweep of the 3-D plugin; -first forms the first iterate, -end also "
+               "evaluates f(t+h, y) and the error estimate) / rhs_rkc (one stage: stencil "
+               "sweep + three-term recursion)")
 
 
 def blas_threads():
