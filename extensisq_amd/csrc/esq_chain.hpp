@@ -59,17 +59,51 @@ namespace esq {
 struct ChainCaps {
     int stage[7], solerr[7];
 };
+// The chain sweeps' tuning knobs, read from the environment ONCE -- when a context or
+// a built-in plugin object is made (chain_tuning_refresh; a separately compiled
+// plugin reads them at its first launch) -- never on the launch path:
+//   ESQ_CHAIN_CAPS="s2,e2,s3,e3,..."  register budget table below
+//   ESQ_CHAIN_ROWS=R                  tile height of every chain sweep (tests: also lifts
+//                                     the small-grid rule)
+//   ESQ_CHAIN_SERPENTINE=0            all tile rows march downwards
+//   ESQ_CHAIN_TALL_WAVES=w            waves per SIMD the tall one-field tiles may use
+struct ChainTuning {
+    bool caps_set = false;
+    int caps[10] = {0};
+    int caps_n = 0;
+    int rows = 0;
+    bool rows_set = false;
+    unsigned serpentine = 1;
+    int tall_waves = 2;
+};
+inline ChainTuning read_chain_tuning() {
+    ChainTuning t;
+    if (const char *env = getenv("ESQ_CHAIN_CAPS")) {
+        t.caps_set = true;
+        t.caps_n = sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", &t.caps[0], &t.caps[1],
+                          &t.caps[2], &t.caps[3], &t.caps[4], &t.caps[5], &t.caps[6],
+                          &t.caps[7], &t.caps[8], &t.caps[9]);
+    }
+    if (const char *env = getenv("ESQ_CHAIN_ROWS")) { t.rows_set = true; t.rows = atoi(env); }
+    if (const char *env = getenv("ESQ_CHAIN_SERPENTINE")) t.serpentine = atoi(env) == 0 ? 0u : 1u;
+    if (const char *env = getenv("ESQ_CHAIN_TALL_WAVES")) t.tall_waves = atoi(env);
+    return t;
+}
+inline ChainTuning &chain_tuning() {
+    static ChainTuning t = read_chain_tuning();
+    return t;
+}
+inline void chain_tuning_refresh() { chain_tuning() = read_chain_tuning(); }
 // split = one field per wave (k_chain2d<..., SPLIT = true>): the budget of a
 // one-field kernel.  Depth 5 and 6 are instantiated with up to 6 memory rows.
 inline ChainCaps chain_caps(bool split = true) {
     ChainCaps c = split ? ChainCaps{{0, 0, 9, 9, 9, 6, 6}, {0, 0, 9, 9, 9, 6, 6}}
                         : ChainCaps{{0, 0, 8, 5, 1, -1, -1}, {0, 0, 7, 2, -1, -1, -1}};
-    if (const char *env = getenv("ESQ_CHAIN_CAPS")) {
-        int v[10];
-        const int got = sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3],
-                               &v[4], &v[5], &v[6], &v[7], &v[8], &v[9]);
+    const ChainTuning &t = chain_tuning();
+    if (t.caps_set) {
+        const int *v = t.caps;
         for (int d = 2; d <= 6; ++d) {
-            if (got >= 2 * (d - 1)) { c.stage[d] = v[2 * (d - 2)]; c.solerr[d] = v[2 * (d - 2) + 1]; }
+            if (t.caps_n >= 2 * (d - 1)) { c.stage[d] = v[2 * (d - 2)]; c.solerr[d] = v[2 * (d - 2) + 1]; }
         }
     }
     return c;

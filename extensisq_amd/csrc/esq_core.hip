@@ -10,6 +10,7 @@
 #include <chrono>
 
 #include "esq_internal.hpp"
+#include "esq_chain.hpp"
 
 namespace esq {
 
@@ -403,6 +404,7 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
 int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
                 int flags) {
     if (!out || n_rows < 1 || n_rows > 64) return ESQ_EINVAL;
+    esq::chain_tuning_refresh();       // the chain sweeps' environment knobs: once per context
     esq_ctx *c = new (std::nothrow) esq_ctx();
     if (!c) return ESQ_ENOMEM;
     *out = c;   // returned even on failure so the caller can read the message

@@ -58,6 +58,7 @@ inline int rhs_variant() {
 
 inline int make(void **out, Rhs proto) {
     if (!out) return ESQ_EINVAL;
+    esq::chain_tuning_refresh();       // the environment, once per plugin object
     Rhs *r = (Rhs *)malloc(sizeof(Rhs));
     if (!r) return ESQ_ENOMEM;
     *r = proto;

@@ -230,17 +230,14 @@ inline int chain_waves_per_cu(Kernel kern, unsigned block) {
 // unchained, 87 with depth-2 chains; at N = 500 100 against 87..98 chained; heat
 // Pr9 at N = 448 90 against 98); ESQ_CHAIN_ROWS (tests) lifts the rule
 inline bool chain_fits_grid(int N, int depth) {
-    if (getenv("ESQ_CHAIN_ROWS")) return true;
+    if (chain_tuning().rows_set) return true;
     const int W = 64 - 2 * (depth - 1);
     const size_t tpr = ((size_t)N / 2 + W - 1) / W;
     return (size_t)N * tpr >= 2048;
 }
 // alternate tile rows march in opposite directions (esq_chain.hpp);
 // ESQ_CHAIN_SERPENTINE=0: all downwards
-inline unsigned chain_serpentine() {
-    const char *e = getenv("ESQ_CHAIN_SERPENTINE");
-    return (e && atoi(e) == 0) ? 0u : 1u;
-}
+inline unsigned chain_serpentine() { return chain_tuning().serpentine; }
 // tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
 // share one tile (the split sweeps: one per field)
 inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_block,
@@ -249,8 +246,7 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
     GeoChain g;
     const int W = 64 - 2 * (depth - 1);
     g.tpr = ((unsigned)N / 2 + W - 1) / W;
-    const char *env = getenv("ESQ_CHAIN_ROWS");           // tuning / tests
-    int R = env ? atoi(env) : 0;
+    int R = chain_tuning().rows_set ? chain_tuning().rows : 0;      // tuning / tests
     if (R <= 0) {
         // ONE round of resident waves at the kernel's own occupancy: the sweeps
         // are latency-bound per wave (a row's loads are one iteration ahead, no
@@ -275,8 +271,7 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
         // chain5<0> 50 us, R = 44 0.540 with 65 us; R = 15, 18, 26 .. 36 -- three waves,
         // or a partial second round -- 0.549 .. 0.600)
         if (tall_if_one_round) {
-            static const int tall_waves = getenv("ESQ_CHAIN_TALL_WAVES")
-                                              ? atoi(getenv("ESQ_CHAIN_TALL_WAVES")) : 2;
+            const int tall_waves = chain_tuning().tall_waves;
             for (int w = tall_waves < waves_per_cu / 4 ? tall_waves : waves_per_cu / 4;
                  w >= 1 && R <= 0; --w) {
                 const int cand = rows_for((size_t)256 * 4 * (size_t)w);
