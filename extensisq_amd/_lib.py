@@ -91,6 +91,7 @@ SIGNATURES = {
     "esq_rkc_error_norm": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, _dp]),
     "esq_rkc_stages_end": (C.c_int, [_vp] + [C.c_int] * 6 + [C.c_double, C.c_int, _vp,
                                     C.c_double, C.c_double, _vp, _vp, _vp]),
+    "esq_rkc_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]),
     "esq_rkc_end_error": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, C.c_double,
                                                             _dp]),
     "esq_rkc_eval_rhs": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int]),

@@ -174,6 +174,15 @@ int esq_rkc_eval_rhs(esq_ctx *c, int dst, double t, int src) {
     return call_rhs(c, t, s, d);
 }
 namespace {
+// how many of the `left` remaining stages the next chain sweep takes (< 2: one stage by
+// itself): never a single stage at the end -- 5 = 3 + 2 rather than 4 + 1 -- and no
+// length the entry has declined
+int rkc_chain_len(int left, int depth, unsigned refused) {
+    int d = left < depth ? left : depth;
+    if (left - d == 1 && d >= 3) --d;
+    while (d >= 2 && ((refused >> d) & 1u)) --d;
+    return d;
+}
 // the end of the step, wanted with the stages (esq_rkc_stages_end): f(t_end, y_{n+1})
 // into a work row and the error estimate's sum of squares
 struct RkcTail {
@@ -249,11 +258,7 @@ int rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3, doubl
         const double *sc = scalars + 5 * (size_t)(j - 2);
         // ---- a chain of d stages: y_{j-1}, y_{j-2} in, y_{j+d-1}, y_{j+d-2} out
         if (c->rhs_rkc_chain && nwork == 4 && c->rkc_depth >= 2) {
-            const int left = m - j + 1;
-            int d = left < c->rkc_depth ? left : c->rkc_depth;
-            // no single stage at the end: 5 = 3 + 2 rather than 4 + 1
-            if (left - d == 1 && d >= 3) --d;
-            while (d >= 2 && ((c->rkc_refused >> d) & 1u)) --d;
+            const int d = rkc_chain_len(m - j + 1, c->rkc_depth, c->rkc_refused);
             if (d >= 2) {
                 const int o1 = free_row(jm1, jm2, ESQ_VEC_NONE);
                 const int o2 = free_row(jm1, jm2, o1);
@@ -382,6 +387,46 @@ int rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3, doubl
     return 0;
 }
 }  // namespace
+// the same walk as rkc_stages, in words (tests/test_step_plans.py)
+int esq_rkc_plan_describe(int m, int max_depth, int end_slots_max, char *buf, size_t buflen) {
+    if (m < 1 || !buf || buflen < 64) return ESQ_EINVAL;
+    const bool can_first = (max_depth & ESQ_RKC_CHAIN_FIRST) != 0;
+    const bool can_last = (max_depth & ESQ_RKC_CHAIN_LAST) != 0;
+    int depth = max_depth & 0xff;
+    if (depth > ESQ_RKC_CHAIN_MAX_DEPTH) depth = ESQ_RKC_CHAIN_MAX_DEPTH;
+    std::string out;
+    int launches = 0;
+    auto put = [&](const std::string &label) {
+        out += out.empty() ? label : " " + label;
+        ++launches;
+    };
+    bool first_pending = depth >= 2 && can_first && m >= 3;
+    if (!first_pending) put("k_rkc_first");
+    bool end_done = false;
+    int j = 2;
+    while (j <= m) {
+        const int d = depth >= 2 ? rkc_chain_len(m - j + 1, depth, 0u) : 1;
+        if (d >= 2) {
+            const bool last = j + d > m;
+            const bool with_end = last && can_last && !first_pending &&
+                                  d + 1 <= end_slots_max && d + 1 <= ESQ_RKC_CHAIN_MAX_DEPTH;
+            put("rkc_chain" + std::to_string(d) +
+                (first_pending ? "-first" : with_end ? "-end" : last ? "-last" : ""));
+            first_pending = false;
+            end_done = with_end;
+            j += d;
+            continue;
+        }
+        if (first_pending) { first_pending = false; put("k_rkc_first"); }
+        put("rhs_rkc");
+        ++j;
+    }
+    if (!end_done) put("rhs+rkcerr");
+    out += " | launches=" + std::to_string(launches);
+    if (out.size() + 1 > buflen) return ESQ_EINVAL;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return 0;
+}
 int esq_rkc_error_norm(esq_ctx *c, int y, int yn, int fn, int fy, double h,
                        double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;

@@ -589,6 +589,15 @@ int  esq_rkc_error_norm(esq_ctx *ctx, int y, int yn, int fn, int fy, double h,
 int  esq_rkc_stages_end(esq_ctx *ctx, int yn, int fn, int w0, int w1, int w2, int w3,
                         double hmus1, int m, const double *scalars, double t_end,
                         double h, int *y_row_out, int *fy_row_out, double *sumsq_out);
+/* The launch sequence esq_rkc_stages_end runs for m stages with a chain entry of the
+ * given depth and forms (ESQ_RKC_CHAIN_FIRST / _LAST or-ed into max_depth, as for
+ * esq_set_rhs_rkc_chain) that takes the LAST form with up to end_slots_max stage
+ * slots (the built-in 3-D sweep: 5, the 2-D one: 6), as text -- no GPU is touched:
+ *   <launch> <launch> ... | launches=<n>
+ * with the labels of esq_profile_kernels (rkc_chain<d>[-first|-end|-last], rhs_rkc,
+ * k_rkc_first, rhs+rkcerr).  max_depth < 2: one launch per stage.
+ * tests/test_step_plans.py pins the sequences with it. */
+int  esq_rkc_plan_describe(int m, int max_depth, int end_slots_max, char *buf, size_t buflen);
 int  esq_rkc_end_error(esq_ctx *ctx, int y, int yn, int fn, int fy, double t_end,
                        double h, double *sumsq_out);
 /* generic K[dst] = rhs(t, K[src]) on physical rows   sommeijer.py:214, 311    */

@@ -316,7 +316,7 @@ def _end_run(N, m, heat=False):
     """all stages + the end of the step (esq_rkc_stages_end) from a fixed state:
     y_{n+1}, f(t + h, y_{n+1}), the error estimate's sum of squares, kernel labels"""
     import ctypes as C
-    from extensisq_amd._lib import PROF_RKC
+    from extensisq_amd._lib import PROF_RKC, PROF_SOLERR
     rhs = esq.Heat2D(N) if heat else esq.Diffusion3D(N)
     rho = rhs.spectral_radius()
     rng = np.random.default_rng(11 + N)
@@ -327,10 +327,22 @@ def _end_run(N, m, heat=False):
     h = (m * m - 1) / (1.54 * rho)
     out = C.c_double()
     s._dev.profile_reset()
-    s._dev.profile_enable([PROF_RKC])
+    s._dev.profile_enable([PROF_RKC, PROF_SOLERR])
     yrow, fyrow = s._stages_end(0.0, h, m, out)
     s._dev.profile_enable(None)
     names = [k[0] for k in s._dev.profile_kernels()]
+    # the launches are the ones the library describes without a GPU (CPU suite:
+    # tests/test_step_plans.py::test_chebyshev_step_programs)
+    if os.environ.get("ESQ_RKC_DEPTH") != "1" and "ESQ_RKC_LAST" not in os.environ:
+        from extensisq_amd import _lib
+        buf = C.create_string_buffer(1 << 14)
+        depth, forms = rhs._rkc_chain_entry(_lib.load())[1] & 0xff, rhs._rkc_chain_forms
+        chained = heat or N >= 48 or os.environ.get("ESQ_RKC_FORCE") == "1"
+        assert _lib.load().esq_rkc_plan_describe(m, (depth if chained else 1) | forms,
+                                                 6 if heat else 5, buf, len(buf)) == 0
+        want = buf.value.decode().split(" | ")[0].split()
+        got = {k[0]: k[2] for k in s._dev.profile_kernels()}
+        assert got == {k: want.count(k) for k in set(want)}, (m, got, want)
     return s._dev.download(SLOT_K, yrow), s._dev.download(SLOT_K, fyrow), out.value, names
 
 

@@ -139,3 +139,68 @@ def test_more_capabilities_never_cost_more(plans):
             for a, b in zip(lines, other):
                 if a.split(":")[0] == b.split(":")[0]:
                     assert cost(a) <= cost(b) + 0.011, (key, caps, a, b)
+
+
+def _rkc_plan(m, depth, forms=0, end_slots=5):
+    import ctypes as C
+    from extensisq_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(1 << 14)
+    assert lib.esq_rkc_plan_describe(m, depth | forms, end_slots, buf, len(buf)) == 0
+    seq, tail = buf.value.decode().split(" | ")
+    launches = seq.split()
+    assert tail == f"launches={len(launches)}"
+    return launches
+
+
+def test_chebyshev_step_programs():
+    """the launch sequence of an SSV2stab step (esq_rkc_stages_end) for a chain entry
+    of a given depth and forms, without a GPU: every stage evaluated exactly once, no
+    single stage left at the end of a chained step, the first iterate and the end of
+    the step inside the first / last chain where the forms allow"""
+    from extensisq_amd._lib import RKC_CHAIN_FIRST as F, RKC_CHAIN_LAST as L
+
+    def stages(launches):
+        n = 0
+        for k in launches:
+            if k.startswith("rkc_chain"):
+                n += int(k[len("rkc_chain")])
+            elif k == "rhs_rkc":
+                n += 1
+        return n
+
+    # BASELINE config 3: m = 100 on the 3-D plugin, four stages per sweep
+    p = _rkc_plan(100, 4, F | L, 5)
+    assert p == ["rkc_chain4-first"] + ["rkc_chain4"] * 23 + ["rkc_chain3-end"]
+    # beyond the Infinity Cache: five per sweep, 99 = 19 x 5 + 4
+    p = _rkc_plan(100, 5, F | L, 5)
+    assert p == ["rkc_chain5-first"] + ["rkc_chain5"] * 18 + ["rkc_chain4-end"]
+    # the 2-D plugin at N >= 1500: six per sweep, the end rides with up to five stages
+    p = _rkc_plan(100, 6, F | L, 6)
+    assert p == ["rkc_chain6-first"] + ["rkc_chain6"] * 15 + ["rkc_chain3-end"]
+    # round 3 / a plugin without a chain entry: one launch per stage
+    p = _rkc_plan(100, 1)
+    assert p == ["k_rkc_first"] + ["rhs_rkc"] * 99 + ["rhs+rkcerr"]
+    # no forms declared: first iterate and end of the step are sweeps of their own
+    p = _rkc_plan(100, 4)
+    assert p == ["k_rkc_first"] + ["rkc_chain4"] * 24 + ["rkc_chain3-last", "rhs+rkcerr"]
+    # short steps: 5 = 3 + 2; one chain from start to end (FIRST wins); one stage
+    assert _rkc_plan(6, 4, F | L) == ["rkc_chain3-first", "rkc_chain2-end"]
+    assert _rkc_plan(4, 4, F | L) == ["rkc_chain3-first", "rhs+rkcerr"]
+    assert _rkc_plan(3, 4, F | L) == ["rkc_chain2-first", "rhs+rkcerr"]
+    assert _rkc_plan(2, 4, F | L) == ["k_rkc_first", "rhs_rkc", "rhs+rkcerr"]
+    assert _rkc_plan(1, 4, F | L) == ["k_rkc_first", "rhs+rkcerr"]
+    # an end that does not fit the entry's stage slots stays a sweep of its own
+    assert _rkc_plan(9, 4, F | L, 4)[-2:] == ["rkc_chain4-last", "rhs+rkcerr"]
+    for depth in range(1, 9):
+        for forms in (0, F, L, F | L):
+            for slots in (4, 5, 6, 9):
+                for m in list(range(1, 40)) + [100, 132, 250]:
+                    p = _rkc_plan(m, depth, forms, slots)
+                    assert stages(p) == m - 1, (m, depth, forms, p)
+                    assert (p.count("k_rkc_first") + sum(k.endswith("-first") for k in p)) == 1
+                    assert (p.count("rhs+rkcerr") + sum(k.endswith("-end") for k in p)) == 1
+                    if depth >= 3 and m - 1 >= 2:
+                        assert "rhs_rkc" not in p, (m, depth, p)
+                    elif depth == 2:                  # (an odd count leaves one)
+                        assert p.count("rhs_rkc") == (m - 1) % 2, (m, p)
