@@ -71,101 +71,6 @@ def norm(x):
     return (np.real(x @ x.conjugate()) / x.size) ** 0.5
 
 
-def h_start(df, a, b, y, yprime, morder, rtol, atol):
-    """Starting step size after H.A. Watts (SLATEC `dhstrt`), the procedure the
-    reference runs once per integration (common.py:519-763, called at :210).
-    Off the per-step hot path: host NumPy on vectors
-    fetched through `df`."""
-    if y.size == 0:
-        return np.inf
-    fi = np.finfo(y.dtype)
-    big = sqrt(fi.max)
-    small = np.nextafter(fi.epsneg, 1.0)
-    relper = small ** 0.375
-    etol = atol + rtol * np.abs(y)
-    dx = b - a
-    absdx = abs(dx)
-
-    # (1) bound on the t-derivative of f and on |f|
-    da = copysign(max(min(relper * abs(a), absdx), 100. * small * abs(a)), dx)
-    if da == 0.0:
-        da = relper * dx
-    sf = df(a + da, y)
-    yp = sf - yprime
-    delf = norm(yp)
-    dfdxb = delf / abs(da) if delf < big * abs(da) else big
-    fbnd = norm(sf)
-
-    # (2) local Lipschitz constant from up to three perturbations
-    dely = relper * norm(y)
-    if dely == 0.0:
-        dely = relper
-    dely = copysign(dely, dx)
-    delf = norm(yprime)
-    fbnd = max(fbnd, delf)
-    spy = np.empty_like(y)
-    pv = np.empty_like(y)
-    if delf:
-        spy[:] = yprime
-        yp[:] = yprime
-    else:
-        spy[:] = 0.0
-        yp[:] = 1.0
-        delf = norm(yp)
-    dfdub = 0.0
-    n_iter = min(y.size + 1, 3)
-    for k in range(1, n_iter + 1):
-        pv[:] = y + dely / delf * yp
-        if k == 2:
-            yp[:] = df(a + da, pv)
-            pv[:] = yp - sf
-        else:
-            yp[:] = df(a, pv)
-            pv[:] = yp - yprime
-        fbnd = max(fbnd, norm(yp))
-        delf = norm(pv)
-        if delf >= big * abs(dely):
-            dfdub = big
-            break
-        dfdub = max(dfdub, delf / abs(dely))
-        if k == n_iter:
-            break
-        if delf == 0.0:
-            delf = 1.0
-        if k == 2:
-            dy = np.where(y, y, dely / relper)
-        else:
-            dy = np.where(pv, pv, delf)
-        spy[:] = np.where(spy, spy, yp)
-        yp[:] = np.where(spy, np.copysign(dy.real, spy.real), dy.real)
-        if np.iscomplexobj(y):
-            yp[:] += 1j * np.where(spy, np.copysign(dy.imag, spy.imag), dy.imag)
-        delf = norm(yp)
-
-    # (3) step from the second-derivative bound and the tolerances
-    ydpb = dfdxb + dfdub * fbnd
-    tolexp = np.log10(etol)
-    tolp = 10.0 ** (0.5 * (tolexp.sum() / y.size + min(tolexp.min(), big))
-                    / (morder + 1))
-    h = absdx
-    if ydpb == 0.0 and fbnd == 0.0:
-        if tolp < 1.0:
-            h = absdx * tolp
-    elif ydpb == 0.0:
-        if tolp < fbnd * absdx:
-            h = tolp / fbnd
-    else:
-        srydpb = sqrt(0.5 * ydpb)
-        if tolp < srydpb * absdx:
-            h = tolp / srydpb
-    if dfdub:
-        h = min(h, 1.0 / dfdub)
-    h = max(h, 100.0 * small * abs(a))
-    if h == 0.0:
-        h = small * abs(b)
-    return copysign(h, dx)
-
-
 class HornerDenseOutput(DenseOutput):
     """Polynomial interpolant y_old + sum_c Q[:, c] x^(c+1), evaluated with
     Horner's rule on the host (ref common.py:766-790).  `scaled=True`: Q
@@ -453,8 +358,8 @@ class RungeKutta(OdeSolver):
         """Watts' starting step (ref `h_start`, common.py:519-763) with every
         vector in HBM: the perturbation vectors live in K rows 1..4, norms come
         back as one double each, the scalar decisions below are the host part.
-        `h_start` above is the same procedure on host arrays (used by the CPU
-        tests to pin this one)."""
+        tests/test_gpu_parity.py::test_device_h_start pins it to the oracle's
+        `first_step_size` (itself pinned to the reference's golden first steps)."""
         import ctypes
         if self.n == 0:
             return np.inf

@@ -57,7 +57,9 @@ REQUIRED = {
     "test_gpu_parity.py::test_each_epilogue_kind_is_bit_identical": 40,
     "test_gpu_parity.py::test_prelaunched_first_stage_is_used_only_when_valid": 4,
     "test_gpu_rkc.py::test_rkc_chained_stage_is_bit_identical": 1,
-    "test_gpu_rkc.py::test_rkc_chain_sweeps_are_bit_identical": 21,
+    "test_gpu_rkc.py::test_rkc_chain_sweeps_are_bit_identical": 35,
+    "test_gpu_rkc.py::test_rkc_depth5_default_path_is_bit_identical": 1,
+    "test_gpu_rkc.py::test_rkc_depth5_step_matches_oracle": 1,
     "test_gpu_rkc.py::test_rkc_chain_plan_and_whole_steps": 1,
     "test_gpu_rkc.py::test_rkc_chain_sweeps_2d_are_bit_identical": 25,
     "test_gpu_rkc.py::test_rkc_chain_2d_whole_steps": 1,

@@ -865,9 +865,10 @@ def test_bs5_interpolants_device_resident(interp):
 @pytest.mark.parametrize("mode", ["host_rhs", "device_rhs"])
 def test_device_h_start(case, mode):
     """the device-resident starting-step estimate (perturbation vectors in K
-    rows, norms by reduction kernels) equals the host NumPy procedure, which
-    tests/test_host_logic.py pins to the oracle and the golden first step"""
-    from extensisq_amd.common import h_start, validate_tol
+    rows, norms by reduction kernels) equals the oracle's `first_step_size`
+    (common.py:519-763; pinned against the reference's golden first steps in
+    tests/test_oracle_golden.py and tests/test_host_logic.py)"""
+    from extensisq_amd.common import validate_tol
     atol = 1e-6
     dev_fun = None
     if case == "decay":
@@ -903,8 +904,8 @@ def test_device_h_start(case, mode):
                 atol=atol)
         y_arr = np.asarray(y, dtype=complex if np.iscomplexobj(y) else float)
         rtol_v, atol_v = validate_tol(1e-4, atol, y_arr)
-        want = abs(h_start(fun, a, b, y_arr, np.asarray(fun(a, y_arr)),
-                           cls.order_secondary, rtol_v, atol_v))
+        want = abs(rk_oracle.first_step_size(fun, a, b, y_arr, np.asarray(fun(a, y_arr)),
+                                             cls.order_secondary, rtol_v, atol_v))
         assert_allclose(s.h_abs, want, rtol=1e-11)
 
 

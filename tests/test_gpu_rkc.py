@@ -159,6 +159,52 @@ def test_full_size_rkc_diffusion_step_matches_oracle():
     assert_allclose(d.errold, o.errold, rtol=1e-5)
 
 
+def test_rkc_depth5_default_path_is_bit_identical(monkeypatch):
+    """N = 180: the plugin picks FIVE stages per chain sweep by itself (device.py:
+    6 vectors x 8 n bytes beyond 256 MiB) -- the launch sequence of every "beyond the
+    Infinity Cache" SSV2stab figure -- against one launch per stage, bit for bit, for
+    stage counts that end in chains of every length"""
+    N = 180
+    assert esq.Diffusion3D(N)._rkc_chain_depth == 5
+    for m in (7, 23, 100):
+        monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+        ref, s1 = _stage_run(N, m)
+        monkeypatch.delenv("ESQ_RKC_DEPTH")
+        got, s2 = _stage_run(N, m)
+        assert np.isfinite(ref).all()
+        np.testing.assert_array_equal(got, ref, err_msg=f"m = {m}")
+        assert s1.nfev == s2.nfev
+        names = [k[0] for k in _profiled_kernels(s2, m)]
+        assert any(k.startswith("rkc_chain5") for k in names), names
+        assert "k_rkc_first" not in names and any("-first" in k for k in names), names
+
+
+def test_rkc_depth5_step_matches_oracle():
+    """one SSV2stab step at N = 200 (n = 8e6: depth-5 chain sweeps by default, the
+    end of the step inside the last one), m = 100 stages, against the oracle's step
+    (sommeijer.py:162-329) -- as test_full_size_rkc_diffusion_step_matches_oracle does
+    at N = 159 for the depth-4 sweeps"""
+    N = 200
+    rhs = esq.Diffusion3D(N)
+    assert rhs._rkc_chain_depth == 5
+    rho = rhs.spectral_radius()
+    h0 = ((100 - 1) ** 2 - 1 + 0.5 * (2 * 100 - 1)) / (1.54 * rho)
+    kw = dict(rtol=1e-3, atol=1e-3, const_jac=True, first_step=h0, max_step=h0,
+              rho_jac=lambda t, y: rho)
+    y0 = pb.diff3d_y0(N)
+    d = esq.SSV2stab(rhs, 0.0, y0, 1.0, **kw)
+    o = rkc_oracle.SSV2stab(pb.diff3d_rhs(N), 0.0, y0, 1.0, **kw)
+    assert d.step() is None and o.step() is None
+    assert int(dev_rkc.maxm[()]) == int(rkc_oracle.maxm[()]) == 100
+    assert int(dev_rkc.nrejct[()]) == int(rkc_oracle.nrejct[()])
+    assert_allclose(d.t, o.t, rtol=1e-12)
+    assert d.nfev == o.nfev
+    assert_allclose(d.y, o.y, rtol=1e-9, atol=1e-12)
+    assert_allclose(d.errold, o.errold, rtol=1e-5)
+    names = [k[0] for k in _profiled_kernels(d, int(dev_rkc.maxm[()]))]
+    assert any(k.startswith("rkc_chain5") for k in names), names
+
+
 @pytest.mark.parametrize("plugin,N", [("heat", 6), ("heat", 130), ("diff3d", 5),
                                       ("diff3d", 24), ("diff3d", 41)])
 def test_rkc_chained_stage_is_bit_identical(monkeypatch, plugin, N):
@@ -200,15 +246,18 @@ def _stage_run(N, m, h_factor=1.0):
 
 @pytest.mark.parametrize("N,planes", [(5, 0), (13, 3), (24, 0), (41, 7), (57, 0),
                                       (64, 5), (70, 16)])
-@pytest.mark.parametrize("depth", [2, 3, 4])
+@pytest.mark.parametrize("depth", [2, 3, 4, 5, 6])
 def test_rkc_chain_sweeps_are_bit_identical(monkeypatch, N, planes, depth):
     """ESQ_RKC_DEPTH stages per marching sweep (esq_rhs_rkc_chain_fn, the 3-D
     plugin's patch sweeps: esq_rkc3d.hpp) against one launch per stage: the final
     iterate of m stages bit for bit, for stage counts that end in chains of every
     length and in a single stage, grids of one and of several patches per plane,
-    forced tile depths (run-in planes, plane ranges that do not divide N)"""
+    forced tile depths (run-in planes, plane ranges that do not divide N).  Depth 5
+    is what the plugin picks by itself from N = 178 (device.py: the sweep's six
+    vectors beyond the Infinity Cache), depth 6 is instantiated for tuning."""
     monkeypatch.setenv("ESQ_RKC_FORCE", "1")
-    for m in (2, 3, 4, 5, 6, 7, 10, 23):
+    monkeypatch.setenv("ESQ_RKC_MAXDEPTH", "6")
+    for m in (2, 3, 4, 5, 6, 7, 8, 10, 23):
         monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
         ref, s1 = _stage_run(N, m)
         monkeypatch.setenv("ESQ_RKC_DEPTH", str(depth))
@@ -219,6 +268,8 @@ def test_rkc_chain_sweeps_are_bit_identical(monkeypatch, N, planes, depth):
         np.testing.assert_array_equal(got, ref, err_msg=f"m = {m}")
         assert s1.nfev == s2.nfev
         names = [k[0] for k in _profiled_kernels(s2, m)]
+        if m - 1 >= depth:
+            assert any(k.startswith("rkc_chain%d" % depth) for k in names), names
         if m - 1 >= 2:
             assert any(k.startswith("rkc_chain") for k in names), names
             # the chain that opens the step forms the first iterate itself ...

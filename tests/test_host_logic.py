@@ -93,32 +93,10 @@ def test_validate_tol_matches_oracle():
             dev_common.validate_tol(bad[0], bad[1], y)
 
 
-@pytest.mark.parametrize("case", ["decay", "duffing", "heat", "zero", "complex",
-                                  "backward"])
-def test_h_start_matches_oracle(case):
-    if case == "decay":
-        fun, a, b, y = (lambda t, y: -0.5 * y), 0.0, 10.0, np.array([2., 4., 8.])
-    elif case == "duffing":
-        fun, a, b, y = pb.duffing_rhs, 0.0, 20.0, np.array([0.0, 0.0])
-    elif case == "heat":
-        fun, a, b, y = pb.heat2d_rhs(12), 0.0, 1.0, pb.heat2d_y0(12)
-    elif case == "zero":
-        fun, a, b, y = (lambda t, y: np.zeros_like(y)), 0.0, 10.0, np.ones(3)
-    elif case == "complex":
-        fun, a, b, y = (lambda t, y: -y), 0.0, 1.0, np.array([0.5 + 1j])
-    else:
-        fun, a, b, y = pb.rational_rhs, 5.0, 1.0, np.array([1 / 3, 2 / 9])
-    f0 = np.asarray(fun(a, y))
-    for order in (4, 5, 7):
-        for atol in (1e-6, np.full(y.size, 1e-8)):
-            got = dev_common.h_start(fun, a, b, y, f0, order, 1e-3, atol)
-            want = rk_oracle.first_step_size(fun, a, b, y, f0, order, 1e-3, atol)
-            assert got == want
-    assert dev_common.h_start(fun, a, b, y[:0], f0[:0], 4, 1e-3, 1e-6) == np.inf
-
-
 def test_h_start_golden(golden_dir):
-    """first step of the 8-shard lock-step reference run (tools/gen_golden.py)"""
+    """the oracle's starting step (the one tests/test_gpu_parity.py::test_device_h_start
+    holds the device procedure to) against the first step of the reference's
+    8-shard lock-step run (tools/gen_golden.py)"""
     import os
     g = np.load(os.path.join(golden_dir, "lockstep.npz"))
     N = int(g["N"])
@@ -129,8 +107,8 @@ def test_h_start_golden(golden_dir):
     def fun(t, y):
         return np.concatenate([f1(t, y[k * n:(k + 1) * n]) for k in range(8)])
     rtol, atol = dev_common.validate_tol(1e-6, 1e-9, y0)
-    h = dev_common.h_start(fun, 0.0, float(g["t_end"]), y0, fun(0.0, y0),
-                           Pr9.order_secondary, rtol, atol)
+    h = rk_oracle.first_step_size(fun, 0.0, float(g["t_end"]), y0, fun(0.0, y0),
+                                  Pr9.order_secondary, rtol, atol)
     assert_allclose(abs(h), float(g["h0"]), rtol=1e-12)
 
 
