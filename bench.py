@@ -578,6 +578,13 @@ def main():
     if local >= visible:
         # the launcher restricted this rank's visibility (one GPU per rank)
         local = local % visible
+    if affinity.get("pinned"):
+        # was the function pinned to (by position in sysfs, before any GPU call) the
+        # device this rank now drives?  HIP's enumeration need not follow PCI order.
+        from extensisq_amd._lib import device_pci_bus_id
+        got = device_pci_bus_id(local)
+        affinity["hip_pci"] = got
+        affinity["pci_matches"] = (got == str(affinity.get("pci", "")).lower()) if got else None
 
     meta = workload_meta(args.config, args.grid, args.plugin)
     w = make_workload(args.config, args.grid, rank, args.plugin)

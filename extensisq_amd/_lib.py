@@ -38,6 +38,7 @@ _vpp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "esq_abi_version": (C.c_int, []),
     "esq_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "esq_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "esq_create": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int]),
     "esq_create2": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "esq_destroy": (C.c_int, [_vp]),
@@ -76,6 +77,9 @@ SIGNATURES = {
     "esq_plan_describe": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_char_p, C.c_size_t]),
+    "esq_step_dry_run": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _vp, C.c_int, C.c_char_p, C.c_size_t]),
     "esq_dense_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int,
                                    _vpp]),
     "esq_dense_eval": (C.c_int, [_vp, C.c_double, _vp]),
@@ -170,8 +174,14 @@ def load():
         fn = getattr(lib, name)     # AttributeError if a symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.esq_abi_version() != ABI_VERSION:
-        raise DeviceError("libextensisq_amd.so ABI version mismatch")
+    ver = lib.esq_abi_version()
+    if ver == -ABI_VERSION and os.environ.get("ESQ_LIB_EXPERIMENT") == "1":
+        pass        # a what-if build (ESQ_CHAIN_EXP): timing only, results wrong by design
+    elif ver != ABI_VERSION:
+        raise DeviceError(
+            "libextensisq_amd.so ABI version mismatch" if ver != -ABI_VERSION else
+            f"{LIB_PATH} is a what-if build of the chain sweeps (ESQ_CHAIN_EXP): its "
+            "results are wrong by design; ESQ_LIB_EXPERIMENT=1 loads it for timing runs")
     _lib = lib
     return lib
 
@@ -192,6 +202,15 @@ def device_count():
     out = C.c_int(0)
     check(load().esq_device_count(C.byref(out)), None, "esq_device_count")
     return out.value
+
+
+def device_pci_bus_id(device):
+    """PCI address of HIP device `device`, lower case ("0000:c1:00.0"); None if the
+    runtime cannot tell"""
+    buf = C.create_string_buffer(64)
+    if load().esq_device_pci_bus_id(int(device), buf, len(buf)) != 0:
+        return None
+    return buf.value.decode().strip().lower() or None
 
 
 def as_ptr(arr):

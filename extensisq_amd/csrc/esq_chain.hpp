@@ -33,6 +33,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/extensisq_amd.h"
 #include "esq_epilogue.hpp"
 #include "esq_terms.hpp"
@@ -89,17 +92,54 @@ inline ChainTuning read_chain_tuning() {
     if (const char *env = getenv("ESQ_CHAIN_TALL_WAVES")) t.tall_waves = atoi(env);
     return t;
 }
-inline ChainTuning &chain_tuning() {
-    static ChainTuning t = read_chain_tuning();
-    return t;
+// (contexts may be made and driven from any thread: the table is copied in and out
+// under a lock)
+struct ChainTuningBox {
+    std::mutex mu;
+    ChainTuning t = read_chain_tuning();
+};
+inline ChainTuningBox &chain_tuning_box() {
+    static ChainTuningBox b;
+    return b;
 }
-inline void chain_tuning_refresh() { chain_tuning() = read_chain_tuning(); }
+inline ChainTuning chain_tuning() {
+    ChainTuningBox &b = chain_tuning_box();
+    std::lock_guard<std::mutex> g(b.mu);
+    return b.t;
+}
+inline void chain_tuning_refresh() {
+    const ChainTuning fresh = read_chain_tuning();
+    ChainTuningBox &b = chain_tuning_box();
+    std::lock_guard<std::mutex> g(b.mu);
+    b.t = fresh;
+}
+// compute units of the device the calling thread has selected (the tile-height rules
+// fill "one round of resident waves"); 256 where there is no device (detached
+// contexts: esq_plan_describe)
+inline int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            v < 1) {
+            (void)hipGetLastError();
+            v = 256;
+        }
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 // split = one field per wave (k_chain2d<..., SPLIT = true>): the budget of a
 // one-field kernel.  Depth 5 and 6 are instantiated with up to 6 memory rows.
 inline ChainCaps chain_caps(bool split = true) {
     ChainCaps c = split ? ChainCaps{{0, 0, 9, 9, 9, 6, 6}, {0, 0, 9, 9, 9, 6, 6}}
                         : ChainCaps{{0, 0, 8, 5, 1, -1, -1}, {0, 0, 7, 2, -1, -1, -1}};
-    const ChainTuning &t = chain_tuning();
+    const ChainTuning t = chain_tuning();
     if (t.caps_set) {
         const int *v = t.caps;
         for (int d = 2; d <= 6; ++d) {

@@ -228,6 +228,11 @@ void launch_publish_scalars(esq_ctx *c, const double *dev, int count,
 // partials -> one double on the host (all-reduced over the communicator if set)
 int finish_reduction(esq_ctx *c, double *out, bool take_min, const double *partials,
                      int count) {
+    if (c->detached) {             // host-side dry run: nothing was enqueued
+        launch_ahead_if_asked(c);
+        if (out) *out = 0.0;
+        return 0;
+    }
     if (!partials) partials = c->partials;
     if (count < 0) count = (int)c->grid_reduce;
     ResultSink rs = next_sink(c, !c->comm);
@@ -253,7 +258,7 @@ int finish_reduction(esq_ctx *c, double *out, bool take_min, const double *parti
     }
     // the next step's first launch goes in behind the reduction, BEFORE the host
     // waits for it (only if the caller asked: esq_rk_solution_error_ahead)
-    launch_ahead_if_asked(c);
+    const bool went_ahead = launch_ahead_if_asked(c);
     int w = wait_slot(c, rs.seq, c->comm ? c->comm_timeout_s : 0.0);
     if (w == ESQ_ETIMEOUT) {
         // a peer never reached the collective
@@ -263,13 +268,16 @@ int finish_reduction(esq_ctx *c, double *out, bool take_min, const double *parti
                     c->comm_timeout_s);
     }
     if (w) return w;
-    c->idle = true;        // the final-sum kernel was the last thing enqueued
+    // idle: the final-sum kernel was the last thing enqueued -- unless the next
+    // step's first sweep went in behind it
+    c->idle = !went_ahead;
     if (out) *out = c->h_slot->value;
     return 0;
 }
 
 int call_rhs(esq_ctx *c, double t, const double *src, double *dst) {
     if (!c->rhs) return fail(c, ESQ_ESTATE, "no device RHS set (esq_set_rhs)");
+    if (c->detached) return 0;                  // host-side dry run
     Prof p(c, ESQ_PROF_RHS, "rhs_plugin", -1, 16.0 * (double)c->len, /*record_now=*/true);
     c->self_valid = false;     // a plugin kernel does not signal its own completion
     int r = c->rhs(c->rhs_user, t, src, dst, c->len, (void *)c->stream);
@@ -390,11 +398,26 @@ using namespace esqi;
 
 extern "C" {
 
+// a what-if build of the chain sweeps (ESQ_CHAIN_EXP != 0, profiles/r04_experiments.md
+// §1: loads replaced by constants / weights made compile-time) computes WRONG results
+// by design: it reports a negative version, which the Python binding refuses unless
+// ESQ_LIB_EXPERIMENT=1 says the caller knows (timing runs only)
+#if defined(ESQ_CHAIN_EXP) && ESQ_CHAIN_EXP != 0
+int esq_abi_version(void) { return -ESQ_ABI_VERSION; }
+#else
 int esq_abi_version(void) { return ESQ_ABI_VERSION; }
+#endif
 
 int esq_device_count(int *count_out) {
     if (!count_out) return ESQ_EINVAL;
     const hipError_t e = hipGetDeviceCount(count_out);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int esq_device_pci_bus_id(int device, char *buf, size_t buflen) {
+    if (!buf || buflen < 16 || device < 0) return ESQ_EINVAL;
+    buf[0] = 0;
+    const hipError_t e = hipDeviceGetPCIBusId(buf, (int)buflen, device);
     return e == hipSuccess ? 0 : (int)e;
 }
 

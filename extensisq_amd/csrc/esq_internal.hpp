@@ -92,9 +92,34 @@ struct Plan {
     bool ynew_ready = false, solerr_ready = false;   // formed by the last launch
 };
 
+// What one launch of a step's program may change besides device memory -- and,
+// therefore, what launch_ahead (esq_step.hip) saves and puts back around the launch
+// it runs on the NEXT step's behalf.  One POD, copied by assignment: a field added
+// here is saved with the rest (tests/test_step_plans.py runs the speculation on a
+// detached context and compares the sub-struct with its copy).
+struct StepState {
+    double *y = nullptr, *ynew = nullptr, *ystage = nullptr, *work = nullptr;
+    bool ynew_ready = false;     // YNEW already formed by the last stage's sweep
+    bool solerr_ready = false;   // ... and the error partial sums too
+    int red_count = 0;           // partials written by the last reducing sweep
+    // rows of K that only the solution/error epilogue of their own (last) chain
+    // sweep reads are not written by a step; every other reader restores them
+    // first (esqi::restore_rows)
+    bool tail_missing = false;            // logical rows `missing_rows` (bit i: K_i)
+    bool tail_accepted = false;           // ... of the step in flight / just accepted
+    unsigned long long missing_rows = 0;
+    double tail_t = 0.0, tail_h = 0.0;    // that step's (t, h)
+    // non-FSAL pairs: f(t_new, y_new) of an accepted step is not evaluated by
+    // esq_rk_accept but as stage 0 of the NEXT step's first chain sweep; whoever
+    // reads logical row 0 earlier has it evaluated first (esqi::restore_rows)
+    bool k0_missing = false;
+    double k0_t = 0.0;
+    long end_fused = 0, end_plain = 0;    // how the end-point evaluations ran
+};
+
 }  // namespace esqi
 
-struct esq_ctx {
+struct esq_ctx : esqi::StepState {
     int device = 0;
     size_t n = 0;          // state dimension as the user counts it
     size_t len = 0;        // doubles per vector (n or 2n)
@@ -117,8 +142,7 @@ struct esq_ctx {
     std::vector<double *> krow;       // physical K rows
     std::vector<int> kmap;            // logical -> physical (step in flight)
     std::vector<int> kmap_last;       // mapping of the step just accepted
-    double *y = nullptr, *ynew = nullptr, *ystage = nullptr, *atolv = nullptr,
-           *work = nullptr;
+    double *atolv = nullptr;          // (y, ynew, ystage, work: StepState)
     double *partials = nullptr;       // kPartialsCap doubles (own kernels use
                                       // <= kMaxPartials, fused sweeps their grid)
     double *partials2 = nullptr;      // second set (min reductions)
@@ -158,9 +182,6 @@ struct esq_ctx {
     bool chain_from_rows = true;          // ESQ_CHAIN_FROM_ROWS=0: never
     unsigned chain_ld_nt[3] = {4, 4, 4};  // ESQ_CHAIN_LDNT: forced load policy of the
     bool chain_ld_nt_set = false;         // first / middle / last chain (tuning)
-    bool ynew_ready = false;     // YNEW already formed by the last stage's sweep
-    bool solerr_ready = false;   // ... and the error partial sums too
-    int red_count = 0;           // partials written by the last reducing sweep
     // first stage argument of the NEXT step, formed at accept time
     bool pre_valid = false;
     double pre_h = 0.0;
@@ -182,7 +203,8 @@ struct esq_ctx {
         bool valid = false;               // launched for (t, h), not yet accepted
         bool committed = false;           // accepted: esq_rk_stages(1, s, t, h) skips it
         double t = 0.0, h = 0.0;
-        unsigned key = 0;                 // plan it is the first entry of
+        unsigned key = 0;                 // plan it is the first entry of ...
+        bool k0_next = false;             // ... built with f(t, y) still to be evaluated
         std::vector<int> kmap;            // the next step's row map (spares swapped in)
         std::vector<int> spares;          // the spare rows once it is accepted
         double *ystage = nullptr, *work = nullptr;
@@ -211,24 +233,14 @@ struct esq_ctx {
     // (what a stage kernel still has to add), and the row's total non-zero count
     std::vector<std::vector<esqi::Term>> stage_terms;
     std::vector<int> stage_nnz;
-    // rows of K that only the solution/error epilogue of their own (last) chain
-    // sweep reads are not written by a step (ESQ_LAZY_ROWS=0: always written);
-    // every other reader restores them first (esqi::restore_rows)
+    // rows left unwritten by their sweep (StepState::tail_missing): ESQ_LAZY_ROWS=0
+    // never; a reader that asks twice within a few steps makes them kept
     bool lazy_rows = true;
     bool keep_rows = false;               // sticky: a reader asked twice in a row
-    bool tail_missing = false;            // logical rows `missing_rows` (bit i: K_i)
-    bool tail_accepted = false;           // ... of the step in flight / just accepted
-    unsigned long long missing_rows = 0;
-    double tail_t = 0.0, tail_h = 0.0;    // that step's (t, h)
     long accepted_steps = 0, last_restore_at = -100, restores = 0;
-    // non-FSAL pairs: f(t_new, y_new) of an accepted step is not evaluated by
-    // esq_rk_accept but as stage 0 of the NEXT step's first chain sweep
-    // (ESQ_LAZY_END=0: at accept time); whoever reads logical row 0 earlier has
-    // it evaluated first (esqi::restore_rows)
+    // the end-point derivative as stage 0 of the next step (StepState::k0_missing):
+    // ESQ_LAZY_END=0: evaluated at accept time
     bool lazy_end = true;
-    bool k0_missing = false;
-    double k0_t = 0.0;
-    long end_fused = 0, end_plain = 0;    // how the end-point evaluations ran
     // launch geometry
     unsigned grid_stream = 0;         // grid for streaming kernels
     unsigned grid_reduce = 0;
@@ -271,7 +283,12 @@ double *slot_ptr(esq_ctx *c, int slot, int row, bool logical = true);
 // The first stage argument formed ahead of time by esq_rk_accept lives in
 // YSTAGE until the next esq_rk_stages: any entry point that may write a vector
 // drops it (ENTER); the read-only ones keep it (ENTER_KEEP).
-#define ENTER_KEEP(c) (void)hipSetDevice((c)->device)
+// (a detached context -- esq_plan_describe, the host-side dry runs -- has no device:
+// selecting "device -1" would leave an error behind on the calling thread)
+#define ENTER_KEEP(c)                                        \
+    do {                                                     \
+        if (!(c)->detached) (void)hipSetDevice((c)->device); \
+    } while (0)
 // before anything but the step itself reads rows of K
 #define ENSURE_ROWS(c)                                   \
     do {                                                 \
@@ -282,7 +299,7 @@ double *slot_ptr(esq_ctx *c, int slot, int row, bool logical = true);
     } while (0)
 #define ENTER(c)                             \
     do {                                     \
-        (void)hipSetDevice((c)->device);     \
+        ENTER_KEEP(c);                       \
         (c)->pre_valid = false;              \
         (c)->idle = false;                   \
         (c)->self_valid = false;             \
@@ -329,7 +346,8 @@ int restore_rows(esq_ctx *c);
 void drop_plans(esq_ctx *c);
 // the next step's first launch behind the reduction just enqueued (finish_reduction
 // calls it before it waits, if esq_rk_solution_error_ahead asked for it)
-void launch_ahead_if_asked(esq_ctx *c);
+// -> whether a launch went into the queue
+bool launch_ahead_if_asked(esq_ctx *c);
 // ---- esq_core.hip ------------------------------------------------------------
 // sink of the next reduction / completion signal (bumps red_seq)
 ResultSink next_sink(esq_ctx *c, bool to_host_value);

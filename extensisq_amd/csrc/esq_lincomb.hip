@@ -41,6 +41,7 @@ void launch_lincomb_small(esq_ctx *c, double *out, const double *base,
 }
 int launch_lincomb(esq_ctx *c, double *out, const double *base, const Terms &tm,
                    int nt, double h, const Prof *p, const double *init) {
+    if (c->detached) return nt <= kMaxTerms ? 0 : ESQ_EINVAL;   // host-side dry run
     if (c->host_slab && c->len_pad / 2 <= 4096) {
         // small host-RHS problem: one workgroup, completion signalled in-kernel
 #define CASE(N) case N: launch_lincomb_small<N>(c, out, base, init, tm, h, p); break;

@@ -60,21 +60,25 @@ void launch_block_n(esq_ctx *c, const BlockArgs &a, int no, const Prof &p) {
 }
 
 int launch_solerr(esq_ctx *c, const Terms2 &tm, int nt, double h, const Prof &p) {
+    if (c->detached) return 0;                  // host-side dry run
     DISPATCH_1_20(launch_solerr_n, nt, c, tm, h, p)
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 int launch_errnorm(esq_ctx *c, const Terms &tm, int nt, double h, const Prof &p) {
+    if (c->detached) return 0;                  // host-side dry run
     DISPATCH_1_20(launch_errnorm_n, nt, c, tm, h, p)
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 int launch_preerr(esq_ctx *c, const Terms2 &tm, int nt, double h, const Prof &p) {
+    if (c->detached) return 0;                  // host-side dry run
     DISPATCH_1_20(launch_preerr_n, nt, c, tm, h, p)
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 int launch_block(esq_ctx *c, const BlockArgs &a, int nt, int no, const Prof &p) {
+    if (c->detached) return 0;                  // host-side dry run
     DISPATCH_1_20(launch_block_n, nt, c, a, no, p)
     HIPCHK(c, hipGetLastError());
     return 0;

@@ -217,14 +217,17 @@ template <int D, int JT, int NW, bool FIRST = false, bool LAST = false>
 int launch_rkc3d(const Rhs *r, const esq_rkc_chain *ch, hipStream_t stream,
                  hipEvent_t e0, hipEvent_t e1) {
     auto kern = esq::k_rkc3d_chain<D, JT, NW, Diff3dSt, FIRST, LAST>;
-    static int slots = 0;                    // workgroups resident on the chip
-    if (slots == 0) {
-        int per_cu = 0;
+    // workgroups resident on the chip: per CU from the occupancy of this
+    // instantiation (asked once), times the CUs of the device in use
+    static std::atomic<int> per_cu_cache{0};
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
+    if (per_cu == 0) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * NW, 0) !=
                 hipSuccess || per_cu < 1)
             per_cu = 1;
-        slots = 256 * per_cu;
+        per_cu_cache.store(per_cu, std::memory_order_relaxed);
     }
+    const int slots = esq::device_cus() * per_cu;
     if (NW * JT - 2 * D < 1) return ESQ_ENOTSUP;
     const esq::Geo3d g = esq::geo_rkc3d(r->N, D, JT, NW, slots, r->rkc_planes);
     esq::Rkc3dArgs<D> a;

@@ -246,7 +246,9 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
     GeoChain g;
     const int W = 64 - 2 * (depth - 1);
     g.tpr = ((unsigned)N / 2 + W - 1) / W;
-    int R = chain_tuning().rows_set ? chain_tuning().rows : 0;      // tuning / tests
+    const ChainTuning tune = chain_tuning();
+    const size_t cus = (size_t)device_cus();
+    int R = tune.rows_set ? tune.rows : 0;                          // tuning / tests
     if (R <= 0) {
         // ONE round of resident waves at the kernel's own occupancy: the sweeps
         // are latency-bound per wave (a row's loads are one iteration ahead, no
@@ -271,18 +273,18 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
         // chain5<0> 50 us, R = 44 0.540 with 65 us; R = 15, 18, 26 .. 36 -- three waves,
         // or a partial second round -- 0.549 .. 0.600)
         if (tall_if_one_round) {
-            const int tall_waves = chain_tuning().tall_waves;
+            const int tall_waves = tune.tall_waves;
             for (int w = tall_waves < waves_per_cu / 4 ? tall_waves : waves_per_cu / 4;
                  w >= 1 && R <= 0; --w) {
-                const int cand = rows_for((size_t)256 * 4 * (size_t)w);
+                const int cand = rows_for(cus * 4 * (size_t)w);
                 if (cand >= (w == 1 ? 24 : 20) && cand <= 48) R = cand;
             }
         }
         size_t rounds = 1;
-        if (R <= 0) R = rows_for((size_t)256 * (size_t)waves_per_cu);
+        if (R <= 0) R = rows_for(cus * (size_t)waves_per_cu);
         while (R > 48) {
             ++rounds;
-            R = rows_for((size_t)256 * (size_t)waves_per_cu * rounds);
+            R = rows_for(cus * (size_t)waves_per_cu * rounds);
         }
         // (the halo rows are recomputed: the Brusselator's heavier rows want depth + 2,
         // the heat sweeps fill the wave slots down to `depth` rows -- Ts5 at N = 1000:

@@ -138,7 +138,9 @@ void epi_common(esq_ctx *c, esq_epilogue &e, int kind) {
 int run_fused(esq_ctx *c, double t, const double *y_in, double *f_out,
               const esq_epilogue &e, Prof &p) {
     c->self_valid = false;     // a plugin kernel does not signal its own completion
-    const int r = c->rhs_fused(c->rhs_user, t, y_in, f_out, &e, c->len,
+    esq_epilogue q = e;
+    if (c->detached) q.dry_run = 1;     // host-side dry run: the plugin's answer, no launch
+    const int r = c->rhs_fused(c->rhs_user, t, y_in, f_out, &q, c->len,
                                (void *)c->stream, (void *)p.start(),
                                (void *)p.stop());
     if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
@@ -398,6 +400,7 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
              n_stored == 0 ? "-K" : "");
     Prof p(c, ESQ_PROF_STAGE, label, nu, alg, false, 8.0 * (reads + writes) * (double)c->len);
     c->self_valid = false;
+    if (c->detached) e.dry_run = 1;     // host-side dry run: the plugin's answer, no launch
     const int r = c->rhs_chain(c->rhs_user, i == 0 ? c->y : c->ystage, &e, c->len,
                                (void *)c->stream, (void *)p.start(), (void *)p.stop());
     // designed traffic incl. the halo rows / columns the plugin's tiles re-read
@@ -1093,14 +1096,8 @@ void launch_ahead(esq_ctx *c, double t_new, double h) {
         a.kmap[col] = c->spare_rows[used++];
     }
     for (size_t q = (size_t)used; q < c->spare_rows.size(); ++q) a.spares.push_back(c->spare_rows[q]);
-    struct Saved {
-        double *y, *ynew, *ystage, *work;
-        bool tail_missing, tail_accepted, k0_missing, ynew_ready, solerr_ready;
-        unsigned long long missing_rows;
-        double tail_t, tail_h;
-        long end_fused;
-    } sv{c->y, c->ynew, c->ystage, c->work, c->tail_missing, c->tail_accepted, c->k0_missing,
-         c->ynew_ready, c->solerr_ready, c->missing_rows, c->tail_t, c->tail_h, c->end_fused};
+    // everything a launch may change besides device memory, by assignment
+    const StepState sv = *c;
     c->kmap = a.kmap;
     // (the new step's y_new buffer: NOT the old state -- the attempt may be rejected,
     // and after an accept the old state is what the interpolant starts from)
@@ -1116,12 +1113,7 @@ void launch_ahead(esq_ctx *c, double t_new, double h) {
     a.k0_done = k0_next && !c->k0_missing;
     a.wrote_ynew = st.op == OP_CHAIN && st.what >= 1;
     c->kmap = kmap_now;
-    c->y = sv.y; c->ynew = sv.ynew; c->ystage = sv.ystage; c->work = sv.work;
-    c->tail_missing = sv.tail_missing; c->tail_accepted = sv.tail_accepted;
-    c->missing_rows = sv.missing_rows; c->tail_t = sv.tail_t; c->tail_h = sv.tail_h;
-    c->k0_missing = sv.k0_missing;
-    c->ynew_ready = sv.ynew_ready; c->solerr_ready = sv.solerr_ready;
-    c->end_fused = sv.end_fused;
+    static_cast<StepState &>(*c) = sv;
     if (r != 0) {                        // refused at run time: the plans learn it
         if (r == ESQ_ENOTSUP || r == kNotApplicable) {
             c->refused.insert(step_signature(st));
@@ -1132,6 +1124,7 @@ void launch_ahead(esq_ctx *c, double t_new, double h) {
     a.valid = true;
     a.t = t_new; a.h = h;
     a.key = plan_key(1, c->s, false, k0_next, lazy_ok);
+    a.k0_next = k0_next;
 }
 
 }  // namespace
@@ -1142,10 +1135,11 @@ void esqi::drop_plans(esq_ctx *c) {
     c->ahead.valid = c->ahead.committed = false;
 }
 
-void esqi::launch_ahead_if_asked(esq_ctx *c) {
+bool esqi::launch_ahead_if_asked(esq_ctx *c) {
     const double h = c->ahead_ask_h, t = c->ahead_ask_t;
     c->ahead_ask_h = 0.0;
     if (h != 0.0) launch_ahead(c, t, h);
+    return h != 0.0 && c->ahead.valid;
 }
 
 // The rows `missing_rows` of the step in flight (or of the step just accepted) exist
@@ -1388,10 +1382,10 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     // YSTAGE may already hold the first stage's argument (esq_rk_accept)
     const bool ready = i_from == 1 && c->pre_valid && c->pre_h == h;
     // ... or the whole first launch of this step may have run already (launch_ahead)
-    struct { bool committed, tail_missing; double t, h; unsigned key;
+    struct { bool committed, tail_missing, k0_next; double t, h; unsigned key;
              unsigned long long missing_rows; } ahead{c->ahead.committed, c->ahead.tail_missing,
-                                                     c->ahead.t, c->ahead.h, c->ahead.key,
-                                                     c->ahead.missing_rows};
+                                                     c->ahead.k0_next, c->ahead.t, c->ahead.h,
+                                                     c->ahead.key, c->ahead.missing_rows};
     bool skip_first = ahead.committed && i_from == 1 && i_to == c->s && ahead.t == t &&
                       ahead.h == h;
     if (c->ahead.valid) ++c->ahead_dropped;     // launched for an attempt that was rejected
@@ -1404,8 +1398,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     c->missing_rows = 0;
     c->ynew_ready = false;
     c->solerr_ready = false;
-    // (the key of the plan that launch belongs to: K[0] was still to come then)
-    const bool k0_then = skip_first ? ((ahead.key >> 17) & 1u) != 0 : c->k0_missing;
+    // (the plan that launch belongs to: K[0] was still to come then)
+    const bool k0_then = skip_first ? ahead.k0_next : c->k0_missing;
     if (skip_first && plan_key(i_from, i_to, false, k0_then, c->lazy_rows && !c->keep_rows) !=
                           ahead.key)
         skip_first = false;
@@ -1466,13 +1460,11 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
 // keys: first = a step that starts from K[0] in memory (the first step, a retry
 // after a rejection), deferred = after an accepted step that left f(t, y) to this
 // one, prelaunched = stage 1's argument formed at accept time.
-int esq_plan_describe(const char *plugin, int N, int s, const double *A, const double *B,
-                      const double *C, const double *E, int fsal, int chain_caps,
-                      int fuse_mask, int lazy_rows, int chain_depth, int src_pays, char *buf,
-                      size_t buflen) {
-    if (!plugin || !A || !B || !C || !E || !buf || buflen < 2 || s < 1 || N < 1) return ESQ_EINVAL;
-    esq_ctx ctx;
-    esq_ctx *c = &ctx;
+// a detached context with one of the built-in plugins' entries and the tableau set
+static int make_detached(esq_ctx *c, void **user_out, const char *plugin, int N, int s,
+                         const double *A, const double *B, const double *C, const double *E,
+                         int fsal, int chain_caps, int fuse_mask, int lazy_rows,
+                         int chain_depth, int src_pays, int extra_rows = 0) {
     c->detached = true;
     c->device = -1;
     void *user = nullptr;
@@ -1499,11 +1491,12 @@ int esq_plan_describe(const char *plugin, int N, int s, const double *A, const d
     } else {
         return ESQ_EINVAL;
     }
+    *user_out = user;
     c->rhs_user = user;
     c->n = c->len = n;
     c->len_pad = ((n + kPadDoubles - 1) / kPadDoubles) * kPadDoubles;
     c->stride = c->len_pad;
-    c->n_rows = s + 1;
+    c->n_rows = s + 1 + extra_rows;
     double *fake = reinterpret_cast<double *>((uintptr_t)1 << 40);
     c->krow.resize(c->n_rows);
     c->kmap.resize(c->n_rows);
@@ -1519,7 +1512,20 @@ int esq_plan_describe(const char *plugin, int N, int s, const double *A, const d
     c->lazy_end = true;
     c->chain_depth = chain_depth;
     c->src_pays = src_pays != 0;
-    int r = esq_rk_set_tableau(c, s, A, B, C, E, fsal);
+    return esq_rk_set_tableau(c, s, A, B, C, E, fsal);
+}
+
+int esq_plan_describe(const char *plugin, int N, int s, const double *A, const double *B,
+                      const double *C, const double *E, int fsal, int chain_caps,
+                      int fuse_mask, int lazy_rows, int chain_depth, int src_pays, char *buf,
+                      size_t buflen) {
+    if (!plugin || !A || !B || !C || !E || !buf || buflen < 2 || s < 1 || N < 1) return ESQ_EINVAL;
+    esq_ctx ctx;
+    esq_ctx *c = &ctx;
+    void *user = nullptr;
+    int r = make_detached(c, &user, plugin, N, s, A, B, C, E, fsal, chain_caps, fuse_mask,
+                          lazy_rows, chain_depth, src_pays);
+    if (r && !user) return r;
     size_t used = 0;
     buf[0] = 0;
     static const char *kOp[] = {"k0", "chain", "src", "accum", "lincomb", "stage", "block",
@@ -1551,6 +1557,112 @@ int esq_plan_describe(const char *plugin, int N, int s, const double *A, const d
         if (used + line.size() + 1 > buflen) { r = ESQ_EINVAL; break; }
         memcpy(buf + used, line.c_str(), line.size() + 1);
         used += line.size();
+    }
+    esq_rhs_free(user);
+    return r;
+}
+
+// ---- whole steps on a detached context: the HOST side of the step -- plans, row
+// maps, the launch ahead of time and what it saves and restores, the lazy rows, the
+// deferred end-point derivative -- run without a GPU (every launch is the plugin's
+// answer to the query instead; reductions return 0).  `script` holds one code per
+// attempt, as RungeKutta._step_impl would make the calls:
+//   0  accepted, next step size named BEFORE the norm is known (a run at max_step:
+//      esq_rk_solution_error_ahead) and confirmed by the accept
+//   1  accepted, next step size named at accept time only
+//   2  rejected (the attempt is repeated with half the step)
+//   3  accepted with a next step size that the following attempt does NOT take
+//   4  accepted; a reader asks for rows of K before the next step (esq_rk_row_id)
+//   5  accepted with the guess of code 0, but the accept names another step size
+// One line per attempt goes to buf:
+//   <code>: state_ok=<0|1> used=<n> dropped=<n> missing=<rows> k0=<0|1> fused=<n> plain=<n>
+// state_ok: every launch_ahead of the attempt left StepState and the row map as it
+// found them.  tests/test_step_plans.py (also under the sanitizer build).
+namespace {
+bool same_state(const StepState &a, const StepState &b) {
+    static_assert(sizeof(StepState) == 104, "a new field of StepState: compare it below");
+    return a.y == b.y && a.ynew == b.ynew && a.ystage == b.ystage && a.work == b.work &&
+           a.ynew_ready == b.ynew_ready && a.solerr_ready == b.solerr_ready &&
+           a.red_count == b.red_count && a.tail_missing == b.tail_missing &&
+           a.tail_accepted == b.tail_accepted && a.missing_rows == b.missing_rows &&
+           a.tail_t == b.tail_t && a.tail_h == b.tail_h && a.k0_missing == b.k0_missing &&
+           a.k0_t == b.k0_t && a.end_fused == b.end_fused && a.end_plain == b.end_plain;
+}
+}  // namespace
+int esq_step_dry_run(const char *plugin, int N, int s, const double *A, const double *B,
+                     const double *C, const double *E, int fsal, int chain_caps,
+                     int fuse_mask, int lazy_rows, int chain_depth, int src_pays,
+                     const int *script, int n_attempts, char *buf, size_t buflen) {
+    if (!plugin || !A || !B || !C || !E || !buf || buflen < 2 || s < 1 || N < 1 || !script ||
+        n_attempts < 1)
+        return ESQ_EINVAL;
+    esq_ctx ctx;
+    esq_ctx *c = &ctx;
+    void *user = nullptr;
+    // (spare rows of the launch ahead of time come from esq_aux_rows: fake addresses)
+    int r = make_detached(c, &user, plugin, N, s, A, B, C, E, fsal, chain_caps, fuse_mask,
+                          lazy_rows, chain_depth, src_pays);
+    if (r && !user) return r;
+    size_t used = 0;
+    buf[0] = 0;
+    double t = 0.0, h = 1.0 / 64;
+    double sumsq = 0.0;
+    for (int q = 0; q < n_attempts && r == 0; ++q) {
+        const int code = script[q];
+        bool ok = true;
+        r = esq_rk_stages(c, 1, s, t, h);
+        if (r) break;
+        {
+            // the speculation by itself: whatever the launch does to the context on the
+            // next step's behalf, the context is afterwards what it was
+            const StepState before = *c;
+            // (the first launch adds the spare rows to the context: compare the
+            // rows of the method, logical 0 .. s)
+            auto head = [&](const std::vector<int> &m) {
+                return std::vector<int>(m.begin(), m.begin() + s + 1);
+            };
+            const std::vector<int> kmap = head(c->kmap), kmap_last = head(c->kmap_last);
+            launch_ahead(c, t + h, h);
+            ok = same_state(before, *c) && kmap == head(c->kmap) &&
+                 kmap_last == head(c->kmap_last);
+            c->ahead.valid = c->ahead.committed = false;
+        }
+        // ... and as the calls of a step make it
+        const double h_guess = (code == 0 || code == 5) ? h : 0.0;
+        r = esq_rk_solution_error_ahead(c, t, h, h_guess, &sumsq);
+        if (r) break;
+        if (code == 2) {                                   // rejected
+            h *= 0.5;
+        } else {
+            const double h_next = code == 5 ? 0.75 * h : h;
+            r = esq_rk_accept(c, t + h, fsal ? 0 : 1, h_next);
+            if (r) break;
+            t += h;
+            h = code == 3 ? 0.875 * h_next : h_next;
+            if (code == 4) {
+                const int id = esq_rk_row_id(c, s > 2 ? s - 1 : 0, 1);
+                if (id < 0) { r = id; break; }
+            }
+        }
+        // invariants of the row maps: permutations of distinct physical rows, the
+        // spares disjoint from both
+        {
+            std::set<int> seen(c->kmap.begin(), c->kmap.begin() + s + 1);
+            ok = ok && (int)seen.size() == s + 1;
+            for (int sp : c->spare_rows) ok = ok && !seen.count(sp);
+            std::set<int> sp(c->spare_rows.begin(), c->spare_rows.end());
+            ok = ok && sp.size() == c->spare_rows.size();
+        }
+        char line[200];
+        snprintf(line, sizeof(line),
+                 "%d: state_ok=%d used=%ld dropped=%ld missing=%d k0=%d fused=%ld plain=%ld\n",
+                 code, ok ? 1 : 0, c->ahead_used, c->ahead_dropped,
+                 c->tail_missing ? __builtin_popcountll(c->missing_rows) : 0,
+                 c->k0_missing ? 1 : 0, c->end_fused, c->end_plain);
+        const size_t len = strlen(line);
+        if (used + len + 1 > buflen) { r = ESQ_EINVAL; break; }
+        memcpy(buf + used, line, len + 1);
+        used += len;
     }
     esq_rhs_free(user);
     return r;

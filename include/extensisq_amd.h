@@ -317,6 +317,10 @@ typedef int (*esq_rhs_rkc_chain_fn)(void *user, const esq_rkc_chain *chain,
 int  esq_abi_version(void);
 /* devices this process can see (a launcher may restrict each rank to one) */
 int  esq_device_count(int *count_out);
+/* PCI address of HIP device `device` ("0000:c1:00.0", NUL-terminated) -- for a
+ * launcher that pinned its CPUs by sysfs position before it touched the GPU and
+ * wants to know afterwards whether that was the device it got (bench.py) */
+int  esq_device_pci_bus_id(int device, char *buf, size_t buflen);
 /* n: state dimension (complex elements if is_complex); n_rows: rows of K
  * (n_stages + 1, plus extra rows for BS5's interpolants / RKC work vectors).
  * Replaces `self.K = np.empty((n_stages + 1, n))`  common.py:216 and the
@@ -496,6 +500,28 @@ int  esq_plan_describe(const char *plugin, int N, int s, const double *A,
                        const double *B, const double *C, const double *E, int fsal,
                        int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
                        int src_pays, char *buf, size_t buflen);
+/* Whole steps on a context WITHOUT a device: the host side of the step -- plans, row
+ * maps, the first launch ahead of time and what it saves and restores, rows left
+ * unwritten, the deferred end-point derivative -- with every launch replaced by the
+ * plugin's answer to the corresponding query (arguments as esq_plan_describe).
+ * `script`: one code per attempt, the calls RungeKutta._step_impl makes:
+ *   0 accepted, the next step size named before the norm is known and confirmed
+ *   1 accepted, the next step size named at accept time
+ *   2 rejected (repeated with half the step)
+ *   3 accepted, but the following attempt takes another step size
+ *   4 accepted, then a reader asks for a row of K (esq_rk_row_id)
+ *   5 accepted with the guess of 0, but the accept names another step size
+ * One line per attempt:
+ *   "<code>: state_ok=<0|1> used=<n> dropped=<n> missing=<rows> k0=<0|1> fused=<n> plain=<n>"
+ * (state_ok: a launch ahead of time left the context's step state and row maps as it
+ * found them, and the row maps are permutations disjoint from the spare rows; the
+ * rest are the counters of esq_rk_launch_ahead_stats / esq_rk_lazy_rows).
+ * tests/test_step_plans.py runs it, also against the sanitizer build of the library. */
+int  esq_step_dry_run(const char *plugin, int N, int s, const double *A,
+                      const double *B, const double *C, const double *E, int fsal,
+                      int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
+                      int src_pays, const int *script, int n_attempts, char *buf,
+                      size_t buflen);
 /* Rows of K that only the solution / error sums of their own sweep read (the
  * stages of a step's last chain sweep, non-FSAL pairs: `self.K[s] = f` of
  * common.py:355 for rows nothing in `_step_impl` reads again) are NOT written

@@ -8,7 +8,8 @@ import pytest
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
 HEADER = os.path.join(ROOT, "include", "extensisq_amd.h")
-LIB = os.path.join(ROOT, "extensisq_amd", "libextensisq_amd.so")
+# (ESQ_LIB: another build of the library -- tests/test_sanitizer_build.py)
+LIB = os.environ.get("ESQ_LIB") or os.path.join(ROOT, "extensisq_amd", "libextensisq_amd.so")
 
 
 def header_symbols():

@@ -175,7 +175,9 @@ def test_rkc_depth5_default_path_is_bit_identical(monkeypatch):
         np.testing.assert_array_equal(got, ref, err_msg=f"m = {m}")
         assert s1.nfev == s2.nfev
         names = [k[0] for k in _profiled_kernels(s2, m)]
-        assert any(k.startswith("rkc_chain5") for k in names), names
+        # (m = 7: six stages = 4 + 2, never a single stage at the end)
+        want = "rkc_chain4" if m == 7 else "rkc_chain5"
+        assert any(k.startswith(want) for k in names), names
         assert "k_rkc_first" not in names and any("-first" in k for k in names), names
 
 
@@ -268,7 +270,7 @@ def test_rkc_chain_sweeps_are_bit_identical(monkeypatch, N, planes, depth):
         np.testing.assert_array_equal(got, ref, err_msg=f"m = {m}")
         assert s1.nfev == s2.nfev
         names = [k[0] for k in _profiled_kernels(s2, m)]
-        if m - 1 >= depth:
+        if m == 23:     # (22 stages: chains of the full depth, whatever ends the step)
             assert any(k.startswith("rkc_chain%d" % depth) for k in names), names
         if m - 1 >= 2:
             assert any(k.startswith("rkc_chain") for k in names), names

@@ -204,3 +204,77 @@ def test_chebyshev_step_programs():
                         assert "rhs_rkc" not in p, (m, depth, p)
                     elif depth == 2:                  # (an odd count leaves one)
                         assert p.count("rhs_rkc") == (m - 1) % 2, (m, p)
+
+
+# ---------------------------------------------------------------------------
+# whole steps on a detached context (esq_step_dry_run): the host side of the step --
+# row maps, the first launch ahead of time with what it saves and restores, rows left
+# unwritten, the deferred end-point derivative -- with no GPU behind it
+# ---------------------------------------------------------------------------
+SCRIPT = [0, 0, 1, 2, 1, 3, 1, 4, 0, 5, 0, 0]
+LINE = re.compile(r"(\d+): state_ok=(\d) used=(\d+) dropped=(\d+) missing=(\d+) k0=(\d) "
+                  r"fused=(\d+) plain=(\d+)")
+
+
+def _dry(cls, plugin, N, script=SCRIPT, caps=15 | gsp.CAP_QUERY, lazy=1, depth=4, src=0):
+    import ctypes as C
+    import numpy as np
+    from extensisq_amd import _lib
+    lib = _lib.load()
+    s = cls.n_stages
+    arrs = [np.ascontiguousarray(getattr(cls, k), dtype=float) for k in "ABCE"]
+    fsal = int(arrs[3][s] != 0)
+    sc = np.asarray(script, dtype=np.int32)
+    buf = C.create_string_buffer(1 << 15)
+    r = lib.esq_step_dry_run(plugin.encode(), N, s, *[_lib.as_ptr(a) for a in arrs], fsal, caps,
+                             gsp.FUSE_ALL | gsp.FUSE_SRC | gsp.FUSE_QUERY, lazy, depth, src,
+                             sc.ctypes.data_as(C.c_void_p), len(sc), buf, len(buf))
+    assert r == 0, r
+    rows = [tuple(int(g) for g in LINE.match(ln).groups())
+            for ln in buf.value.decode().strip().split("\n")]
+    assert [row[0] for row in rows] == list(script)
+    return rows
+
+
+@pytest.mark.parametrize("plugin,N", gsp.PLUGINS)
+def test_launch_ahead_leaves_the_step_state_as_it_found_it(plugin, N):
+    """every tableau x plugin x capability set: whatever launch_ahead runs on the next
+    step's behalf, the context's StepState and row maps are afterwards what they were,
+    and the row maps stay permutations disjoint from the spare rows -- through accepted
+    and rejected attempts, confirmed and wrong guesses of the next step size, a reader
+    in between"""
+    import extensisq_amd as esq
+    classes = [getattr(esq, m) for m in gsp.METHODS] + [gsp.heun()]
+    has_chain = plugin in ("bruss2d", "heat2d")
+    for cls in classes:
+        for caps in (range(16) if has_chain else [0]):
+            for lazy in (0, 1):
+                rows = _dry(cls, plugin, N, caps=caps | gsp.CAP_QUERY, lazy=lazy)
+                assert all(row[1] == 1 for row in rows), (cls.__name__, caps, lazy, rows)
+                used, dropped = [row[2] for row in rows], [row[3] for row in rows]
+                assert used == sorted(used) and dropped == sorted(dropped)
+                # one launch ahead per attempt at most, each used or dropped once
+                assert used[-1] + dropped[-1] <= len(SCRIPT)
+                if not has_chain:
+                    assert used[-1] == 0 or cls.__name__ in ("Ts5", "BS5", "Heun"), rows
+
+
+def test_launch_ahead_script_of_the_metric_configuration():
+    """Pr8 on the Brusselator plugin, N = 2236, all capabilities: which attempts find
+    their first sweep in the queue already, which launches are dropped, what stays
+    unwritten, how the end-point derivatives run"""
+    import extensisq_amd as esq
+    rows = _dry(esq.Pr8, "bruss2d", 2236)
+    #        attempt:  0  0  1  2  1  3  1  4  0  5  0  0
+    assert [r[2] for r in rows] == [0, 1, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8]      # used
+    assert [r[3] for r in rows] == [0, 0, 0, 0, 0, 0, 1, 2, 2, 3, 3, 3]      # dropped
+    # K_1 and K_9 .. K_12 unwritten after every attempt but the one a reader followed
+    assert [r[4] for r in rows] == [5, 5, 5, 5, 5, 5, 5, 0, 5, 5, 5, 5]
+    # every end-point derivative inside a chain sweep (none after the rejected attempt)
+    assert [r[6] for r in rows] == [1, 2, 3, 3, 4, 5, 6, 7, 8, 9, 10, 11]
+    assert all(r[7] == 0 and r[5] == 0 for r in rows)
+    # an FSAL pair: nothing is missing, a reader drops nothing
+    rows = _dry(esq.Ts5, "heat2d", 1000, src=1)
+    assert [r[2] for r in rows] == [0, 1, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9]
+    assert [r[3] for r in rows] == [0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2]
+    assert all(r[4] == 0 and r[5] == 0 and r[6] == 0 for r in rows)

@@ -3,6 +3,7 @@
 #   tools/ab_chain.sh <config> <depth> [<depth> ...]     (depth 1 = one sweep per stage)
 # extra environment (ESQ_BLOCK_ACC, ESQ_CHAIN_ROWS ...) is passed through
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 OUT=$ROOT/gpurun_out
 CFG=${1:-pr8}; shift
 python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras > /dev/null 2>&1

@@ -3,6 +3,7 @@
 #   tools/ab_env.sh <VAR>=<value-B> <rounds> <config> [config ...]     (A = unset)
 KV=$1; ROUNDS=$2; shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 for cfg in "$@"; do
   for r in $(seq 1 $ROUNDS); do
     for side in A B; do

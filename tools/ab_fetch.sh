@@ -2,6 +2,7 @@
 # HBM-side read bytes per kernel (FETCH_SIZE, one --pmc pass) for environment settings:
 #   tools/ab_fetch.sh <config> "VAR=a" "VAR=b" ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 OUT=$ROOT/gpurun_out
 CFG=${1:-pr8}; shift
 cd /tmp && export TMPDIR=/tmp

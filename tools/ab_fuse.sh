@@ -5,6 +5,7 @@
 CFG=${1:-pr8}
 ROUNDS=${2:-2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 OUT=$ROOT/gpurun_out/ab_fuse_$CFG.jsonl
 : > $OUT
 for r in $(seq 1 $ROUNDS); do

@@ -5,6 +5,7 @@
 # variant, round by round
 VARS=$1; ROUNDS=$2; shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 for cfg in "$@"; do
   for r in $(seq 1 $ROUNDS); do
     for side in A ${VARS//,/ }; do

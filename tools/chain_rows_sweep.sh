@@ -2,6 +2,7 @@
 # tile height of the chain sweeps (ESQ_CHAIN_ROWS) on one bench config, same box:
 #   tools/chain_rows_sweep.sh <config> <rows> [rows ...]      (0 = the planner's choice)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 cfg=$1; shift
 for r in "$@"; do
   if [ "$r" = 0 ]; then unset ESQ_CHAIN_ROWS; else export ESQ_CHAIN_ROWS=$r; fi

@@ -2,6 +2,7 @@
 # one bench config under a list of environment settings, same box:
 #   tools/env_sweep.sh <config> "VAR=a" "VAR=b VAR2=c" ...      ("" = defaults)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 cfg=$1; shift
 i=0
 for kv in "$@"; do

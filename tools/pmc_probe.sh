@@ -3,6 +3,7 @@
 # pass, --kernel-trace only).  Output: gpurun_out/pmc_probe_<config>_<k>/
 CFG=${1:-pr8}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 k=0

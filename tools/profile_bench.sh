@@ -10,6 +10,7 @@
 # condenses them into profiles/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 # a fresh box runs its first seconds of GPU work measurably slower: warm it up

@@ -4,6 +4,7 @@
 # prints ms/step and the per-kernel table of each run (gpurun_out/rkc_d<depth>_<round>.json)
 GRID=${1:-159}; ROUNDS=${2:-2}; shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 for r in $(seq 1 $ROUNDS); do
   for d in ${ESQ_SWEEP_DEPTHS:-1 2 3 4}; do
     ESQ_RKC_DEPTH=$d python3 $ROOT/bench.py --config rkc --grid $GRID --steps ${ESQ_SWEEP_STEPS:-20} --warmup 5 \

@@ -1,5 +1,9 @@
 #!/bin/bash
+# PMC groups (memory side, L2, TA, SQ) of the Chebyshev chain sweeps, one rocprofv3 pass each:
+#   [GRIDARG="--grid 400"] tools/rkc_pmc_probe.sh       (GRIDARG: extra bench.py arguments,
+#   default: the BASELINE grid N = 159); tables per kernel label on stdout
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 k=0

@@ -3,6 +3,7 @@
 #   tools/rkc_shape_sweep.sh <grid> "<depth>:<JT>,<NW> ..."
 GRID=${1:-159}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 for spec in $1; do
     d=${spec%%:*}; cfg=${spec#*:}
     ESQ_RKC_MAXDEPTH=$d ESQ_RKC_DEPTH=$d ESQ_RKC_CFG=$cfg python3 $ROOT/bench.py --config rkc --grid $GRID \

@@ -7,6 +7,7 @@ CFG=${SPEC%@*}
 GRID=""
 if [ "$SPEC" != "$CFG" ]; then GRID="--grid ${SPEC#*@}"; fi
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 k=0
