@@ -253,6 +253,11 @@ def dry_run(args, rank, world, ctl):
         timing = dict(elapsed=elapsed, elapsed_min=fastest, elapsed_prof=elapsed,
                       rejected=0, nfev_timed=0)
         lock = world > 1 and not args.replicas
+        # (the real run raises when ncclCommCount disagrees with the world size:
+        # rehearsed here with a number from the environment)
+        seen = int(os.environ.get("ESQ_BENCH_DRY_RCCL_NRANKS", world))
+        if lock and seen != world:
+            raise RuntimeError(f"RCCL sees {seen} ranks, expected {world}")
         out = assemble(args, meta, world, 1000, timing, table,
                        lockstep_on=lock, rccl_nranks=world if lock else None,
                        preflight="dry-run" if lock else None,
@@ -262,6 +267,11 @@ def dry_run(args, rank, world, ctl):
                                      "collective_median": 0.0, "calls": 0,
                                      "path": "dry-run"} if lock else None,
                        affinity=pin_to_gpu_numa(rank))
+        if lock and args.config != "pr9":
+            m9 = workload_meta("pr9", None)
+            out["config"]["config5_pr9_lockstep"] = {
+                "workload": m9["label"] + ", dry-run", "value": 1.0, "ms_per_step": 1.0,
+                "ms_per_step_rank_min": 1.0, "rejected_steps_in_timed_region": 0}
         out["metric"] = "dry-run"
         out["value"] = n_total / elapsed
         out["max_elapsed"] = elapsed
@@ -505,6 +515,9 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
             # N = 1 only (rank 0 measures them after the timed region)
             "solve_ivp": None, "sustained": None, "generic_plugin": None,
             "adaptive": None, "rows_kept": None,
+            # N > 1, lock-step, any config but pr9: BASELINE.json configs[4] (Pr9, one
+            # heat IVP per GPU) measured in the same command after the headline
+            "config5_pr9_lockstep": None,
         },
         "roofline": {
             "bound": "hbm", "kernel": meta["kernel"],
@@ -605,7 +618,7 @@ def main():
             preflight = lockstep.preflight(group, rank, world, local, ctl)
             allreduce_us = lockstep.time_allreduce(group, local, ctl)
 
-        def timed(lock_group):
+        def timed(lock_group, w=w):
             solver = w["cls"](w["rhs"], 0.0, w["y0"], 1.0e9, device=local,
                               lockstep=lock_group, **w["kw"])
             dev = solver._dev
@@ -658,6 +671,23 @@ def main():
             replicas = {"value": world * n * args.steps / el2,
                         "ms_per_step": 1e3 * el2 / args.steps}
             del _s2, _r2, _b2
+        config5 = None
+        if world > 1 and group is not None and args.config != "pr9" and not args.no_extras:
+            # BASELINE.json configs[4] proper in the same command: Pr9, one heat IVP of
+            # N = 2236 per GPU (seeds 1234 + rank), lock-step over the SAME communicator
+            # (a second group object: the norm is taken over this workload's sizes)
+            from extensisq_amd.common import LockstepGroup
+            w9 = make_workload("pr9", None, rank)
+            n9 = w9["y0"].size
+            g9 = LockstepGroup(group.comm, world * n9, offset=rank * n9)
+            _s9, _r9, _b9, el9, fast9, rej9, _nf9, _c9 = timed(g9, w9)
+            config5 = {"workload": w9["label"] + f", n={n9} per GPU, seeds 1234 ... "
+                                                 f"{1234 + world - 1}, lock-step",
+                       "value": world * n9 * args.steps / el9,
+                       "ms_per_step": 1e3 * el9 / args.steps,
+                       "ms_per_step_rank_min": 1e3 * fast9 / args.steps,
+                       "rejected_steps_in_timed_region": rej9}
+            del _s9, _r9, _b9
     except BaseException:
         # a rank that dies must not leave its peers blocked in the all-reduce
         lockstep.abort_lockstep(group)
@@ -670,6 +700,7 @@ def main():
                        lockstep_on=group is not None, rccl_nranks=rccl_nranks,
                        preflight=preflight, replicas=replicas,
                        allreduce_us=allreduce_us, affinity=affinity)
+        out["config"]["config5_pr9_lockstep"] = config5
         if world == 1:
             # further driver-visible figures of the same workload -- none of them
             # the headline

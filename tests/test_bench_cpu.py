@@ -114,6 +114,9 @@ def test_json_line_has_the_same_shape_for_one_and_eight_ranks():
     # replicas_no_collective is measured only where there is a collective to drop
     extra = {"/config/replicas_no_collective/value",
              "/config/replicas_no_collective/ms_per_step"} | {
+        "/config/config5_pr9_lockstep/" + k for k in (
+            "workload", "value", "ms_per_step", "ms_per_step_rank_min",
+            "rejected_steps_in_timed_region")} | {
         "/config/allreduce_us/" + k for k in ("median", "p99", "median_without_collective",
                                               "collective_median", "calls", "path")}
     assert _shape(one) == _shape(one_world) == _shape(eight) - extra
@@ -133,3 +136,30 @@ def test_json_line_has_the_same_shape_for_one_and_eight_ranks():
     assert eight["config"]["ms_per_step_rank_min"] <= eight["config"]["ms_per_step_rank_max"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in eight["roofline"]
+
+
+def test_eight_rank_lines_of_both_multi_gpu_configs():
+    """the first lease of an 8-GPU node: `bench.py --gpus 8` (the metric workload) carries
+    BASELINE.json configs[4] -- Pr9, one heat IVP per GPU, lock-step -- as
+    `config.config5_pr9_lockstep` of the same line, and `--config pr9` is that
+    configuration as the headline; a communicator that does not span the world is a
+    failed run (rc != 0, no JSON)"""
+    def run(extra_args, env):
+        return subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "3",
+                               "--warmup", "1", "--dry-run"] + extra_args,
+                              capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    res = run([], clean_env())
+    assert res.returncode == 0, res.stderr[-2000:]
+    pr8 = json.loads(res.stdout.strip().splitlines()[-1])
+    c5 = pr8["config"]["config5_pr9_lockstep"]
+    assert "Pr9" in c5["workload"] and c5["ms_per_step"] > 0
+    assert "Pr8" in pr8["config"]["workload"] and "lockstep x8" in pr8["config"]["parallelism"]
+    res = run(["--config", "pr9"], clean_env())
+    assert res.returncode == 0, res.stderr[-2000:]
+    pr9 = json.loads(res.stdout.strip().splitlines()[-1])
+    assert "Pr9" in pr9["config"]["workload"] and pr9["n_gpus"] == 8
+    assert pr9["config"]["config5_pr9_lockstep"] is None          # it IS the headline
+    assert pr9["config"]["rccl_nranks"] == 8 and "lockstep x8" in pr9["config"]["parallelism"]
+    res = run(["--config", "pr9"], clean_env(ESQ_BENCH_DRY_RCCL_NRANKS="7"))
+    assert res.returncode != 0 and res.stdout.strip() == ""
+    assert "RCCL sees 7 ranks, expected 8" in res.stderr
