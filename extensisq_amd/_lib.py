@@ -47,6 +47,10 @@ SIGNATURES = {
     "esq_vector_len": (C.c_size_t, [_vp]),
     "esq_upload": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "esq_download": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "esq_snapshot_begin": (C.c_int, [_vp, C.c_int, C.c_int, _vpp]),
+    "esq_snapshot_copy": (C.c_int, [_vp, _vp, C.c_int]),
+    "esq_host_pin": (C.c_int, [_vp, C.c_size_t]),
+    "esq_host_unpin": (C.c_int, [_vp]),
     "esq_copy": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "esq_rk_set_tableau": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "esq_set_tol": (C.c_int, [_vp, C.c_double, _vp, C.c_size_t]),

@@ -24,8 +24,11 @@ from scipy.integrate._ivp.common import (validate_first_step,
                                          validate_max_step, warn_extraneous)
 
 from ._lib import (SLOT_K, SLOT_WORK, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, VEC_NONE,
-                   VEC_Y, as_ptr)
+                   VEC_Y, DeviceError, as_ptr)
 from .device import DeviceContext, DeviceRHS
+from .lazy import LazyState
+
+LAZY_MIN_BYTES = 8 << 20       # states below this are downloaded at once
 
 # failed-step counter shared with the RKC module (reference: common.py:14)
 NFS = np.array(0)
@@ -313,6 +316,14 @@ class RungeKutta(OdeSolver):
         self._f_host = None
         self._K_host = None
         self._y_old_host = None
+        # large device-resident states: `solver.y` is a deferred mirror (lazy.py);
+        # ESQ_LAZY_Y=0: downloaded at once, as small states always are
+        self._lazy_on = (self._device_rhs is not None and not self._dev.host_slab
+                         and y_host.nbytes >= LAZY_MIN_BYTES
+                         and os.environ.get("ESQ_LAZY_Y", "1") != "0")
+        self._state_gen = 0          # accepted steps: which state the device holds
+        self._lazy_live = []         # [weakref(mirror), generation, copy-done event]
+        self._lazy_eager = False     # the caller stores its states: copy at once
         if self._device_rhs is not None:
             self._dev.set_rhs(self._device_rhs)
             self._chk(self._lib.esq_rk_eval_rhs(self._ctx, 0, float(self.t),
@@ -481,16 +492,102 @@ class RungeKutta(OdeSolver):
     @property
     def y(self):
         """current state; downloaded from HBM on first access after a step
-        (a fresh array each step, as scipy stores it by reference)"""
+        (a fresh array each step, as scipy stores it by reference).  A large
+        device-resident state comes back as a `LazyState` (lazy.py): an array-like
+        that downloads when it is really used -- plain `solve_ivp` reads `solver.y`
+        after every step (ivp.py:665) whether it needs it or not"""
         if self._y_host is None:
-            self._y_host = self._dev.download(SLOT_Y)
+            self._y_host = (self._new_lazy_state() if self._lazy_on
+                            else self._dev.download(SLOT_Y))
+        if isinstance(self._y_host, LazyState) and self._y_host.materialized:
+            self._y_host = self._y_host.materialize()
         return self._y_host
 
     @y.setter
     def y(self, value):
+        if self._dev is not None and value is not None:
+            # mirrors of the state that is about to be replaced: download first
+            self._retire_lazy_states(everything=True)
+            if isinstance(value, LazyState):
+                value = value.materialize()
         self._y_host = value
         if self._dev is not None and value is not None:
             self._dev.upload(SLOT_Y, 0, value)
+
+    # -- deferred mirrors of the state (lazy.py)
+    def _begin_snapshot(self, slot):
+        """-> (copy_fn, out): the download of `slot` as it is NOW, to be run by the
+        copy worker beside the steps that follow (esq_snapshot_begin / _copy)"""
+        import ctypes
+        from .device import _warm
+        out, locked = _warm.take(self.n, self._dev.dtype, pinned=True)
+        token = ctypes.c_void_p()
+        lib, ptr = self._lib, out.ctypes.data_as(ctypes.c_void_p)
+        try:
+            self._chk(lib.esq_snapshot_begin(self._ctx, slot, 0, ctypes.byref(token)),
+                      "esq_snapshot_begin")
+        except Exception:
+            if locked:
+                lib.esq_host_unpin(ptr)
+            raise
+
+        def copy_fn():
+            code = lib.esq_snapshot_copy(token, ptr, int(locked))
+            if code != 0:
+                raise DeviceError(f"esq_snapshot_copy failed with code {code}")
+            return out
+        return copy_fn, out
+
+    def _new_lazy_state(self):
+        import weakref
+        gen = self._state_gen
+        solver = self                 # (an unread mirror keeps its solver alive)
+
+        def fetch():
+            age = solver._state_gen - gen
+            if age == 0:
+                return solver._dev.download(SLOT_Y)
+            if age == 1:              # after one more accept: the "previous state"
+                return solver._dev.download(SLOT_YNEW)
+            raise DeviceError("this state is no longer on the device")   # (retired before)
+        mirror = LazyState(fetch, self.n, self._dev.dtype)
+        entry = [weakref.ref(mirror), gen, None]
+        if self._lazy_eager:
+            mirror.start_copy(lambda: self._begin_snapshot(SLOT_Y))
+            entry[2] = mirror._pending[0] if mirror._pending else None
+        self._lazy_live.append(entry)
+        return mirror
+
+    def _retire_lazy_states(self, everything=False):
+        """Before a step starts: the device is about to overwrite the buffer of the
+        state before the current one.  Mirrors of it that somebody still holds are
+        downloaded now -- and if that took a synchronous copy, the caller evidently
+        stores its states: from now on every new mirror starts its copy at once,
+        beside the following steps.  Copies under way are waited for either way."""
+        if not self._lazy_live:
+            return
+        keep = []
+        for entry in self._lazy_live:
+            ref, gen, done = entry
+            mirror = ref()
+            if not everything and gen >= self._state_gen:
+                if mirror is not None and not mirror.materialized:
+                    keep.append(entry)
+                continue
+            if mirror is not None and not mirror.materialized:
+                if done is None:
+                    self._lazy_eager = True
+                mirror.materialize()
+            elif done is not None:
+                if not done.is_set():
+                    done.wait()       # nobody waits for it, but it reads the buffer
+                if mirror is None:
+                    self._lazy_eager = False      # copied for nobody: stop that
+        self._lazy_live = keep
+
+    def step(self):
+        self._retire_lazy_states()
+        return super().step()
 
     @property
     def f(self):
@@ -693,6 +790,7 @@ class RungeKutta(OdeSolver):
             self._dev.upload(SLOT_K, self.n_stages, self.fun(t_new, y_new))
         self._chk(self._lib.esq_rk_accept(self._ctx, t_new, end_eval, h_next),
                   "esq_rk_accept")
+        self._state_gen += 1
         self._invalidate_mirrors()
 
     def _guess_next_step(self, t_new, h_abs):

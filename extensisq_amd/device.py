@@ -32,7 +32,7 @@ class WarmBuffers:
 
     MIN_BYTES = 8 << 20
 
-    def __init__(self, depth=3, workers=2):
+    def __init__(self, depth=6, workers=4):
         import threading
         self.depth, self.workers = depth, workers
         self._lock = threading.Lock()
@@ -43,6 +43,8 @@ class WarmBuffers:
         self._seen = {}             # nbytes -> downloads so far
         self._threads = []
         self._memset = None
+        self._pin = False           # page-lock the warm arrays too (`take(pinned=True)`)
+        self._pinned = set()        # addresses of ready arrays that are page-locked
         self.enabled = os.environ.get("ESQ_WARM_BUFFERS", "1") != "0"
 
     def _worker(self):
@@ -55,10 +57,19 @@ class WarmBuffers:
                 self._pending += 1
             buf = np.empty(nbytes, dtype=np.uint8)
             self._memset(buf.ctypes.data, 0, nbytes)      # faults the pages in
+            # a caller that copies beside the step (esq_snapshot_copy) wants its
+            # destination page-locked: 0.2 ms for 80 MB of resident pages, here
+            # instead of on the copy worker
+            pinned = self._pin and _lib.load().esq_host_pin(buf.ctypes.data, nbytes) == 0
             with self._wake:
                 self._pending -= 1
                 if nbytes == self._nbytes and len(self._ready) < self.depth:
                     self._ready.append(buf)
+                    if pinned:
+                        self._pinned.add(buf.ctypes.data)
+                    pinned = False
+            if pinned:                                    # not wanted any more
+                _lib.load().esq_host_unpin(buf.ctypes.data)
 
     def _start(self):
         import threading
@@ -72,26 +83,48 @@ class WarmBuffers:
             th.start()
             self._threads.append(th)
 
-    def take(self, n, dtype):
-        """an (n,) array of `dtype` to download into; warm if one is ready"""
+    def _drop_ready(self):
+        for buf in self._ready:
+            if buf.ctypes.data in self._pinned:
+                _lib.load().esq_host_unpin(buf.ctypes.data)
+        self._ready = []
+        self._pinned = set()
+
+    def take(self, n, dtype, pinned=False):
+        """an (n,) array of `dtype` to download into; warm if one is ready.
+        pinned=True: -> (array, is_page_locked); the caller (the copy worker's
+        esq_snapshot_copy) releases the lock.  Arrays handed out otherwise are
+        never page-locked."""
         nbytes = int(n) * np.dtype(dtype).itemsize
         if not self.enabled or nbytes < self.MIN_BYTES:
-            return np.empty(n, dtype=dtype)
+            out = np.empty(n, dtype=dtype)
+            return (out, False) if pinned else out
+        locked = False
         with self._wake:
             count = self._seen.get(nbytes, 0) + 1
             self._seen = {nbytes: count}
             if count < 2:                     # a pattern, not a one-off
-                return np.empty(n, dtype=dtype)
+                out = np.empty(n, dtype=dtype)
+                return (out, False) if pinned else out
             if nbytes != self._nbytes:
                 self._nbytes = nbytes
-                self._ready = []
+                self._drop_ready()
+            if pinned:
+                self._pin = True
             buf = self._ready.pop() if self._ready else None
+            if buf is not None and buf.ctypes.data in self._pinned:
+                self._pinned.discard(buf.ctypes.data)
+                locked = True
             if not self._threads:
                 self._start()
             self._wake.notify_all()
         if buf is None:
-            return np.empty(n, dtype=dtype)
-        return buf.view(dtype)
+            out = np.empty(n, dtype=dtype)
+            return (out, False) if pinned else out
+        if locked and not pinned:
+            _lib.load().esq_host_unpin(buf.ctypes.data)
+            locked = False
+        return (buf.view(dtype), locked) if pinned else buf.view(dtype)
 
 
 _warm = WarmBuffers()

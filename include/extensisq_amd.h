@@ -348,6 +348,25 @@ size_t esq_vector_len(const esq_ctx *ctx);
  * always the first stage of the step in flight; esq_rk_accept rotates). */
 int  esq_upload(esq_ctx *ctx, int slot, int row, const double *host);
 int  esq_download(esq_ctx *ctx, int slot, int row, double *host);
+/* A download that runs BESIDE the steps that follow (plain solve_ivp keeps every
+ * accepted `solver.y`, scipy ivp.py:665, 702: 80 MB per step at n = 1e7, three times
+ * the step's own time).  esq_snapshot_begin (the thread that drives the context)
+ * marks the point in the context's stream at which the vector is final and returns
+ * a token; esq_snapshot_copy (ANY thread, typically a copy worker; blocks until the
+ * data is in `host`; touches nothing of the context but its copy stream) waits for
+ * that point on a second stream and copies.  The caller guarantees that nothing
+ * overwrites the vector before the copy has returned -- a state vector of an
+ * explicit pair is next written two steps after it was formed (Python side:
+ * extensisq_amd/lazy.py).  host == NULL: give the token back without copying.
+ * Copies of 8 MB and more run into a PINNED destination: host_is_pinned != 0 says the
+ * caller has pinned `host` already (esq_host_pin: a helper thread does it while the
+ * step runs), otherwise the call pins it; either way it is unpinned before the call
+ * returns.  Not for host-slab contexts (ESQ_ENOTSUP). */
+int  esq_snapshot_begin(esq_ctx *ctx, int slot, int row, void **token_out);
+int  esq_snapshot_copy(void *token, double *host, int host_is_pinned);
+/* page-lock / release a host buffer (hipHostRegister, portable across devices) */
+int  esq_host_pin(void *host, size_t bytes);
+int  esq_host_unpin(void *host);
 /* device-to-device copy between two (slot,row) vectors, asynchronous */
 int  esq_copy(esq_ctx *ctx, int dst_slot, int dst_row, int src_slot, int src_row);
 

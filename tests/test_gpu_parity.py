@@ -934,6 +934,119 @@ def test_solve_ivp_device_rhs_t_eval_and_events(name):
     assert_allclose(got.t_events[0], ref.t_events[0], rtol=1e-7)
 
 
+# ------------------------------------- deferred mirrors of large states (lazy.py)
+def _lazy_pair(monkeypatch, cls, N=1024, **kw):
+    """two solvers of the same IVP (heat, n = N^2 >= 8 MB / 8): `solver.y` deferred /
+    downloaded at once"""
+    rho = esq.Heat2D(N).spectral_radius()
+    kw = dict(dict(rtol=1e-6, atol=1e-9, first_step=0.5 / rho, max_step=1.0 / rho,
+                   nfev_stiff_detect=0), **kw)
+    y0 = pb.heat2d_y0(N, seed=3)
+    a = cls(esq.Heat2D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_LAZY_Y", "0")
+    b = cls(esq.Heat2D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_LAZY_Y")
+    assert a._lazy_on and not b._lazy_on
+    return a, b
+
+
+@pytest.mark.parametrize("name", ["Pr8", "Ts5", "BS5"])
+def test_lazy_state_mirror_matches_the_immediate_download(monkeypatch, name):
+    """`solver.y` of a large device-resident state is a LazyState: nothing is copied
+    until it is used; used one step later, or kept by the caller over many steps
+    (what plain solve_ivp does, ivp.py:702), it holds the state of ITS step, bit for
+    bit what a solver that downloads at once returns -- distinct arrays, as the
+    reference's (common.py:343)"""
+    from extensisq_amd.lazy import LazyState
+    a, b = _lazy_pair(monkeypatch, DEV[name])
+    kept, want = [], []
+    for k in range(7):
+        assert a.step() is None and b.step() is None
+        ya, yb = a.y, b.y
+        assert isinstance(ya, LazyState) and not ya.materialized
+        assert isinstance(yb, np.ndarray)
+        assert a.y is ya                              # one mirror per state
+        kept.append(ya)
+        want.append(yb)
+        if k == 0:
+            assert not a._lazy_eager
+        if k >= 2:
+            # the caller stores its states: from the third step on the copies run
+            # beside the steps (esq_snapshot_*), started when the mirror is made
+            assert a._lazy_eager and ya._pending is not None
+    for k, (ya, yb) in enumerate(zip(kept, want)):
+        np.testing.assert_array_equal(np.asarray(ya), yb, err_msg=f"state {k}")
+    arrays = [np.asarray(m) for m in kept]
+    assert len({x.ctypes.data for x in arrays}) == len(arrays)
+    assert a.t == b.t and a.nfev == b.nfev
+    # used late: the state before the current one is still on the device
+    assert a.step() is None and b.step() is None
+    ya, yb = a.y, b.y
+    del kept, arrays
+    assert a.step() is None and b.step() is None
+    np.testing.assert_array_equal(ya + 0.0, yb)
+    # not used at all: nothing is copied, and the eager copies stop again
+    for _ in range(4):
+        assert a.step() is None and b.step() is None
+        a.y, b.y
+    assert not a._lazy_eager
+    np.testing.assert_array_equal(np.asarray(a.y), b.y)
+
+
+def test_lazy_state_survives_an_assignment_to_the_state(monkeypatch):
+    """`solver.y = value` uploads a new state: a mirror of the old one that somebody
+    holds has been downloaded before"""
+    a, b = _lazy_pair(monkeypatch, esq.Pr8)
+    assert a.step() is None and b.step() is None
+    ya, yb = a.y, b.y
+    a.y = 2.0 * np.asarray(yb)
+    b.y = 2.0 * yb
+    assert ya.materialized
+    np.testing.assert_array_equal(np.asarray(ya), yb)
+    assert a.step() is None and b.step() is None
+    np.testing.assert_array_equal(np.asarray(a.y), b.y)
+
+
+@pytest.mark.parametrize("mode", ["stored", "t_eval", "dense", "events"])
+def test_solve_ivp_with_deferred_states(monkeypatch, mode):
+    """the drop-in call on a large state, every way scipy uses `solver.y`
+    (ivp.py:665-736): kept per step, ignored (t_eval / dense_output), handed to an
+    event function -- results bit-identical to immediate downloads"""
+    N = 1024
+    rho = esq.Heat2D(N).spectral_radius()
+    y0 = pb.heat2d_y0(N, seed=5)
+    tf = 9.3 / rho
+    kw = dict(rtol=1e-6, atol=1e-9, first_step=0.5 / rho, max_step=1.0 / rho,
+              nfev_stiff_detect=0)
+    seen = []
+    if mode == "t_eval":
+        kw["t_eval"] = [0.3 * tf, tf]
+    elif mode == "dense":
+        kw["dense_output"] = True
+    elif mode == "events":
+        mid = (N // 2) * N + N // 2
+
+        def event(t, y):
+            seen.append(type(y).__name__)
+            return y[mid] - 0.5 * (y0[mid] + y0[mid] * np.exp(-2 * np.pi ** 2 * tf))
+        kw["events"] = event
+    got = solve_ivp(esq.Heat2D(N), (0.0, tf), y0, method=esq.Pr8, **kw)
+    if mode == "events":
+        assert "LazyState" in seen
+    monkeypatch.setenv("ESQ_LAZY_Y", "0")
+    ref = solve_ivp(esq.Heat2D(N), (0.0, tf), y0, method=esq.Pr8, **kw)
+    assert got.success and ref.success and got.nfev == ref.nfev
+    np.testing.assert_array_equal(got.t, ref.t)
+    np.testing.assert_array_equal(got.y, ref.y)
+    assert isinstance(got.y, np.ndarray)
+    if mode == "dense":
+        tc = np.linspace(0.0, tf, 5)
+        np.testing.assert_array_equal(got.sol(tc), ref.sol(tc))
+    if mode == "events":
+        np.testing.assert_array_equal(got.t_events[0], ref.t_events[0])
+        np.testing.assert_array_equal(got.y_events[0], ref.y_events[0])
+
+
 # ---------------------------------------------------- user-compiled RHS plugin
 PLUGIN_SRC = r'''
 #include <hip/hip_runtime.h>

@@ -1,0 +1,108 @@
+"""extensisq_amd/lazy.py without a GPU: the array-like that `solver.y` returns for a
+large device-resident state downloads on first real use, once, and then behaves like
+the ndarray it holds (what scipy's solve_ivp and user event functions do with it)."""
+import threading
+
+import numpy as np
+import pytest
+from numpy.testing import assert_array_equal
+
+from extensisq_amd.lazy import CopyWorker, LazyState
+
+
+def make(n=7):
+    calls = []
+    data = np.linspace(-1.0, 2.0, n)
+
+    def fetch():
+        calls.append(1)
+        return data.copy()
+    return LazyState(fetch, n, np.float64), data, calls
+
+
+def test_metadata_costs_nothing():
+    m, data, calls = make()
+    assert m.shape == (7,) and m.size == 7 and m.ndim == 1 and len(m) == 7
+    assert m.dtype == np.float64 and not m.materialized
+    assert "on device" in repr(m)
+    assert calls == []
+
+
+def test_first_real_use_downloads_once():
+    m, data, calls = make()
+    assert_array_equal(np.asarray(m), data)
+    assert_array_equal(np.asarray(m), data)
+    assert calls == [1] and m.materialized
+    assert np.asarray(m) is m.materialize()              # no second copy
+    assert np.array(m, copy=True) is not m.materialize()
+
+
+@pytest.mark.parametrize("use", [
+    lambda m: m[2], lambda m: m[1:4], lambda m: m + 1.0, lambda m: 2.0 * m, lambda m: m @ m,
+    lambda m: -m, lambda m: m < 0.5, lambda m: np.sin(m), lambda m: np.linalg.norm(m),
+    lambda m: np.vstack([m, m]).T, lambda m: np.concatenate([m, m]), lambda m: m.copy(),
+    lambda m: m.sum(), lambda m: m.T, lambda m: list(m), lambda m: np.maximum(m, 0.0),
+    lambda m: np.add(m, m, out=np.empty(7)), lambda m: float(m[0]), lambda m: m.astype(np.float32),
+    lambda m: np.asarray(m, dtype=complex), lambda m: m[:, np.newaxis] * np.ones(3)])
+def test_behaves_like_the_array(use):
+    m, data, calls = make()
+    got, want = use(m), use(data)
+    assert calls == [1]
+    assert type(got) is type(want) or np.isscalar(want)
+    assert_array_equal(np.asarray(got), np.asarray(want))
+
+
+def test_what_solve_ivp_does_with_stored_states():
+    """ivp.py:702, 734: `ys.append(y)` every step, `np.vstack(ys).T` at the end"""
+    ms = [make(5) for _ in range(4)]
+    ys = [m for m, _d, _c in ms]
+    out = np.vstack(ys).T
+    assert out.shape == (5, 4)
+    for k, (_m, data, calls) in enumerate(ms):
+        assert_array_equal(out[:, k], data)
+        assert calls == [1]
+
+
+def test_setitem_writes_the_host_copy():
+    m, data, calls = make()
+    m[0] = 5.0
+    assert m[0] == 5.0 and calls == [1]
+
+
+def test_copy_under_way_is_waited_for():
+    gate = threading.Event()
+    out = np.zeros(4)
+
+    def begin():
+        def copy_fn():
+            gate.wait(5.0)
+            out[:] = [1.0, 2.0, 3.0, 4.0]
+            return out
+        return copy_fn, out
+    m = LazyState(lambda: (_ for _ in ()).throw(AssertionError("not the sync path")), 4,
+                  np.float64)
+    m.start_copy(begin)
+    assert not m.materialized
+    threading.Timer(0.05, gate.set).start()
+    assert_array_equal(np.asarray(m), [1.0, 2.0, 3.0, 4.0])
+    assert np.asarray(m) is out
+
+
+def test_a_failed_copy_raises_in_the_reader():
+    def begin():
+        def copy_fn():
+            raise RuntimeError("device lost")
+        return copy_fn, np.zeros(2)
+    m = LazyState(lambda: np.zeros(2), 2, np.float64)
+    m.start_copy(begin)
+    with pytest.raises(RuntimeError, match="device lost"):
+        np.asarray(m)
+
+
+def test_copy_worker_runs_jobs_in_order():
+    w = CopyWorker()
+    seen = []
+    jobs = [w.submit(lambda k=k: seen.append(k) or k) for k in range(5)]
+    for done, _box in jobs:
+        assert done.wait(5.0)
+    assert seen == list(range(5)) and [b[0] for _d, b in jobs] == list(range(5))
