@@ -145,6 +145,7 @@ SIGNATURES = {
     "esq_rhs_heat2d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_bruss2d_chain": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_heat2d_chain": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "esq_rhs_diff3d_chain": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_diff3d_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_diag_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),
     "esq_rhs_cdiag_fused": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp, _vp, _vp]),

@@ -30,6 +30,19 @@ from .lazy import LazyState
 
 LAZY_MIN_BYTES = 8 << 20       # states below this are downloaded at once
 
+
+def _read_by_solve_ivp():
+    """is `solver.y` being read by the loop of scipy's `solve_ivp` (ivp.py:665)?  That
+    loop reads the state after EVERY step whether it uses it or not; only it gets the
+    deferred mirror, so that direct users of a solver see plain ndarrays"""
+    import sys
+    try:
+        code = sys._getframe(2).f_code
+    except ValueError:
+        return False
+    return code.co_name == "solve_ivp" and code.co_filename.replace("\\", "/").endswith(
+        "scipy/integrate/_ivp/ivp.py")
+
 # failed-step counter shared with the RKC module (reference: common.py:14)
 NFS = np.array(0)
 NFI = np.array(0)     # kept for import compatibility (implicit methods: unused)
@@ -316,11 +329,13 @@ class RungeKutta(OdeSolver):
         self._f_host = None
         self._K_host = None
         self._y_old_host = None
-        # large device-resident states: `solver.y` is a deferred mirror (lazy.py);
-        # ESQ_LAZY_Y=0: downloaded at once, as small states always are
+        # large device-resident states: `solver.y` READ BY scipy's solve_ivp loop is a
+        # deferred mirror (lazy.py); every other caller gets the ndarray it always
+        # got.  ESQ_LAZY_Y=0: never; ESQ_LAZY_Y=always: for every caller
+        mode = os.environ.get("ESQ_LAZY_Y", "1")
         self._lazy_on = (self._device_rhs is not None and not self._dev.host_slab
-                         and y_host.nbytes >= LAZY_MIN_BYTES
-                         and os.environ.get("ESQ_LAZY_Y", "1") != "0")
+                         and y_host.nbytes >= LAZY_MIN_BYTES and mode != "0")
+        self._lazy_always = mode == "always"
         self._state_gen = 0          # accepted steps: which state the device holds
         self._lazy_live = []         # [weakref(mirror), generation, copy-done event]
         self._lazy_eager = False     # the caller stores its states: copy at once
@@ -497,9 +512,12 @@ class RungeKutta(OdeSolver):
         that downloads when it is really used -- plain `solve_ivp` reads `solver.y`
         after every step (ivp.py:665) whether it needs it or not"""
         if self._y_host is None:
-            self._y_host = (self._new_lazy_state() if self._lazy_on
-                            else self._dev.download(SLOT_Y))
-        if isinstance(self._y_host, LazyState) and self._y_host.materialized:
+            lazy = self._lazy_on and (self._lazy_always or _read_by_solve_ivp())
+            self._y_host = self._new_lazy_state() if lazy else self._dev.download(SLOT_Y)
+        if isinstance(self._y_host, LazyState) and (
+                self._y_host.materialized
+                or not (self._lazy_always or _read_by_solve_ivp())):
+            # (used already -- or a caller other than solve_ivp's loop asks: the array)
             self._y_host = self._y_host.materialize()
         return self._y_host
 

@@ -86,6 +86,7 @@ struct PlanStep {
     signed char i, depth, what;       // what: 0 next argument, 1 y_new (FSAL), 2 y_new + error
     bool lazy, from_rows, skip_out;   // chain forms
     float reads, writes;              // designed words per element (halo re-reads not counted)
+    float amp = 0.0f;                 // chain: read amplification the plugin reported (0: none)
 };
 struct Plan {
     std::vector<PlanStep> steps;

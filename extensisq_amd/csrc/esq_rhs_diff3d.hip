@@ -2,6 +2,7 @@
 // (BASELINE.json configs[3], the SSV2stab workload).
 #include "esq_rhs_common.hpp"
 #include "esq_rkc3d.hpp"
+#include "esq_chain3d.hpp"
 
 using namespace esq_rhs;
 
@@ -327,6 +328,16 @@ int esq_rhs_diff3d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void
         case 6: return launch_rkc3d_d<6>(r, ch, s, e0, e1);
         default: return ESQ_ENOTSUP;
     }
+}
+
+// D consecutive Runge-Kutta stages per launch (esq_rhs_chain_fn, esq_chain3d.hpp)
+int esq_rhs_diff3d_chain(void *user, const double *y_in, const esq_chain *chain, size_t n,
+                         void *stream, void *start_event, void *stop_event) {
+    Rhs *r = (Rhs *)user;
+    if (!r || r->kind != DIFF3D || n != r->n || !chain) return ESQ_EINVAL;
+    const double c = (double)(r->N + 1) * (double)(r->N + 1);
+    return esq::chain3d(Diff3dSt{c}, r->N, y_in, chain, r->rkc_planes, r->rkc_force != 0,
+                        stream, start_event, stop_event);
 }
 
 int esq_rhs_diff3d_create(void **user_out, int N) {

@@ -162,6 +162,7 @@ bool may_fuse(const esq_ctx *c, int kind) {
 struct Dry {
     double reads = 0.0, writes = 0.0;
     bool made = false;                 // block sweep: also wrote the boundary stage's argument
+    double amp = 0.0;                  // chain: the plugin's own read amplification (0: not told)
 };
 int ask_fused(esq_ctx *c, double t, const double *y_in, double *f_out, esq_epilogue &e) {
     if (!(c->fuse_mask & ESQ_FUSE_QUERY)) return 0;
@@ -387,10 +388,13 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
         dry->reads = reads; dry->writes = writes;
         if (!(c->chain_caps & ESQ_CHAIN_CAP_QUERY)) return 0;
         int used = 0;
+        double amp_q = 0.0;
         e.partials_used = &used;
+        e.read_amplification = &amp_q;     // (a plugin may price its tile geometry itself)
         e.dry_run = 1;
         const int rq = c->rhs_chain(c->rhs_user, i == 0 ? c->y : c->ystage, &e, c->len,
                                     (void *)c->stream, nullptr, nullptr);
+        dry->amp = amp_q;
         return rq == 0 ? 0 : ESQ_ENOTSUP;
     }
     double amp = 1.0;
@@ -702,7 +706,10 @@ double step_cost(const esq_ctx *c, const PlanStep &st) {
     const double launch = 2.0 / (word_us > 1e-3 ? word_us : 1e-3);
     double u = st.reads + kW * st.writes;
     if (st.op == OP_CHAIN) {
-        u = 1.15 * (st.reads * kHalo[st.depth < 8 ? st.depth : 7] + kW * st.writes);
+        // (a plugin that prices its own tile geometry -- the 3-D sweeps, whose halo
+        // grows with the surface of a tile -- is taken at its word)
+        const double halo = st.amp > 0.0f ? (double)st.amp : kHalo[st.depth < 8 ? st.depth : 7];
+        u = 1.15 * (st.reads * halo + kW * st.writes);
         if (st.depth == 2) u *= 1.25;
     }
     return u + launch;
@@ -733,7 +740,7 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
                   bool lazy = false, bool from_rows = false, bool skip_out = false) {
         return PlanStep{(unsigned char)op, (signed char)i, (signed char)depth,
                         (signed char)what, lazy, from_rows, skip_out, (float)d.reads,
-                        (float)d.writes};
+                        (float)d.writes, (float)d.amp};
     };
     auto refused = [&](const PlanStep &st) { return c->refused.count(step_signature(st)) != 0; };
     std::map<unsigned long long, std::pair<int, Dry>> asked;     // chain queries, memoised
@@ -1484,6 +1491,7 @@ static int make_detached(esq_ctx *c, void **user_out, const char *plugin, int N,
         if (esq_rhs_diff3d_create(&user, N)) return ESQ_EINVAL;
         n = (size_t)N * N * N;
         c->rhs = esq_rhs_diff3d; c->rhs_fused = esq_rhs_diff3d_fused;
+        c->rhs_chain = esq_rhs_diff3d_chain;
     } else if (name == "plain") {                 // an esq_rhs_fn-only plugin
         if (esq_rhs_heat2d_create(&user, N)) return ESQ_EINVAL;
         n = (size_t)N * N;

@@ -580,6 +580,10 @@ class Diffusion3D(_Builtin):
     _symbol_fused = "esq_rhs_diff3d_fused"
     _symbol_rkc = "esq_rhs_diff3d_rkc"
     _symbol_rkc_chain = "esq_rhs_diff3d_rkc_chain"
+    _symbol_chain = "esq_rhs_diff3d_chain"
+    # the chain sweeps start a step from the state and leave rows unwritten; they
+    # do not form their own input from memory rows (no FROM_ROWS / SKIP_OUT)
+    _chain_caps = _lib.CHAIN_CAP_QUERY | 1 | 2
     _fuse_default = True
     _fuse_src = False                 # no on-the-fly first-stage input in 3-D
 

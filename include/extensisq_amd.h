@@ -770,6 +770,9 @@ int  esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chai
 int  esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
                           size_t n, void *stream, void *start_event,
                           void *stop_event);
+int  esq_rhs_diff3d_chain(void *user, const double *y_in, const esq_chain *chain,
+                          size_t n, void *stream, void *start_event,
+                          void *stop_event);
 int  esq_rhs_diff3d_fused(void *user, double t, const double *y_in, double *f,
                           const esq_epilogue *epi, size_t n, void *stream,
                           void *start_event, void *stop_event);

@@ -95,6 +95,8 @@ REQUIRED = {
     # next rows
     "test_gpu_parity.py::test_device_dense_output_large_n": 8,
     "test_gpu_parity.py::test_device_h_start": 18,
+    "test_gpu_parity.py::test_diffusion3d_erk_chain_sweeps_are_bit_identical": 21,
+    "test_gpu_parity.py::test_diffusion3d_erk_chain_sweeps_match_oracle": 8,
     "test_gpu_parity.py::test_lazy_state_mirror_matches_the_immediate_download": 3,
     "test_gpu_parity.py::test_lazy_state_survives_an_assignment_to_the_state": 1,
     "test_gpu_parity.py::test_solve_ivp_with_deferred_states": 4,

@@ -616,7 +616,10 @@ def test_diffusion3d_erk_fused_sweeps(monkeypatch, name, N):
     h = 1.0 / rho
     # (tolerances at which no attempt is rejected: every run takes bitwise the same h)
     kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+    # (one sweep per stage: the chain sweeps have test_diffusion3d_erk_chain_sweeps)
+    monkeypatch.setenv("ESQ_CHAIN_DEPTH", "1")
     fused = DEV[name](esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_CHAIN_DEPTH")
     monkeypatch.setenv("ESQ_CHAIN", "0")
     plain = DEV[name](esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
     monkeypatch.delenv("ESQ_CHAIN")
@@ -643,6 +646,87 @@ def test_diffusion3d_erk_fused_sweeps(monkeypatch, name, N):
     assert_equal(fused.y, plain.y)
     assert_equal(fused.K, plain.K)
     assert fused.nfev == plain.nfev
+
+
+@pytest.mark.parametrize("N,planes", [(5, 0), (13, 3), (24, 0), (41, 7), (57, 0), (64, 5),
+                                      (70, 16)])
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_diffusion3d_erk_chain_sweeps_are_bit_identical(monkeypatch, N, planes, depth):
+    """D consecutive stages per marching sweep on the 3-D plugin (esq_rhs_diff3d_chain,
+    csrc/esq_chain3d.hpp) against one sweep per stage: K and y bit for bit over three
+    steps (the second and third start with the end-point derivative as stage 0 of
+    their first chain, rows are left unwritten and restored for the comparison), the
+    error norm to rounding; grids of one and of several patches per plane, odd and
+    even, forced tile depths (run-in planes, plane ranges that do not divide N)"""
+    from extensisq_amd._lib import PROF_RHS, PROF_SOLERR, PROF_STAGE
+    monkeypatch.setenv("ESQ_RKC_FORCE", "1")
+    monkeypatch.setenv("ESQ_RKC_PLANES", str(planes))
+    rng = np.random.default_rng(100 + N)
+    y0 = pb.diff3d_y0(N) + 0.1 * rng.standard_normal(N ** 3)
+    h = 1.0 / (12.0 * (N + 1) ** 2)
+    kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+    chained = []
+    for name in ("Pr8", "Ts5", "BS5", "Pr9", "CK5"):
+        monkeypatch.setenv("ESQ_CHAIN_DEPTH", str(depth))
+        a = DEV[name](esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+        monkeypatch.setenv("ESQ_CHAIN_DEPTH", "1")
+        b = DEV[name](esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+        a._dev.profile_reset()
+        a._dev.profile_enable([PROF_STAGE, PROF_RHS, PROF_SOLERR])
+        for k in range(3):
+            assert a.step() is None and b.step() is None
+            assert a.t == b.t
+            assert_allclose(a.error_norm_old, b.error_norm_old, rtol=1e-11)
+        a._dev.profile_enable(None)
+        labels = [row[0] for row in a._dev.profile_kernels()]
+        # (the planner takes a chain where its words x tile amplification cost less)
+        chained += [name] if any(lab.startswith("chain") for lab in labels) else []
+        assert_equal(np.asarray(a.y), np.asarray(b.y), err_msg=name)
+        assert_equal(a.K, b.K, err_msg=name)
+        assert a.nfev == b.nfev
+    assert "Pr8" in chained and len(chained) >= 3, chained
+
+
+@pytest.mark.parametrize("name", ["Pr8", "Ts5", "BS5", "Pr9"])
+@pytest.mark.parametrize("N", [64, 159])
+def test_diffusion3d_erk_chain_sweeps_match_oracle(name, N):
+    """the default launch plan of an explicit pair on the 3-D plugin (chain sweeps from
+    N = 48) against the oracle's step from the same (t, y, h), and bit-identical to the
+    entry-free run (ESQ_CHAIN=0) over three steps; BASELINE.json configs[3]'s grid"""
+    import os
+    y0 = pb.diff3d_y0(N)
+    if N < 100:
+        y0 = y0 + 1e-3 * np.random.default_rng(N).standard_normal(N ** 3)
+    rho = 12.0 * (N + 1) ** 2
+    h = 1.0 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-3, atol=1e-6, nfev_stiff_detect=0)
+    chained = DEV[name](esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+    os.environ["ESQ_CHAIN"] = "0"
+    try:
+        plain = DEV[name](esq.Diffusion3D(N), 0.0, y0, 1.0, **kw)
+    finally:
+        del os.environ["ESQ_CHAIN"]
+    plain._prelaunch = False
+    o = rk_oracle.METHODS[name](pb.diff3d_rhs(N), 0.0, y0, 1.0, **kw)
+    y_old = o.y
+    assert chained.step() is None and plain.step() is None and o.step() is None
+    # (a stage argument y + h sum_j a_ij K_j is rounded at eps * sum_j |a_ij| |h K_j| ~
+    # eps * sum_j |a_ij| * |y| where h L ~ 1, and the RHS amplifies that by L)
+    row_sum = max(1.0, float(np.abs(DEV[name].A).sum(axis=1).max()))
+    check_step(chained, o.K, o.y, o.error_norm_old, o.h_abs, y_old, o.h_previous,
+               1e-3, 1e-6, k_rtol=2e-13, lipschitz=rho * row_sum)
+    from extensisq_amd._lib import PROF_RHS, PROF_SOLERR, PROF_STAGE
+    chained._dev.profile_reset()
+    chained._dev.profile_enable([PROF_STAGE, PROF_RHS, PROF_SOLERR])
+    for _ in range(2):
+        assert chained.step() is None and plain.step() is None
+        assert_allclose(chained.error_norm_old, plain.error_norm_old, rtol=1e-11)
+    chained._dev.profile_enable(None)
+    labels = [row[0] for row in chained._dev.profile_kernels()]
+    assert any(lab.startswith("chain") for lab in labels), labels
+    assert_equal(np.asarray(chained.y), np.asarray(plain.y))
+    assert_equal(chained.K, plain.K)
+    assert chained.nfev == plain.nfev
 
 
 @pytest.mark.parametrize("name,plugin,N", [("Pr8", "bruss", 2236), ("Ts5", "heat", 1000),
@@ -942,11 +1026,16 @@ def _lazy_pair(monkeypatch, cls, N=1024, **kw):
     kw = dict(dict(rtol=1e-6, atol=1e-9, first_step=0.5 / rho, max_step=1.0 / rho,
                    nfev_stiff_detect=0), **kw)
     y0 = pb.heat2d_y0(N, seed=3)
+    # (by default only scipy's solve_ivp loop gets the mirror: `always` = every reader)
+    monkeypatch.setenv("ESQ_LAZY_Y", "always")
     a = cls(esq.Heat2D(N), 0.0, y0, 1.0, **kw)
     monkeypatch.setenv("ESQ_LAZY_Y", "0")
     b = cls(esq.Heat2D(N), 0.0, y0, 1.0, **kw)
     monkeypatch.delenv("ESQ_LAZY_Y")
-    assert a._lazy_on and not b._lazy_on
+    assert a._lazy_on and a._lazy_always and not b._lazy_on
+    # a solver made without the switch hands a direct reader the plain array
+    c = cls(esq.Heat2D(N), 0.0, y0, 1.0, **kw)
+    assert c._lazy_on and isinstance(c.y, np.ndarray)
     return a, b
 
 

@@ -120,9 +120,11 @@ def test_baseline_configuration_plans(plans):
     # a plugin with esq_rhs_fn only: one library kernel + one RHS launch per stage
     plain = plans["Pr8/plain100/caps0/lazy1"]
     assert plain[0].count("accum[") == 12 and plain[0].count("rhs[") == 12
-    # the 3-D plugin fuses every stage but has no chain entry
-    d3 = plans["Pr8/diff3d159/caps0/lazy1"]
-    assert "chain" not in d3[0] and d3[0].count("stage[") == 10 and "solerr[12]" in d3[0]
+    # the 3-D plugin (csrc/esq_chain3d.hpp): chains of three and four stages, the end of
+    # the step inside the last one; 38 words per element and step (13 fused sweeps: 104)
+    d3 = plans["Pr8/diff3d159/caps3/lazy1"]
+    assert d3[1].startswith("deferred: chain[0,3,0]L chain[3,3,0]L chain[6,4,0]L chain[10,3,2]L "
+                            "| launches=4 words=24+14 ")
 
 
 def test_more_capabilities_never_cost_more(plans):
@@ -245,9 +247,10 @@ def test_launch_ahead_leaves_the_step_state_as_it_found_it(plugin, N):
     in between"""
     import extensisq_amd as esq
     classes = [getattr(esq, m) for m in gsp.METHODS] + [gsp.heun()]
-    has_chain = plugin in ("bruss2d", "heat2d")
+    has_chain = plugin in ("bruss2d", "heat2d", "diff3d")
     for cls in classes:
-        for caps in (range(16) if has_chain else [0]):
+        for caps in (range(16) if plugin != "diff3d" and has_chain else
+                     [0, 1, 2, 3] if has_chain else [0]):
             for lazy in (0, 1):
                 rows = _dry(cls, plugin, N, caps=caps | gsp.CAP_QUERY, lazy=lazy)
                 assert all(row[1] == 1 for row in rows), (cls.__name__, caps, lazy, rows)

@@ -54,8 +54,10 @@ def table():
     classes = [(m, getattr(esq, m)) for m in METHODS] + [("Heun", heun())]
     for name, cls in classes:
         for plugin, N in PLUGINS:
-            has_chain = plugin in ("bruss2d", "heat2d")
-            for caps in (range(16) if has_chain else [0]):
+            # (the 3-D plugin's chain entry: plain chains, from the state, rows unwritten)
+            all_caps = (range(16) if plugin in ("bruss2d", "heat2d")
+                        else [0, 1, 2, 3] if plugin == "diff3d" else [0])
+            for caps in all_caps:
                 for lazy in (0, 1):
                     # working sets inside the Infinity Cache take stage 1 from the state
                     src = 1 if (plugin, N) == ("heat2d", 1000) else 0
