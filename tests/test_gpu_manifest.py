@@ -101,6 +101,13 @@ REQUIRED = {
     "test_gpu_parity.py::test_lazy_state_survives_an_assignment_to_the_state": 1,
     "test_gpu_parity.py::test_solve_ivp_with_deferred_states": 4,
     "test_gpu_stiffness.py::test_diagnosis_matches_reference": 1,
+    # csrc/esq_stencil3d.hpp with user functors: the reference's two demo problems
+    "test_gpu_stencil3d.py::test_tanh_heat_rhs_matches_the_twin": 3,
+    "test_gpu_stencil3d.py::test_combustion_rhs_matches_the_twin": 3,
+    "test_gpu_stencil3d.py::test_explicit_pairs_on_the_generic_sweep": 8,
+    "test_gpu_stencil3d.py::test_chebyshev_stage_entry_on_the_generic_sweep": 2,
+    "test_gpu_stencil3d.py::test_published_heat_table_device_rhs": 6,
+    "test_gpu_stencil3d.py::test_published_combustion_table_device_rhs": 4,
 }
 
 
