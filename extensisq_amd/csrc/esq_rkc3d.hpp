@@ -122,6 +122,9 @@ inline double amp_rkc3d(const Geo3d &g, int D) {
 // that evaluates f(t + h, y_{n+1}) with the error estimate as stage slot D - 1 -- the
 // final iterate is still in the window registers, y_n and f_n arrive down the delay
 // lines the stages use anyway.
+#ifndef ESQ_RKC3D_EARLY
+#define ESQ_RKC3D_EARLY -1
+#endif
 template <int D, int JT, int NW, class St, bool FIRST = false, bool LAST = false>
 __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st, Geo3d g) {
     // edge rows of the D centre planes: slot w + 1 belongs to wave w, slots 0 and
@@ -187,36 +190,6 @@ __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st,
                                    __dmul_rn(ca.omn[k], c0)),
                          __dmul_rn(ca.hmus[k], __dsub_rn(fy, __dmul_rn(ca.ajm1[k], gg))));
     };
-    // windows: wm[k], wc[k] = Y_k at planes (centre - 1, centre) of stage k;
-    // dy[k], df[k] = y_n, f_n at stage k's centre plane (a delay line)
-    double wm[D][JT], wc[D][JT], dy[D][JT], df[D][JT];
-#pragma unroll
-    for (int k = 0; k < D; ++k)
-#pragma unroll
-        for (int r = 0; r < JT; ++r) wm[k][r] = wc[k][r] = dy[k][r] = df[k][r] = 0.0;
-    const int ibase = i_lo - (D - 1);                 // stage 0's first centre plane
-    auto first = [&](double y, double f) -> double {          // k_rkc_first's rounding
-        return __dadd_rn(y, __dmul_rn(ca.hmus1, f));
-    };
-    // FIRST: y_n, f_n at stage 0's centre plane (loaded as the plane AFTER the
-    // centre one iteration earlier)
-    double cy[JT], cf[JT];
-#pragma unroll
-    for (int r = 0; r < JT; ++r) {
-        if constexpr (FIRST) {
-            wm[0][r] = first(ld(ry, ibase - 1, r), ld(rf, ibase - 1, r));
-            cy[r] = ld(ry, ibase, r);
-            cf[r] = ld(rf, ibase, r);
-            wc[0][r] = first(cy[r], cf[r]);
-        } else {
-            wm[0][r] = ld(ra, ibase - 1, r);
-            wc[0][r] = ld(ra, ibase, r);
-            cy[r] = cf[r] = 0.0;
-        }
-    }
-    // operands of stage 0's plane, requested ONE ITERATION AHEAD (beyond the last
-    // iteration: one more plane is requested and never used)
-    double pa[JT], pb[JT], py[JT], pf[JT];
 #define ESQ_RKC3D_LOAD(IT)                                                  \
     {                                                                       \
         const int i_ = ibase + (IT);                                        \
@@ -232,101 +205,282 @@ __global__ __launch_bounds__(64 * NW) void k_rkc3d_chain(Rkc3dArgs<D> ca, St st,
             }                                                               \
         }                                                                   \
     }
-    ESQ_RKC3D_LOAD(0)
-    const int iters = Re + 2 * (D - 1);
-    for (int it = 0; it < iters; ++it) {
-        const int i0 = ibase + it;
-        double wp[JT], ykm1[JT];
+    // TWO forms of the marching loop, by tile shape (same arithmetic, same results):
+    //  * wide tiles (D JT >= 16: D = 5 on four rows per thread sits at 249 of 256
+    //    registers): ONE arriving plane handed from stage to stage, each window moving
+    //    on as soon as its stage is done;
+    //  * narrow tiles: an arriving plane per stage, all windows moving on at the end of
+    //    the iteration -- rkc_chain4 on sixteen waves of two rows 49.9 -> 46.2 us, SSV2stab
+    //    at N = 159 1.315 -> 1.235 ms/step (same-box A/B, profiles/r05_experiments.md §2);
+    //    the same form on the wide tiles spills (N = 400: 19.0 -> 29.4 ms/step).
+    // ESQ_RKC3D_EARLY=0|1 at compile time forces one form (tuning builds).
+    constexpr bool kEarly = ESQ_RKC3D_EARLY >= 0 ? ESQ_RKC3D_EARLY != 0 : D * JT >= 16;
+    if constexpr (kEarly) {
+        // windows: wm[k], wc[k] = Y_k at planes (centre - 1, centre) of stage k;
+        // dy[k], df[k] = y_n, f_n at stage k's centre plane (a delay line)
+        double wm[D][JT], wc[D][JT], dy[D][JT], df[D][JT];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int r = 0; r < JT; ++r) wm[k][r] = wc[k][r] = dy[k][r] = df[k][r] = 0.0;
+        const int ibase = i_lo - (D - 1);                 // stage 0's first centre plane
+        auto first = [&](double y, double f) -> double {          // k_rkc_first's rounding
+            return __dadd_rn(y, __dmul_rn(ca.hmus1, f));
+        };
+        // FIRST: y_n, f_n at stage 0's centre plane (loaded as the plane AFTER the
+        // centre one iteration earlier)
+        double cy[JT], cf[JT];
 #pragma unroll
         for (int r = 0; r < JT; ++r) {
             if constexpr (FIRST) {
-                wp[r] = first(py[r], pf[r]);
-                ykm1[r] = cy[r];
-                dy[0][r] = cy[r];
-                df[0][r] = cf[r];
-                cy[r] = py[r];
-                cf[r] = pf[r];
+                wm[0][r] = first(ld(ry, ibase - 1, r), ld(rf, ibase - 1, r));
+                cy[r] = ld(ry, ibase, r);
+                cf[r] = ld(rf, ibase, r);
+                wc[0][r] = first(cy[r], cf[r]);
             } else {
-                wp[r] = pa[r];
-                ykm1[r] = pb[r];
-                dy[0][r] = py[r];
-                df[0][r] = pf[r];
+                wm[0][r] = ld(ra, ibase - 1, r);
+                wc[0][r] = ld(ra, ibase, r);
+                cy[r] = cf[r] = 0.0;
             }
         }
-        ESQ_RKC3D_LOAD(it + 1)
-        // the slices' edge rows of all D centre planes change hands
+        // operands of stage 0's plane, requested ONE ITERATION AHEAD (beyond the last
+        // iteration: one more plane is requested and never used)
+        double pa[JT], pb[JT], py[JT], pf[JT];
+        ESQ_RKC3D_LOAD(0)
+        const int iters = Re + 2 * (D - 1);
+        for (int it = 0; it < iters; ++it) {
+            const int i0 = ibase + it;
+            double wp[JT], ykm1[JT];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            xch[it & 1][k][w + 1][0][lane] = wc[k][0];
-            xch[it & 1][k][w + 1][1][lane] = wc[k][JT - 1];
-        }
-        __syncthreads();
-        double eu[D], ed[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            eu[k] = xch[it & 1][k][w][1][lane];
-            ed[k] = xch[it & 1][k][w + 2][0][lane];
-        }
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            double nw[JT];
-            if (it >= 2 * k) {                                   // wave-uniform
-                const int ik = i0 - k;
-                const bool pl_ok = ik >= 0 && ik < N;
-#pragma unroll
-                for (int r = 0; r < JT; ++r) {
-                    const double up = r > 0 ? wc[k][r > 0 ? r - 1 : 0] : eu[k];
-                    const double dn = r < JT - 1 ? wc[k][r < JT - 1 ? r + 1 : r] : ed[k];
-                    const double lf = lane_left(wc[k][r]);
-                    const double rt = lane_right(wc[k][r]);
-                    const double fy = st.eval(wm[k][r], wp[r], up, dn, lf, rt, wc[k][r]);
-                    if (LAST && k == D - 1) {
-                        nw[r] = (pl_ok && in[r]) ? fy : 0.0;
-                        if (so[r] != 0xffffffffu) {              // a point this tile stores
-                            const double er =
-                                __dadd_rn(__dmul_rn(0.8, __dsub_rn(dy[k][r], wc[k][r])),
-                                          __dmul_rn(ca.h04, __dadd_rn(df[k][r], fy)));
-                            const size_t e = (size_t)ik * (size_t)N * (size_t)N + so[r] / 8u;
-                            local += ratio_sq1(er, wc[k][r], dy[k][r], ca.red.atol_vec,
-                                               ca.red.atol_s, ca.red.rtol, e, ca.red.n_valid);
-                        }
-                    } else {
-                        const double v = one(k, wc[k][r], ykm1[r], dy[k][r], df[k][r], fy);
-                        nw[r] = (pl_ok && in[r]) ? v : 0.0;
-                    }
+            for (int r = 0; r < JT; ++r) {
+                if constexpr (FIRST) {
+                    wp[r] = first(py[r], pf[r]);
+                    ykm1[r] = cy[r];
+                    dy[0][r] = cy[r];
+                    df[0][r] = cf[r];
+                    cy[r] = py[r];
+                    cf[r] = pf[r];
+                } else {
+                    wp[r] = pa[r];
+                    ykm1[r] = pb[r];
+                    dy[0][r] = py[r];
+                    df[0][r] = pf[r];
                 }
-                if (k == D - 1) {
-                    // the last stage is only ever at planes [i_lo, i_hi)
-                    const unsigned pl = (unsigned)ik * plane_bytes;
+            }
+            ESQ_RKC3D_LOAD(it + 1)
+            // the slices' edge rows of all D centre planes change hands
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                xch[it & 1][k][w + 1][0][lane] = wc[k][0];
+                xch[it & 1][k][w + 1][1][lane] = wc[k][JT - 1];
+            }
+            __syncthreads();
+            double eu[D], ed[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                eu[k] = xch[it & 1][k][w][1][lane];
+                ed[k] = xch[it & 1][k][w + 2][0][lane];
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                double nw[JT];
+                if (it >= 2 * k) {                                   // wave-uniform
+                    const int ik = i0 - k;
+                    const bool pl_ok = ik >= 0 && ik < N;
 #pragma unroll
                     for (int r = 0; r < JT; ++r) {
-                        buf_st(ro, so[r], pl, nw[r]);
-                        buf_st(rp, so[r], pl, wc[k][r]);
+                        const double up = r > 0 ? wc[k][r > 0 ? r - 1 : 0] : eu[k];
+                        const double dn = r < JT - 1 ? wc[k][r < JT - 1 ? r + 1 : r] : ed[k];
+                        const double lf = lane_left(wc[k][r]);
+                        const double rt = lane_right(wc[k][r]);
+                        const double fy = st.eval(wm[k][r], wp[r], up, dn, lf, rt, wc[k][r]);
+                        if (LAST && k == D - 1) {
+                            nw[r] = (pl_ok && in[r]) ? fy : 0.0;
+                            if (so[r] != 0xffffffffu) {              // a point this tile stores
+                                const double er =
+                                    __dadd_rn(__dmul_rn(0.8, __dsub_rn(dy[k][r], wc[k][r])),
+                                              __dmul_rn(ca.h04, __dadd_rn(df[k][r], fy)));
+                                const size_t e = (size_t)ik * (size_t)N * (size_t)N + so[r] / 8u;
+                                local += ratio_sq1(er, wc[k][r], dy[k][r], ca.red.atol_vec,
+                                                   ca.red.atol_s, ca.red.rtol, e, ca.red.n_valid);
+                            }
+                        } else {
+                            const double v = one(k, wc[k][r], ykm1[r], dy[k][r], df[k][r], fy);
+                            nw[r] = (pl_ok && in[r]) ? v : 0.0;
+                        }
                     }
-                }
-            } else {
+                    if (k == D - 1) {
+                        // the last stage is only ever at planes [i_lo, i_hi)
+                        const unsigned pl = (unsigned)ik * plane_bytes;
 #pragma unroll
-                for (int r = 0; r < JT; ++r) nw[r] = 0.0;
+                        for (int r = 0; r < JT; ++r) {
+                            buf_st(ro, so[r], pl, nw[r]);
+                            buf_st(rp, so[r], pl, wc[k][r]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < JT; ++r) nw[r] = 0.0;
+                }
+                // Y_k's window moves one plane on; its old lower plane is Y_{(k+1)-1}
+                // at stage k + 1's centre plane, the fresh values are that stage's
+                // upper plane
+#pragma unroll
+                for (int r = 0; r < JT; ++r) {
+                    const double old = wm[k][r];
+                    wm[k][r] = wc[k][r];
+                    wc[k][r] = wp[r];
+                    ykm1[r] = old;
+                    wp[r] = nw[r];
+                }
             }
-            // Y_k's window moves one plane on; its old lower plane is Y_{(k+1)-1}
-            // at stage k + 1's centre plane, the fresh values are that stage's
-            // upper plane
+#pragma unroll
+            for (int k = D - 1; k >= 1; --k)
+#pragma unroll
+                for (int r = 0; r < JT; ++r) {
+                    dy[k][r] = dy[k - 1][r];
+                    df[k][r] = df[k - 1][r];
+                }
+        }
+    } else {
+        // windows: W[k][0], W[k][1] = Y_k at planes (centre - 1, centre) of stage k,
+        // W[k][2] the plane that arrives in this iteration -- one per stage; ALL windows
+        // move one plane on at the END of the iteration
+        double W[D][3][JT], dy[D][JT], df[D][JT];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
 #pragma unroll
             for (int r = 0; r < JT; ++r) {
-                const double old = wm[k][r];
-                wm[k][r] = wc[k][r];
-                wc[k][r] = wp[r];
-                ykm1[r] = old;
-                wp[r] = nw[r];
+                W[k][0][r] = W[k][1][r] = W[k][2][r] = 0.0;
+                dy[k][r] = df[k][r] = 0.0;
+            }
+        const int ibase = i_lo - (D - 1);                 // stage 0's first centre plane
+        auto first = [&](double y, double f) -> double {          // k_rkc_first's rounding
+            return __dadd_rn(y, __dmul_rn(ca.hmus1, f));
+        };
+        // FIRST: y_n, f_n at stage 0's centre plane (loaded as the plane AFTER the
+        // centre one iteration earlier)
+        double cy[JT], cf[JT];
+#pragma unroll
+        for (int r = 0; r < JT; ++r) {
+            if constexpr (FIRST) {
+                W[0][0][r] = first(ld(ry, ibase - 1, r), ld(rf, ibase - 1, r));
+                cy[r] = ld(ry, ibase, r);
+                cf[r] = ld(rf, ibase, r);
+                W[0][1][r] = first(cy[r], cf[r]);
+            } else {
+                W[0][0][r] = ld(ra, ibase - 1, r);
+                W[0][1][r] = ld(ra, ibase, r);
+                cy[r] = cf[r] = 0.0;
             }
         }
-#pragma unroll
-        for (int k = D - 1; k >= 1; --k)
+        // operands of stage 0's plane, requested ONE ITERATION AHEAD (beyond the last
+        // iteration: one more plane is requested and never used)
+        double pa[JT], pb[JT], py[JT], pf[JT];
+        ESQ_RKC3D_LOAD(0)
+        const int iters = Re + 2 * (D - 1);
+        auto body = [&](const int it) {
+            constexpr int LO = 0, CE = 1, UP = 2;
+            const int i0 = ibase + it;
+            double ykm1[JT];
 #pragma unroll
             for (int r = 0; r < JT; ++r) {
-                dy[k][r] = dy[k - 1][r];
-                df[k][r] = df[k - 1][r];
+                if constexpr (FIRST) {
+                    W[0][UP][r] = first(py[r], pf[r]);
+                    ykm1[r] = cy[r];
+                    dy[0][r] = cy[r];
+                    df[0][r] = cf[r];
+                    cy[r] = py[r];
+                    cf[r] = pf[r];
+                } else {
+                    W[0][UP][r] = pa[r];
+                    ykm1[r] = pb[r];
+                    dy[0][r] = py[r];
+                    df[0][r] = pf[r];
+                }
             }
+            ESQ_RKC3D_LOAD(it + 1)
+            // the slices' edge rows of all D centre planes change hands
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                xch[it & 1][k][w + 1][0][lane] = W[k][CE][0];
+                xch[it & 1][k][w + 1][1][lane] = W[k][CE][JT - 1];
+            }
+            __syncthreads();
+            double eu[D], ed[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                eu[k] = xch[it & 1][k][w][1][lane];
+                ed[k] = xch[it & 1][k][w + 2][0][lane];
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                double nw[JT];
+                if (it >= 2 * k) {                                   // wave-uniform
+                    const int ik = i0 - k;
+                    const bool pl_ok = ik >= 0 && ik < N;
+#pragma unroll
+                    for (int r = 0; r < JT; ++r) {
+                        const double wcr = W[k][CE][r];
+                        const double up = r > 0 ? W[k][CE][r > 0 ? r - 1 : 0] : eu[k];
+                        const double dn = r < JT - 1 ? W[k][CE][r < JT - 1 ? r + 1 : r] : ed[k];
+                        const double lf = lane_left(wcr);
+                        const double rt = lane_right(wcr);
+                        const double fy = st.eval(W[k][LO][r], W[k][UP][r], up, dn, lf, rt, wcr);
+                        const double dyk = dy[k][r], dfk = df[k][r];
+                        if (LAST && k == D - 1) {
+                            nw[r] = (pl_ok && in[r]) ? fy : 0.0;
+                            if (so[r] != 0xffffffffu) {              // a point this tile stores
+                                const double er =
+                                    __dadd_rn(__dmul_rn(0.8, __dsub_rn(dyk, wcr)),
+                                              __dmul_rn(ca.h04, __dadd_rn(dfk, fy)));
+                                const size_t e = (size_t)ik * (size_t)N * (size_t)N + so[r] / 8u;
+                                local += ratio_sq1(er, wcr, dyk, ca.red.atol_vec,
+                                                   ca.red.atol_s, ca.red.rtol, e, ca.red.n_valid);
+                            }
+                        } else {
+                            const double v = one(k, wcr, ykm1[r], dyk, dfk, fy);
+                            nw[r] = (pl_ok && in[r]) ? v : 0.0;
+                        }
+                    }
+                    if (k == D - 1) {
+                        // the last stage is only ever at planes [i_lo, i_hi)
+                        const unsigned pl = (unsigned)ik * plane_bytes;
+#pragma unroll
+                        for (int r = 0; r < JT; ++r) {
+                            buf_st(ro, so[r], pl, nw[r]);
+                            buf_st(rp, so[r], pl, W[k][CE][r]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < JT; ++r) nw[r] = 0.0;
+                }
+                // Y_k's old lower plane is Y_{(k+1)-1} at stage k + 1's centre plane, the
+                // fresh values are that stage's arriving plane
+#pragma unroll
+                for (int r = 0; r < JT; ++r) {
+                    ykm1[r] = W[k][LO][r];
+                    if (k + 1 < D) W[k + 1 < D ? k + 1 : k][UP][r] = nw[r];
+                }
+            }
+            // every window moves one plane on, every delay line one stage
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+#pragma unroll
+                for (int r = 0; r < JT; ++r) {
+                    W[k][0][r] = W[k][1][r];
+                    W[k][1][r] = W[k][2][r];
+                }
+#pragma unroll
+            for (int k = D - 1; k >= 1; --k)
+#pragma unroll
+                for (int r = 0; r < JT; ++r) {
+                    dy[k][r] = dy[k - 1][r];
+                    df[k][r] = df[k - 1][r];
+                }
+        };
+        for (int it = 0; it < iters; ++it) body(it);
     }
 #undef ESQ_RKC3D_LOAD
     if constexpr (LAST) block_partial_w<NW>(local, ca.red.partials);
