@@ -469,8 +469,9 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
     floor = sum(r["floor_bytes"] for r in dom)
     alg = sum(r["algorithmic_bytes"] for r in dom)
     achieved = floor / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(args.config if not args.grid else
-                                       f"{args.config}_{args.grid}")
+    traffic, traffic_src = pmc_traffic("_".join(
+        [args.config] + ([args.plugin] if args.plugin else [])
+        + ([str(args.grid)] if args.grid else [])))
     all_moved = sum(r["moved_bytes"] for r in table.values())
     all_floor = sum(r["floor_bytes"] for r in table.values())
     all_ms = sum(r["total_ms"] for r in table.values())

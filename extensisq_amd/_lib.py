@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # `make VARIANT=...` in csrc/); must sit next to the package like the default one
 LIB_PATH = os.environ.get("ESQ_LIB") or os.path.join(_HERE, "libextensisq_amd.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
 EPI_RKCERR = 6

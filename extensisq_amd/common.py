@@ -31,6 +31,52 @@ from .lazy import LazyState
 LAZY_MIN_BYTES = 8 << 20       # states below this are downloaded at once
 
 
+class _EsqOptions:
+    """`esq_options={"chain_depth": 3, "lazy_y": "always", ...}` of a solver constructor
+    (and so of `solve_ivp(..., method=Pr8, esq_options=...)`): the library's tuning
+    switches -- the `ESQ_*` environment variables of DESIGN.md §3.4, lower case without
+    the prefix -- for THIS solver only.  The switches are read when a context, a plugin
+    object or a plan is made, all of which happens inside the constructor: they are put
+    into the environment for its duration and taken out again."""
+
+    def __init__(self, options):
+        self.options = dict(options or {})
+        for key in self.options:
+            if not isinstance(key, str) or not key.replace("_", "").isalnum():
+                raise ValueError(f"esq_options: bad key {key!r}")
+        self._saved = {}
+
+    def __enter__(self):
+        for key, value in self.options.items():
+            name = "ESQ_" + key.upper()
+            self._saved[name] = os.environ.get(name)
+            if isinstance(value, bool):
+                value = int(value)
+            os.environ[name] = str(value)
+        return self
+
+    def __exit__(self, *exc):
+        for name, old in self._saved.items():
+            if old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = old
+        return False
+
+
+def _with_esq_options(init):
+    """constructor decorator: the `esq_options=` keyword (see `_EsqOptions`)"""
+    import functools
+
+    @functools.wraps(init)
+    def wrapper(self, *args, esq_options=None, **kwargs):
+        if esq_options is None:
+            return init(self, *args, **kwargs)
+        with _EsqOptions(esq_options):
+            return init(self, *args, **kwargs)
+    return wrapper
+
+
 def _read_by_solve_ivp():
     """is `solver.y` being read by the loop of scipy's `solve_ivp` (ivp.py:665)?  That
     loop reads the state after EVERY step whether it uses it or not; only it gets the
@@ -275,6 +321,7 @@ class RungeKutta(OdeSolver):
     _extra_rows = 0           # BS5 asks for more K rows
 
     # ------------------------------------------------------------------ ctor
+    @_with_esq_options
     def __init__(self, fun, t0, y0, t_bound, max_step=np.inf, rtol=1e-3,
                  atol=1e-6, vectorized=False, first_step=None,
                  nfev_stiff_detect=5000, sc_params=None, support_complex=True,

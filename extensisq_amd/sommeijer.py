@@ -20,7 +20,7 @@ from scipy.integrate._ivp.common import (validate_first_step,
                                          validate_max_step, warn_extraneous)
 
 from ._lib import SLOT_K, as_ptr
-from .common import NFS, CubicDenseOutput, validate_tol
+from .common import NFS, CubicDenseOutput, _with_esq_options, validate_tol
 from .device import DeviceContext, DeviceRHS
 
 nrejct = NFS                  # rejected steps (shared counter)
@@ -70,6 +70,7 @@ class SSV2stab(OdeSolver):
     # physical row roles inside the context (rotated on the host)
     _N_ROWS = 9
 
+    @_with_esq_options
     def __init__(self, fun, t0, y0, t_bound, max_step=np.inf, rtol=1e-3,
                  atol=1e-6, vectorized=False, first_step=None,
                  const_jac=False, rho_jac=None, device=0, lockstep=None,

@@ -1082,6 +1082,42 @@ def test_lazy_state_mirror_matches_the_immediate_download(monkeypatch, name):
     np.testing.assert_array_equal(np.asarray(a.y), b.y)
 
 
+def test_esq_options_reach_the_library_through_solve_ivp():
+    """`solve_ivp(..., method=Pr8, esq_options={...})`: the ESQ_* switches as a keyword
+    of the drop-in call (scipy hands unknown options to the solver's constructor,
+    ivp.py:621) -- here: one sweep per stage instead of chain sweeps; same results"""
+    import os
+    N = 96
+    rho = esq.Brusselator2D(N).spectral_radius()
+    y0 = pb.bruss2d_y0(N)
+    kw = dict(rtol=1e-6, atol=1e-9, first_step=0.25 / rho, max_step=0.25 / rho,
+              nfev_stiff_detect=0)
+    seen = []
+
+    class Spy(esq.Pr8):
+        def _step_impl(self):
+            out = super()._step_impl()
+            seen.append(self)
+            return out
+
+    a = solve_ivp(esq.Brusselator2D(N), (0.0, 3.0 / rho), y0, method=Spy,
+                  esq_options={"chain_rows": 12}, **kw)
+    chained = seen[-1]
+    b = solve_ivp(esq.Brusselator2D(N), (0.0, 3.0 / rho), y0, method=Spy,
+                  esq_options={"chain_rows": 12, "chain_depth": 1}, **kw)
+    single = seen[-1]
+    assert "ESQ_CHAIN_ROWS" not in os.environ and "ESQ_CHAIN_DEPTH" not in os.environ
+    np.testing.assert_array_equal(a.y, b.y)
+    for s, want in ((chained, True), (single, False)):
+        s._dev.profile_reset()
+        s._dev.profile_enable([0, 1, 2])
+        s.status = "running"
+        s.t_bound = s.t + 1.0
+        assert s.step() is None
+        labels = [row[0] for row in s._dev.profile_kernels()]
+        assert any(lab.startswith("chain") for lab in labels) == want, labels
+
+
 def test_lazy_state_survives_an_assignment_to_the_state(monkeypatch):
     """`solver.y = value` uploads a new state: a mirror of the old one that somebody
     holds has been downloaded before"""

@@ -178,3 +178,28 @@ def test_an_aborted_communicator_is_dropped_by_every_attached_context():
     assert grp.sync_aborted() is True
     assert lib.cleared == [11] and grp.comm is None
     assert grp.sync_aborted() is True and lib.cleared == [11]
+
+
+def test_esq_options_live_for_the_constructor_only(monkeypatch):
+    """`esq_options=` of a solver constructor: the library's ESQ_* switches for this
+    solver only -- in the environment while the constructor runs, gone (or back to what
+    they were) afterwards; a bad key is refused"""
+    import os
+    monkeypatch.setenv("ESQ_CHAIN_DEPTH", "3")
+    monkeypatch.delenv("ESQ_LAZY_Y", raising=False)
+    seen = {}
+
+    class Probe:
+        @dev_common._with_esq_options
+        def __init__(self, a, b=2):
+            seen.update(depth=os.environ.get("ESQ_CHAIN_DEPTH"), lazy=os.environ.get("ESQ_LAZY_Y"),
+                        ahead=os.environ.get("ESQ_LAUNCH_AHEAD"), a=a, b=b)
+
+    Probe(1, b=5, esq_options={"chain_depth": 1, "lazy_y": "always", "launch_ahead": False})
+    assert seen == dict(depth="1", lazy="always", ahead="0", a=1, b=5)
+    assert os.environ["ESQ_CHAIN_DEPTH"] == "3" and "ESQ_LAZY_Y" not in os.environ
+    assert "ESQ_LAUNCH_AHEAD" not in os.environ
+    Probe(7)                                      # no options: the environment as it is
+    assert seen["depth"] == "3" and seen["lazy"] is None and seen["a"] == 7
+    with pytest.raises(ValueError):
+        Probe(1, esq_options={"chain depth; rm": 1})

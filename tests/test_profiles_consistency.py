@@ -17,10 +17,11 @@ import pytest
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
 P = os.path.join(ROOT, "profiles")
-TAG = "r04"
+TAG = "r05"
 
 
-@pytest.mark.parametrize("config", ["pr8", "ts5", "pr9", "rkc", "pr8_7070", "rkc_400"])
+@pytest.mark.parametrize("config", ["pr8", "ts5", "pr9", "rkc", "pr8_7070", "rkc_400", "pr8_diff3d",
+                                    "pr8_diff3d_400"])
 def test_bench_and_profiles_agree(config):
     with open(os.path.join(P, f"{TAG}_bench_{config}.json")) as fh:
         bench = json.load(fh)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py (run on the GPU box from the repo root):
-#   tools/profile_bench.sh [config[@grid] ...]  (default: pr8; pr8@7070 = n 1e8)
+#   tools/profile_bench.sh [config[:plugin][@grid] ...]  (default: pr8; pr8@7070 = n 1e8;
+#   pr8:diff3d = Pr8 on the 3-D plugin, pr8:diff3d@400 the same at N = 400)
 # per config:
 #   1. kernel trace + stats of the driver-style bench command
 #   2. HBM traffic counters, one --pmc pass each (FETCH_SIZE, WRITE_SIZE) --
@@ -20,9 +21,11 @@ python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp -
 # state for a while: the driver's command read 0.533 ms/step behind one, 0.484 on the
 # same box otherwise):  1. the bench JSONs (the driver's own command first),
 # 2. kernel trace + stats,  3. the PMC passes.
-spec() {       # -> CFG GRID TAG STEPS
-    CFG=${1%@*}; GRID=""; TAG=$CFG; STEPS=20
-    if [ "$1" != "$CFG" ]; then GRID="--grid ${1#*@}"; TAG=${CFG}_${1#*@}; STEPS=${ESQ_PROF_STEPS:-10}; fi
+spec() {       # -> CFG GRID TAG STEPS (GRID also carries --plugin)
+    local base=${1%@*}
+    CFG=${base%%:*}; GRID=""; TAG=$CFG; STEPS=20
+    if [ "$base" != "$CFG" ]; then GRID="--plugin ${base#*:}"; TAG=${CFG}_${base#*:}; fi
+    if [ "$1" != "$base" ]; then GRID="$GRID --grid ${1#*@}"; TAG=${TAG}_${1#*@}; STEPS=${ESQ_PROF_STEPS:-10}; fi
 }
 FLAGS="--no-cpu-baseline --no-solve-ivp --no-extras"
 for SPEC in "${@:-pr8}"; do

@@ -41,6 +41,11 @@ def label(name):
     if m:
         sol = "+solerr" if m.group(3) == "3" else ""
         return f"chain{m.group(1)}{sol}<{m.group(2)}>"
+    # 3-D chain sweeps of the explicit pairs (round 5): k_chain3d<D, NU, JT, NW, KINDLAST, St>
+    m = re.search(r"k_chain3d<(\d+), (\d+), \d+, \d+, (\d+)", name)
+    if m:
+        sol = "+solerr" if m.group(3) == "3" else ""
+        return f"chain{m.group(1)}{sol}<{m.group(2)}>"
     m = re.search(r"k_rkc3d_chain<(\d+)", name)
     if m:                                   # 3-D Chebyshev chain sweeps (round 4)
         return f"rkc_chain{m.group(1)}"
@@ -50,7 +55,8 @@ def label(name):
         return "rhs_rkc"
     # one-stage sweeps of the 2-D stencil plugins (round 4: esq_stencil2d.hpp) and the
     # 3-D pair / row sweeps: k_stencil2d_sweep<NF, PERIODIC, Fn, Epi...<NT>, Src>
-    m = re.search(r"k_(?:stencil2d_sweep|diff3d_pairs|diff3d_sweep)<.*?Epi(\w+?)(?:<(\d+)|[,>])", name)
+    m = re.search(r"k_(?:stencil2d_sweep|diff3d_pairs|diff3d_sweep|stencil3d_pairs|"
+                  r"stencil3d_march|stencil3d_points)<.*?Epi(\w+?)(?:<(\d+)|[,>])", name)
     if m:
         kind = m.group(1).lower()
         if kind == "none":
@@ -106,8 +112,13 @@ def one(tag, cfg):
         s = stats[label(r["Name"])]
         s[0] += int(r["Calls"])
         s[1] += float(r["TotalDurationNs"])
-    base, _, grid = cfg.partition("_")       # "pr8_7070": tools/profile_bench.sh pr8@7070
-    flags = f"--config {base}" + (f" --grid {grid}" if grid else "")
+    # "pr8_7070": tools/profile_bench.sh pr8@7070; "pr8_diff3d[_400]": pr8:diff3d[@400]
+    parts = cfg.split("_")
+    base = parts[0]
+    plugin = next((x for x in parts[1:] if not x.isdigit()), "")
+    grid = next((x for x in parts[1:] if x.isdigit()), "")
+    flags = (f"--config {base}" + (f" --plugin {plugin}" if plugin else "")
+             + (f" --grid {grid}" if grid else ""))
     out = {"command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- "
                       f"python3 bench.py {flags} --steps 3 --warmup 1; "
                       f"kernel times: rocprofv3 --kernel-trace --stats -- python3 "
