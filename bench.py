@@ -226,6 +226,25 @@ def pin_to_gpu_numa(local):
         return {"pinned": False, "why": repr(exc)}
 
 
+def repin_to_pci(bdf):
+    """affinity of this process -> the CPUs of the NUMA node of PCI function `bdf`"""
+    try:
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as fh:
+            node = int(fh.read().strip())
+        if node < 0:
+            return {"repinned": False, "why": "no NUMA node known for " + bdf}
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as fh:
+            cpus = set()
+            for part in fh.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus)
+        return {"repinned": True, "numa_node": node, "cpus": len(cpus), "pci": bdf,
+                "pci_matches": True}
+    except Exception as exc:                                   # noqa: BLE001
+        return {"repinned": False, "why": repr(exc)}
+
+
 def dry_run(args, rank, world, ctl):
     """control-plane rehearsal without a GPU (tests/test_bench_cpu.py): spawn,
     rendezvous, id exchange, barrier, min/max-over-ranks timing -- and the SAME
@@ -599,6 +618,11 @@ def main():
         got = device_pci_bus_id(local)
         affinity["hip_pci"] = got
         affinity["pci_matches"] = (got == str(affinity.get("pci", "")).lower()) if got else None
+        if got and not affinity["pci_matches"]:
+            # the guess by position was wrong: move to the CPUs of the node the device
+            # really hangs on (the pinned result slot was allocated under the first
+            # affinity; everything allocated from here on is local)
+            affinity.update(repin_to_pci(got))
 
     meta = workload_meta(args.config, args.grid, args.plugin)
     w = make_workload(args.config, args.grid, rank, args.plugin)
@@ -899,9 +923,12 @@ def _solve_ivp_run(w, device, steps, extra):
     h = w["kw"]["max_step"]
     stamps = []
 
+    flags = []
+
     class Timed(w["cls"]):
         def _step_impl(self):
             stamps.append(time.perf_counter())
+            flags.append((getattr(self, "_lazy_eager", None), len(getattr(self, "_lazy_live", []))))
             return super()._step_impl()
 
     t0 = time.perf_counter()
@@ -912,6 +939,10 @@ def _solve_ivp_run(w, device, steps, extra):
     # entry to entry of consecutive steps: the step itself, the download of
     # solver.y and scipy's loop body
     gaps = np.diff(stamps)
+    if os.environ.get("ESQ_BENCH_DEBUG"):
+        print("[solve_ivp gaps ms]", extra, " ".join(f"{1e3 * g:.2f}" for g in gaps),
+              file=sys.stderr)
+        print("[solve_ivp lazy flags]", flags, file=sys.stderr)
     per_step = float(np.median(gaps)) if gaps.size else float("nan")
     return {"ms_per_step": 1e3 * per_step, "steps": n_steps,
             "value": w["y0"].size / per_step,

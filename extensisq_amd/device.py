@@ -130,6 +130,33 @@ class WarmBuffers:
 _warm = WarmBuffers()
 
 
+# Contexts whose Python owner has been garbage-collected, waiting to be destroyed.
+# A solver is always part of a reference cycle (scipy's OdeSolver keeps closures over
+# itself), so it is freed by the CYCLIC collector -- at an arbitrary allocation, in
+# whichever thread happens to allocate (the copy worker, a warm-buffer thread), possibly
+# while another solver's state download is in flight.  Destroying a context there (a
+# stream synchronisation and a 2 GB hipFree, which waits for the whole device) left every
+# later device-to-host copy of that process at half the PCIe rate (bench.py: plain
+# solve_ivp 2.80 instead of 1.44 ms/step after the scratch solver of the device warm-up
+# had been collected).  `__del__` therefore only parks the handle; it is destroyed at the
+# next well-defined point: when a context is made or closed explicitly, or at exit.
+_graveyard = []
+_graveyard_lock = __import__("threading").Lock()
+
+
+def _drain_graveyard():
+    with _graveyard_lock:
+        dead, _graveyard[:] = list(_graveyard), []
+    for lib, handle in dead:
+        try:
+            lib.esq_destroy(handle)
+        except Exception:                                     # noqa: BLE001
+            pass
+
+
+__import__("atexit").register(_drain_graveyard)
+
+
 class DeviceContext:
     """Thin owner of one `esq_ctx` (one device, one stream, one HBM slab)."""
 
@@ -139,6 +166,7 @@ class DeviceContext:
 
     def __init__(self, n, n_rows, is_complex=False, device=0, host_rhs=False):
         self.lib = _lib.load()
+        _drain_graveyard()              # contexts of collected solvers: freed here
         self.n = int(n)
         self.n_rows = int(n_rows)
         self.is_complex = bool(is_complex)
@@ -165,13 +193,19 @@ class DeviceContext:
 
     # -- lifetime
     def close(self):
+        """destroy the context now (the caller's thread, the caller's moment)"""
         if getattr(self, "handle", None):
             self.lib.esq_destroy(self.handle)
             self.handle = None
+        _drain_graveyard()
 
     def __del__(self):
+        # (not here: see _graveyard)
         try:
-            self.close()
+            if getattr(self, "handle", None):
+                with _graveyard_lock:
+                    _graveyard.append((self.lib, self.handle))
+                self.handle = None
         except Exception:
             pass
 
