@@ -77,13 +77,14 @@ def _with_esq_options(init):
     return wrapper
 
 
-def _read_by_solve_ivp():
+def _read_by_solve_ivp(depth=2):
     """is `solver.y` being read by the loop of scipy's `solve_ivp` (ivp.py:665)?  That
     loop reads the state after EVERY step whether it uses it or not; only it gets the
-    deferred mirror, so that direct users of a solver see plain ndarrays"""
+    deferred mirror, so that direct users of a solver see plain ndarrays.  `depth`:
+    frames between this function and the reader of the property"""
     import sys
     try:
-        code = sys._getframe(2).f_code
+        code = sys._getframe(depth).f_code
     except ValueError:
         return False
     return code.co_name == "solve_ivp" and code.co_filename.replace("\\", "/").endswith(
@@ -290,7 +291,114 @@ class LockstepGroup:
                 f"min over ranks {lo}, max {hi}")
 
 
-class RungeKutta(OdeSolver):
+
+class _LazyStateMixin:
+    """Deferred mirrors of the solver's state (lazy.py) for the solver classes: the
+    state of generation g (g accepted steps) is on the device while the solver is at
+    generation g (`_lazy_where(0)`) and g + 1 (`_lazy_where(1)`: the "previous state"
+    the dense output starts from); `step()` retires older mirrors first."""
+
+    def _lazy_init(self, nbytes, host_slab):
+        # large device-resident states: `solver.y` READ BY scipy's solve_ivp loop is a
+        # deferred mirror; every other caller gets the ndarray it always got.
+        # ESQ_LAZY_Y=0: never; ESQ_LAZY_Y=always: for every caller
+        mode = os.environ.get("ESQ_LAZY_Y", "1")
+        self._lazy_on = (self._device_rhs is not None and not host_slab
+                         and nbytes >= LAZY_MIN_BYTES and mode != "0")
+        self._lazy_always = mode == "always"
+        self._state_gen = 0          # accepted steps: which state the device holds
+        self._lazy_live = []         # [weakref(mirror), generation, copy-done event]
+        self._lazy_eager = False     # the caller stores its states: copy at once
+
+    def _lazy_where(self, age):
+        """(slot, row) of the state `age` accepted steps ago (age 0 or 1)"""
+        raise NotImplementedError
+
+    def _lazy_y(self):
+        """the `y` property's value: the cached host copy, a mirror, or a download"""
+        if self._y_host is None:
+            lazy = self._lazy_on and (self._lazy_always or _read_by_solve_ivp(3))
+            self._y_host = (self._new_lazy_state() if lazy
+                            else self._dev.download(*self._lazy_where(0)))
+        if isinstance(self._y_host, LazyState) and (
+                self._y_host.materialized
+                or not (self._lazy_always or _read_by_solve_ivp(3))):
+            # (used already -- or a caller other than solve_ivp's loop asks: the array)
+            self._y_host = self._y_host.materialize()
+        return self._y_host
+
+    # -- deferred mirrors of the state (lazy.py)
+    def _begin_snapshot(self, slot, row=0):
+        """-> (copy_fn, out): the download of (slot, row) as it is NOW, to be run by the
+        copy worker beside the steps that follow (esq_snapshot_begin / _copy)"""
+        import ctypes
+        from .device import _warm
+        out, locked = _warm.take(self.n, self._dev.dtype, pinned=True)
+        token = ctypes.c_void_p()
+        lib, ptr = self._lib, out.ctypes.data_as(ctypes.c_void_p)
+        try:
+            self._chk(lib.esq_snapshot_begin(self._ctx, slot, row, ctypes.byref(token)),
+                      "esq_snapshot_begin")
+        except Exception:
+            if locked:
+                lib.esq_host_unpin(ptr)
+            raise
+
+        def copy_fn():
+            code = lib.esq_snapshot_copy(token, ptr, int(locked))
+            if code != 0:
+                raise DeviceError(f"esq_snapshot_copy failed with code {code}")
+            return out
+        return copy_fn, out
+
+    def _new_lazy_state(self):
+        import weakref
+        gen = self._state_gen
+        solver = self                 # (an unread mirror keeps its solver alive)
+
+        def fetch():
+            age = solver._state_gen - gen
+            if age in (0, 1):         # (1: after one more accept, the "previous state")
+                return solver._dev.download(*solver._lazy_where(age))
+            raise DeviceError("this state is no longer on the device")   # (retired before)
+        mirror = LazyState(fetch, self.n, self._dev.dtype)
+        entry = [weakref.ref(mirror), gen, None]
+        if self._lazy_eager:
+            mirror.start_copy(lambda: self._begin_snapshot(*self._lazy_where(0)))
+            entry[2] = mirror._pending[0] if mirror._pending else None
+        self._lazy_live.append(entry)
+        return mirror
+
+    def _retire_lazy_states(self, everything=False):
+        """Before a step starts: the device is about to overwrite the buffer of the
+        state before the current one.  Mirrors of it that somebody still holds are
+        downloaded now -- and if that took a synchronous copy, the caller evidently
+        stores its states: from now on every new mirror starts its copy at once,
+        beside the following steps.  Copies under way are waited for either way."""
+        if not self._lazy_live:
+            return
+        keep = []
+        for entry in self._lazy_live:
+            ref, gen, done = entry
+            mirror = ref()
+            if not everything and gen >= self._state_gen:
+                if mirror is not None and not mirror.materialized:
+                    keep.append(entry)
+                continue
+            if mirror is not None and not mirror.materialized:
+                if done is None:
+                    self._lazy_eager = True
+                mirror.materialize()
+            elif done is not None:
+                if not done.is_set():
+                    done.wait()       # nobody waits for it, but it reads the buffer
+                if mirror is None:
+                    self._lazy_eager = False      # copied for nobody: stop that
+        self._lazy_live = keep
+
+
+
+class RungeKutta(_LazyStateMixin, OdeSolver):
     """Base class of the device-resident explicit Runge-Kutta methods.
 
     Subclasses provide the tableau as class attributes exactly like the
@@ -376,16 +484,7 @@ class RungeKutta(OdeSolver):
         self._f_host = None
         self._K_host = None
         self._y_old_host = None
-        # large device-resident states: `solver.y` READ BY scipy's solve_ivp loop is a
-        # deferred mirror (lazy.py); every other caller gets the ndarray it always
-        # got.  ESQ_LAZY_Y=0: never; ESQ_LAZY_Y=always: for every caller
-        mode = os.environ.get("ESQ_LAZY_Y", "1")
-        self._lazy_on = (self._device_rhs is not None and not self._dev.host_slab
-                         and y_host.nbytes >= LAZY_MIN_BYTES and mode != "0")
-        self._lazy_always = mode == "always"
-        self._state_gen = 0          # accepted steps: which state the device holds
-        self._lazy_live = []         # [weakref(mirror), generation, copy-done event]
-        self._lazy_eager = False     # the caller stores its states: copy at once
+        self._lazy_init(y_host.nbytes, self._dev.host_slab)
         if self._device_rhs is not None:
             self._dev.set_rhs(self._device_rhs)
             self._chk(self._lib.esq_rk_eval_rhs(self._ctx, 0, float(self.t),
@@ -558,15 +657,7 @@ class RungeKutta(OdeSolver):
         device-resident state comes back as a `LazyState` (lazy.py): an array-like
         that downloads when it is really used -- plain `solve_ivp` reads `solver.y`
         after every step (ivp.py:665) whether it needs it or not"""
-        if self._y_host is None:
-            lazy = self._lazy_on and (self._lazy_always or _read_by_solve_ivp())
-            self._y_host = self._new_lazy_state() if lazy else self._dev.download(SLOT_Y)
-        if isinstance(self._y_host, LazyState) and (
-                self._y_host.materialized
-                or not (self._lazy_always or _read_by_solve_ivp())):
-            # (used already -- or a caller other than solve_ivp's loop asks: the array)
-            self._y_host = self._y_host.materialize()
-        return self._y_host
+        return self._lazy_y()
 
     @y.setter
     def y(self, value):
@@ -579,76 +670,8 @@ class RungeKutta(OdeSolver):
         if self._dev is not None and value is not None:
             self._dev.upload(SLOT_Y, 0, value)
 
-    # -- deferred mirrors of the state (lazy.py)
-    def _begin_snapshot(self, slot):
-        """-> (copy_fn, out): the download of `slot` as it is NOW, to be run by the
-        copy worker beside the steps that follow (esq_snapshot_begin / _copy)"""
-        import ctypes
-        from .device import _warm
-        out, locked = _warm.take(self.n, self._dev.dtype, pinned=True)
-        token = ctypes.c_void_p()
-        lib, ptr = self._lib, out.ctypes.data_as(ctypes.c_void_p)
-        try:
-            self._chk(lib.esq_snapshot_begin(self._ctx, slot, 0, ctypes.byref(token)),
-                      "esq_snapshot_begin")
-        except Exception:
-            if locked:
-                lib.esq_host_unpin(ptr)
-            raise
-
-        def copy_fn():
-            code = lib.esq_snapshot_copy(token, ptr, int(locked))
-            if code != 0:
-                raise DeviceError(f"esq_snapshot_copy failed with code {code}")
-            return out
-        return copy_fn, out
-
-    def _new_lazy_state(self):
-        import weakref
-        gen = self._state_gen
-        solver = self                 # (an unread mirror keeps its solver alive)
-
-        def fetch():
-            age = solver._state_gen - gen
-            if age == 0:
-                return solver._dev.download(SLOT_Y)
-            if age == 1:              # after one more accept: the "previous state"
-                return solver._dev.download(SLOT_YNEW)
-            raise DeviceError("this state is no longer on the device")   # (retired before)
-        mirror = LazyState(fetch, self.n, self._dev.dtype)
-        entry = [weakref.ref(mirror), gen, None]
-        if self._lazy_eager:
-            mirror.start_copy(lambda: self._begin_snapshot(SLOT_Y))
-            entry[2] = mirror._pending[0] if mirror._pending else None
-        self._lazy_live.append(entry)
-        return mirror
-
-    def _retire_lazy_states(self, everything=False):
-        """Before a step starts: the device is about to overwrite the buffer of the
-        state before the current one.  Mirrors of it that somebody still holds are
-        downloaded now -- and if that took a synchronous copy, the caller evidently
-        stores its states: from now on every new mirror starts its copy at once,
-        beside the following steps.  Copies under way are waited for either way."""
-        if not self._lazy_live:
-            return
-        keep = []
-        for entry in self._lazy_live:
-            ref, gen, done = entry
-            mirror = ref()
-            if not everything and gen >= self._state_gen:
-                if mirror is not None and not mirror.materialized:
-                    keep.append(entry)
-                continue
-            if mirror is not None and not mirror.materialized:
-                if done is None:
-                    self._lazy_eager = True
-                mirror.materialize()
-            elif done is not None:
-                if not done.is_set():
-                    done.wait()       # nobody waits for it, but it reads the buffer
-                if mirror is None:
-                    self._lazy_eager = False      # copied for nobody: stop that
-        self._lazy_live = keep
+    def _lazy_where(self, age):
+        return (SLOT_Y, 0) if age == 0 else (SLOT_YNEW, 0)
 
     def step(self):
         self._retire_lazy_states()

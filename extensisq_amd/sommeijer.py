@@ -20,7 +20,9 @@ from scipy.integrate._ivp.common import (validate_first_step,
                                          validate_max_step, warn_extraneous)
 
 from ._lib import SLOT_K, as_ptr
-from .common import NFS, CubicDenseOutput, _with_esq_options, validate_tol
+from .common import (NFS, CubicDenseOutput, _LazyStateMixin, _with_esq_options,
+                     validate_tol)
+from .lazy import LazyState
 from .device import DeviceContext, DeviceRHS
 
 nrejct = NFS                  # rejected steps (shared counter)
@@ -63,7 +65,7 @@ def chebyshev_scalars(m, t, h):
     return h * mus1, table
 
 
-class SSV2stab(OdeSolver):
+class SSV2stab(_LazyStateMixin, OdeSolver):
     """Stabilized second-order RKC solver (device-resident).  Same constructor
     as the reference (sommeijer.py:93-95) plus `device` and `lockstep`."""
 
@@ -121,6 +123,7 @@ class SSV2stab(OdeSolver):
         self._ctx = self._dev.handle
         self._dev.set_tol(self.rtol, self.atol)
         self._r = dict(yn=0, fn=1, w=[2, 3, 4, 8], yold=5, fold=6, V=7)
+        self._lazy_init(y_host.nbytes, self._dev.host_slab)
         self._have_V = False
         self._n_norm = self.n
         self._lockstep = lockstep
@@ -163,15 +166,28 @@ class SSV2stab(OdeSolver):
 
     @property
     def y(self):
-        if self._y_host is None:
-            self._y_host = self._dev.download(SLOT_K, self._r["yn"])
-        return self._y_host
+        """current state; a large device-resident state read by scipy's solve_ivp loop
+        comes back as a deferred mirror (lazy.py), as for the explicit pairs"""
+        return self._lazy_y()
 
     @y.setter
     def y(self, value):
+        if self._dev is not None and value is not None:
+            self._retire_lazy_states(everything=True)
+            if isinstance(value, LazyState):
+                value = value.materialize()
         self._y_host = value
         if self._dev is not None and value is not None:
             self._dev.upload(SLOT_K, self._r["yn"], value)
+
+    def _lazy_where(self, age):
+        # (the rows of the previous step stay untouched for one more accepted step:
+        # the interpolant starts from them)
+        return (SLOT_K, self._r["yn"] if age == 0 else self._r["yold"])
+
+    def step(self):
+        self._retire_lazy_states()
+        return super().step()
 
     def _eval_rhs(self, dst, t, src, count=True):
         """row[dst] = fun(t, row[src]); `count=False` mirrors `fun_single`
@@ -415,6 +431,7 @@ class SSV2stab(OdeSolver):
         r["w"] = idle + [r["yold"], r["fold"]]
         r["yold"], r["fold"] = r["yn"], r["fn"]
         r["yn"], r["fn"] = yrow, fyrow
+        self._state_gen += 1
         self._y_host = None
         self.absh = max(hmin, min(self.max_step, self._predicted_step(err, absh)))
         self.errold = err

@@ -100,6 +100,7 @@ REQUIRED = {
     "test_gpu_parity.py::test_lazy_state_mirror_matches_the_immediate_download": 3,
     "test_gpu_parity.py::test_lazy_state_survives_an_assignment_to_the_state": 1,
     "test_gpu_parity.py::test_solve_ivp_with_deferred_states": 4,
+    "test_gpu_rkc.py::test_solve_ivp_with_deferred_states_rkc": 3,
     "test_gpu_parity.py::test_esq_options_reach_the_library_through_solve_ivp": 1,
     "test_gpu_stiffness.py::test_diagnosis_matches_reference": 1,
     # csrc/esq_stencil3d.hpp with user functors: the reference's two demo problems

@@ -717,3 +717,46 @@ def test_rkc_fused_tail_matches_unfused(monkeypatch, plugin, N):
         np.testing.assert_array_equal(fa, fb)
         assert_allclose(a.errold, b.errold, rtol=1e-12)
     assert a.nfev == b.nfev
+
+
+@pytest.mark.parametrize("mode", ["stored", "t_eval", "dense"])
+def test_solve_ivp_with_deferred_states_rkc(monkeypatch, mode):
+    """SSV2stab through plain `solve_ivp` on a state of 16 MB: `solver.y` as scipy's loop
+    reads it is a deferred mirror (extensisq_amd/lazy.py) -- kept per step, ignored
+    (t_eval / dense_output): results bit-identical to immediate downloads, and the
+    mirrors of a direct reader are plain arrays"""
+    from extensisq_amd.lazy import LazyState
+    N = 128
+    rhs = esq.Diffusion3D(N)
+    rho = rhs.spectral_radius()
+    y0 = pb.diff3d_y0(N)
+    tf = 6e-4
+    kw = dict(rtol=1e-3, atol=1e-3, const_jac=True, rho_jac=lambda t, y: rho)
+    if mode == "t_eval":
+        kw["t_eval"] = [0.4 * tf, tf]
+    elif mode == "dense":
+        kw["dense_output"] = True
+    seen = []
+
+    class Spy(esq.SSV2stab):
+        def _step_impl(self):
+            out = super()._step_impl()
+            seen.append((self._lazy_on, self._lazy_eager))
+            return out
+
+    got = solve_ivp(esq.Diffusion3D(N), (0.0, tf), y0, method=Spy, **kw)
+    assert seen and all(on for on, _e in seen)
+    if mode == "stored" and len(seen) > 3:
+        assert seen[-1][1]                     # the copies run beside the steps by then
+    monkeypatch.setenv("ESQ_LAZY_Y", "0")
+    ref = solve_ivp(esq.Diffusion3D(N), (0.0, tf), y0, method=esq.SSV2stab, **kw)
+    assert got.success and ref.success and got.nfev == ref.nfev
+    np.testing.assert_array_equal(got.t, ref.t)
+    np.testing.assert_array_equal(got.y, ref.y)
+    if mode == "dense":
+        tc = np.linspace(0.0, tf, 5)
+        np.testing.assert_array_equal(got.sol(tc), ref.sol(tc))
+    monkeypatch.delenv("ESQ_LAZY_Y")
+    s = esq.SSV2stab(esq.Diffusion3D(N), 0.0, y0, tf, **{k: v for k, v in kw.items()
+                                                        if k not in ("t_eval", "dense_output")})
+    assert s.step() is None and isinstance(s.y, np.ndarray) and not isinstance(s.y, LazyState)
