@@ -59,6 +59,21 @@ struct CombustionFn {
     }
 };
 
+// ---- u_t = cx u_xx + cy u_yy + cz u_zz, homogeneous Dirichlet, N^3 interior points of a
+// grid of mesh width 1 / (N + 1): NOT one of the notebook's problems -- a one-field functor
+// that declares kZeroOutside && kAutonomous and therefore gets the 16-byte sweeps and both
+// kinds of chain sweeps (esq_chain3d.hpp, esq_rkc3d.hpp) of the header besides
+struct AnisoFn {
+    static constexpr bool kZeroOutside = true, kAutonomous = true;
+    double ci, cj, cl;                            // coefficient / h^2 along i, j, l
+    __device__ double ghost(int, int, int, int, int, double, double) const { return 0.0; }
+    __device__ void eval(const esq::Nb3 (&nb)[1], int, int, int, double, double (&f)[1]) const {
+        const esq::Nb3 &u = nb[0];
+        f[0] = (ci * ((u.below + u.above) - 2.0 * u.c) + cj * ((u.up + u.dn) - 2.0 * u.c)) +
+               cl * ((u.lf + u.rt) - 2.0 * u.c);
+    }
+};
+
 template <class Fn>
 struct User {
     int N;
@@ -66,6 +81,7 @@ struct User {
 };
 using Tanh = esq::Stencil3D<1, TanhHeatFn>;
 using Comb = esq::Stencil3D<2, CombustionFn>;
+using Aniso = esq::Stencil3D<1, AnisoFn>;
 
 }  // namespace
 
@@ -94,3 +110,18 @@ using Comb = esq::Stencil3D<2, CombustionFn>;
     }
 DEMO_ENTRIES(tanh3d, Tanh, TanhHeatFn, 1)
 DEMO_ENTRIES(comb3d, Comb, CombustionFn, 2)
+DEMO_ENTRIES(aniso3d, Aniso, AnisoFn, 1)
+// the chain entries of the one-field homogeneous functor (tuning knobs from the
+// environment, as the built-in plugin reads them: ESQ_RKC_FORCE / ESQ_RKC_PLANES for tests)
+extern "C" int aniso3d_chain(void *user, const double *y_in, const esq_chain *chain, size_t n,
+                             void *stream, void *e0, void *e1) {
+    const User<AnisoFn> *u = (const User<AnisoFn> *)user;
+    if (!u || n != Aniso::points(u->N)) return ESQ_EINVAL;
+    return Aniso::chain(u->fn, u->N, y_in, chain, stream, e0, e1, esq::stencil3d_tuning_from_env());
+}
+extern "C" int aniso3d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void *stream,
+                                 void *e0, void *e1) {
+    const User<AnisoFn> *u = (const User<AnisoFn> *)user;
+    if (!u || n != Aniso::points(u->N)) return ESQ_EINVAL;
+    return Aniso::rkc_chain(u->fn, u->N, ch, stream, e0, e1, esq::stencil3d_tuning_from_env());
+}

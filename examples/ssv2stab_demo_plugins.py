@@ -78,6 +78,53 @@ class _DemoPlugin(esq.CFunctionRHS):
         return _ptr(self._entries["rkc"])
 
 
+class _ChainPlugin(_DemoPlugin):
+    """... + the chain entries of a one-field homogeneous functor"""
+    _chain_caps = esq._lib.CHAIN_CAP_QUERY | 1 | 2      # from the state, rows unwritten
+    _rkc_chain_depth = 4
+
+    def __init__(self, prefix, user, n):
+        super().__init__(prefix, user, n)
+        lib = _lib()
+        self._entries["chain"] = getattr(lib, f"{prefix}_chain")
+        self._entries["rkc_chain"] = getattr(lib, f"{prefix}_rkc_chain")
+
+    def _chain_entry(self, lib_):
+        return _ptr(self._entries["chain"])
+
+    def _rkc_chain_entry(self, lib_):
+        depth = int(os.environ.get("ESQ_RKC_MAXDEPTH", self._rkc_chain_depth))
+        return (_ptr(self._entries["rkc_chain"]),
+                depth | esq._lib.RKC_CHAIN_FIRST | esq._lib.RKC_CHAIN_LAST)
+
+
+class _AnisoFn(C.Structure):
+    _fields_ = [("ci", C.c_double), ("cj", C.c_double), ("cl", C.c_double)]
+
+
+class _AnisoUser(C.Structure):
+    _fields_ = [("N", C.c_int), ("fn", _AnisoFn)]
+
+
+def aniso_diffusion(N, cx=1.0, cy=0.5, cz=2.0):
+    """u_t = cx u_xx + cy u_yy + cz u_zz on N^3 interior points, homogeneous Dirichlet: a
+    user functor with the header's fast sweeps and chain sweeps.
+    -> (device RHS, NumPy twin with the same operation order, spectral radius)"""
+    h2 = (N + 1.0) ** 2
+    ci, cj, cl = cy * h2, cx * h2, cz * h2          # array axes (i, j, l) <-> (y, x, z)
+    rhs = _ChainPlugin("aniso3d", _AnisoUser(N, _AnisoFn(ci, cj, cl)), N ** 3)
+
+    def twin(t, y):
+        w = np.zeros((N + 2,) * 3)
+        w[1:-1, 1:-1, 1:-1] = y.reshape(N, N, N)
+        c = w[1:-1, 1:-1, 1:-1]
+        di = (w[:-2, 1:-1, 1:-1] + w[2:, 1:-1, 1:-1]) - 2.0 * c
+        dj = (w[1:-1, :-2, 1:-1] + w[1:-1, 2:, 1:-1]) - 2.0 * c
+        dl = (w[1:-1, 1:-1, :-2] + w[1:-1, 1:-1, 2:]) - 2.0 * c
+        return ((ci * di + cj * dj) + cl * dl).reshape(-1)
+    return rhs, twin, 4.0 * (ci + cj + cl)
+
+
 class _TanhFn(C.Structure):
     _fields_ = [("inv_h2", C.c_double), ("step", C.c_double)]
 

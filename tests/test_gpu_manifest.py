@@ -108,6 +108,7 @@ REQUIRED = {
     "test_gpu_stencil3d.py::test_combustion_rhs_matches_the_twin": 3,
     "test_gpu_stencil3d.py::test_explicit_pairs_on_the_generic_sweep": 8,
     "test_gpu_stencil3d.py::test_chebyshev_stage_entry_on_the_generic_sweep": 2,
+    "test_gpu_stencil3d.py::test_user_functor_with_the_fast_sweeps_and_chain_sweeps": 3,
     "test_gpu_stencil3d.py::test_published_heat_table_device_rhs": 6,
     "test_gpu_stencil3d.py::test_published_combustion_table_device_rhs": 4,
 }

@@ -156,6 +156,71 @@ def test_chebyshev_stage_entry_on_the_generic_sweep(monkeypatch, problem):
     assert a.nfev == b.nfev and a.nfev > 10
 
 
+@pytest.mark.parametrize("N,planes", [(13, 3), (40, 0), (64, 5)])
+def test_user_functor_with_the_fast_sweeps_and_chain_sweeps(monkeypatch, N, planes):
+    """a one-field homogeneous functor compiled by the user (anisotropic diffusion): its
+    RHS bit for bit its NumPy twin (16-byte pair sweep, odd and even N); explicit pairs
+    with the 3-D chain sweeps of the header (esq_chain3d.hpp) bit-identical to one sweep
+    per stage and to the entry-free run, within the oracle's single-step bounds;
+    SSV2stab's Chebyshev chain sweeps (esq_rkc3d.hpp) bit-identical to one launch per
+    stage -- everything `Diffusion3D` has, from a 12-line functor"""
+    from oracle.tolerances import check_step
+    from extensisq_amd._lib import PROF_RHS, PROF_RKC, PROF_SOLERR, PROF_STAGE
+    monkeypatch.setenv("ESQ_RKC_FORCE", "1")
+    monkeypatch.setenv("ESQ_RKC_PLANES", str(planes))
+    rhs, twin, rho = demo.aniso_diffusion(N)
+    rng = np.random.default_rng(N)
+    y0 = rng.standard_normal(N ** 3)
+    assert_equal(rhs(0.0, y0), twin(0.0, y0))
+    h = 1.0 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-1, atol=1e-1, nfev_stiff_detect=0)
+    for name in ("Pr8", "Ts5"):
+        cls = getattr(esq, name)
+        chained = cls(demo.aniso_diffusion(N)[0], 0.0, y0, 1.0, **kw)
+        monkeypatch.setenv("ESQ_CHAIN_DEPTH", "1")
+        single = cls(demo.aniso_diffusion(N)[0], 0.0, y0, 1.0, **kw)
+        monkeypatch.delenv("ESQ_CHAIN_DEPTH")
+        monkeypatch.setenv("ESQ_CHAIN", "0")
+        bare = cls(demo.aniso_diffusion(N)[0], 0.0, y0, 1.0, **kw)
+        monkeypatch.delenv("ESQ_CHAIN")
+        o = rk_oracle.METHODS[name](twin, 0.0, y0, 1.0, **kw)
+        y_old = o.y
+        for s in (chained, single, bare, o):
+            assert s.step() is None
+        row_sum = max(1.0, float(np.abs(cls.A).sum(axis=1).max()))
+        check_step(chained, o.K, o.y, o.error_norm_old, o.h_abs, y_old, o.h_previous, 1e-1, 1e-1,
+                   k_rtol=2e-13, lipschitz=rho * row_sum)
+        chained._dev.profile_reset()
+        chained._dev.profile_enable([PROF_STAGE, PROF_RHS, PROF_SOLERR])
+        for _ in range(2):
+            for s in (chained, single, bare):
+                assert s.step() is None
+        chained._dev.profile_enable(None)
+        labels = [row[0] for row in chained._dev.profile_kernels()]
+        assert any(lab.startswith("chain") for lab in labels), labels
+        for other in (single, bare):
+            assert_equal(np.asarray(chained.y), np.asarray(other.y))
+            assert_equal(chained.K, other.K)
+    # SSV2stab: chain sweeps of four stages against one launch per stage
+    skw = dict(rtol=1e-3, atol=1e-3, const_jac=True, rho_jac=lambda t, y: rho,
+               first_step=(30 ** 2 - 1) / (1.54 * rho) * 0.999)
+    a = esq.SSV2stab(demo.aniso_diffusion(N)[0], 0.0, y0, 1.0, **skw)
+    monkeypatch.setenv("ESQ_RKC_DEPTH", "1")
+    b = esq.SSV2stab(demo.aniso_diffusion(N)[0], 0.0, y0, 1.0, **skw)
+    monkeypatch.delenv("ESQ_RKC_DEPTH")
+    monkeypatch.setenv("ESQ_RKC_LAST", "0")      # (the end of the step: other summation tree)
+    a0 = esq.SSV2stab(demo.aniso_diffusion(N)[0], 0.0, y0, 1.0, **skw)
+    monkeypatch.delenv("ESQ_RKC_LAST")
+    a._dev.profile_enable([PROF_RKC])
+    for _ in range(3):
+        assert a.step() is None and b.step() is None and a0.step() is None
+        assert a0.t == b.t and a0.errold == b.errold
+        assert_equal(np.asarray(a0.y), np.asarray(b.y))
+        assert abs(a.t - b.t) <= 1e-12 * b.t
+        assert_allclose(np.asarray(a.y), np.asarray(b.y), rtol=1e-10, atol=1e-12)
+    assert any(row[0].startswith("rkc_chain") for row in a._dev.profile_kernels())
+
+
 @pytest.mark.parametrize("tol,expect", [
     (1e-1, (6, 1, 402, 132)),      # docs/Demo_SSV2stab.ipynb:350-356
     (1e-2, (15, 4, 729, 85)),
