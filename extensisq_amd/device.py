@@ -144,9 +144,12 @@ _graveyard = []
 _graveyard_lock = __import__("threading").Lock()
 
 
-def _drain_graveyard():
+def _drain_graveyard(timeout=60.0):
     with _graveyard_lock:
         dead, _graveyard[:] = list(_graveyard), []
+    if dead:
+        from . import lazy
+        lazy._worker.wait_idle(timeout)  # no state download may still read from them
     for lib, handle in dead:
         try:
             lib.esq_destroy(handle)
@@ -154,7 +157,7 @@ def _drain_graveyard():
             pass
 
 
-__import__("atexit").register(_drain_graveyard)
+__import__("atexit").register(_drain_graveyard, 2.0)
 
 
 class DeviceContext:
@@ -195,6 +198,8 @@ class DeviceContext:
     def close(self):
         """destroy the context now (the caller's thread, the caller's moment)"""
         if getattr(self, "handle", None):
+            from . import lazy
+            lazy._worker.wait_idle()
             self.lib.esq_destroy(self.handle)
             self.handle = None
         _drain_graveyard()

@@ -33,6 +33,8 @@ class CopyWorker:
         self._q = queue.Queue()
         self._thread = None
         self._lock = threading.Lock()
+        self._idle = threading.Condition(self._lock)
+        self._inflight = 0
 
     def _run(self):
         while True:
@@ -43,6 +45,15 @@ class CopyWorker:
             except BaseException as exc:          # noqa: BLE001 - handed to the waiter
                 box.append(exc)
             done.set()
+            with self._idle:
+                self._inflight -= 1
+                self._idle.notify_all()
+
+    def wait_idle(self, timeout=60.0):
+        """every copy handed in so far has finished (a context must not be destroyed
+        under a copy that reads from it: device.py)"""
+        with self._idle:
+            return self._idle.wait_for(lambda: self._inflight == 0, timeout)
 
     def submit(self, fn):
         """-> (event, box): box[0] is fn()'s result (or the exception it raised)
@@ -52,6 +63,7 @@ class CopyWorker:
                 self._thread = threading.Thread(target=self._run, daemon=True,
                                                 name="esq-copy-worker")
                 self._thread.start()
+            self._inflight += 1
         done, box = threading.Event(), []
         self._q.put((fn, done, box))
         return done, box

@@ -106,3 +106,9 @@ def test_copy_worker_runs_jobs_in_order():
     for done, _box in jobs:
         assert done.wait(5.0)
     assert seen == list(range(5)) and [b[0] for _d, b in jobs] == list(range(5))
+    assert w.wait_idle(5.0)
+    gate = threading.Event()
+    w.submit(lambda: gate.wait(5.0))
+    assert not w.wait_idle(0.05)                 # a copy under way: a context must wait
+    gate.set()
+    assert w.wait_idle(5.0)
