@@ -97,6 +97,7 @@ REQUIRED = {
     "test_gpu_parity.py::test_device_h_start": 18,
     "test_gpu_parity.py::test_diffusion3d_erk_chain_sweeps_are_bit_identical": 21,
     "test_gpu_parity.py::test_diffusion3d_erk_chain_sweeps_match_oracle": 8,
+    "test_gpu_parity.py::test_free_controller_with_rejections_on_the_3d_plugin_matches_oracle": 2,
     "test_gpu_parity.py::test_lazy_state_mirror_matches_the_immediate_download": 3,
     "test_gpu_parity.py::test_lazy_state_survives_an_assignment_to_the_state": 1,
     "test_gpu_parity.py::test_solve_ivp_with_deferred_states": 4,

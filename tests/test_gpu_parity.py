@@ -561,6 +561,36 @@ def test_full_size_free_controller_with_rejections_matches_oracle():
     assert_allclose(d.y, o.y, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("name", ["Pr8", "Ts5"])
+def test_free_controller_with_rejections_on_the_3d_plugin_matches_oracle(name):
+    """explicit pairs on `Diffusion3D` (N = 96: the 3-D chain sweeps by default), the
+    controller left alone from a first step 30 x the stability limit: rejected attempts,
+    their retries (K[0] re-used, no first launch ahead of a rejected attempt) and the
+    accepted steps that follow are the oracle's -- same counts of accepted steps,
+    rejected steps and RHS evaluations, same times"""
+    N = 96
+    rng = np.random.default_rng(9)
+    y0 = pb.diff3d_y0(N) + 1e-2 * rng.standard_normal(N ** 3)
+    h_stab = 1.0 / (12.0 * (N + 1) ** 2)
+    kw = dict(first_step=30 * h_stab, rtol=1e-5, atol=1e-8, nfev_stiff_detect=0)
+    d, o = _pair(name, esq.Diffusion3D(N), pb.diff3d_rhs(N), 0.0, y0, 80 * h_stab, **kw)
+    accepted = 0
+    while o.status == "running" and accepted < 6:
+        assert o.step() is None
+        accepted += 1
+    nfs_ref = int(rk_oracle.NFS[()])
+    d._dev.profile_enable([0, 1, 2])
+    for _ in range(accepted):
+        assert d.step() is None
+    labels = [row[0] for row in d._dev.profile_kernels()]
+    assert any(lab.startswith("chain") for lab in labels), labels
+    assert int(esq.NFS[()]) == nfs_ref and nfs_ref >= 1
+    assert d.nfev == o.nfev
+    assert_allclose(d.t, o.t, rtol=1e-9)
+    assert_allclose(d.h_abs, o.h_abs, rtol=1e-6)
+    assert_allclose(np.asarray(d.y), o.y, rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("name,mk,y0f", [
     ("Pr8", lambda: esq.Brusselator2D(64), lambda: pb.bruss2d_y0(64)),
     ("Pr9", lambda: esq.Heat2D(96), lambda: pb.heat2d_y0(96)),
