@@ -91,6 +91,9 @@ __global__ __launch_bounds__(64 * NW) void k_chain3d(const double *__restrict__ 
     const int Re = i_hi - i_lo;
     const unsigned plane_bytes = (unsigned)N * (unsigned)N * 8u;
     const size_t vec_bytes = (size_t)plane_bytes * (size_t)N;
+    // the chain's derivatives are streamed out (non-temporal) where the library says
+    // that nothing reads them soon (esq_chain.f_store_nt)
+    const bool f_nt = ca.f_nt != 0;
     // the chain's input T_0; ca.y == nullptr: the chain starts from the state itself
     // (stage 0 = f(t, y)), the base of every target is that input
     const bool own_base = ca.y == nullptr;
@@ -146,7 +149,11 @@ __global__ __launch_bounds__(64 * NW) void k_chain3d(const double *__restrict__ 
                     xch[b][k][NW + 1][e][lane] = 0.0;
                 }
     }
-    auto ld = [&](rsrc_t v, int i, int r) -> double {
+    // (every load cacheable: the library's per-row streaming hint, esq_chain.load_nt, is
+    // NOT followed here -- the halo points of neighbouring tiles meet in L2, and
+    // non-temporal loads lose those hits: the step's last chain 117 -> 132 us at N = 159,
+    // 1.51 -> 1.93 ms at N = 400, profiles/r05_experiments.md §1)
+    auto ld = [&](rsrc_t v, int i, int r, unsigned) -> double {
         const bool ok = i >= 0 && i < N;                         // uniform
         return buf_ld(v, ok ? vo[r] : 0xffffffffu, ok ? (unsigned)i * plane_bytes : 0u);
     };
@@ -166,8 +173,8 @@ __global__ __launch_bounds__(64 * NW) void k_chain3d(const double *__restrict__ 
     const int ibase = i_lo - (D - 1);                 // stage 0's first centre plane
 #pragma unroll
     for (int r = 0; r < JT; ++r) {
-        wm[0][r] = ld(rin, ibase - 1, r);
-        wc[0][r] = ld(rin, ibase, r);
+        wm[0][r] = ld(rin, ibase - 1, r, 0);
+        wc[0][r] = ld(rin, ibase, r, 0);
     }
     // operands of stage 0's plane: the input one plane up, the base state and the
     // memory rows at the plane; requested ONE ITERATION AHEAD -- right behind the
@@ -177,10 +184,10 @@ __global__ __launch_bounds__(64 * NW) void k_chain3d(const double *__restrict__ 
     {                                                                       \
         const int i_ = ibase + (IT);                                        \
         _Pragma("unroll") for (int r = 0; r < JT; ++r) {                    \
-            pin[r] = ld(rin, i_ + 1, r);                                    \
-            py[r] = ld(ry, i_, r);                                          \
+            pin[r] = ld(rin, i_ + 1, r, 0);                                 \
+            py[r] = ld(ry, i_, r, 1);                                       \
             _Pragma("unroll") for (int u = 0; u < NU; ++u)                  \
-                pu[u][r] = ld(ru[u], i_, r);                                \
+                pu[u][r] = ld(ru[u], i_, r, 8 + u);                         \
         }                                                                   \
     }
     if (ESQ_CHAIN3D_PF) ESQ_CHAIN3D_LOAD(0)
@@ -242,7 +249,8 @@ __global__ __launch_bounds__(64 * NW) void k_chain3d(const double *__restrict__ 
                     const double rt = lane_right(wc[k][r]);
                     const double fK = st.eval(wm[k][r], wp[r], up, dn, lf, rt, wc[k][r]);
                     // K_k of the points this tile owns (planes [i_lo, i_hi) only)
-                    buf_st(rk[k], pl_own ? so[r] : 0xffffffffu, pl, fK);
+                    if (f_nt) buf_st_p<2>(rk[k], pl_own ? so[r] : 0xffffffffu, pl, fK);
+                    else buf_st(rk[k], pl_own ? so[r] : 0xffffffffu, pl, fK);
                     // K_k enters the sums of the later targets
 #pragma unroll
                     for (int e = k; e < D; ++e) {
