@@ -347,25 +347,28 @@ struct Stencil3D {
         hipExtLaunchKernelGGL((k_stencil3d_march<R, St, Epi>), dim3(grid), dim3(kBlock), 0, s, e0,
                               e1, 0, y_in, f, N, St{fn}, grid, bpp, epi);
     }
-    // one sweep with epilogue `epi`, by the functor's class and the tuning
-    template <class Epi>
+    // one sweep with epilogue `epi`, by the functor's class and the tuning (callers have
+    // refused N < 2 for the fast class).  SHORT: the Chebyshev stage also runs the
+    // marching sweep with 1 / 2 / 4 planes per workgroup (instantiated for its epilogue
+    // only: every instantiation of this function costs compile time x ~60 epilogues)
+    template <bool SHORT = false, class Epi>
     static void sweep(const Fn &fn, int N, double t, const double *y_in, double *f,
                       const Epi &epi, const Stencil3dTuning &tune, hipStream_t s,
-                      hipEvent_t e0, hipEvent_t e1, bool short_march = false) {
+                      hipEvent_t e0, hipEvent_t e1) {
         if constexpr (kFast) {
-            if (N >= 2) {
+            if (tune.march_r == 0) { launch_pairs(fn, N, y_in, f, epi, s, e0, e1); return; }
+            if constexpr (SHORT) {
                 switch (tune.march_r) {
-                    case 0: launch_pairs(fn, N, y_in, f, epi, s, e0, e1); return;
-                    case 1: if (short_march) { launch_march<1>(fn, N, y_in, f, epi, s, e0, e1); return; } break;
-                    case 2: if (short_march) { launch_march<2>(fn, N, y_in, f, epi, s, e0, e1); return; } break;
-                    case 4: if (short_march) { launch_march<4>(fn, N, y_in, f, epi, s, e0, e1); return; } break;
+                    case 1: launch_march<1>(fn, N, y_in, f, epi, s, e0, e1); return;
+                    case 2: launch_march<2>(fn, N, y_in, f, epi, s, e0, e1); return;
+                    case 4: launch_march<4>(fn, N, y_in, f, epi, s, e0, e1); return;
                     default: break;
                 }
-                launch_march<8>(fn, N, y_in, f, epi, s, e0, e1);
-                return;
             }
+            launch_march<8>(fn, N, y_in, f, epi, s, e0, e1);
+        } else {
+            launch_points(fn, N, t, y_in, f, epi, s, e0, e1);
         }
-        launch_points(fn, N, t, y_in, f, epi, s, e0, e1);
     }
 
     // f = fun(t, y)                                                 (esq_rhs_fn)
@@ -416,8 +419,8 @@ struct Stencil3D {
         e.mu = mu; e.nu = nu; e.omn = omn; e.hmus = hmus; e.ajm1 = ajm1;
         // (planes per workgroup of the marching sweep: with the five vectors of a
         // Chebyshev stage resident in the Infinity Cache short marches win)
-        sweep(fn, N, t, yjm1, nullptr, e, tune, (hipStream_t)stream, (hipEvent_t)start_event,
-              (hipEvent_t)stop_event, /*short_march=*/true);
+        sweep</*SHORT=*/true>(fn, N, t, yjm1, nullptr, e, tune, (hipStream_t)stream,
+                              (hipEvent_t)start_event, (hipEvent_t)stop_event);
         return (int)hipGetLastError();
     }
 
