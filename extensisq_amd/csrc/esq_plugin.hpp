@@ -226,8 +226,9 @@ ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
 // (depth, kind_last, nu) -> launch(ChainArgs<D, NU>, integral_constant<kind_last>).
 // Instantiated: depth 2, 3 and 4 with up to 9 memory rows, 5 and 6 with up to 6.
 // MAXD: deepest chain the caller's kernel is instantiated for (compile time grows
-// with every depth)
-template <int MAXD = 4, class Launch>
+// with every depth); MIND: the shallowest (a plugin may spread its depths over several
+// translation units that compile in parallel: esq_rhs_bruss2d_chain*.hip)
+template <int MAXD = 4, int MIND = 2, class Launch>
 int dispatch_chain(const esq_chain *c, Launch &&launch) {
     if (!c || c->nu < 0 || (!c->out && c->kind_last != ESQ_EPI_STAGE)) return ESQ_EINVAL;
     if (c->from_rows && !c->y) return ESQ_EINVAL;
@@ -283,25 +284,34 @@ int dispatch_chain(const esq_chain *c, Launch &&launch) {
     ESQ_CHAIN_CASE_(DD, 6)
     switch (c->depth) {
         case 2:
-            switch (c->nu) {
-                ESQ_CHAIN_CASES_0_6_(2) ESQ_CHAIN_CASE_(2, 7) ESQ_CHAIN_CASE_(2, 8)
-                ESQ_CHAIN_CASE_(2, 9)
-                default: return ESQ_ENOTSUP;
+            if constexpr (MIND <= 2 && MAXD >= 2) {
+                switch (c->nu) {
+                    ESQ_CHAIN_CASES_0_6_(2) ESQ_CHAIN_CASE_(2, 7) ESQ_CHAIN_CASE_(2, 8)
+                    ESQ_CHAIN_CASE_(2, 9)
+                    default: return ESQ_ENOTSUP;
+                }
             }
+            return ESQ_ENOTSUP;
         case 3:
-            switch (c->nu) {
-                ESQ_CHAIN_CASES_0_6_(3) ESQ_CHAIN_CASE_(3, 7) ESQ_CHAIN_CASE_(3, 8)
-                ESQ_CHAIN_CASE_(3, 9)
-                default: return ESQ_ENOTSUP;
+            if constexpr (MIND <= 3 && MAXD >= 3) {
+                switch (c->nu) {
+                    ESQ_CHAIN_CASES_0_6_(3) ESQ_CHAIN_CASE_(3, 7) ESQ_CHAIN_CASE_(3, 8)
+                    ESQ_CHAIN_CASE_(3, 9)
+                    default: return ESQ_ENOTSUP;
+                }
             }
+            return ESQ_ENOTSUP;
         case 4:
-            switch (c->nu) {
-                ESQ_CHAIN_CASES_0_6_(4) ESQ_CHAIN_CASE_(4, 7) ESQ_CHAIN_CASE_(4, 8)
-                ESQ_CHAIN_CASE_(4, 9)
-                default: return ESQ_ENOTSUP;
+            if constexpr (MIND <= 4 && MAXD >= 4) {
+                switch (c->nu) {
+                    ESQ_CHAIN_CASES_0_6_(4) ESQ_CHAIN_CASE_(4, 7) ESQ_CHAIN_CASE_(4, 8)
+                    ESQ_CHAIN_CASE_(4, 9)
+                    default: return ESQ_ENOTSUP;
+                }
             }
+            return ESQ_ENOTSUP;
         case 5:
-            if constexpr (MAXD >= 5) {
+            if constexpr (MIND <= 5 && MAXD >= 5) {
                 switch (c->nu) {
                     ESQ_CHAIN_CASES_0_6_(5)
                     default: return ESQ_ENOTSUP;
@@ -309,7 +319,7 @@ int dispatch_chain(const esq_chain *c, Launch &&launch) {
             }
             return ESQ_ENOTSUP;
         case 6:
-            if constexpr (MAXD >= 6) {
+            if constexpr (MIND <= 6 && MAXD >= 6) {
                 switch (c->nu) {
                     ESQ_CHAIN_CASES_0_6_(6)
                     default: return ESQ_ENOTSUP;

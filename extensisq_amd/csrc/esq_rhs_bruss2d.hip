@@ -1,8 +1,6 @@
 // esq_rhs_bruss2d.hip -- 2-D Brusselator reaction-diffusion, periodic
 // (BASELINE.json configs[2], the north-star workload).
-#include "esq_rhs_common.hpp"
-
-using namespace esq_rhs;
+#include "esq_rhs_bruss2d.hpp"
 
 namespace {
 
@@ -37,39 +35,6 @@ __global__ __launch_bounds__(kBlock) void k_bruss2d(
         f[k] = fu;
         f[NN + k] = fv;
     }
-}
-
-// The plugin's pointwise functor: centres and five-point Laplacians of (u, v) ->
-// (du, dv), same operation order as k_bruss2d.  Everything else -- the one-stage
-// sweep with its epilogues, the marching chain sweeps, the launch geometry -- is
-// esq_stencil2d.hpp, shared with the heat plugin and with user plugins.
-struct BrussFn {
-    double d, A, B;
-    __device__ __forceinline__ void eval(const double2 (&c)[2], const double2 (&lap)[2],
-                                         double2 (&f)[2]) const {
-        const double uuvx = c[0].x * c[0].x * c[1].x, uuvy = c[0].y * c[0].y * c[1].y;
-        f[0].x = ((A + uuvx) - (B + 1.0) * c[0].x) + d * lap[0].x;
-        f[0].y = ((A + uuvy) - (B + 1.0) * c[0].y) + d * lap[0].y;
-        f[1].x = (B * c[0].x - uuvx) + d * lap[1].x;
-        f[1].y = (B * c[0].y - uuvy) + d * lap[1].y;
-    }
-    // one field only (split chain sweeps: a wave per field), same operations
-    __device__ __forceinline__ double2 eval_one(int field, const double2 (&c)[2],
-                                                double2 lap) const {
-        const double uuvx = c[0].x * c[0].x * c[1].x, uuvy = c[0].y * c[0].y * c[1].y;
-        if (field == 0)
-            return make_double2(((A + uuvx) - (B + 1.0) * c[0].x) + d * lap.x,
-                                ((A + uuvy) - (B + 1.0) * c[0].y) + d * lap.y);
-        return make_double2((B * c[0].x - uuvx) + d * lap.x, (B * c[0].y - uuvy) + d * lap.y);
-    }
-};
-
-// one field per wave in the chain sweeps (default), or both fields in one wave
-// (ESQ_CHAIN_SPLIT=0: the first version, narrower register caps)
-using BrussSplit = esq::Stencil2D<2, true, BrussFn, true>;
-using BrussJoint = esq::Stencil2D<2, true, BrussFn, false>;
-inline BrussFn fn_of(const Rhs *r) {
-    return BrussFn{r->alpha * ((double)r->N * (double)r->N), r->a, r->b};
 }
 
 }  // namespace
@@ -120,9 +85,12 @@ int esq_rhs_bruss2d_chain(void *user, const double *y_in, const esq_chain *chain
                           void *stop_event) {
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != BRUSS2D || n != r->n || !chain) return ESQ_EINVAL;
-    static const bool split = !getenv("ESQ_CHAIN_SPLIT") || atoi(getenv("ESQ_CHAIN_SPLIT")) != 0;
-    return split ? BrussSplit::chain(fn_of(r), r->N, y_in, chain, stream, start_event, stop_event)
-                 : BrussJoint::chain(fn_of(r), r->N, y_in, chain, stream, start_event, stop_event);
+    // (the depths live in three translation units: esq_rhs_bruss2d.hpp)
+    if (chain->depth <= 3)
+        return bruss2d_chain_d23(r, y_in, chain, stream, start_event, stop_event);
+    if (chain->depth == 4)
+        return bruss2d_chain_d4(r, y_in, chain, stream, start_event, stop_event);
+    return bruss2d_chain_d56(r, y_in, chain, stream, start_event, stop_event);
 }
 
 }  // extern "C"

@@ -1,8 +1,6 @@
 // esq_rhs_heat2d.hip -- 2-D heat equation, 5-point Laplacian, Dirichlet 0
 // (BASELINE.json configs[1], configs[4]).
-#include "esq_rhs_common.hpp"
-
-using namespace esq_rhs;
+#include "esq_rhs_heat2d.hpp"
 
 namespace {
 
@@ -23,20 +21,6 @@ __global__ __launch_bounds__(kBlock) void k_heat2d(const double *__restrict__ u,
     const double rt = j + 1 < (unsigned)N ? u[k + 1] : 0.0;
     f[k] = c * (((up + dn) + (lf + rt)) - 4.0 * uc);
 }
-
-// the plugin's pointwise functor: f = c * laplacian (everything else:
-// esq_stencil2d.hpp)
-struct HeatFn {
-    double c;
-    __device__ __forceinline__ void eval(const double2 (&)[1], const double2 (&lap)[1],
-                                         double2 (&f)[1]) const {
-        f[0].x = c * lap[0].x;
-        f[0].y = c * lap[0].y;
-    }
-};
-
-using Heat = esq::Stencil2D<1, false, HeatFn>;
-inline HeatFn fn_of(const Rhs *r) { return HeatFn{(double)(r->N + 1) * (double)(r->N + 1)}; }
 
 }  // namespace
 
@@ -91,15 +75,17 @@ int esq_rhs_heat2d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void
     return Heat::rkc_chain(fn_of(r), r->N, ch, stream, start_event, stop_event);
 }
 
-// the one-field rows are light: tall tiles where one wave per SIMD fills the chip,
-// tiles down to `depth` rows (esq_stencil2d.hpp, geo_chain)
+// (the depths live in three translation units: esq_rhs_heat2d.hpp)
 int esq_rhs_heat2d_chain(void *user, const double *y_in, const esq_chain *chain,
                           size_t n, void *stream, void *start_event,
                           void *stop_event) {
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != HEAT2D || n != r->n || !chain) return ESQ_EINVAL;
-    return Heat::chain(fn_of(r), r->N, y_in, chain, stream, start_event, stop_event,
-                       /*tall_tiles=*/true, /*min_rows=*/-1);
+    if (chain->depth <= 3)
+        return heat2d_chain_d23(r, y_in, chain, stream, start_event, stop_event);
+    if (chain->depth == 4)
+        return heat2d_chain_d4(r, y_in, chain, stream, start_event, stop_event);
+    return heat2d_chain_d56(r, y_in, chain, stream, start_event, stop_event);
 }
 
 }  // extern "C"

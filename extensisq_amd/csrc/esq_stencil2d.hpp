@@ -441,6 +441,9 @@ struct Stencil2D {
 
     // `depth` consecutive stages in one marching sweep          (esq_rhs_chain_fn)
     // tall_tiles / min_rows: tile-height rules of geo_chain (light one-field rows)
+    // LO..HI: the depths this call is instantiated for (a plugin may give each range
+    // a translation unit of its own; a depth outside it: ESQ_ENOTSUP)
+    template <int LO = 2, int HI = 6>
     static int chain(const Fn &fn, int N, const double *y_in, const esq_chain *chain,
                      void *stream, void *start_event, void *stop_event,
                      bool tall_tiles = false, int min_rows = 0) {
@@ -488,7 +491,8 @@ struct Stencil2D {
                                   chain_serpentine());
         };
         // (several fields in one wave: the register budget ends at depth 4)
-        const int rc = dispatch_chain<(split || NF == 1) ? 6 : 4>(
+        constexpr int kDeepest = (split || NF == 1) ? 6 : 4;
+        const int rc = dispatch_chain<(HI < kDeepest ? HI : kDeepest), LO>(
             chain, [&](auto ca, auto kind, auto from_c) {
                 body(ca, kind, std::integral_constant<bool, split>{}, from_c); });
         if (rc || chain->dry_run) return rc;
