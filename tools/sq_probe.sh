@@ -1,11 +1,13 @@
 #!/bin/bash
 # Where the waves of each sweep spend their cycles (one --pmc group per pass,
-# --kernel-trace only): tools/sq_probe.sh <config>[@grid].  Output on stdout and in
+# --kernel-trace only): tools/sq_probe.sh <config>[:plugin][@grid].  Output on stdout and in
 # gpurun_out/sq_probe_<config>_<k>/
 SPEC=${1:-pr8}
-CFG=${SPEC%@*}
+CP=${SPEC%@*}
 GRID=""
-if [ "$SPEC" != "$CFG" ]; then GRID="--grid ${SPEC#*@}"; fi
+if [ "$SPEC" != "$CP" ]; then GRID="--grid ${SPEC#*@}"; fi
+CFG=${CP%:*}
+if [ "$CP" != "$CFG" ]; then GRID="$GRID --plugin ${CP#*:}"; fi
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out
 OUT=$ROOT/gpurun_out
@@ -29,7 +31,9 @@ for f in glob.glob("$OUT/sq_probe_${CFG}_*/p_counter_collection.csv"):
         c=re.search(r"k_chain2d<\d+, (?:true|false), (\d+), (\d+), (\d+)", name)
         m=re.search(r"k_(\w+)_sweep<.*Epi(\w+?)<(\d+)", name)
         k3=re.search(r"k_rkc3d_chain<(\d+), (\d+), (\d+)", name)
-        if k3: lab = f"rkc_chain{k3.group(1)}[JT={k3.group(2)},NW={k3.group(3)}]"
+        c3=re.search(r"k_chain3d<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
+        if c3: lab = f"chain3d{c3.group(1)}{'+solerr' if c3.group(5)=='3' else ''}<{c3.group(2)}>"
+        elif k3: lab = f"rkc_chain{k3.group(1)}[JT={k3.group(2)},NW={k3.group(3)}]"
         elif c: lab = f"chain{c.group(1)}{'+solerr' if c.group(3)=='3' else ''}<{c.group(2)}>"
         else: lab = f"{m.group(2)}<{m.group(3)}>" + ("/src" if "SrcAxpy" in name else "") if m else re.sub(r"\(.*","",name)[-30:]
         agg[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
