@@ -958,5 +958,31 @@ def _solve_ivp_run(w, device, steps, extra):
                     "identical work in the reference)"}
 
 
+def _watchdog():
+    """A default run takes well under a minute.  One that is still going after
+    ESQ_BENCH_STACKS_S (300 s) writes every thread's Python stack to stderr -- so
+    that a hang on the driver's box leaves a trace -- and after ESQ_BENCH_LIMIT_S
+    (1500 s; 0 = never) does so again and exits with code 70 instead of holding the
+    GPU box until an outer limit kills it without a word."""
+    import faulthandler
+    stacks = float(os.environ.get("ESQ_BENCH_STACKS_S", "300"))
+    limit = float(os.environ.get("ESQ_BENCH_LIMIT_S", "1500"))
+    if stacks > 0:
+        faulthandler.dump_traceback_later(stacks, exit=False)
+    if limit > 0:
+        import threading
+
+        def bail():
+            sys.stderr.write("bench.py: still running after %.0f s -- giving up\n" % limit)
+            faulthandler.dump_traceback(all_threads=True)
+            sys.stderr.flush()
+            os._exit(70)
+
+        t = threading.Timer(limit, bail)
+        t.daemon = True
+        t.start()
+
+
 if __name__ == "__main__":
+    _watchdog()
     main()

@@ -15,7 +15,7 @@ mkdir -p $ROOT/gpurun_out
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 # a fresh box runs its first seconds of GPU work measurably slower: warm it up
-python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras > /dev/null 2>&1
+timeout 900 python3 $ROOT/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-solve-ivp --no-extras > /dev/null 2>&1
 # Three passes over the configs, so that no un-profiled number is taken behind a
 # counter-collection run (rocprofv3 --pmc leaves the device in its profiling power
 # state for a while: the driver's command read 0.533 ms/step behind one, 0.484 on the
@@ -32,31 +32,31 @@ for SPEC in "${@:-pr8}"; do
     spec $SPEC
     if [ "$CFG" = driver ]; then
         # the driver's own command line (its flags), extras and CPU baseline included
-        python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 \
+        timeout 900 python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 \
             > $OUT/prof_driver_bench.json 2> $OUT/prof_driver_bench.err
         continue
     fi
-    python3 $ROOT/bench.py --config $CFG $GRID --steps $STEPS --warmup 5 $FLAGS \
+    timeout 900 python3 $ROOT/bench.py --config $CFG $GRID --steps $STEPS --warmup 5 $FLAGS \
         > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_${TAG}_bench.err
 done
 for SPEC in "${@:-pr8}"; do
     spec $SPEC
     if [ "$CFG" = driver ]; then
-        rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_driver_stats -o bench -- \
+        timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_driver_stats -o bench -- \
             python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/prof_driver_stats.log 2>&1
         continue
     fi
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -o bench -- \
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_stats -o bench -- \
         python3 $ROOT/bench.py --config $CFG $GRID --steps $STEPS --warmup 5 $FLAGS \
         > $OUT/prof_${TAG}_stats.log 2>&1
 done
 for SPEC in "${@:-pr8}"; do
     spec $SPEC
     [ "$CFG" = driver ] && continue
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_fetch -o bench -- \
+    timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_fetch -o bench -- \
         python3 $ROOT/bench.py --config $CFG $GRID --steps 3 --warmup 1 $FLAGS \
         > $OUT/prof_${TAG}_fetch.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_write -o bench -- \
+    timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_write -o bench -- \
         python3 $ROOT/bench.py --config $CFG $GRID --steps 3 --warmup 1 $FLAGS \
         > $OUT/prof_${TAG}_write.log 2>&1
 done
