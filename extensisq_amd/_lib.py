@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # `make VARIANT=...` in csrc/); must sit next to the package like the default one
 LIB_PATH = os.environ.get("ESQ_LIB") or os.path.join(_HERE, "libextensisq_amd.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
 EPI_RKCERR = 6
@@ -49,6 +49,7 @@ SIGNATURES = {
     "esq_download": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "esq_snapshot_begin": (C.c_int, [_vp, C.c_int, C.c_int, _vpp]),
     "esq_snapshot_copy": (C.c_int, [_vp, _vp, C.c_int]),
+    "esq_copy_lane_info": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "esq_host_pin": (C.c_int, [_vp, C.c_size_t]),
     "esq_host_unpin": (C.c_int, [_vp]),
     "esq_copy": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -216,6 +217,19 @@ def device_pci_bus_id(device):
     if load().esq_device_pci_bus_id(int(device), buf, len(buf)) != 0:
         return None
     return buf.value.decode().strip().lower() or None
+
+
+def copy_lane_info(device=0):
+    """the record of the large downloads of `device` (esq_copy_lane_info): the fastest
+    timed first piece, the copy kernel's reference piece and the latest whole download
+    (GB/s), downloads finished by the DMA engines / by the copy kernel"""
+    best, ref, last = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+    eng, ker = C.c_long(0), C.c_long(0)
+    if load().esq_copy_lane_info(int(device), C.byref(best), C.byref(ref), C.byref(last),
+                                 C.byref(eng), C.byref(ker)) != 0:
+        return None
+    return {"best_probe_gbs": best.value, "kernel_ref_gbs": ref.value, "last_gbs": last.value,
+            "engine_copies": eng.value, "kernel_copies": ker.value}
 
 
 def as_ptr(arr):

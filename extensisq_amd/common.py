@@ -1007,6 +1007,7 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
             diagnose(self, lotsfl)
 
     def __del__(self):
+        # (never a blocking call in a finalizer: DeviceContext.park)
         dev = getattr(self, "_dev", None)
         if dev is not None:
-            dev.close()
+            dev.park()

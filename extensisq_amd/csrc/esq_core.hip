@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 
 #include "esq_internal.hpp"
 #include "esq_chain.hpp"
@@ -349,6 +350,168 @@ int host_wait(esq_ctx *c, bool already_idle) {
 // destination for the duration of the call: measured for 80 MB into a fresh
 // NumPy array 4.3 ms (register 2.8 + copy 1.5 at 54 GB/s) against 6.5-7 ms for
 // the staged pageable copy.
+// ---- large device-to-host copies ------------------------------------------------
+// hipMemcpyAsync hands the copy to one of the device's DMA engines, and these have a
+// state of their own: in the same process, on the same stream, into the same kind of
+// pinned buffer, 80 MB take 1.42 ms (56 GB/s) for a while and then 2.8-3.2 ms (25-30
+// GB/s) for a while -- every stream of the process at once, fresh ones too, whichever
+// buffer (tools/ivp_modes.sh: plain solve_ivp several times in one process; which runs
+// are slow changes from process to process).  A copy by a KERNEL into the page-locked
+// destination is not affected (4 to 512 workgroups: 53-55 GB/s in either state of the
+// engines) but has a price of its own: its stores over the link hold up the stores of a
+// sweep that runs beside it (the step's first chain sweep 0.10 -> 1.4 ms: plain
+// solve_ivp 1.86 ms/step beside kernel copies of 8 workgroups, 2.05 with 128, 1.44
+// beside fast engine copies, 2.8 beside slow ones).  So, for every download of 16 MiB
+// and more:
+//   * it runs on ONE stream per device and process (made once, never destroyed);
+//   * the engines copy the first kProbeBytes and are timed; if that piece was slower
+//     than 0.8 x the fastest such piece seen so far, the kernel copies the rest,
+//     otherwise the engines do.  No history beyond that maximum: the engines are back
+//     in use with the first download that finds them fast.
+// (ESQ_D2H_MODE=engine / kernel pins the choice, ESQ_D2H_BLOCKS the kernel's grid.)
+constexpr int kLaneDevices = 64;
+constexpr size_t kLaneMinBytes = (size_t)8 << 20, kProbeBytes = (size_t)8 << 20;
+struct CopyLane {
+    hipStream_t stream = nullptr;
+    bool failed = false;
+    double best_probe_gbs = 0.0;   // fastest timed first piece
+    double kernel_ref_gbs = 0.0;   // a piece of the same size by the kernel, timed once
+    double last_gbs = 0.0;         // the latest whole download
+    long engine_copies = 0, kernel_copies = 0;
+};
+std::mutex g_lane_mu;
+CopyLane g_lane[kLaneDevices];
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// dst: device-visible address of pinned host memory; 16-byte pieces + one double
+__global__ __launch_bounds__(256) void k_d2h(const u32x4 *__restrict__ src,
+                                             u32x4 *__restrict__ dst, size_t n16,
+                                             int tail) {
+    const size_t stride = (size_t)gridDim.x * 256u;
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    // four loads in flight per thread, then four stores over the link
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 a = __builtin_nontemporal_load(src + i);
+        const u32x4 b = __builtin_nontemporal_load(src + i + stride);
+        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride);
+        const u32x4 d = __builtin_nontemporal_load(src + i + 3 * stride);
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+    if (tail && blockIdx.x == 0 && threadIdx.x == 0)
+        ((double *)(dst + n16))[0] = ((const double *)(src + n16))[0];
+}
+
+// the process's download stream of `device` (the current device); nullptr: none
+hipStream_t copy_lane(int device) {
+    if (device < 0 || device >= kLaneDevices) return nullptr;
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    CopyLane &ln = g_lane[device];
+    if (!ln.stream && !ln.failed) {
+        // the highest priority there is: a hardware queue of its own (streams of one
+        // priority share a few, and kernels of one queue run in order -- the copy
+        // kernel would wait for the step's sweeps and they for it), dispatched first
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            least = greatest = 0;
+        }
+        static const int prio = (int)env_uint("ESQ_D2H_PRIORITY", 1);
+        const hipError_t e = prio && greatest != least
+            ? hipStreamCreateWithPriority(&ln.stream, hipStreamNonBlocking, greatest)
+            : hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ln.stream = nullptr;
+            ln.failed = true;
+        }
+    }
+    return ln.stream;
+}
+
+// One large copy on `stream` (everything it depends on has been waited for); blocks
+// until the bytes are in `host`.  `pinned`: the destination is page-locked (a kernel
+// cannot write to any other, and a staged pageable copy says nothing about the engines)
+hipError_t lane_copy(int device, hipStream_t stream, void *host, const void *dev, size_t bytes,
+                     bool pinned) {
+    static const int mode = [] {                    // 0 auto, 1 engine, 2 kernel
+        const char *m = getenv("ESQ_D2H_MODE");
+        return !m ? 0 : !strcmp(m, "engine") ? 1 : !strcmp(m, "kernel") ? 2 : 0;
+    }();
+    static const unsigned blocks = env_uint("ESQ_D2H_BLOCKS", 8);
+    const bool lane_ok = device >= 0 && device < kLaneDevices && bytes >= kLaneMinBytes;
+    void *dst = nullptr;
+    bool can_kernel = lane_ok && pinned && mode != 1 && blocks > 0 && bytes % 8 == 0 &&
+                      bytes >= 2 * kProbeBytes && ((uintptr_t)dev & 15) == 0;
+    if (can_kernel && (hipHostGetDevicePointer(&dst, host, 0) != hipSuccess || !dst ||
+                       ((uintptr_t)dst & 15) != 0)) {
+        (void)hipGetLastError();
+        can_kernel = false;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipSuccess;
+    size_t done = 0;
+    bool by_kernel = can_kernel && mode == 2;
+    if (can_kernel && mode == 0) {
+        e = hipMemcpyAsync(host, dev, kProbeBytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        done = kProbeBytes;
+        const double gbs = (double)kProbeBytes * 1e-9 /
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        bool want_ref;
+        {
+            std::lock_guard<std::mutex> lk(g_lane_mu);
+            want_ref = g_lane[device].kernel_ref_gbs == 0.0 && bytes >= 3 * kProbeBytes;
+        }
+        double ref = 0.0;
+        if (want_ref) {
+            // once per process: what the kernel makes of a piece of that size -- the
+            // yardstick for a process whose FIRST download finds the engines slow
+            hipLaunchKernelGGL(k_d2h, dim3(blocks), dim3(256), 0, stream, (const u32x4 *)dev,
+                               (u32x4 *)dst, (size_t)0, 0);               // (code object load)
+            (void)hipStreamSynchronize(stream);
+            const auto k0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(k_d2h, dim3(blocks), dim3(256), 0, stream,
+                               (const u32x4 *)((const char *)dev + done),
+                               (u32x4 *)((char *)dst + done), kProbeBytes / 16, 0);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            ref = (double)kProbeBytes * 1e-9 /
+                  std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count();
+            done += kProbeBytes;
+        }
+        std::lock_guard<std::mutex> lk(g_lane_mu);
+        CopyLane &ln = g_lane[device];
+        if (ref > 0.0) ln.kernel_ref_gbs = ref;
+        if (gbs > ln.best_probe_gbs) ln.best_probe_gbs = gbs;
+        // slow: against the engines' own best, or -- no fast piece seen yet -- the kernel's
+        const double bar = ln.best_probe_gbs > 0.9 * ln.kernel_ref_gbs ? ln.best_probe_gbs
+                                                                       : 0.9 * ln.kernel_ref_gbs;
+        by_kernel = gbs < 0.8 * bar;
+    }
+    if (by_kernel) {
+        const size_t rest = bytes - done;
+        hipLaunchKernelGGL(k_d2h, dim3(blocks), dim3(256), 0, stream,
+                           (const u32x4 *)((const char *)dev + done),
+                           (u32x4 *)((char *)dst + done), rest / 16, (int)((rest / 8) & 1));
+        e = hipGetLastError();
+    } else {
+        e = hipMemcpyAsync((char *)host + done, (const char *)dev + done, bytes - done,
+                           hipMemcpyDeviceToHost, stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess || !lane_ok) return e;
+    const double gbs = (double)bytes * 1e-9 /
+                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    CopyLane &ln = g_lane[device];
+    ln.last_gbs = gbs;
+    ++(by_kernel ? ln.kernel_copies : ln.engine_copies);
+    return e;
+}
+
 int d2h(esq_ctx *c, void *host, const void *dev, size_t bytes, bool was_idle) {
     if (in_host_slab(c, dev)) {
         const int w = host_wait(c, was_idle);
@@ -357,10 +520,22 @@ int d2h(esq_ctx *c, void *host, const void *dev, size_t bytes, bool was_idle) {
         return 0;
     }
     bool pinned = false;
-    if (bytes >= ((size_t)8 << 20))
-        pinned = hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess;
-    hipError_t e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipStream_t lane = nullptr;
+    if (bytes >= kLaneMinBytes) {
+        pinned = hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable) ==
+                 hipSuccess;
+        if (!pinned) (void)hipGetLastError();
+        lane = copy_lane(c->device);
+    }
+    hipError_t e = hipSuccess;
+    if (lane) {
+        // behind everything the context has enqueued, on the process's download stream
+        e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = lane_copy(c->device, lane, host, dev, bytes, pinned);
+    } else {
+        e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
     if (pinned) (void)hipHostUnregister(host);
     if (e != hipSuccess)
         return fail(c, (int)e, "device-to-host copy failed: %s", hipGetErrorString(e));
@@ -541,10 +716,9 @@ int esq_destroy(esq_ctx *c) {
     }
     for (double *p : c->aux_slabs) (void)hipFree(p);
     if (c->h_slot) (void)hipHostFree(c->h_slot);
-    for (hipStream_t cs : {c->copy_stream, c->copy_stream2}) {
-        if (!cs) continue;
-        (void)hipStreamSynchronize(cs);
-        (void)hipStreamDestroy(cs);
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -592,8 +766,7 @@ int esq_download(esq_ctx *c, int slot, int row, double *host) {
 struct esq_snapshot {
     int device;
     hipEvent_t ready;        // recorded on the context's stream: the vector is final
-    hipStream_t stream;      // the context's two copy streams (owned by the context):
-    hipStream_t stream2;     // each takes half of the vector
+    hipStream_t stream;      // the process's download stream of the device (copy_lane)
     const double *src;
     size_t bytes;
 };
@@ -605,18 +778,15 @@ int esq_snapshot_begin(esq_ctx *c, int slot, int row, void **token_out) {
     if (slot == ESQ_SLOT_K) ENSURE_ROWS(c);
     const double *d = slot_ptr(c, slot, row);
     if (!d) return fail(c, ESQ_EINVAL, "bad slot/row %d/%d", slot, row);
-    // TWO copy streams, half of the vector each: which DMA engine a stream's copies run
-    // on is the runtime's choice, and not every engine moves data over PCIe at the
-    // link's rate (the same 80 MB copy took 1.43 ms in one process and 2.80 ms in
-    // another, depending on the streams made before; with blit kernels instead of the
-    // engines 1.95) -- two engines together saturate the link either way
-    if (!c->copy_stream)
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    if (!c->copy_stream2)
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
-    esq_snapshot *tk = new esq_snapshot{c->device, nullptr, c->copy_stream, c->copy_stream2, d,
-                                        ((slot == ESQ_SLOT_ATOL) ? c->n : c->len) *
-                                            sizeof(double)};
+    const size_t bytes = ((slot == ESQ_SLOT_ATOL) ? c->n : c->len) * sizeof(double);
+    hipStream_t lane = bytes >= kLaneMinBytes ? copy_lane(c->device) : nullptr;
+    if (!lane) {
+        // (small vectors, or no lane to be had: a stream of the context's own)
+        if (!c->copy_stream)
+            HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        lane = c->copy_stream;
+    }
+    esq_snapshot *tk = new esq_snapshot{c->device, nullptr, lane, d, bytes};
     hipError_t e = hipEventCreateWithFlags(&tk->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(tk->ready, c->stream);
     if (e != hipSuccess) {
@@ -627,9 +797,21 @@ int esq_snapshot_begin(esq_ctx *c, int slot, int row, void **token_out) {
     *token_out = tk;
     return 0;
 }
+int esq_copy_lane_info(int device, double *best_probe_gbs_out, double *kernel_ref_gbs_out,
+                       double *last_gbs_out, long *engine_copies_out, long *kernel_copies_out) {
+    if (device < 0 || device >= kLaneDevices) return ESQ_EINVAL;
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    const CopyLane &ln = g_lane[device];
+    if (best_probe_gbs_out) *best_probe_gbs_out = ln.best_probe_gbs;
+    if (kernel_ref_gbs_out) *kernel_ref_gbs_out = ln.kernel_ref_gbs;
+    if (last_gbs_out) *last_gbs_out = ln.last_gbs;
+    if (engine_copies_out) *engine_copies_out = ln.engine_copies;
+    if (kernel_copies_out) *kernel_copies_out = ln.kernel_copies;
+    return 0;
+}
 int esq_host_pin(void *host, size_t bytes) {
     if (!host || bytes == 0) return ESQ_EINVAL;
-    const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterPortable);
+    const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
     if (e != hipSuccess) (void)hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -649,22 +831,25 @@ int esq_snapshot_copy(void *token, double *host, int host_is_pinned) {
         // pageable path is half as fast): pinned ahead of time by the caller
         // (esq_host_pin, 0.2 ms for 80 MB of resident pages) or here; unpinned here
         bool pinned = host_is_pinned != 0;
-        if (!pinned && tk->bytes >= ((size_t)8 << 20)) {
-            pinned = hipHostRegister(host, tk->bytes, hipHostRegisterPortable) == hipSuccess;
+        if (!pinned && tk->bytes >= kLaneMinBytes) {
+            pinned = hipHostRegister(host, tk->bytes, hipHostRegisterMapped | hipHostRegisterPortable) ==
+                     hipSuccess;
             if (!pinned) (void)hipGetLastError();
         }
-        // (split at a 4 KiB boundary; small vectors: one stream)
-        const size_t half = tk->bytes >= ((size_t)8 << 20) ? ((tk->bytes / 2) & ~(size_t)4095) : tk->bytes;
-        e = hipStreamWaitEvent(tk->stream, tk->ready, 0);
-        if (e == hipSuccess && half < tk->bytes) e = hipStreamWaitEvent(tk->stream2, tk->ready, 0);
+        static const bool dbg = getenv("ESQ_SNAPSHOT_DEBUG") != nullptr;
+        const auto t_a = std::chrono::steady_clock::now();
+        e = hipEventSynchronize(tk->ready);              // (the copy itself is timed)
+        const auto t_b = std::chrono::steady_clock::now();
         if (e == hipSuccess)
-            e = hipMemcpyAsync(host, tk->src, half, hipMemcpyDeviceToHost, tk->stream);
-        if (e == hipSuccess && half < tk->bytes)
-            e = hipMemcpyAsync((char *)host + half, (const char *)tk->src + half, tk->bytes - half,
-                               hipMemcpyDeviceToHost, tk->stream2);
-        if (e == hipSuccess) e = hipStreamSynchronize(tk->stream);
-        if (e == hipSuccess && half < tk->bytes) e = hipStreamSynchronize(tk->stream2);
+            e = lane_copy(tk->device, tk->stream, host, tk->src, tk->bytes, pinned);
+        const auto t_c = std::chrono::steady_clock::now();
         if (pinned) (void)hipHostUnregister(host);
+        if (dbg)
+            fprintf(stderr, "[esq_snapshot_copy] %zu B, caller-pinned %d, pinned %d: wait %.3f ms, "
+                    "copy %.3f ms, unpin %.3f ms\n", tk->bytes, host_is_pinned, (int)pinned,
+                    std::chrono::duration<double, std::milli>(t_b - t_a).count(),
+                    std::chrono::duration<double, std::milli>(t_c - t_b).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count());
     } else if (host_is_pinned && host) {
         (void)hipHostUnregister(host);
     }

@@ -129,8 +129,8 @@ struct esq_ctx : esqi::StepState {
     int n_rows = 0;
     bool cplx = false;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;     // esq_snapshot_*: downloads beside the step,
-    hipStream_t copy_stream2 = nullptr;    // half of the vector on each
+    hipStream_t copy_stream = nullptr;     // esq_snapshot_* of small vectors (large ones:
+                                           // the process's download stream, esq_core.hip)
     double *slab = nullptr;
     // small host-RHS problems: the slab is pinned, device-mapped HOST memory --
     // kernels read and write it over PCIe, uploads and downloads are plain

@@ -140,19 +140,23 @@ _warm = WarmBuffers()
 # solve_ivp 2.80 instead of 1.44 ms/step after the scratch solver of the device warm-up
 # had been collected).  `__del__` therefore only parks the handle; it is destroyed at the
 # next well-defined point: when a context is made or closed explicitly, or at exit.
-_graveyard = []
-_graveyard_lock = __import__("threading").Lock()
+_graveyard = __import__("collections").deque()     # (append / popleft: atomic, no lock --
+                                                   # a finalizer may run inside ANY allocation)
 
 
 def _drain_graveyard(timeout=60.0):
-    with _graveyard_lock:
-        dead, _graveyard[:] = list(_graveyard), []
+    dead = []
+    while True:
+        try:
+            dead.append(_graveyard.popleft())
+        except IndexError:
+            break
     if dead:
         from . import lazy
         lazy._worker.wait_idle(timeout)  # no state download may still read from them
-    for lib, handle in dead:
+    for free, what in dead:             # (esq_destroy, context) / (esq_rhs_free, plugin data)
         try:
-            lib.esq_destroy(handle)
+            free(what)
         except Exception:                                     # noqa: BLE001
             pass
 
@@ -204,15 +208,21 @@ class DeviceContext:
             self.handle = None
         _drain_graveyard()
 
-    def __del__(self):
-        # (not here: see _graveyard)
+    def park(self):
+        """give the context up WITHOUT destroying it now: it is destroyed when the next
+        context is made or closed, or at exit (_graveyard).  Never blocks, takes no lock:
+        this is what finalizers call -- the collector runs them inside any allocation of
+        any thread, e.g. between the two halves of CopyWorker.submit, where a wait for
+        the copy worker would wait for the job its own caller has not queued yet."""
         try:
-            if getattr(self, "handle", None):
-                with _graveyard_lock:
-                    _graveyard.append((self.lib, self.handle))
-                self.handle = None
-        except Exception:
+            handle, self.handle = getattr(self, "handle", None), None
+            if handle:
+                _graveyard.append((self.lib.esq_destroy, handle))
+        except Exception:                                     # noqa: BLE001
             pass
+
+    def __del__(self):
+        self.park()
 
     def _chk(self, code, what):
         check(code, self.handle, what)
@@ -414,6 +424,7 @@ class DeviceRHS:
     _fuse_src = False          # the fused entry accepts the on-the-fly first-stage input
     _fuse_mask = None          # epilogue kinds the fused entry implements (None: all)
     _fuse_query = False        # the fused entry honours esq_epilogue.dry_run
+    _owns_user = True          # the user pointers of _create are freed with esq_rhs_free
 
     def __init__(self):
         self._bound = {}       # device -> (fn, user)
@@ -481,9 +492,17 @@ class DeviceRHS:
         self._bound = {}
 
     def __del__(self):
+        # (a finalizer: nothing that blocks or frees device memory here -- park())
         try:
-            self.close()
-        except Exception:
+            lib = _lib.load()
+            for ctx in self._host_ctx.values():
+                ctx.park()
+            self._host_ctx = {}
+            for fn, user in self._bound.values():
+                if user and self._owns_user:
+                    _graveyard.append((lib.esq_rhs_free, user))
+            self._bound = {}
+        except Exception:                                     # noqa: BLE001
             pass
 
 
@@ -656,6 +675,8 @@ class CFunctionRHS(DeviceRHS):
         self._user = C.c_void_p(user_ptr) if isinstance(user_ptr, int) else user_ptr
         self.n = int(n)
         self.is_complex = bool(is_complex)
+
+    _owns_user = False          # (the caller's pointer: never freed here)
 
     def _create(self, lib, device):
         return self._fn, None if self._user is None else self._user

@@ -459,6 +459,7 @@ class SSV2stab(_LazyStateMixin, OdeSolver):
                                 dl(SLOT_K, r["fn"]))
 
     def __del__(self):
+        # (never a blocking call in a finalizer: DeviceContext.park)
         dev = getattr(self, "_dev", None)
         if dev is not None:
-            dev.close()
+            dev.park()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ESQ_ABI_VERSION 6
+#define ESQ_ABI_VERSION 7
 
 /* error codes (negative = misuse) */
 #define ESQ_EINVAL   (-1)   /* bad argument (row/slot out of range, NULL, ...) */
@@ -364,7 +364,23 @@ int  esq_download(esq_ctx *ctx, int slot, int row, double *host);
  * returns.  Not for host-slab contexts (ESQ_ENOTSUP). */
 int  esq_snapshot_begin(esq_ctx *ctx, int slot, int row, void **token_out);
 int  esq_snapshot_copy(void *token, double *host, int host_is_pinned);
-/* page-lock / release a host buffer (hipHostRegister, portable across devices) */
+/* Downloads of 8 MiB and more (esq_download, esq_snapshot_copy) run on ONE stream per
+ * device and process, and not always through hipMemcpyAsync alone: the device's DMA
+ * engines have states in which they move data to the host at half the link's rate (every
+ * stream of the process at once, for many copies in a row); a copy by a small (8-workgroup)
+ * kernel into the page-locked destination does not, but slows the sweeps that run beside
+ * it.  For 16 MiB and more the engines copy the first 8 MiB and are timed; if that piece
+ * was slower than 0.8 x the fastest such piece so far (or, while none was fast, than
+ * 0.72 x what the kernel made of an 8 MiB piece, timed once per process), the kernel
+ * copies the rest, otherwise the engines do (ESQ_D2H_MODE=engine | kernel pins the
+ * choice, ESQ_D2H_BLOCKS the kernel's workgroups).  This reports the record: the fastest
+ * first piece, the kernel's reference piece and the latest whole download (GB/s), and how
+ * many downloads were finished either way. */
+int  esq_copy_lane_info(int device, double *best_probe_gbs_out, double *kernel_ref_gbs_out,
+                        double *last_gbs_out, long *engine_copies_out,
+                        long *kernel_copies_out);
+/* page-lock / release a host buffer (hipHostRegister: mapped into the device's address
+ * space, portable across devices) */
 int  esq_host_pin(void *host, size_t bytes);
 int  esq_host_unpin(void *host);
 /* device-to-device copy between two (slot,row) vectors, asynchronous */

@@ -112,3 +112,100 @@ def test_copy_worker_runs_jobs_in_order():
     assert not w.wait_idle(0.05)                 # a copy under way: a context must wait
     gate.set()
     assert w.wait_idle(5.0)
+
+
+# ---------------------------------------------------------------------------
+# finalizers: the collector runs them inside ANY allocation of ANY thread -- e.g.
+# between the two halves of CopyWorker.submit (the job counted, not yet queued), where
+# a wait for the copy worker waits for a job its own caller has not handed in yet
+# (60 s per occurrence on the GPU box before this was fixed)
+# ---------------------------------------------------------------------------
+class _FakeLib:
+    def __init__(self):
+        self.destroyed, self.freed = [], []
+
+    def esq_destroy(self, handle):
+        self.destroyed.append(handle)
+
+    def esq_rhs_free(self, user):
+        self.freed.append(user)
+
+
+def _fake_context(lib, handle):
+    from extensisq_amd.device import DeviceContext
+    ctx = object.__new__(DeviceContext)
+    ctx.lib, ctx.handle = lib, handle
+    return ctx
+
+
+def test_finalizers_park_and_never_wait(monkeypatch):
+    import gc
+    from extensisq_amd import device, lazy
+    from extensisq_amd.common import RungeKutta
+    from extensisq_amd.sommeijer import SSV2stab
+    waits = []
+    monkeypatch.setattr(lazy._worker, "wait_idle", lambda timeout=60.0: waits.append(timeout) or True)
+    device._drain_graveyard()
+    waits.clear()
+    lib = _FakeLib()
+    for k, cls in enumerate((RungeKutta, SSV2stab)):
+        solver = object.__new__(cls)
+        solver._dev = _fake_context(lib, 100 + k)
+        solver.__del__()                                   # what the collector calls
+        assert solver._dev.handle is None
+    ctx = _fake_context(lib, 200)
+    del ctx
+    gc.collect()
+    # nothing destroyed, nobody waited for: three handles parked
+    assert lib.destroyed == [] and waits == []
+    assert sorted(h for _, h in device._graveyard) == [100, 101, 200]
+    # ... until the next well-defined point (a context is made / closed, exit)
+    device._drain_graveyard()
+    assert sorted(lib.destroyed) == [100, 101, 200] and len(waits) == 1
+    assert len(device._graveyard) == 0
+    device._drain_graveyard()                              # (nothing parked: no wait)
+    assert len(waits) == 1
+
+
+def test_plugin_finalizer_frees_only_what_it_owns(monkeypatch):
+    from extensisq_amd import _lib, device, lazy
+    monkeypatch.setattr(lazy._worker, "wait_idle", lambda timeout=60.0: True)
+    lib = _FakeLib()
+    monkeypatch.setattr(_lib, "load", lambda: lib)
+    device._drain_graveyard()
+    owned = object.__new__(device.Heat2D)
+    owned._bound, owned._host_ctx = {0: ("fn", 11)}, {0: _fake_context(lib, 300)}
+    users = object.__new__(device.CFunctionRHS)
+    users._bound, users._host_ctx = {0: ("fn", 12)}, {}
+    owned.__del__()
+    users.__del__()
+    assert lib.freed == [] and lib.destroyed == []         # parked, not freed in the finalizer
+    device._drain_graveyard()
+    assert lib.freed == [11] and lib.destroyed == [300]    # the caller's pointer (12) is the caller's
+
+
+def test_a_collection_inside_submit_does_not_stall(monkeypatch):
+    """the scenario itself: a solver is collected while CopyWorker.submit has counted its
+    job but not queued it"""
+    import time
+    from extensisq_amd import device, lazy
+    from extensisq_amd.common import RungeKutta
+    worker = CopyWorker()
+    monkeypatch.setattr(lazy, "_worker", worker)
+    lib = _FakeLib()
+    real_event = threading.Event
+
+    def event_with_a_collection():
+        solver = object.__new__(RungeKutta)
+        solver._dev = _fake_context(lib, 400)
+        solver.__del__()                                   # (the collector, right here)
+        return real_event()
+    monkeypatch.setattr(lazy.threading, "Event", event_with_a_collection)
+    t0 = time.perf_counter()
+    done, box = worker.submit(lambda: 7)
+    assert done.wait(5.0) and box == [7]
+    assert time.perf_counter() - t0 < 2.0
+    assert worker.wait_idle(5.0)
+    monkeypatch.setattr(lazy.threading, "Event", real_event)
+    device._drain_graveyard()
+    assert lib.destroyed and set(lib.destroyed) == {400}   # (Thread() makes an Event too)
