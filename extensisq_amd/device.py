@@ -130,16 +130,17 @@ class WarmBuffers:
 _warm = WarmBuffers()
 
 
-# Contexts whose Python owner has been garbage-collected, waiting to be destroyed.
-# A solver is always part of a reference cycle (scipy's OdeSolver keeps closures over
-# itself), so it is freed by the CYCLIC collector -- at an arbitrary allocation, in
-# whichever thread happens to allocate (the copy worker, a warm-buffer thread), possibly
-# while another solver's state download is in flight.  Destroying a context there (a
-# stream synchronisation and a 2 GB hipFree, which waits for the whole device) left every
-# later device-to-host copy of that process at half the PCIe rate (bench.py: plain
-# solve_ivp 2.80 instead of 1.44 ms/step after the scratch solver of the device warm-up
-# had been collected).  `__del__` therefore only parks the handle; it is destroyed at the
-# next well-defined point: when a context is made or closed explicitly, or at exit.
+# Contexts (and plugin data) whose Python owner has been garbage-collected, waiting to be
+# destroyed.  A solver is always part of a reference cycle (scipy's OdeSolver keeps
+# closures over itself), so it is freed by the CYCLIC collector -- inside an arbitrary
+# allocation, in whichever thread happens to allocate (the copy worker, a warm-buffer
+# thread, the main thread between two statements of CopyWorker.submit), possibly while
+# another solver's state download is in flight.  A finalizer that destroys a context
+# there synchronises a stream, frees 2 GB (which waits for the whole device) and -- if
+# it first waits for the copy worker, as close() must -- can wait for a job its own
+# thread has counted but not queued yet: 60 s per occurrence until round 5.  Finalizers
+# therefore only PARK what they own (DeviceContext.park); it is destroyed at the next
+# well-defined point: when a context is made or closed explicitly, or at exit.
 _graveyard = __import__("collections").deque()     # (append / popleft: atomic, no lock --
                                                    # a finalizer may run inside ANY allocation)
 

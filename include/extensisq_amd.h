@@ -353,8 +353,8 @@ int  esq_download(esq_ctx *ctx, int slot, int row, double *host);
  * the step's own time).  esq_snapshot_begin (the thread that drives the context)
  * marks the point in the context's stream at which the vector is final and returns
  * a token; esq_snapshot_copy (ANY thread, typically a copy worker; blocks until the
- * data is in `host`; touches nothing of the context but its copy stream) waits for
- * that point on a second stream and copies.  The caller guarantees that nothing
+ * data is in `host`; touches nothing of the context) waits for that point on the
+ * process's download stream of the device (esq_copy_lane_info below) and copies.  The caller guarantees that nothing
  * overwrites the vector before the copy has returned -- a state vector of an
  * explicit pair is next written two steps after it was formed (Python side:
  * extensisq_amd/lazy.py).  host == NULL: give the token back without copying.
