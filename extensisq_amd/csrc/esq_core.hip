@@ -434,11 +434,10 @@ hipStream_t copy_lane(int device) {
 // cannot write to any other, and a staged pageable copy says nothing about the engines)
 hipError_t lane_copy(int device, hipStream_t stream, void *host, const void *dev, size_t bytes,
                      bool pinned) {
-    static const int mode = [] {                    // 0 auto, 1 engine, 2 kernel
-        const char *m = getenv("ESQ_D2H_MODE");
-        return !m ? 0 : !strcmp(m, "engine") ? 1 : !strcmp(m, "kernel") ? 2 : 0;
-    }();
-    static const unsigned blocks = env_uint("ESQ_D2H_BLOCKS", 8);
+    // (read per download -- they are milliseconds apart: tests switch it in one process)
+    const char *m = getenv("ESQ_D2H_MODE");
+    const int mode = !m ? 0 : !strcmp(m, "engine") ? 1 : !strcmp(m, "kernel") ? 2 : 0;
+    const unsigned blocks = env_uint("ESQ_D2H_BLOCKS", 8);
     const bool lane_ok = device >= 0 && device < kLaneDevices && bytes >= kLaneMinBytes;
     void *dst = nullptr;
     bool can_kernel = lane_ok && pinned && mode != 1 && blocks > 0 && bytes % 8 == 0 &&

@@ -1048,6 +1048,43 @@ def test_solve_ivp_device_rhs_t_eval_and_events(name):
     assert_allclose(got.t_events[0], ref.t_events[0], rtol=1e-7)
 
 
+# ------------------------------------- large downloads: DMA engines / copy kernel
+@pytest.mark.parametrize("n", [2 * 1048576 + 0, 3 * 1048576 + 1, 3 * 1048576 + 2, 4194304 + 777])
+def test_large_downloads_by_engine_and_by_kernel_are_the_same_bytes(monkeypatch, n):
+    """esq_download and esq_snapshot_copy of >= 8 MiB run on the process's download
+    stream: by the DMA engines, by the copy kernel, or the engines' timed first piece
+    + either (csrc/esq_core.hip, lane_copy) -- odd lengths (a last lone double), lengths
+    below the three-piece threshold, a destination that is not 16-byte aligned"""
+    import ctypes as C
+    from extensisq_amd import _lib
+    from extensisq_amd.device import DeviceContext
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    data = rng.standard_normal(n)
+    dev = DeviceContext(n, 2)
+    dev.upload(_lib.SLOT_Y, 0, data)
+    before = _lib.copy_lane_info(0)
+    for mode in ("engine", "kernel", "auto", "kernel"):
+        monkeypatch.setenv("ESQ_D2H_MODE", mode)
+        np.testing.assert_array_equal(dev.download(_lib.SLOT_Y, 0), data)
+        # the snapshot path, page-locked by the caller (as the warm buffers do) and not
+        for shift, pin in ((0, True), (0, False), (1, True)):
+            raw = np.full(n + 2, np.nan)
+            out = raw[shift:shift + n]                   # shift 1: 8 mod 16
+            token = C.c_void_p()
+            assert lib.esq_snapshot_begin(dev.handle, _lib.SLOT_Y, 0, C.byref(token)) == 0
+            ptr = out.ctypes.data_as(C.c_void_p)
+            locked = pin and lib.esq_host_pin(ptr, out.nbytes) == 0
+            assert lib.esq_snapshot_copy(token, ptr, int(locked)) == 0
+            np.testing.assert_array_equal(out, data)
+            assert np.isnan(raw[:shift]).all() and np.isnan(raw[shift + n:]).all()
+    after = _lib.copy_lane_info(0)
+    assert after["engine_copies"] > before["engine_copies"]
+    if 8 * n >= 2 * (8 << 20):                           # (two pieces at least)
+        assert after["kernel_copies"] > before["kernel_copies"]
+    dev.close()
+
+
 # ------------------------------------- deferred mirrors of large states (lazy.py)
 def _lazy_pair(monkeypatch, cls, N=1024, **kw):
     """two solvers of the same IVP (heat, n = N^2 >= 8 MB / 8): `solver.y` deferred /
