@@ -365,9 +365,11 @@ int host_wait(esq_ctx *c, bool already_idle) {
 // and more:
 //   * it runs on ONE stream per device and process (made once, never destroyed);
 //   * the engines copy the first kProbeBytes and are timed; if that piece was slower
-//     than 0.8 x the fastest such piece seen so far, the kernel copies the rest,
-//     otherwise the engines do.  No history beyond that maximum: the engines are back
-//     in use with the first download that finds them fast.
+//     than 0.8 x the fastest such piece seen so far (a process whose first download
+//     already meets slow engines: than 0.72 x what the kernel made of the second
+//     8 MiB, timed once), the kernel copies the rest, otherwise the engines do.  No
+//     history beyond those two rates: the engines are back in use with the first
+//     download that finds them fast.
 // (ESQ_D2H_MODE=engine / kernel pins the choice, ESQ_D2H_BLOCKS the kernel's grid.)
 constexpr int kLaneDevices = 64;
 constexpr size_t kLaneMinBytes = (size_t)8 << 20, kProbeBytes = (size_t)8 << 20;
@@ -407,24 +409,14 @@ hipStream_t copy_lane(int device) {
     if (device < 0 || device >= kLaneDevices) return nullptr;
     std::lock_guard<std::mutex> lk(g_lane_mu);
     CopyLane &ln = g_lane[device];
-    if (!ln.stream && !ln.failed) {
-        // the highest priority there is: a hardware queue of its own (streams of one
-        // priority share a few, and kernels of one queue run in order -- the copy
-        // kernel would wait for the step's sweeps and they for it), dispatched first
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
-            (void)hipGetLastError();
-            least = greatest = 0;
-        }
-        static const int prio = (int)env_uint("ESQ_D2H_PRIORITY", 1);
-        const hipError_t e = prio && greatest != least
-            ? hipStreamCreateWithPriority(&ln.stream, hipStreamNonBlocking, greatest)
-            : hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            ln.stream = nullptr;
-            ln.failed = true;
-        }
+    if (!ln.stream && !ln.failed &&
+        hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess) {
+        // (a stream of the highest priority was tried for the kernel copies' sake: the
+        // kernel trace shows them in a hardware queue of their own either way, and the
+        // sweeps beside them as slow)
+        (void)hipGetLastError();
+        ln.stream = nullptr;
+        ln.failed = true;
     }
     return ln.stream;
 }
