@@ -49,6 +49,7 @@ SIGNATURES = {
     "esq_download": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "esq_snapshot_begin": (C.c_int, [_vp, C.c_int, C.c_int, _vpp]),
     "esq_snapshot_copy": (C.c_int, [_vp, _vp, C.c_int]),
+    "esq_release_cached_memory": (C.c_int, [_vp]),
     "esq_copy_lane_info": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "esq_host_pin": (C.c_int, [_vp, C.c_size_t]),
     "esq_host_unpin": (C.c_int, [_vp]),
@@ -217,6 +218,14 @@ def device_pci_bus_id(device):
     if load().esq_device_pci_bus_id(int(device), buf, len(buf)) != 0:
         return None
     return buf.value.decode().strip().lower() or None
+
+
+def release_cached_memory():
+    """free the device memory the library keeps from destroyed solvers for the next ones
+    (esq_release_cached_memory); -> bytes freed"""
+    held = C.c_size_t(0)
+    check(load().esq_release_cached_memory(C.byref(held)), None, "esq_release_cached_memory")
+    return held.value
 
 
 def copy_lane_info(device=0):

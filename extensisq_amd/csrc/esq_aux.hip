@@ -13,6 +13,7 @@ struct esq_dense {
     int np = 0;
     unsigned grid = 0;
     double *mem = nullptr;      // (np + 2) vectors: Qh columns, base, scratch
+    size_t mem_bytes = 0;
     hipStream_t stream = nullptr;
 };
 template <int NT>
@@ -35,14 +36,15 @@ int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
     d->len_pad = c->len_pad;
     d->np = p;
     d->grid = c->grid_stream;
-    hipError_t e = hipMalloc(&d->mem, (size_t)(p + 2) * d->len_pad * sizeof(double));
+    d->mem_bytes = (size_t)(p + 2) * d->len_pad * sizeof(double);
+    hipError_t e = dev_acquire(c->device, (void **)&d->mem, d->mem_bytes);
     if (e != hipSuccess) {
         delete d;
         return fail(c, (int)e, "hipMalloc for the interpolant failed: %s",
                     hipGetErrorString(e));
     }
     e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { (void)hipFree(d->mem); delete d; return fail(c, (int)e, "stream"); }
+    if (e != hipSuccess) { dev_release(d->device, d->mem, d->mem_bytes); delete d; return fail(c, (int)e, "stream"); }
     DenseArgs a;
     int nt = 0;
     for (int j = 0; j < rows; ++j) {
@@ -113,7 +115,7 @@ int esq_dense_destroy(esq_dense *d) {
     if (!d) return 0;
     (void)hipSetDevice(d->device);
     if (d->stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
-    if (d->mem) (void)hipFree(d->mem);
+    if (d->mem) dev_release(d->device, d->mem, d->mem_bytes);
     delete d;
     return 0;
 }

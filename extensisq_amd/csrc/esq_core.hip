@@ -350,27 +350,116 @@ int host_wait(esq_ctx *c, bool already_idle) {
 // destination for the duration of the call: measured for 80 MB into a fresh
 // NumPy array 4.3 ms (register 2.8 + copy 1.5 at 54 GB/s) against 6.5-7 ms for
 // the staged pageable copy.
+// ---- device memory is kept, not freed ------------------------------------------
+// Device memory that has been FREED ONCE -- by this process or by one before it on the
+// same device -- and is allocated again is slow to read for the DMA engines: 76 MiB to
+// the host take 2.8 ms from it, 1.41 ms from memory handed out for the first time, at
+// any offset, for as long as the allocation lives (tools/alloc_probe.py: three fresh
+// 1.2 GB buffers 1.41 each; two freed, two new ones in their place 2.8; a fresh 8 GB
+// one 1.41; everything freed, then 11 GB physically contiguous: 2.8.  Kernels see no
+// difference).  A process that makes one solver after the other -- consecutive
+// solve_ivp calls -- ran on such memory from its second solver on whenever the new
+// slab was allocated after the old one's hipFree, i.e. nearly always.  So the slabs of
+// contexts and the interpolants' blocks go back to a small cache instead -- exact
+// sizes, per device, oldest out when ESQ_SLAB_CACHE_MB (default: a quarter of the
+// device's memory) or eight blocks are exceeded -- and the next solver of that size
+// gets the same, still-fast allocation, without a hipMalloc.  A request that hipMalloc
+// cannot serve empties the cache and tries again.  What the cache cannot help: the
+// FIRST slab of a process on a device other processes have used (it may be slow memory,
+// and then stays that solver size's memory for the life of the process).
+struct CachedBlock { int device; void *ptr; size_t bytes; };
+std::mutex g_block_mu;
+std::vector<CachedBlock> g_blocks;              // oldest first
+constexpr size_t kCacheMinBytes = (size_t)8 << 20;
+constexpr size_t kCacheMaxBlocks = 8;
+
+size_t cache_cap_bytes() {
+    static const size_t cap = [] {
+        const char *e = getenv("ESQ_SLAB_CACHE_MB");
+        if (e && *e) return (size_t)strtoull(e, nullptr, 10) << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)0; }
+        return total_b / 4;
+    }();
+    return cap;
+}
+void drop_cached_locked(int device_or_all) {
+    for (size_t k = 0; k < g_blocks.size();) {
+        if (device_or_all < 0 || g_blocks[k].device == device_or_all) {
+            (void)hipSetDevice(g_blocks[k].device);
+            (void)hipFree(g_blocks[k].ptr);
+            g_blocks.erase(g_blocks.begin() + (long)k);
+        } else {
+            ++k;
+        }
+    }
+}
+// (the current device is `device`)
+hipError_t dev_acquire(int device, void **ptr, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_block_mu);
+        for (size_t k = g_blocks.size(); k-- > 0;)           // newest first
+            if (g_blocks[k].device == device && g_blocks[k].bytes == bytes) {
+                *ptr = g_blocks[k].ptr;
+                g_blocks.erase(g_blocks.begin() + (long)k);
+                return hipSuccess;
+            }
+    }
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(g_block_mu);
+            drop_cached_locked(device);
+        }
+        (void)hipSetDevice(device);
+        e = hipMalloc(ptr, bytes);
+    }
+    return e;
+}
+void dev_release(int device, void *ptr, size_t bytes) {
+    if (!ptr) return;
+    const size_t cap = cache_cap_bytes();
+    if (bytes >= kCacheMinBytes && bytes <= cap) {
+        std::lock_guard<std::mutex> lk(g_block_mu);
+        g_blocks.push_back({device, ptr, bytes});
+        size_t held = 0;
+        for (const auto &b : g_blocks) held += b.bytes;
+        while (!g_blocks.empty() && (held > cap || g_blocks.size() > kCacheMaxBlocks)) {
+            held -= g_blocks.front().bytes;
+            (void)hipSetDevice(g_blocks.front().device);
+            (void)hipFree(g_blocks.front().ptr);
+            g_blocks.erase(g_blocks.begin());
+        }
+        (void)hipSetDevice(device);
+        return;
+    }
+    (void)hipFree(ptr);
+}
+
 // ---- large device-to-host copies ------------------------------------------------
-// hipMemcpyAsync hands the copy to one of the device's DMA engines, and these have a
-// state of their own: in the same process, on the same stream, into the same kind of
-// pinned buffer, 80 MB take 1.42 ms (56 GB/s) for a while and then 2.8-3.2 ms (25-30
-// GB/s) for a while -- every stream of the process at once, fresh ones too, whichever
-// buffer (tools/ivp_modes.sh: plain solve_ivp several times in one process; which runs
-// are slow changes from process to process).  A copy by a KERNEL into the page-locked
-// destination is not affected (4 to 512 workgroups: 53-55 GB/s in either state of the
-// engines) but has a price of its own: its stores over the link hold up the stores of a
-// sweep that runs beside it (the step's first chain sweep 0.10 -> 1.4 ms: plain
-// solve_ivp 1.86 ms/step beside kernel copies of 8 workgroups, 2.05 with 128, 1.44
-// beside fast engine copies, 2.8 beside slow ones).  So, for every download of 16 MiB
-// and more:
-//   * it runs on ONE stream per device and process (made once, never destroyed);
-//   * the engines copy the first kProbeBytes and are timed; if that piece was slower
-//     than 0.8 x the fastest such piece seen so far (a process whose first download
-//     already meets slow engines: than 0.72 x what the kernel made of the second
-//     8 MiB, timed once), the kernel copies the rest, otherwise the engines do.  No
-//     history beyond those two rates: the engines are back in use with the first
-//     download that finds them fast.
-// (ESQ_D2H_MODE=engine / kernel pins the choice, ESQ_D2H_BLOCKS the kernel's grid.)
+// Every download of 8 MiB and more runs on ONE stream per device and process (made
+// once, never destroyed), by hipMemcpyAsync -- the device's DMA engines -- into a
+// page-locked destination: 56 GB/s from memory that was allocated for the first time,
+// 25-30 GB/s from memory that has been freed and allocated again (above: why the
+// contexts' memory is cached, not freed).
+//
+// EXPERIMENTAL, opt-in (ESQ_D2H_MODE=auto | kernel): a copy by a KERNEL into the
+// page-locked destination runs at 53-55 GB/s whatever memory it reads (4 to 512
+// workgroups), at a price -- its stores over the link hold up the stores of a sweep that
+// runs beside it (the step's first chain sweep 0.10 -> 1.4 ms: plain solve_ivp 1.86
+// ms/step beside kernel copies of 8 workgroups, 2.05 with 128, 1.44 beside fast engine
+// copies, 2.8 beside slow ones).  `auto`: the engines copy the first kProbeBytes of a
+// download of >= 16 MiB and are timed; if that piece was slower than 0.8 x the fastest
+// such piece seen so far (a process whose first download already meets slow memory:
+// than 0.72 x what the kernel made of the second 8 MiB, timed once), the kernel copies
+// the rest.  NOT the default: with `auto`, two of seven runs of the whole GPU test suite
+// died of "Memory access fault by GPU ... Write access to a read-only page" at a host
+// address (six of six runs with the engines alone did not) -- a kernel's store through
+// hipHostGetDevicePointer of freshly registered memory is evidently not always backed
+// by a writable mapping, and three attempts to reproduce it in isolation (registrations
+// sharing a page, the runtime's own pin of an upload's source in the same pages, huge
+// pages) did not (profiles/r05_experiments.md, section 5).
 constexpr int kLaneDevices = 64;
 constexpr size_t kLaneMinBytes = (size_t)8 << 20, kProbeBytes = (size_t)8 << 20;
 struct CopyLane {
@@ -427,8 +516,8 @@ hipStream_t copy_lane(int device) {
 hipError_t lane_copy(int device, hipStream_t stream, void *host, const void *dev, size_t bytes,
                      bool pinned) {
     // (read per download -- they are milliseconds apart: tests switch it in one process)
-    const char *m = getenv("ESQ_D2H_MODE");
-    const int mode = !m ? 0 : !strcmp(m, "engine") ? 1 : !strcmp(m, "kernel") ? 2 : 0;
+    const char *m = getenv("ESQ_D2H_MODE");          // default: the engines alone
+    const int mode = !m ? 1 : !strcmp(m, "auto") ? 0 : !strcmp(m, "kernel") ? 2 : 1;
     const unsigned blocks = env_uint("ESQ_D2H_BLOCKS", 8);
     const bool lane_ok = device >= 0 && device < kLaneDevices && bytes >= kLaneMinBytes;
     void *dst = nullptr;
@@ -620,7 +709,7 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
         memset(c->slab_host, 0, slab_doubles * sizeof(double));
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->slab, c->slab_host, 0));
     } else {
-        HIPCHK(c, hipMalloc(&c->slab, slab_doubles * sizeof(double)));
+        HIPCHK(c, dev_acquire(c->device, (void **)&c->slab, slab_doubles * sizeof(double)));
         HIPCHK(c, hipMemsetAsync(c->slab, 0, slab_doubles * sizeof(double), c->stream));
     }
     c->krow.resize(n_rows);
@@ -703,9 +792,9 @@ int esq_destroy(esq_ctx *c) {
     if (c->host_slab) {
         if (c->slab_host) (void)hipHostFree(c->slab_host);
     } else if (c->slab) {
-        (void)hipFree(c->slab);
+        dev_release(c->device, c->slab, c->slab_doubles * sizeof(double));
     }
-    for (double *p : c->aux_slabs) (void)hipFree(p);
+    for (const auto &a : c->aux_slabs) dev_release(c->device, a.first, a.second);
     if (c->h_slot) (void)hipHostFree(c->h_slot);
     if (c->copy_stream) {
         (void)hipStreamSynchronize(c->copy_stream);
@@ -786,6 +875,14 @@ int esq_snapshot_begin(esq_ctx *c, int slot, int row, void **token_out) {
         return fail(c, (int)e, "snapshot event: %s", hipGetErrorString(e));
     }
     *token_out = tk;
+    return 0;
+}
+int esq_release_cached_memory(size_t *bytes_out) {
+    std::lock_guard<std::mutex> lk(g_block_mu);
+    size_t held = 0;
+    for (const auto &b : g_blocks) held += b.bytes;
+    drop_cached_locked(-1);
+    if (bytes_out) *bytes_out = held;
     return 0;
 }
 int esq_copy_lane_info(int device, double *best_probe_gbs_out, double *kernel_ref_gbs_out,
@@ -944,9 +1041,9 @@ int esq_aux_rows(esq_ctx *c, int count, int *first_id) {
         mem = reinterpret_cast<double *>(((uintptr_t)2 << 40) +
                                          (uintptr_t)c->n_rows * c->stride * sizeof(double));
     } else {
-        HIPCHK(c, hipMalloc(&mem, bytes));
+        HIPCHK(c, dev_acquire(c->device, (void **)&mem, bytes));
         HIPCHK(c, hipMemsetAsync(mem, 0, bytes, c->stream));
-        c->aux_slabs.push_back(mem);
+        c->aux_slabs.push_back({mem, bytes});
     }
     *first_id = c->n_rows;
     for (int r = 0; r < count; ++r) {

@@ -22,6 +22,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/extensisq_amd.h"
@@ -141,7 +142,7 @@ struct esq_ctx : esqi::StepState {
     bool idle = true;                 // nothing enqueued since the last wait
     bool self_valid = false;          // the last kernel enqueued publishes self_seq
     unsigned long long self_seq = 0;
-    std::vector<double *> aux_slabs;  // lazily added work rows (esq_aux_rows)
+    std::vector<std::pair<double *, size_t>> aux_slabs;  // lazily added work rows (esq_aux_rows): block, bytes
     std::vector<double *> krow;       // physical K rows
     std::vector<int> kmap;            // logical -> physical (step in flight)
     std::vector<int> kmap_last;       // mapping of the step just accepted
@@ -336,6 +337,10 @@ int finish_reduction(esq_ctx *c, double *out, bool take_min = false,
                      const double *partials = nullptr, int count = -1);
 int host_wait(esq_ctx *c, bool already_idle);
 int d2h(esq_ctx *c, void *host, const void *dev, size_t bytes, bool was_idle = false);
+// device memory of contexts and interpolants: handed back to a small per-process cache
+// instead of hipFree (esq_core.hip: why), taken from it when the size matches
+hipError_t dev_acquire(int device, void **ptr, size_t bytes);
+void dev_release(int device, void *ptr, size_t bytes);
 int h2d(esq_ctx *c, void *dev, const void *host, size_t bytes, bool was_idle);
 int call_rhs(esq_ctx *c, double t, const double *src, double *dst);
 int build_row_terms(esq_ctx *c, const double *coef, int count, Terms &tm,

@@ -364,18 +364,23 @@ int  esq_download(esq_ctx *ctx, int slot, int row, double *host);
  * returns.  Not for host-slab contexts (ESQ_ENOTSUP). */
 int  esq_snapshot_begin(esq_ctx *ctx, int slot, int row, void **token_out);
 int  esq_snapshot_copy(void *token, double *host, int host_is_pinned);
+/* The device memory of destroyed contexts and interpolants (blocks of 8 MiB and more) is
+ * kept in a small per-process cache instead of being freed -- memory that hipMalloc hands
+ * out a second time is read by the DMA engines at half the rate of memory allocated for the
+ * first time (csrc/esq_core.hip), and the next solver of the same size starts without a
+ * hipMalloc.  At most eight blocks and ESQ_SLAB_CACHE_MB (default: a quarter of the device's
+ * memory; 0 = no cache); a request the device cannot serve empties it first.  This frees
+ * everything cached now and says how many bytes that was. */
+int  esq_release_cached_memory(size_t *bytes_out);
 /* Downloads of 8 MiB and more (esq_download, esq_snapshot_copy) run on ONE stream per
- * device and process, and not always through hipMemcpyAsync alone: the device's DMA
- * engines have states in which they move data to the host at half the link's rate (every
- * stream of the process at once, for many copies in a row); a copy by a small (8-workgroup)
- * kernel into the page-locked destination does not, but slows the sweeps that run beside
- * it.  For 16 MiB and more the engines copy the first 8 MiB and are timed; if that piece
- * was slower than 0.8 x the fastest such piece so far (or, while none was fast, than
- * 0.72 x what the kernel made of an 8 MiB piece, timed once per process), the kernel
- * copies the rest, otherwise the engines do (ESQ_D2H_MODE=engine | kernel pins the
- * choice, ESQ_D2H_BLOCKS the kernel's workgroups).  This reports the record: the fastest
- * first piece, the kernel's reference piece and the latest whole download (GB/s), and how
- * many downloads were finished either way. */
+ * device and process, through the device's DMA engines (hipMemcpyAsync) into a page-locked
+ * destination.  ESQ_D2H_MODE=auto | kernel (experimental, see csrc/esq_core.hip: it has
+ * crashed test runs) lets a small copy kernel take over from engines that read slow --
+ * recycled -- memory: with `auto` the engines copy the first 8 MiB of a download of 16 MiB
+ * and more and are timed, and the kernel copies the rest if that piece was slower than
+ * 0.8 x the fastest seen.  This reports the record: the fastest first piece, the kernel's
+ * reference piece (both 0 with the engines alone), the latest whole download (GB/s), and
+ * how many downloads were finished either way. */
 int  esq_copy_lane_info(int device, double *best_probe_gbs_out, double *kernel_ref_gbs_out,
                         double *last_gbs_out, long *engine_copies_out,
                         long *kernel_copies_out);

@@ -1052,9 +1052,13 @@ def test_solve_ivp_device_rhs_t_eval_and_events(name):
 @pytest.mark.parametrize("n", [2 * 1048576 + 0, 3 * 1048576 + 1, 3 * 1048576 + 2, 4194304 + 777])
 def test_large_downloads_by_engine_and_by_kernel_are_the_same_bytes(monkeypatch, n):
     """esq_download and esq_snapshot_copy of >= 8 MiB run on the process's download
-    stream: by the DMA engines, by the copy kernel, or the engines' timed first piece
-    + either (csrc/esq_core.hip, lane_copy) -- odd lengths (a last lone double), lengths
-    below the three-piece threshold, a destination that is not 16-byte aligned"""
+    stream: by the DMA engines (the default) and -- only with ESQ_TEST_D2H_KERNEL=1: the
+    copy kernel is experimental and has killed test runs with a GPU memory fault,
+    csrc/esq_core.hip -- by the copy kernel, or the engines' timed first piece + either;
+    odd lengths (a last lone double), lengths below the three-piece threshold, a
+    destination that is not 16-byte aligned"""
+    import os
+    with_kernel = os.environ.get("ESQ_TEST_D2H_KERNEL") == "1"
     import ctypes as C
     from extensisq_amd import _lib
     from extensisq_amd.device import DeviceContext
@@ -1064,8 +1068,11 @@ def test_large_downloads_by_engine_and_by_kernel_are_the_same_bytes(monkeypatch,
     dev = DeviceContext(n, 2)
     dev.upload(_lib.SLOT_Y, 0, data)
     before = _lib.copy_lane_info(0)
-    for mode in ("engine", "kernel", "auto", "kernel"):
-        monkeypatch.setenv("ESQ_D2H_MODE", mode)
+    for mode in ("engine", "kernel", "auto", "kernel") if with_kernel else ("engine", None):
+        if mode is None:
+            monkeypatch.delenv("ESQ_D2H_MODE")
+        else:
+            monkeypatch.setenv("ESQ_D2H_MODE", mode)
         np.testing.assert_array_equal(dev.download(_lib.SLOT_Y, 0), data)
         # the snapshot path, page-locked by the caller (as the warm buffers do) and not
         for shift, pin in ((0, True), (0, False), (1, True)):
@@ -1080,9 +1087,46 @@ def test_large_downloads_by_engine_and_by_kernel_are_the_same_bytes(monkeypatch,
             assert np.isnan(raw[:shift]).all() and np.isnan(raw[shift + n:]).all()
     after = _lib.copy_lane_info(0)
     assert after["engine_copies"] > before["engine_copies"]
-    if 8 * n >= 2 * (8 << 20):                           # (two pieces at least)
+    if with_kernel and 8 * n >= 2 * (8 << 20):           # (two pieces at least)
         assert after["kernel_copies"] > before["kernel_copies"]
+    if not with_kernel:
+        assert after["kernel_copies"] == before["kernel_copies"]
     dev.close()
+
+
+def test_device_memory_of_a_destroyed_context_serves_the_next_one():
+    """the slab of a closed context is kept and handed to the next context of that size
+    (csrc/esq_core.hip: memory that hipMalloc hands out a second time is slow for the
+    DMA engines); a context of another size gets memory of its own; the cache can be
+    emptied; reused memory starts zeroed like fresh memory"""
+    from extensisq_amd import _lib
+    from extensisq_amd.device import DeviceContext
+    lib = _lib.load()
+    _lib.release_cached_memory()
+    n = 3 * 1048576 + 5
+
+    a = DeviceContext(n, 4)
+    a.upload(_lib.SLOT_Y, 0, np.full(n, 7.0))
+    a.close()
+    held = _lib.release_cached_memory()
+    assert held >= 8 * n * 4                              # the slab was in the cache ...
+    assert _lib.release_cached_memory() == 0              # ... and is not any more
+    b = DeviceContext(n, 4)
+    b.upload(_lib.SLOT_Y, 0, np.full(n, 7.0))
+    b.upload(_lib.SLOT_YNEW, 0, np.full(n, 9.0))
+    b.close()
+    c = DeviceContext(n, 4)                               # takes b's slab
+    assert _lib.release_cached_memory() == 0              # (nothing left behind)
+    np.testing.assert_array_equal(c.download(_lib.SLOT_Y, 0), np.zeros(n))
+    np.testing.assert_array_equal(c.download(_lib.SLOT_YNEW, 0), np.zeros(n))
+    d = DeviceContext(n + 2048, 4)                        # another size: its own memory
+    c.upload(_lib.SLOT_Y, 0, np.full(n, 1.0))
+    d.upload(_lib.SLOT_Y, 0, np.full(n + 2048, 2.0))
+    np.testing.assert_array_equal(c.download(_lib.SLOT_Y, 0), np.full(n, 1.0))
+    np.testing.assert_array_equal(d.download(_lib.SLOT_Y, 0), np.full(n + 2048, 2.0))
+    c.close()
+    d.close()
+    assert _lib.release_cached_memory() >= 8 * (2 * n + 2048) * 4
 
 
 # ------------------------------------- deferred mirrors of large states (lazy.py)
