@@ -374,14 +374,15 @@ constexpr size_t kCacheMinBytes = (size_t)8 << 20;
 constexpr size_t kCacheMaxBlocks = 8;
 
 size_t cache_cap_bytes() {
-    static const size_t cap = [] {
-        const char *e = getenv("ESQ_SLAB_CACHE_MB");
-        if (e && *e) return (size_t)strtoull(e, nullptr, 10) << 20;
+    // (the switch is read per release -- they are rare: tests and esq_options change it)
+    const char *e = getenv("ESQ_SLAB_CACHE_MB");
+    if (e && *e) return (size_t)strtoull(e, nullptr, 10) << 20;
+    static const size_t dflt = [] {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)0; }
         return total_b / 4;
     }();
-    return cap;
+    return dflt;
 }
 void drop_cached_locked(int device_or_all) {
     for (size_t k = 0; k < g_blocks.size();) {

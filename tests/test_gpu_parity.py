@@ -1094,7 +1094,7 @@ def test_large_downloads_by_engine_and_by_kernel_are_the_same_bytes(monkeypatch,
     dev.close()
 
 
-def test_device_memory_of_a_destroyed_context_serves_the_next_one():
+def test_device_memory_of_a_destroyed_context_serves_the_next_one(monkeypatch):
     """the slab of a closed context is kept and handed to the next context of that size
     (csrc/esq_core.hip: memory that hipMalloc hands out a second time is slow for the
     DMA engines); a context of another size gets memory of its own; the cache can be
@@ -1127,6 +1127,18 @@ def test_device_memory_of_a_destroyed_context_serves_the_next_one():
     c.close()
     d.close()
     assert _lib.release_cached_memory() >= 8 * (2 * n + 2048) * 4
+    # the cap: nothing is kept with ESQ_SLAB_CACHE_MB=0; the oldest block goes first
+    monkeypatch.setenv("ESQ_SLAB_CACHE_MB", "0")
+    e = DeviceContext(n, 4)
+    e.close()
+    assert _lib.release_cached_memory() == 0
+    slab_mb = 8 * n * (4 + 6) / 2 ** 20                   # (rows + fixed slots, roughly)
+    monkeypatch.setenv("ESQ_SLAB_CACHE_MB", str(int(1.5 * slab_mb)))
+    f, g = DeviceContext(n, 4), DeviceContext(n + 4096, 4)
+    f.close()
+    g.close()                                             # f's slab has to make room
+    held = _lib.release_cached_memory()
+    assert 8 * (n + 4096) * 4 <= held < 8 * (2 * n) * 4 + (64 << 20)
 
 
 # ------------------------------------- deferred mirrors of large states (lazy.py)
