@@ -59,14 +59,15 @@ class CopyWorker:
     def submit(self, fn):
         """-> (event, box): box[0] is fn()'s result (or the exception it raised)
         once the event is set"""
+        done, box = threading.Event(), []
         with self._lock:
             if self._thread is None:
                 self._thread = threading.Thread(target=self._run, daemon=True,
                                                 name="esq-copy-worker")
                 self._thread.start()
+            # counted and queued in one piece (the queue is unbounded: no wait here)
+            self._q.put((fn, done, box))
             self._inflight += 1
-        done, box = threading.Event(), []
-        self._q.put((fn, done, box))
         return done, box
 
 
