@@ -14,8 +14,7 @@ its buffer), so the solver retires live mirrors at the start of `step()`:
 a mirror that is still referenced by then -- a caller that stores the states, like
 plain `solve_ivp` -- is downloaded before its source goes, and from then on every
 new mirror starts its copy at once on the process's download stream (`esq_snapshot_*`,
-a copy worker thread; csrc/esq_core.hip `lane_copy`: the DMA engines, or a copy kernel
-while they are in their slow state): the 1.4 ms copy of state k runs beside steps
+a copy worker thread; csrc/esq_core.hip `lane_copy`): the 1.4 ms copy of state k runs beside steps
 k + 1 and k + 2 instead of in front of them.  Each mirror owns a fresh host array (scipy stores
 them by reference: they must be distinct arrays, as in the reference, common.py:343).
 """
