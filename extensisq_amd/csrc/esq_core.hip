@@ -351,8 +351,8 @@ int host_wait(esq_ctx *c, bool already_idle) {
 // NumPy array 4.3 ms (register 2.8 + copy 1.5 at 54 GB/s) against 6.5-7 ms for
 // the staged pageable copy.
 // ---- device memory is kept, not freed ------------------------------------------
-// Device memory that has been FREED ONCE -- by this process or by one before it on the
-// same device -- and is allocated again is slow to read for the DMA engines: 76 MiB to
+// Device memory that has been FREED ONCE -- by this process, at times by one before it
+// on the same device -- and is allocated again is slow to read for the DMA engines: 76 MiB to
 // the host take 2.8 ms from it, 1.41 ms from memory handed out for the first time, at
 // any offset, for as long as the allocation lives (tools/alloc_probe.py: three fresh
 // 1.2 GB buffers 1.41 each; two freed, two new ones in their place 2.8; a fresh 8 GB
