@@ -391,7 +391,11 @@ class _LazyStateMixin:
                 mirror.materialize()
             elif done is not None:
                 if not done.is_set():
-                    done.wait()       # nobody waits for it, but it reads the buffer
+                    # nobody waits for it, but it reads the buffer
+                    from .lazy import COPY_TIMEOUT_S
+                    if not done.wait(COPY_TIMEOUT_S):
+                        raise DeviceError("a state download has not finished after "
+                                          f"{COPY_TIMEOUT_S:.0f} s")
                 if mirror is None:
                     self._lazy_eager = False      # copied for nobody: stop that
         self._lazy_live = keep

@@ -25,6 +25,9 @@ import numpy as np
 from numpy.lib.mixins import NDArrayOperatorsMixin
 
 
+COPY_TIMEOUT_S = 300.0          # a download beside the step takes milliseconds
+
+
 class CopyWorker:
     """one daemon thread that runs `esq_snapshot_copy` calls (ctypes releases the
     GIL: the solver's thread goes on stepping)"""
@@ -116,7 +119,10 @@ class LazyState(NDArrayOperatorsMixin):
         if self._arr is None:
             if self._pending is not None:
                 done, box, out = self._pending
-                done.wait()
+                if not done.wait(COPY_TIMEOUT_S):
+                    raise RuntimeError(
+                        f"the download of a state has not finished after {COPY_TIMEOUT_S:.0f} s "
+                        "(copy worker stuck on the device?)")
                 self._pending = None
                 if box and isinstance(box[0], BaseException):
                     raise box[0]
