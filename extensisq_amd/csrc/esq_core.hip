@@ -367,12 +367,25 @@ int host_wait(esq_ctx *c, bool already_idle) {
 // cannot serve empties the cache and tries again.  What the cache cannot help: the
 // FIRST slab of a process on a device other processes have used (it may be slow memory,
 // and then stays that solver size's memory for the life of the process).
-struct CachedBlock { int device; void *ptr; size_t bytes; };
+// Every block remembers the rate of the latest engine download that read from it
+// (lane_copy times them all): a request is served by a block known to be fast before
+// one nobody has read from yet, and by one known to be slow only when a new hipMalloc
+// -- made while the slow block is still held, so that it is other memory -- fails; a
+// process whose first slab happened to be slow memory thus gets a second chance with
+// every solver it makes, until a fast block is found and kept.
+struct Block { int device; char *ptr; size_t bytes; double gbs; };   // gbs 0: not read yet
 std::mutex g_block_mu;
-std::vector<CachedBlock> g_blocks;              // oldest first
+std::vector<Block> g_blocks;                    // cached; oldest first
+std::vector<Block> g_live;                      // handed out
+double g_best_gbs = 0.0;                        // fastest engine download of the process
 constexpr size_t kCacheMinBytes = (size_t)8 << 20;
 constexpr size_t kCacheMaxBlocks = 8;
 
+// (slow memory halves the rate; a download beside a running sweep reaches 0.73 of it:
+// tools/numa_probe.py)
+int block_rank_locked(const Block &b) {         // 2 known fast, 1 unknown, 0 known slow
+    return b.gbs == 0.0 ? 1 : b.gbs >= 0.6 * g_best_gbs ? 2 : 0;
+}
 size_t cache_cap_bytes() {
     // (the switch is read per release -- they are rare: tests and esq_options change it)
     const char *e = getenv("ESQ_SLAB_CACHE_MB");
@@ -395,47 +408,97 @@ void drop_cached_locked(int device_or_all) {
         }
     }
 }
+// the best cached block of that size (newest among equals) leaves the cache; false: none
+bool take_cached_locked(int device, size_t bytes, int min_rank, Block *out) {
+    long pick = -1;
+    int best = -1;
+    for (size_t k = g_blocks.size(); k-- > 0;) {
+        const Block &b = g_blocks[k];
+        if (b.device != device || b.bytes != bytes) continue;
+        const int r = block_rank_locked(b);
+        if (r > best) { best = r; pick = (long)k; }
+    }
+    if (pick < 0 || best < min_rank) return false;
+    *out = g_blocks[(size_t)pick];
+    g_blocks.erase(g_blocks.begin() + pick);
+    return true;
+}
 // (the current device is `device`)
 hipError_t dev_acquire(int device, void **ptr, size_t bytes) {
+    Block b{device, nullptr, bytes, 0.0};
     {
         std::lock_guard<std::mutex> lk(g_block_mu);
-        for (size_t k = g_blocks.size(); k-- > 0;)           // newest first
-            if (g_blocks[k].device == device && g_blocks[k].bytes == bytes) {
-                *ptr = g_blocks[k].ptr;
-                g_blocks.erase(g_blocks.begin() + (long)k);
-                return hipSuccess;
-            }
+        if (take_cached_locked(device, bytes, /*min_rank=*/1, &b)) {
+            g_live.push_back(b);
+            *ptr = b.ptr;
+            return hipSuccess;
+        }
     }
+    // (a cached block of that size, if there is one, is known to be slow: it stays where
+    // it is while hipMalloc looks for other memory)
     hipError_t e = hipMalloc(ptr, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         {
             std::lock_guard<std::mutex> lk(g_block_mu);
+            if (take_cached_locked(device, bytes, /*min_rank=*/0, &b)) {
+                g_live.push_back(b);
+                *ptr = b.ptr;
+                return hipSuccess;
+            }
             drop_cached_locked(device);
         }
         (void)hipSetDevice(device);
         e = hipMalloc(ptr, bytes);
     }
+    if (e == hipSuccess && bytes >= kCacheMinBytes) {
+        std::lock_guard<std::mutex> lk(g_block_mu);
+        g_live.push_back({device, (char *)*ptr, bytes, 0.0});
+    }
     return e;
 }
 void dev_release(int device, void *ptr, size_t bytes) {
     if (!ptr) return;
+    double gbs = 0.0;
+    {
+        std::lock_guard<std::mutex> lk(g_block_mu);
+        for (size_t k = 0; k < g_live.size(); ++k)
+            if (g_live[k].ptr == (char *)ptr) {
+                gbs = g_live[k].gbs;
+                g_live.erase(g_live.begin() + (long)k);
+                break;
+            }
+    }
     const size_t cap = cache_cap_bytes();
     if (bytes >= kCacheMinBytes && bytes <= cap) {
         std::lock_guard<std::mutex> lk(g_block_mu);
-        g_blocks.push_back({device, ptr, bytes});
+        g_blocks.push_back({device, (char *)ptr, bytes, gbs});
         size_t held = 0;
         for (const auto &b : g_blocks) held += b.bytes;
         while (!g_blocks.empty() && (held > cap || g_blocks.size() > kCacheMaxBlocks)) {
-            held -= g_blocks.front().bytes;
-            (void)hipSetDevice(g_blocks.front().device);
-            (void)hipFree(g_blocks.front().ptr);
-            g_blocks.erase(g_blocks.begin());
+            // out: a block known to be slow before any other, the oldest among equals
+            size_t out = 0;
+            for (size_t k = 1; k < g_blocks.size(); ++k)
+                if (block_rank_locked(g_blocks[k]) < block_rank_locked(g_blocks[out])) out = k;
+            held -= g_blocks[out].bytes;
+            (void)hipSetDevice(g_blocks[out].device);
+            (void)hipFree(g_blocks[out].ptr);
+            g_blocks.erase(g_blocks.begin() + (long)out);
         }
         (void)hipSetDevice(device);
         return;
     }
     (void)hipFree(ptr);
+}
+// an engine download of `bytes` from `dev` ran at `gbs`: the block it read from knows
+void note_block_rate(int device, const void *dev, double gbs) {
+    std::lock_guard<std::mutex> lk(g_block_mu);
+    if (gbs > g_best_gbs) g_best_gbs = gbs;
+    for (auto &b : g_live)
+        if (b.device == device && (const char *)dev >= b.ptr && (const char *)dev < b.ptr + b.bytes) {
+            b.gbs = gbs;
+            return;
+        }
 }
 
 // ---- large device-to-host copies ------------------------------------------------
@@ -586,10 +649,13 @@ hipError_t lane_copy(int device, hipStream_t stream, void *host, const void *dev
     if (e != hipSuccess || !lane_ok) return e;
     const double gbs = (double)bytes * 1e-9 /
                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::lock_guard<std::mutex> lk(g_lane_mu);
-    CopyLane &ln = g_lane[device];
-    ln.last_gbs = gbs;
-    ++(by_kernel ? ln.kernel_copies : ln.engine_copies);
+    {
+        std::lock_guard<std::mutex> lk(g_lane_mu);
+        CopyLane &ln = g_lane[device];
+        ln.last_gbs = gbs;
+        ++(by_kernel ? ln.kernel_copies : ln.engine_copies);
+    }
+    if (!by_kernel && pinned && done == 0) note_block_rate(device, dev, gbs);
     return e;
 }
 
