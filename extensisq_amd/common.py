@@ -90,6 +90,24 @@ def _read_by_solve_ivp(depth=2):
     return code.co_name == "solve_ivp" and code.co_filename.replace("\\", "/").endswith(
         "scipy/integrate/_ivp/ivp.py")
 
+def _inside_solve_ivp(max_depth=16):
+    """is scipy's `solve_ivp` among the callers (a solver constructed by it: ivp.py:590)?"""
+    import sys
+    try:
+        frame = sys._getframe(1)
+    except ValueError:
+        return False
+    for _ in range(max_depth):
+        if frame is None:
+            return False
+        code = frame.f_code
+        if code.co_name == "solve_ivp" and code.co_filename.replace("\\", "/").endswith(
+                "scipy/integrate/_ivp/ivp.py"):
+            return True
+        frame = frame.f_back
+    return False
+
+
 # failed-step counter shared with the RKC module (reference: common.py:14)
 NFS = np.array(0)
 NFI = np.array(0)     # kept for import compatibility (implicit methods: unused)
@@ -309,6 +327,13 @@ class _LazyStateMixin:
         self._state_gen = 0          # accepted steps: which state the device holds
         self._lazy_live = []         # [weakref(mirror), generation, copy-done event]
         self._lazy_eager = False     # the caller stores its states: copy at once
+        if self._lazy_on and not self._lazy_always and _inside_solve_ivp():
+            # scipy will read the state after every step and, unless t_eval / dense_output
+            # say otherwise, keep it: two page-locked arrays are made ready while the
+            # constructor runs (the first two kept states are downloaded synchronously:
+            # 12 + 22 ms into cold arrays, 1.5 ms each into these)
+            from .device import _warm
+            _warm.expect(nbytes, count=2)
 
     def _lazy_where(self, age):
         """(slot, row) of the state `age` accepted steps ago (age 0 or 1)"""

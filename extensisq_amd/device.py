@@ -45,13 +45,14 @@ class WarmBuffers:
         self._memset = None
         self._pin = False           # page-lock the warm arrays too (`take(pinned=True)`)
         self._pinned = set()        # addresses of ready arrays that are page-locked
+        self._expected = 0          # arrays asked for ahead of the pattern (`expect`)
         self.enabled = os.environ.get("ESQ_WARM_BUFFERS", "1") != "0"
 
     def _worker(self):
         while True:
             with self._wake:
                 while not (self._nbytes and
-                           len(self._ready) + self._pending < self.depth):
+                           len(self._ready) + self._pending < self._target()):
                     self._wake.wait()
                 nbytes = self._nbytes
                 self._pending += 1
@@ -71,6 +72,11 @@ class WarmBuffers:
             if pinned:                                    # not wanted any more
                 _lib.load().esq_host_unpin(buf.ctypes.data)
 
+    def _target(self):
+        # arrays to keep ready: the full depth once the pattern has shown (two downloads
+        # of the size), before that only what `expect` asked for
+        return self.depth if self._seen.get(self._nbytes, 0) >= 2 else self._expected
+
     def _start(self):
         import threading
         libc = C.CDLL(None)
@@ -89,6 +95,24 @@ class WarmBuffers:
                 _lib.load().esq_host_unpin(buf.ctypes.data)
         self._ready = []
         self._pinned = set()
+
+    def expect(self, nbytes, count=2):
+        """downloads of `nbytes` are about to begin: start making `count` page-locked
+        arrays now (the pattern has not shown yet: `take` engages after two downloads)"""
+        nbytes = int(nbytes)
+        if not self.enabled or nbytes < self.MIN_BYTES:
+            return
+        with self._wake:
+            if nbytes != self._nbytes:
+                self._nbytes = nbytes
+                self._drop_ready()
+            self._seen = {nbytes: max(self._seen.get(nbytes, 0), 1)}
+            self._pin = True
+            if len(self._ready) + self._pending < count:
+                self._expected = count
+            if not self._threads:
+                self._start()
+            self._wake.notify_all()
 
     def take(self, n, dtype, pinned=False):
         """an (n,) array of `dtype` to download into; warm if one is ready.

@@ -209,3 +209,31 @@ def test_a_collection_inside_submit_does_not_stall(monkeypatch):
     monkeypatch.setattr(lazy.threading, "Event", real_event)
     device._drain_graveyard()
     assert lib.destroyed and set(lib.destroyed) == {400}   # (Thread() makes an Event too)
+
+
+def test_warm_buffers_can_be_asked_for_ahead_of_the_pattern():
+    """`expect`: a solver made by solve_ivp knows that per-step downloads are coming; two
+    arrays are faulted in while its constructor runs, the full depth only once the
+    downloads have shown"""
+    import time
+    from extensisq_amd.device import WarmBuffers
+    w = WarmBuffers(depth=4, workers=2)
+    nbytes = 16 << 20
+    assert w.take(nbytes // 8, np.float64).nbytes == nbytes      # a one-off: cold, no threads
+    assert not w._threads
+    w2 = WarmBuffers(depth=4, workers=2)
+    w2.expect(nbytes, count=2)
+    t0 = time.time()
+    while len(w2._ready) < 2 and time.time() - t0 < 20:
+        time.sleep(0.01)
+    time.sleep(0.2)
+    assert len(w2._ready) == 2                                   # two, not the full depth
+    ready = {b.ctypes.data for b in w2._ready}
+    out = w2.take(nbytes // 8, np.float64)                       # the first download: warm
+    assert out.ctypes.data in ready and out.shape == (nbytes // 8,)
+    t0 = time.time()
+    while len(w2._ready) < 4 and time.time() - t0 < 20:          # the pattern has shown
+        time.sleep(0.01)
+    assert len(w2._ready) == 4
+    w2.expect(8 << 20)                                           # another size: start over
+    assert w2._nbytes == 8 << 20 and all(b.nbytes == 8 << 20 for b in w2._ready)
