@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # `make VARIANT=...` in csrc/); must sit next to the package like the default one
 LIB_PATH = os.environ.get("ESQ_LIB") or os.path.join(_HERE, "libextensisq_amd.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
 EPI_RKCERR = 6
@@ -22,6 +22,7 @@ FUSE_SRC = 0x20
 FUSE_QUERY = 0x80
 RKC_CHAIN_FIRST, RKC_CHAIN_LAST = 0x100, 0x200
 CHAIN_CAP_ALL, CHAIN_CAP_QUERY = 15, 16
+CHAIN_CAP_PRE, CHAIN_CAP_ERRNORM = 32, 64
 CREATE_HOST_SLAB = 1
 SLOT_K, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, SLOT_ATOL, SLOT_WORK = range(6)
 PROF_STAGE, PROF_RHS, PROF_SOLERR, PROF_RKC = range(4)
@@ -73,6 +74,8 @@ SIGNATURES = {
     "esq_rk_set_launch_ahead": (C.c_int, [_vp, C.c_int]),
     "esq_rk_launch_ahead_stats": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "esq_rk_pre_error": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _dp]),
+    "esq_rk_set_pre": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "esq_rk_pre_result": (C.c_int, [_vp, _dp]),
     "esq_rk_custom_sol_err": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, C.c_int,
                                         _dp]),
     "esq_rk_accept": (C.c_int, [_vp, C.c_double, C.c_int, C.c_double]),
@@ -83,6 +86,13 @@ SIGNATURES = {
     "esq_plan_describe": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_char_p, C.c_size_t]),
+    "esq_plan_describe_pre": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        _vp, _vp, C.c_int, C.c_char_p, C.c_size_t]),
+    "esq_step_dry_run_pre": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       _vp, _vp, C.c_int, _vp, C.c_int, C.c_char_p,
+                                       C.c_size_t]),
     "esq_step_dry_run": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _vp, C.c_int, C.c_char_p, C.c_size_t]),

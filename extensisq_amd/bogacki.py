@@ -4,14 +4,17 @@ estimates: an early one after six stages that can reject a step before the
 last two RHS evaluations, and the usual one at the end.  Reference counterpart:
 extensisq/bogacki.py:103-393.
 
-Device mapping: stages and both error norms are HIP kernels
-(`esq_rk_stages`, `esq_rk_pre_error`, `esq_rk_solution_error`); the controller
-below is host scalar arithmetic."""
+Device mapping: a whole attempt is TWO chain sweeps -- stages 1..5 with the early
+estimate as their last target, then stage 6, y_new, the FSAL stage and the error
+norm -- enqueued in one go (`RungeKutta._step_impl_early`, `esq_rk_set_pre`); with
+a Python right-hand side the round-5 sequence of pieces (`esq_rk_stages`,
+`esq_rk_pre_error`, `esq_rk_solution_error`).  The controller is host scalar
+arithmetic."""
 import numpy as np
 
 from ._lib import SLOT_K, SLOT_WORK, SLOT_YNEW, SLOT_YSTAGE, as_ptr  # noqa: F401
 from ._tableau import install
-from .common import NFS, RungeKutta
+from .common import RungeKutta
 
 
 class BS5(RungeKutta):
@@ -32,45 +35,12 @@ class BS5(RungeKutta):
         return self._rms_from_sumsq(
             self._dev.rk_pre_error_sumsq(h, self.E_pre, self.B_scale_pre))
 
+    def _early_estimate(self):
+        return self.E_pre, self.B_scale_pre
+
     def _step_impl(self):
         """ref bogacki.py:238-338"""
-        t = self.t
-        s = self.n_stages
-        h_abs, min_step = self._reassess_stepsize(t)
-        rejected = False
-        while True:
-            if h_abs < min_step:
-                return False, self.TOO_SMALL_STEP
-            h = h_abs * self.direction
-            t_new = t + h
-            self._run_stages(1, s - 1, t, h)
-            pre = self._estimate_error_norm_pre(None, h)
-            if pre > 1:
-                # early rejection: the last two evaluations are saved
-                rejected = True
-                h_abs *= self._reject_factor(pre)
-                NFS[()] += 1
-                if self.nfev_stiff_detect:
-                    self.jflstp += 1
-                continue
-            self._run_stages(s - 1, s, t, h)
-            error_norm = self._solution_and_error(t, h)
-            if error_norm < 1:
-                h_abs *= self._accept_factor(error_norm, h, rejected)
-                break
-            if np.isnan(error_norm) or np.isinf(error_norm):
-                return False, "Overflow or underflow encountered."
-            rejected = True
-            h_abs *= self._reject_factor(error_norm)
-            NFS[()] += 1
-            self.jflstp += 1
-        self._finish_step(t_new, h, h_abs)
-        self.h_previous = h
-        self.h_abs = h_abs
-        self.error_norm_old = error_norm
-        self.t = t_new
-        self._diagnose_stiffness()
-        return True, None
+        return self._step_impl_early(nan_check_first=True)
 
     # ------------------------------------------------------------ interpolants
     def _extra_stage(self, row, a_row, c, h):

@@ -497,8 +497,21 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
         # step is followed by stages 1 .. s) let the library enqueue the next step's
         # first launch ahead of time; BS5 / CFMR7osc / CKdisc run their stages in
         # pieces and would only repeat it
+        # the pairs that test an early error estimate (BS5, CFMR7osc) take whole
+        # steps too where the state lives on the device: the estimate rides on the
+        # chain sweep that completes its last stage, the rest of the attempt is
+        # enqueued behind it as if it had passed, ONE wait per attempt
+        # (esq_rk_set_pre; ESQ_PRE_WHOLE=0: the piecewise sequence of round 5)
+        pre = self._early_estimate()
+        self._pre_whole = (pre is not None and self._device_rhs is not None
+                           and not is_cplx and not self._dev.host_slab
+                           and os.environ.get("ESQ_PRE_WHOLE", "1") != "0")
+        if self._pre_whole:
+            self._dev.rk_set_pre(*pre)
+        self.pre_discards = 0        # attempts whose speculative tail was thrown away
         self._launch_ahead = (self._device_rhs is not None
-                              and type(self)._step_impl is RungeKutta._step_impl
+                              and (type(self)._step_impl is RungeKutta._step_impl
+                                   or self._pre_whole)
                               and os.environ.get("ESQ_LAUNCH_AHEAD", "1") != "0")
         self._dev._chk(self._lib.esq_rk_set_launch_ahead(self._ctx,
                                                          int(self._launch_ahead)),
@@ -921,6 +934,77 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
             return 0.0
         h_lim, min_step, _ = self._limit_step(t_new, h_abs)
         return h_lim * self.direction if h_lim >= min_step else 0.0
+
+    # ------------------------------------- pairs with an early error estimate
+    def _early_estimate(self):
+        """(e_pre, b_scale_pre) -- weights over K[:p] of an error estimate that is
+        tested after stage p - 1, before the step's last stage(s) -- or None"""
+        return None
+
+    def _step_impl_early(self, nan_check_first):
+        """`_step_impl` of BS5 (ref bogacki.py:238-338) and CFMR7osc (calvo.py:152-253):
+        the generic step with an early rejection test after stage s - 2.  Device-resident
+        states take the attempt WHOLE (`_pre_whole`): stages, early estimate, last stage
+        and final estimate are enqueued in one go, the host waits once and then looks
+        at the early estimate first -- exactly the decisions of the piecewise sequence
+        (a rejected attempt's speculative tail is counted in `pre_discards`, not in
+        `nfev`).  `nan_check_first`: BS5 tests for NaN before the rejection bookkeeping,
+        CFMR7osc after it."""
+        t = self.t
+        s = self.n_stages
+        h_abs, min_step = self._reassess_stepsize(t)
+        rejected = False
+        while True:
+            if h_abs < min_step:
+                return False, self.TOO_SMALL_STEP
+            h = h_abs * self.direction
+            t_new = t + h
+            if self._pre_whole:
+                if self._lockstep is not None:
+                    self._lockstep.check_identical(self._dev, "(t, h)", (t, h))
+                self._chk(self._lib.esq_rk_stages(self._ctx, 1, s, t, h), "esq_rk_stages")
+                sumsq = self._dev.rk_solution_error_sumsq(
+                    t, h, self._guess_next_step(t_new, h_abs))
+                pre = self._rms_from_sumsq(self._dev.rk_pre_result_sumsq())
+                self.nfev += s - 2
+                if not pre > 1:
+                    self.nfev += 1 + self.FSAL
+                    error_norm = self._rms_from_sumsq(sumsq)
+                else:
+                    self.pre_discards += 1
+            else:
+                self._run_stages(1, s - 1, t, h)
+                pre = self._estimate_error_norm_pre(None, h)
+            if pre > 1:
+                # early rejection: the last evaluation(s) are saved
+                rejected = True
+                h_abs *= self._reject_factor(pre)
+                NFS[()] += 1
+                if self.nfev_stiff_detect:
+                    self.jflstp += 1
+                continue
+            if not self._pre_whole:
+                self._run_stages(s - 1, s, t, h)
+                error_norm = self._solution_and_error(t, h)
+            if error_norm < 1:
+                h_abs *= self._accept_factor(error_norm, h, rejected)
+                break
+            bad = np.isnan(error_norm) or np.isinf(error_norm)
+            if bad and nan_check_first:
+                return False, "Overflow or underflow encountered."
+            rejected = True
+            h_abs *= self._reject_factor(error_norm)
+            NFS[()] += 1
+            self.jflstp += 1
+            if bad:
+                return False, "Overflow or underflow encountered."
+        self._finish_step(t_new, h, h_abs)
+        self.h_previous = h
+        self.h_abs = h_abs
+        self.error_norm_old = error_norm
+        self.t = t_new
+        self._diagnose_stiffness()
+        return True, None
 
     # ----------------------------------------------------------------- step
     def _step_impl(self):

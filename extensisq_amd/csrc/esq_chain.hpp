@@ -181,7 +181,16 @@ struct ChainArgs {
 // NF fields of N x N (state = field 0, field 1, ... one after the other);
 // Fn::eval(centres, laplacians) -> derivatives, all per column pair.
 // KINDLAST: ESQ_EPI_STAGE (the last target is a stage argument / y_new of an
-// FSAL pair) or ESQ_EPI_SOLERR (y_new and the error partial sums).
+// FSAL pair), ESQ_EPI_SOLERR (y_new and the error partial sums; ca.out == nullptr:
+// the target is only the partner of y in the scale -- the early error estimate of
+// BS5, whose y_pre nobody reads, bogacki.py:343-346) or ESQ_EPI_ERRNORM (FSAL pairs:
+// the chain's LAST STAGE is the end-point evaluation K_s = f(t + h, y_new) -- its
+// argument, target D - 1, is y_new and is stored to ca.out as well as handed on in
+// registers -- and "target D" is no vector but the error sum
+//     err = h * (sum_u cu[D-1][u] rows[u] + sum_{k < D} ck[D-1][k] K_k)
+// with the error weights E where a stage target has its row of A; the partial sums
+// of |err / (atol + rtol max(|y|, |y_new|))|^2 go to ca.red.partials.  common.py:
+// 341-351 in one sweep with the stages before it).
 #ifndef ESQ_CHAIN_PREFETCH
 #define ESQ_CHAIN_PREFETCH true
 #endif
@@ -206,6 +215,8 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
     constexpr int H = D - 1;                       // halo rows / lanes per side
     constexpr int W = 64 - 2 * H;                  // last-stage pairs per tile
     constexpr bool SOLERR = KINDLAST == ESQ_EPI_SOLERR;
+    constexpr bool ERRN = KINDLAST == ESQ_EPI_ERRNORM;
+    static_assert(!ERRN || D >= 2, "the end-point stage follows at least one stage");
     constexpr int WAVES = SPLIT ? NFT : kBlock / 64;    // waves per workgroup
     // SPLIT: the centre rows of all D stages, double-buffered by iteration parity
     __shared__ double2 xch[SPLIT ? 2 : 1][SPLIT ? D : 1][SPLIT ? NFT : 1][SPLIT ? 64 : 1];
@@ -536,8 +547,25 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                         if (k + 1 < D) {
                             wp[k + 1 < D ? k + 1 : k][f] =
                                 make_double2(actk ? t.x : 0.0, actk ? t.y : 0.0);
+                            // ERRNORM: the end-point stage's argument is y_new
+                            if (ERRN && k == D - 2 && own && store_ok) st2(ca.out, k2, t);
+                        } else if (ERRN) {
+                            // the error sum of the row: this stage's input (centre) is
+                            // y_new, yf the state it started from
+                            if (own && store_ok) {
+                                const double2 er = make_double2(__dmul_rn(ca.h, s.x),
+                                                                __dmul_rn(ca.h, s.y));
+                                if (ca.red.atol_vec)
+                                    local += ratio_sq<false>(er, yf[k][f], cc[f], ca.red.atol_vec,
+                                                             ca.red.atol_s, ca.red.rtol, k2,
+                                                             ca.red.n_valid);
+                                else
+                                    local += ratio_sq<false>(er, yf[k][f], cc[f], nullptr,
+                                                             ca.red.atol_s, ca.red.rtol, k2,
+                                                             ca.red.n_valid);
+                            }
                         } else if (own && store_ok) {
-                            if (SOLERR || ca.out) st2(ca.out, k2, t);
+                            if (ca.out) st2(ca.out, k2, t);
                             if (SOLERR) {
                                 const double2 er = make_double2(__dmul_rn(ca.h, acce[k][f].x),
                                                                 __dmul_rn(ca.h, acce[k][f].y));
@@ -577,7 +605,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             }
         }
     }
-    if (SOLERR) block_partial_w<WAVES>(local, ca.red.partials);
+    if (SOLERR || ERRN) block_partial_w<WAVES>(local, ca.red.partials);
 }
 #undef ESQ_CHAIN_LOAD_ROW
 #undef ESQ_CHAIN_FORM_T0

@@ -324,6 +324,11 @@ int chain3d(const St &st, int N, const double *y_in, const esq_chain *chain, int
             bool force, void *stream, void *start_event, void *stop_event) {
     if (!chain) return ESQ_EINVAL;
     if (chain->from_rows) return ESQ_ENOTSUP;
+    // (not in 3-D: the FSAL end-point stage inside the chain, a solution/error target
+    // that is not stored -- the plugin does not declare ESQ_CHAIN_CAP_PRE / _ERRNORM)
+    if (chain->kind_last == ESQ_EPI_ERRNORM ||
+        (chain->kind_last == ESQ_EPI_SOLERR && !chain->out))
+        return ESQ_ENOTSUP;
     if (chain->depth < 2 || chain->depth > MAXD) return ESQ_ENOTSUP;
     // (32-bit byte offsets into a vector; grids below 48^3: a tile's run-in planes
     // and halo points outweigh the saving)
@@ -351,7 +356,8 @@ int chain3d(const St &st, int N, const double *y_in, const esq_chain *chain, int
     int rc_launch = 0;
     const int rc = dispatch_chain<MAXD>(chain, [&](auto ca, auto kind, auto from_c) {
         using CA = decltype(ca);
-        if constexpr (decltype(from_c)::value || CA::kD > MAXD) {
+        if constexpr (decltype(from_c)::value || CA::kD > MAXD ||
+                      decltype(kind)::value == ESQ_EPI_ERRNORM) {
             rc_launch = ESQ_ENOTSUP;
         } else {
             constexpr int DD = CA::kD, JT = Chain3dShape<DD>::JT, NW = Chain3dShape<DD>::NW;

@@ -276,6 +276,34 @@ int finish_reduction(esq_ctx *c, double *out, bool take_min, const double *parti
     return 0;
 }
 
+// the early estimate of a whole-step attempt: partials -> pre[seq % kPreSlots] of the
+// pinned slot, behind a sequence number; the host picks it up after the attempt's
+// final reduction (esq_rk_pre_result)
+int publish_pre(esq_ctx *c, const double *partials, int count) {
+    const unsigned long long seq = ++c->pre.seq;
+    c->pre_last_seq = seq;
+    if (c->detached) return 0;
+    auto &slot = c->h_slot->pre[seq % kPreSlots];
+    ResultSink rs;
+    rs.seq = seq;
+    rs.host_seq = &slot.seq;
+    rs.host_value = c->comm ? nullptr : &slot.value;
+    double *dev = c->d_result + 8 + (seq % kPreSlots);
+    rs.dev = c->comm ? dev : nullptr;
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(1024), 0, c->stream, partials, count, rs);
+    HIPCHK(c, hipGetLastError());
+    if (c->comm) {
+        const int r = g_rccl.AllReduce(dev, dev, 1, kNcclFloat64, kNcclSum, c->comm, c->stream);
+        if (r != 0)
+            return fail(c, 1000 + r, "ncclAllReduce failed: %s",
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        rs.host_value = &slot.value;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, dev, rs);
+        HIPCHK(c, hipGetLastError());
+    }
+    return 0;
+}
+
 int call_rhs(esq_ctx *c, double t, const double *src, double *dst) {
     if (!c->rhs) return fail(c, ESQ_ESTATE, "no device RHS set (esq_set_rhs)");
     if (c->detached) return 0;                  // host-side dry run

@@ -53,10 +53,15 @@ struct ProfKernel {    // per-label totals since the last reset
 };
 // pinned host slot a reduction's result lands in: the value(s), then the
 // sequence number of the reduction (system-scope release), polled by the host
+constexpr int kPreSlots = 4;          // early estimates in flight: a ring (one step ahead)
 struct HostSlot {
     double value;
     unsigned long long seq;
     double vals[kSlotScalars];     // lock-step scalars (esq_allreduce_scalars)
+    // the early error estimates of whole-step attempts (esq_rk_set_pre): nobody waits
+    // for them -- the attempt's final reduction is what the host waits for -- and the
+    // NEXT attempt's may land before this one's has been read (launch_ahead)
+    struct { double value; unsigned long long seq; } pre[kPreSlots];
 };
 
 // one non-zero entry of a coefficient row
@@ -80,11 +85,15 @@ enum PlanOp : unsigned char {
     OP_BLOCK_SWEEP,   // RHS sweep of stage i + blocked accumulation at boundary i + 1
     OP_YNEW_SWEEP,    // FSAL: RHS sweep of the last stage + y_new
     OP_SOLERR_SWEEP,  // others: RHS sweep of the last stage + y_new + error partial sums
-    OP_RHS            // plain RHS launch of stage i
+    OP_RHS,           // plain RHS launch of stage i
+    OP_PRE_KERNEL     // the early estimate by the library's own pass (k_pre_error) where no
+                      // chain sweep carries it; its sum is published, not waited for
 };
 struct PlanStep {
     unsigned char op;
-    signed char i, depth, what;       // what: 0 next argument, 1 y_new (FSAL), 2 y_new + error
+    signed char i, depth, what;       // what: 0 next argument, 1 y_new (FSAL), 2 y_new + error,
+                                      // 3 the early estimate (+ next argument where it is
+                                      // y_pre), 4 FSAL: y_new, the end-point stage, error
     bool lazy, from_rows, skip_out;   // chain forms
     float reads, writes;              // designed words per element (halo re-reads not counted)
     float amp = 0.0f;                 // chain: read amplification the plugin reported (0: none)
@@ -117,6 +126,8 @@ struct StepState {
     bool k0_missing = false;
     double k0_t = 0.0;
     long end_fused = 0, end_plain = 0;    // how the end-point evaluations ran
+    // sequence number of the early estimate of the attempt in flight (0: none)
+    unsigned long long pre_last_seq = 0;
 };
 
 }  // namespace esqi
@@ -182,6 +193,15 @@ struct esq_ctx : esqi::StepState {
     // plugin entry changes (esqi::drop_plans)
     std::map<unsigned, esqi::Plan> plans;
     std::set<unsigned long long> refused;
+    // early error estimate of BS5 / CFMR7osc (esq_rk_set_pre): weights over K[0..rows),
+    // tested after stage rows - 1; rows == 0: none
+    struct Pre {
+        int rows = 0;
+        std::vector<double> e, b;
+        bool b_is_next = false;           // b == A[rows, :rows]: y_pre IS stage `rows`' argument
+        unsigned long long seq = 0;       // estimates published so far
+        long fused = 0, plain = 0;        // inside a chain sweep / by k_pre_error
+    } pre;
     bool detached = false;                // no device behind the context (esq_plan_describe)
     bool chain_from_rows = true;          // ESQ_CHAIN_FROM_ROWS=0: never
     unsigned chain_ld_nt[3] = {4, 4, 4};  // ESQ_CHAIN_LDNT: forced load policy of the
@@ -216,6 +236,9 @@ struct esq_ctx : esqi::StepState {
         bool tail_missing = false;        // rows the sweep left unwritten (lazy rows)
         unsigned long long missing_rows = 0;
         bool k0_done = false;             // it evaluated f(t, y) of the new state
+        int red_count = 0;                // partials of a reducing sweep (the whole step in
+                                          // one launch: Ts5's chain through the error norm)
+        unsigned long long pre_seq = 0;   // its early estimate (0: none)
     } ahead;
     long ahead_used = 0, ahead_dropped = 0;
     // which sweeps stream the fresh derivative out with non-temporal stores
@@ -373,6 +396,9 @@ int launch_lincomb(esq_ctx *c, double *out, const double *base, const Terms &tm,
 int launch_solerr(esq_ctx *c, const Terms2 &tm, int nt, double h, const Prof &p);
 int launch_errnorm(esq_ctx *c, const Terms &tm, int nt, double h, const Prof &p);
 int launch_preerr(esq_ctx *c, const Terms2 &tm, int nt, double h, const Prof &p);
+// ---- esq_core.hip: the early estimate's sum -> its slot of the ring (all-reduced over
+// the communicator if set); nobody waits.  -> c->pre_last_seq
+int publish_pre(esq_ctx *c, const double *partials, int count);
 int launch_block(esq_ctx *c, const BlockArgs &a, int nt, int no, const Prof &p);
 
 // ---- esq_comm.hip ------------------------------------------------------------

@@ -223,113 +223,106 @@ ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
     a.red.n_valid = c->n_valid; a.red.partials = c->partials;
     return a;
 }
-// (depth, kind_last, nu) -> launch(ChainArgs<D, NU>, integral_constant<kind_last>).
+// (depth, kind_last, nu) -> launch(ChainArgs<D, NU>, integral_constant<kind_last>,
+// bool_constant<from_rows>).
 // Instantiated: depth 2, 3 and 4 with up to 9 memory rows, 5 and 6 with up to 6.
+//   from-rows form: either kind with 1..3 memory rows (the first chain of a step); depth
+//   >= 3 with 4..6 rows (a chain in the MIDDLE of a step: the chain before it then leaves
+//   its last target unwritten); depth >= 3, solution/error kind, 7+ rows (the chain that
+//   ends a step)
+//   ESQ_EPI_ERRNORM (FSAL pairs: the end-point stage and the error norm inside the
+//   chain): up to 6 memory rows; plain up to depth 4, from rows at every depth (the
+//   whole step of a six-stage pair from K[0]; the two sweeps that end a BS5 step)
 // MAXD: deepest chain the caller's kernel is instantiated for (compile time grows
 // with every depth); MIND: the shallowest (a plugin may spread its depths over several
 // translation units that compile in parallel: esq_rhs_bruss2d_chain*.hip)
-template <int MAXD = 4, int MIND = 2, class Launch>
-int dispatch_chain(const esq_chain *c, Launch &&launch) {
-    if (!c || c->nu < 0 || (!c->out && c->kind_last != ESQ_EPI_STAGE)) return ESQ_EINVAL;
-    if (c->from_rows && !c->y) return ESQ_EINVAL;
-    if (c->kind_last == ESQ_EPI_SOLERR && (!c->partials || !c->y)) return ESQ_EINVAL;
-    if (c->kind_last != ESQ_EPI_STAGE && c->kind_last != ESQ_EPI_SOLERR)
+template <int DD, int K, class Launch>
+int dispatch_chain_case(const esq_chain *c, Launch &&launch) {
+    using Stage = std::integral_constant<int, ESQ_EPI_STAGE>;
+    using SolErr = std::integral_constant<int, ESQ_EPI_SOLERR>;
+    using ErrNorm = std::integral_constant<int, ESQ_EPI_ERRNORM>;
+    if (c->kind_last == ESQ_EPI_ERRNORM) {
+        if constexpr (K <= 6) {
+            if (c->from_rows) {
+                if constexpr (K >= 1) {
+                    if (!c->dry_run) launch(make_chain_args<DD, K>(c), ErrNorm{}, std::true_type{});
+                    return 0;
+                }
+                return ESQ_ENOTSUP;
+            }
+            if constexpr (DD <= 4) {
+                if (!c->dry_run) launch(make_chain_args<DD, K>(c), ErrNorm{}, std::false_type{});
+                return 0;
+            }
+        }
         return ESQ_ENOTSUP;
-    /* the from-rows form is instantiated for either kind with 1..6 memory rows (the
-     * first chain of a step; depth >= 3 from 4 rows on: a chain in the middle) and
-     * for the solution/error kind with 7+ rows (the chain that ends a step) */ \
-#define ESQ_CHAIN_CASE_(DD, K)                                                     \
-    case K:                                                                        \
-        if (c->from_rows) {                                                        \
-            if constexpr (DD >= 3 && K >= 4 && K <= 6) {                           \
-                /* a chain in the MIDDLE of a step too (round 4): the chain before */ \
-                /* it then leaves its last target unwritten                        */ \
-                if (c->dry_run) return 0;                                          \
-                if (c->kind_last == ESQ_EPI_STAGE)                                 \
-                    launch(make_chain_args<DD, K>(c),                              \
-                           std::integral_constant<int, ESQ_EPI_STAGE>{}, std::true_type{}); \
-                else                                                               \
-                    launch(make_chain_args<DD, K>(c),                              \
-                           std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::true_type{}); \
-                return 0;                                                          \
-            } else if constexpr (DD >= 3 && K >= 7) {                              \
-                if (c->kind_last != ESQ_EPI_SOLERR) return ESQ_ENOTSUP;            \
-                if (c->dry_run) return 0;                                          \
-                launch(make_chain_args<DD, K>(c),                                  \
-                       std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::true_type{}); \
-                return 0;                                                          \
-            } else if constexpr (K >= 1 && K <= 3) {                               \
-                if (c->dry_run) return 0;                                          \
-                if (c->kind_last == ESQ_EPI_STAGE)                                 \
-                    launch(make_chain_args<DD, K>(c),                              \
-                           std::integral_constant<int, ESQ_EPI_STAGE>{}, std::true_type{}); \
-                else                                                               \
-                    launch(make_chain_args<DD, K>(c),                              \
-                           std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::true_type{}); \
-                return 0;                                                          \
-            }                                                                      \
-            return ESQ_ENOTSUP;                                                    \
-        }                                                                          \
-        if (c->dry_run) return 0;                                                  \
-        if (c->kind_last == ESQ_EPI_STAGE)                                         \
-            launch(make_chain_args<DD, K>(c),                                      \
-                   std::integral_constant<int, ESQ_EPI_STAGE>{}, std::false_type{}); \
-        else                                                                       \
-            launch(make_chain_args<DD, K>(c),                                      \
-                   std::integral_constant<int, ESQ_EPI_SOLERR>{}, std::false_type{}); \
-        return 0;
-#define ESQ_CHAIN_CASES_0_6_(DD)                                                   \
-    ESQ_CHAIN_CASE_(DD, 0) ESQ_CHAIN_CASE_(DD, 1) ESQ_CHAIN_CASE_(DD, 2)           \
-    ESQ_CHAIN_CASE_(DD, 3) ESQ_CHAIN_CASE_(DD, 4) ESQ_CHAIN_CASE_(DD, 5)           \
-    ESQ_CHAIN_CASE_(DD, 6)
-    switch (c->depth) {
-        case 2:
-            if constexpr (MIND <= 2 && MAXD >= 2) {
-                switch (c->nu) {
-                    ESQ_CHAIN_CASES_0_6_(2) ESQ_CHAIN_CASE_(2, 7) ESQ_CHAIN_CASE_(2, 8)
-                    ESQ_CHAIN_CASE_(2, 9)
-                    default: return ESQ_ENOTSUP;
-                }
-            }
-            return ESQ_ENOTSUP;
-        case 3:
-            if constexpr (MIND <= 3 && MAXD >= 3) {
-                switch (c->nu) {
-                    ESQ_CHAIN_CASES_0_6_(3) ESQ_CHAIN_CASE_(3, 7) ESQ_CHAIN_CASE_(3, 8)
-                    ESQ_CHAIN_CASE_(3, 9)
-                    default: return ESQ_ENOTSUP;
-                }
-            }
-            return ESQ_ENOTSUP;
-        case 4:
-            if constexpr (MIND <= 4 && MAXD >= 4) {
-                switch (c->nu) {
-                    ESQ_CHAIN_CASES_0_6_(4) ESQ_CHAIN_CASE_(4, 7) ESQ_CHAIN_CASE_(4, 8)
-                    ESQ_CHAIN_CASE_(4, 9)
-                    default: return ESQ_ENOTSUP;
-                }
-            }
-            return ESQ_ENOTSUP;
-        case 5:
-            if constexpr (MIND <= 5 && MAXD >= 5) {
-                switch (c->nu) {
-                    ESQ_CHAIN_CASES_0_6_(5)
-                    default: return ESQ_ENOTSUP;
-                }
-            }
-            return ESQ_ENOTSUP;
-        case 6:
-            if constexpr (MIND <= 6 && MAXD >= 6) {
-                switch (c->nu) {
-                    ESQ_CHAIN_CASES_0_6_(6)
-                    default: return ESQ_ENOTSUP;
-                }
-            }
-            return ESQ_ENOTSUP;
+    }
+    if (c->from_rows) {
+        if constexpr ((DD >= 3 && K >= 4 && K <= 6) || (K >= 1 && K <= 3)) {
+            if (c->dry_run) return 0;
+            if (c->kind_last == ESQ_EPI_STAGE)
+                launch(make_chain_args<DD, K>(c), Stage{}, std::true_type{});
+            else
+                launch(make_chain_args<DD, K>(c), SolErr{}, std::true_type{});
+            return 0;
+        } else if constexpr (DD >= 3 && K >= 7) {
+            if (c->kind_last != ESQ_EPI_SOLERR) return ESQ_ENOTSUP;
+            if (!c->dry_run) launch(make_chain_args<DD, K>(c), SolErr{}, std::true_type{});
+            return 0;
+        }
+        return ESQ_ENOTSUP;
+    }
+    if (c->dry_run) return 0;
+    if (c->kind_last == ESQ_EPI_STAGE)
+        launch(make_chain_args<DD, K>(c), Stage{}, std::false_type{});
+    else
+        launch(make_chain_args<DD, K>(c), SolErr{}, std::false_type{});
+    return 0;
+}
+template <int DD, int MAXK, class Launch>
+int dispatch_chain_rows(const esq_chain *c, Launch &&launch) {
+#define ESQ_CHAIN_CASE_(K)                                         \
+    case K:                                                        \
+        if constexpr (K <= MAXK) return dispatch_chain_case<DD, K>(c, launch); \
+        return ESQ_ENOTSUP;
+    switch (c->nu) {
+        ESQ_CHAIN_CASE_(0) ESQ_CHAIN_CASE_(1) ESQ_CHAIN_CASE_(2) ESQ_CHAIN_CASE_(3)
+        ESQ_CHAIN_CASE_(4) ESQ_CHAIN_CASE_(5) ESQ_CHAIN_CASE_(6) ESQ_CHAIN_CASE_(7)
+        ESQ_CHAIN_CASE_(8) ESQ_CHAIN_CASE_(9)
         default: return ESQ_ENOTSUP;
     }
 #undef ESQ_CHAIN_CASE_
-#undef ESQ_CHAIN_CASES_0_6_
+}
+template <int MAXD = 4, int MIND = 2, class Launch>
+int dispatch_chain(const esq_chain *c, Launch &&launch) {
+    if (!c || c->nu < 0) return ESQ_EINVAL;
+    // (ESQ_EPI_SOLERR with out == NULL: the target is the scale's partner only)
+    if (!c->out && c->kind_last == ESQ_EPI_ERRNORM) return ESQ_EINVAL;
+    if (c->from_rows && !c->y) return ESQ_EINVAL;
+    if ((c->kind_last == ESQ_EPI_SOLERR || c->kind_last == ESQ_EPI_ERRNORM) &&
+        (!c->partials || !c->y))
+        return ESQ_EINVAL;
+    if (c->kind_last != ESQ_EPI_STAGE && c->kind_last != ESQ_EPI_SOLERR &&
+        c->kind_last != ESQ_EPI_ERRNORM)
+        return ESQ_ENOTSUP;
+    switch (c->depth) {
+        case 2:
+            if constexpr (MIND <= 2 && MAXD >= 2) return dispatch_chain_rows<2, 9>(c, launch);
+            return ESQ_ENOTSUP;
+        case 3:
+            if constexpr (MIND <= 3 && MAXD >= 3) return dispatch_chain_rows<3, 9>(c, launch);
+            return ESQ_ENOTSUP;
+        case 4:
+            if constexpr (MIND <= 4 && MAXD >= 4) return dispatch_chain_rows<4, 9>(c, launch);
+            return ESQ_ENOTSUP;
+        case 5:
+            if constexpr (MIND <= 5 && MAXD >= 5) return dispatch_chain_rows<5, 6>(c, launch);
+            return ESQ_ENOTSUP;
+        case 6:
+            if constexpr (MIND <= 6 && MAXD >= 6) return dispatch_chain_rows<6, 6>(c, launch);
+            return ESQ_ENOTSUP;
+        default: return ESQ_ENOTSUP;
+    }
 }
 
 #undef ESQ_EPI_CASE_

@@ -34,10 +34,10 @@ struct BrussFn {
     }
 };
 
-// one field per wave in the chain sweeps (default), or both fields in one wave
-// (ESQ_CHAIN_SPLIT=0: the first version, narrower register caps)
+// one field per wave in the chain sweeps (both fields in one wave -- round 3's first
+// version, narrower register caps, Pr8 0.93 against 0.69 ms/step -- was retired in
+// round 6 together with its switch: half of this plugin's compile time)
 using BrussSplit = esq::Stencil2D<2, true, BrussFn, true>;
-using BrussJoint = esq::Stencil2D<2, true, BrussFn, false>;
 inline BrussFn fn_of(const Rhs *r) {
     return BrussFn{r->alpha * ((double)r->N * (double)r->N), r->a, r->b};
 }
@@ -47,11 +47,8 @@ inline BrussFn fn_of(const Rhs *r) {
 template <int LO, int HI>
 inline int bruss2d_chain_range(Rhs *r, const double *y_in, const esq_chain *chain,
                                void *stream, void *start_event, void *stop_event) {
-    static const bool split = !getenv("ESQ_CHAIN_SPLIT") || atoi(getenv("ESQ_CHAIN_SPLIT")) != 0;
-    return split ? BrussSplit::chain<LO, HI>(fn_of(r), r->N, y_in, chain, stream, start_event,
-                                             stop_event)
-                 : BrussJoint::chain<LO, HI>(fn_of(r), r->N, y_in, chain, stream, start_event,
-                                             stop_event);
+    return BrussSplit::chain<LO, HI>(fn_of(r), r->N, y_in, chain, stream, start_event,
+                                     stop_event);
 }
 
 }  // namespace

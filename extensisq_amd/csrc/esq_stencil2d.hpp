@@ -477,7 +477,8 @@ struct Stencil2D {
             const GeoChain g = geo_chain(N, CA::kD, wpc, kSplit ? 1 : kBlock / 64,
                                          kSplit ? NF : 1, tall_tiles,
                                          min_rows < 0 ? CA::kD : min_rows);
-            if (decltype(kind)::value == ESQ_EPI_SOLERR) {
+            if (decltype(kind)::value == ESQ_EPI_SOLERR ||
+                decltype(kind)::value == ESQ_EPI_ERRNORM) {
                 if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
                 if (chain->partials_used) *chain->partials_used = (int)g.grid;
             }

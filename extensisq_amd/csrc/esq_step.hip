@@ -225,17 +225,33 @@ int sweep_next_stage(esq_ctx *c, int i, double t, double h, bool from_state = fa
 // sweeps of stages i .. i + depth - 1; the arguments of the later stages stay in
 // registers.  what_last: 0 = the last target is the argument of stage i + depth,
 // 1 = y_new of an FSAL pair (weights B), 2 = y_new + error partial sums
-// (non-FSAL: weights B and E).  Returns 0, kNotApplicable / ESQ_ENOTSUP (the
+// (non-FSAL: weights B and E), 3 = the EARLY error estimate of BS5 / CFMR7osc
+// (esq_rk_set_pre: the last target is y_pre with the estimate's weights -- also the
+// argument of stage i + depth where the two coincide, else not stored -- and the
+// estimate's partial sums; its sum is published right behind the sweep, nobody
+// waits), 4 = FSAL pairs: the chain runs THROUGH the end of the step -- stages
+// i .. s - 1, y_new, the end-point stage K_s = f(t + h, y_new), the error partial
+// sums (depth counts the end-point stage: i + depth == s + 1).
+// Returns 0, kNotApplicable / ESQ_ENOTSUP (the
 // caller tries a shorter chain or single sweeps) or an error.
 int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
                 bool lazy_rows = false, bool from_rows = false, bool skip_out = false,
                 Dry *dry = nullptr) {
     const int s = c->s;
     if (depth < 2 || depth > ESQ_CHAIN_MAX_DEPTH || s > 62) return kNotApplicable;
+    const bool pre = what_last == 3, through = what_last == 4;
+    if (pre && (c->pre.rows != i + depth || i + depth >= s)) return kNotApplicable;
+    if (through && (!c->fsal || i + depth != s + 1 || i < 1)) return kNotApplicable;
+    // the early estimate's y_pre is stored only where it is the next stage's argument
+    const bool pre_out = pre && c->pre.b_is_next && !skip_out;
+    if (pre && !pre_out && !(c->chain_caps & ESQ_CHAIN_CAP_PRE)) return kNotApplicable;
+    if (through && !(c->chain_caps & ESQ_CHAIN_CAP_ERRNORM)) return kNotApplicable;
     esq_chain e;
     memset(&e, 0, sizeof(e));
     e.depth = depth;
-    e.kind_last = what_last == 2 ? ESQ_EPI_SOLERR : ESQ_EPI_STAGE;
+    e.kind_last = (what_last == 2 || pre) ? ESQ_EPI_SOLERR
+                  : through               ? ESQ_EPI_ERRNORM
+                                          : ESQ_EPI_STAGE;
     // per target: weights by COLUMN first (memory rows and chain members alike)
     double cw[ESQ_CHAIN_MAX_DEPTH][64] = {{0}}, ew[64] = {0};
     bool part[ESQ_CHAIN_MAX_DEPTH][64] = {{false}};
@@ -245,7 +261,30 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     int n_init = 0;
     for (int q = 0; q < depth; ++q) {            // target q + 1
         const int stage = i + q + 1;             // the stage this target feeds
-        if (q + 1 < depth || what_last == 0) {
+        if (through && q == depth - 1) {
+            // "target depth": the error sum over K_0 .. K_s (weights E where a stage
+            // target has its row of A; K_s, the chain's last derivative, always part)
+            int nz = 0;
+            for (int j = 0; j <= s; ++j) {
+                if (c->E[j] == 0.0 && j != s) continue;
+                cw[q][j] = c->E[j];
+                part[q][j] = true;
+                ++nz;
+            }
+            alg += 8.0 * (nz + 3) * (double)c->len;
+        } else if (pre && q == depth - 1) {
+            int nz = 0;
+            for (int j = 0; j < c->pre.rows; ++j) {
+                const double bj = c->pre.b[j], ej = c->pre.e[j];
+                const bool self = j == c->pre.rows - 1;      // the fresh row: always part
+                if (bj == 0.0 && ej == 0.0 && !self) continue;
+                cw[q][j] = bj;
+                ew[j] = ej;
+                part[q][j] = true;
+                ++nz;
+            }
+            alg += 8.0 * (nz + 1) * (double)c->len;
+        } else if (q + 1 < depth - (through ? 1 : 0) || what_last == 0) {
             for (const Term &term : c->stage_terms[stage]) {
                 cw[q][term.col] = term.c;
                 part[q][term.col] = true;
@@ -258,6 +297,8 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
         } else {
             int nz = 0;
             for (int j = 0; j < s; ++j) {
+                // (y_new: the last target, or -- the chain goes through the end of
+                // the step -- the argument of the end-point stage)
                 const double bj = c->B[j], ej = what_last == 2 ? c->E[j] : 0.0;
                 // the fresh last row is always part of the solution/error sums
                 // (a zero weight contributes fma(0, v, s), as in EpiSolErr)
@@ -284,6 +325,11 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
         for (int j = 0; j < s; ++j)
             if (part[q][j] && (j < i || j >= i + depth)) use[j] = true;
     }
+    // a chain through the end of the step that forms its own input may read rows for
+    // that alone (BS5: a_61 K_1, which no solution or error weight touches): one row
+    // more against the launch and the 7 + 1 words of the argument's own kernel
+    if (from_rows && through && i >= 1)
+        for (const Term &term : c->stage_terms[i]) use[term.col] = true;
     // memory rows: the leading partial sums first (each the start of its target's
     // chain: weight 1, fma(1, p, 0) == p), then the K rows by ascending column
     int nu = 0;
@@ -328,29 +374,31 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     unsigned long long skipped = 0;
     int n_stored = 0;
     for (int k = 0; k < depth; ++k) {
-        e.t[k] = t + c->C[i + k] * h;
+        e.t[k] = i + k < s ? t + c->C[i + k] * h : t + h;
         // lazy_rows: a derivative that nothing after this sweep reads -- no later
         // stage's row of A (the stage right behind the chain gets its whole
         // argument from the chain), no solution / error weight outside this sweep
         // -- is not written (restore_rows re-evaluates it for whoever asks)
         const int col = i + k;
-        bool needed = !lazy_rows;
+        bool needed = !lazy_rows || col == s;        // (K_s is the next step's K_0)
         for (int st = i + depth + (what_last == 0 ? 1 : 0); st < s && !needed; ++st)
             needed = c->A[(size_t)st * s + col] != 0.0;
-        if (!needed && what_last != 2)
+        if (!needed && what_last != 2 && !through)
             needed = c->B[col] != 0.0 || c->E[col] != 0.0;
         e.f_out[k] = needed ? c->krow[c->kmap[col]] : nullptr;
         if (!needed) skipped |= 1ull << col;
         n_stored += needed;
     }
     // skip_out: the next chain forms its own input (from_rows)
-    e.out = what_last == 0 ? (skip_out ? nullptr : c->work) : c->ynew;
+    e.out = what_last == 0 ? (skip_out ? nullptr : c->work)
+            : pre          ? (pre_out ? c->work : nullptr)
+                           : c->ynew;
     e.f_store_nt = c->epi_nt & 1;
     // loads: a row (and y) that nothing after this sweep reads again is streamed,
     // the others stay cacheable -- the next chain finds them in the Infinity Cache
     // (Pr8, n = 1e7: K_0, K_2..K_4 cacheable in the middle chain: 0.527 -> 0.509 ms)
     {
-        unsigned m = what_last == 2 ? 2u : 0u;             // y: last read of the step
+        unsigned m = (what_last == 2 || through) ? 2u : 0u;   // y: last read of the step
         for (int u = 0; u < nu; ++u) {
             int col = -1;
             for (int j = 0; j <= s && col < 0; ++j)
@@ -359,13 +407,13 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
             if (col >= 0 && col < s) {
                 for (int st = i + depth + (what_last == 0 ? 1 : 0); st < s && !later; ++st)
                     later = c->A[(size_t)st * s + col] != 0.0;
-                if (!later && what_last != 2)
+                if (!later && what_last != 2 && !through)
                     later = c->B[col] != 0.0 || c->E[col] != 0.0;
             }
             if (!later) m |= 1u << (8 + u);
         }
         if (c->chain_ld_nt_set) {                          // ESQ_CHAIN_LDNT (tuning)
-            const unsigned o = c->chain_ld_nt[i == 0 ? 0 : what_last == 2 ? 2 : 1];
+            const unsigned o = c->chain_ld_nt[i == 0 ? 0 : (what_last == 2 || through) ? 2 : 1];
             m = (o & 3u) | ((o & 4u) ? 0xffffff00u : 0u);
         }
         e.load_nt = (int)m;
@@ -382,7 +430,7 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     // last target out
     // nu counts the partial sums too
     const double reads = ((i == 0 || from_rows) ? 1 : 2) + nu,
-                 writes = n_stored + (skip_out ? 0 : 1);
+                 writes = n_stored + (e.out ? 1 : 0);
     (void)n_init;
     if (dry) {
         dry->reads = reads; dry->writes = writes;
@@ -400,7 +448,8 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     double amp = 1.0;
     e.read_amplification = &amp;
     char label[24];
-    snprintf(label, sizeof(label), "chain%d%s%s", depth, what_last == 2 ? "+solerr" : "",
+    snprintf(label, sizeof(label), "chain%d%s%s", depth,
+             what_last == 2 ? "+solerr" : pre ? "+pre" : through ? "+errnorm" : "",
              n_stored == 0 ? "-K" : "");
     Prof p(c, ESQ_PROF_STAGE, label, nu, alg, false, 8.0 * (reads + writes) * (double)c->len);
     c->self_valid = false;
@@ -414,7 +463,7 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
     }
     if (r == ESQ_ENOTSUP) { p.cancel(); return r; }
     if (r != 0) { p.cancel(); return fail(c, ESQ_ERHS, "chain RHS entry returned %d", r); }
-    if (what_last == 0 && !skip_out) std::swap(c->ystage, c->work);
+    if ((what_last == 0 && !skip_out) || pre_out) std::swap(c->ystage, c->work);
     if (skipped) {
         c->missing_rows |= skipped;
         c->tail_missing = true;
@@ -423,6 +472,34 @@ int sweep_chain(esq_ctx *c, int i, int depth, double t, double h, int what_last,
         c->tail_h = h;
     }
     return 0;
+}
+
+// the early estimate by the library's own pass over the rows (k_pre_error: y_pre in
+// registers); its sum goes to the estimate's slot, nobody waits
+int pre_kernel(esq_ctx *c, double h, Dry *dry = nullptr) {
+    int nz = 0;
+    for (int j = 0; j < c->pre.rows; ++j) nz += c->pre.b[j] != 0.0 || c->pre.e[j] != 0.0;
+    if (dry) { dry->reads = nz + 1; dry->writes = 0; return 0; }
+    // (rows this step's chains left unwritten: only if the estimate reads one of them)
+    bool need = c->k0_missing && (c->pre.b[0] != 0.0 || c->pre.e[0] != 0.0);
+    for (int j = 0; j < c->pre.rows && c->tail_missing; ++j)
+        need = need || (((c->missing_rows >> j) & 1ull) &&
+                        (c->pre.b[j] != 0.0 || c->pre.e[j] != 0.0));
+    if (need) {
+        const int rr = esqi::restore_rows(c);
+        if (rr) return rr;
+    }
+    Terms2 tm;
+    const int nt = build_row_terms2(c, c->pre.b.data(), c->pre.rows, c->pre.e.data(),
+                                    c->pre.rows, tm, c->kmap);
+    if (nt < 1) return fail(c, ESQ_EINVAL, "bad weights");
+    {
+        Prof p(c, ESQ_PROF_SOLERR, "k_pre_error", nt, 8.0 * (nt + 1) * (double)c->len);
+        const int r = launch_preerr(c, tm, nt, h, p);
+        if (r) return r;
+    }
+    ++c->pre.plain;
+    return publish_pre(c, c->partials, (int)c->grid_reduce);
 }
 
 bool may_use_src(const esq_ctx *c) {
@@ -679,6 +756,10 @@ unsigned plan_key(int i_from, int i_to, bool ready, bool k0_missing, bool lazy) 
     return (unsigned)i_from | ((unsigned)i_to << 8) | (ready ? 1u << 16 : 0u) |
            (k0_missing ? 1u << 17 : 0u) | (lazy ? 1u << 18 : 0u);
 }
+// stage the early estimate is tested BEFORE (esq_rk_set_pre), for a whole step; 0: none
+int pre_at(const esq_ctx *c, int i_from, int i_to) {
+    return (c->pre.rows && i_from == 1 && i_to == c->s) ? c->pre.rows : 0;
+}
 unsigned long long step_signature(const PlanStep &st) {
     return (unsigned long long)st.op | ((unsigned long long)(unsigned char)st.i << 8) |
            ((unsigned long long)(unsigned char)st.depth << 16) |
@@ -731,9 +812,14 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
     // ESQ_PLAN_GREEDY=1: the first option in order of preference (round 3's rule:
     // the longest chain first) instead of the cheapest sequence
     static const bool greedy = env_uint("ESQ_PLAN_GREEDY", 0) != 0;
+    // whole steps of the pairs with an early estimate: it is tested before stage P
+    const int P = pre_at(c, i_from, i_to);
     auto crosses = [&](int lo, int hi) {       // a boundary J with lo < J <= hi
         for (const auto &b : c->blocks)
             if (b.J > lo && b.J <= hi) return true;
+        // (a chain of stages lo .. hi - 1 forms stage hi's argument: it may END at the
+        // estimate -- hi == P, the estimate its last target -- not reach over it)
+        if (P && lo < P && hi > P) return true;
         return false;
     };
     auto mk = [&](PlanOp op, int i, const Dry &d, int depth = 0, int what = 0,
@@ -769,8 +855,14 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
         if (i + D == s && i_to == s)
             return c->fsal ? (may_fuse(c, ESQ_EPI_STAGE) ? 1 : -1)
                            : (may_fuse(c, ESQ_EPI_SOLERR) ? 2 : -1);
+        // (the chain that evaluates the stage before the early estimate carries it)
+        if (P && i + D == P) return may_fuse(c, ESQ_EPI_SOLERR) ? 3 : -1;
         return (i + D < i_to && may_fuse(c, ESQ_EPI_STAGE)) ? 0 : -1;
     };
+    // FSAL pairs: a chain may run THROUGH the end of the step (y_new, the end-point
+    // stage, the error sums; what = 4, depth counts the end-point stage)
+    const bool through_cap = c->fsal && i_to == s && (c->chain_caps & ESQ_CHAIN_CAP_ERRNORM) &&
+                             may_fuse(c, ESQ_EPI_ERRNORM) && may_fuse(c, ESQ_EPI_STAGE);
     const bool lazy = lazy_ok && c->rhs && i_to == s && (c->chain_caps & ESQ_CHAIN_CAP_SKIP_ROWS);
     const bool from_cap = c->chain_from_rows && (c->chain_caps & ESQ_CHAIN_CAP_FROM_ROWS);
     const bool skip_cap = from_cap && (c->chain_caps & ESQ_CHAIN_CAP_SKIP_OUT) && i_to == s;
@@ -801,6 +893,14 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
         auto push = [&](std::vector<PlanStep> steps, int next, bool rdy, bool bd = false,
                         bool yn = false, bool se = false) {
             PlanOption o;
+            // stage P - 1 is done: the early estimate, by the library's own pass unless
+            // the chain carried it
+            if (P && i < P && next == P &&
+                !(steps.back().op == OP_CHAIN && steps.back().what == 3)) {
+                Dry dp;
+                pre_kernel(c, h, &dp);
+                steps.push_back(mk(OP_PRE_KERNEL, P, dp));
+            }
             o.steps = std::move(steps);
             o.next = next; o.ready = rdy; o.block_done = bd; o.ynew = yn; o.solerr = se;
             for (const PlanStep &st : o.steps) o.cost += step_cost(c, st);
@@ -811,6 +911,26 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
         // plan's depth, as with the fused end-point stage)
         const bool first_from = first && i == 1 && !ready && chains && from_cap && i_to == s &&
                                 !block_at(c, 2);
+        if (chains && !bnext && through_cap && i >= (P ? P : 1)) {
+            // through the end of the step: stages i .. s - 1 and the end-point stage,
+            // one stage deeper than the plan's depth (as with the deferred end-point
+            // derivative in front of a first chain)
+            const int D = s + 1 - i;
+            int d_max = c->chain_depth + 1 + (first_from ? 1 : 0);
+            if (d_max > ESQ_CHAIN_MAX_DEPTH) d_max = ESQ_CHAIN_MAX_DEPTH;
+            if (D >= 2 && D <= d_max && !crosses(i, s)) {
+                Dry d;
+                if (from_cap && ask_chain(i, D, 4, lazy, true, false, d))
+                    push({mk(OP_CHAIN, i, d, D, 4, lazy, true, false)}, s, false, false, true,
+                         true);
+                if (D <= c->chain_depth + 1 && ask_chain(i, D, 4, lazy, false, false, d)) {
+                    std::vector<PlanStep> st;
+                    if (!ready) st.push_back(argument(i, block_done));
+                    st.push_back(mk(OP_CHAIN, i, d, D, 4, lazy, false, false));
+                    push(std::move(st), s, false, false, true, true);
+                }
+            }
+        }
         if (chains && i + 1 < i_to && !bnext) {
             const int d_top = first_from && c->chain_depth < ESQ_CHAIN_MAX_DEPTH
                                   ? c->chain_depth + 1 : c->chain_depth;
@@ -820,7 +940,8 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
                 if (what < 0) continue;
                 // a chain that hands over to one that forms its own input need not
                 // write its last target
-                for (int skip = (what == 0 && skip_cap) ? 1 : 0; skip >= 0; --skip) {
+                const bool hands_on = what == 0 || (what == 3 && c->pre.b_is_next);
+                for (int skip = (hands_on && skip_cap) ? 1 : 0; skip >= 0; --skip) {
                     // a chain that ends the step, or the first one of a step: its
                     // input from the rows it reads anyway
                     // ... any chain whose first argument is a combination of rows it
@@ -831,14 +952,14 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
                         (from_anywhere || what == 2 || first_from) &&
                         ask_chain(i, D, what, lazy, true, skip != 0, d))
                         push({mk(OP_CHAIN, i, d, D, what, lazy, true, skip != 0)}, i + D,
-                             what == 0 && !skip, false, what >= 1, what == 2);
+                             hands_on && !skip, false, what == 1 || what == 2, what == 2);
                     if (D > c->chain_depth) continue;      // (that depth: from rows only)
                     if (ask_chain(i, D, what, lazy, false, skip != 0, d)) {
                         std::vector<PlanStep> st;
                         if (!ready) st.push_back(argument(i, block_done));
                         st.push_back(mk(OP_CHAIN, i, d, D, what, lazy, false, skip != 0));
-                        push(std::move(st), i + D, what == 0 && !skip, false, what >= 1,
-                             what == 2);
+                        push(std::move(st), i + D, hands_on && !skip, false,
+                             what == 1 || what == 2, what == 2);
                     }
                 }
             }
@@ -903,7 +1024,16 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
         Dry d;
         if (c->fsal) { d.reads = ynew ? 0 : nb + 1; d.writes = ynew ? 0 : 1; }
         else { d.reads = solerr ? 0 : ne + 1; d.writes = solerr ? 0 : 1; }
-        return d.reads > 0 ? step_cost(c, mk(OP_ACCUM, s, d)) : 0.0;
+        double cost = d.reads > 0 ? step_cost(c, mk(OP_ACCUM, s, d)) : 0.0;
+        if (c->fsal && !solerr && through_cap) {
+            // the end-point sweep with the error norm (esq_rk_solution_error): the same
+            // for every plan but those that run through the end of the step
+            Dry de;
+            for (int j = 0; j < s; ++j) de.reads += c->E[j] != 0.0;
+            de.reads += 2; de.writes = 1;
+            cost += step_cost(c, mk(OP_ACCUM, s, de));
+        }
+        return cost;
     };
     // ---- cheapest sequence from (i, ready, block_done) to the end of the range
     struct Best { double cost = -1.0; int pick = -1; };
@@ -968,27 +1098,32 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
     dk.reads = 1; dk.writes = 1;
     const PlanStep k0 = mk(OP_RHS_K0, 0, dk);
     double best = step_cost(c, k0) + solve(i_from, false, false, true, false, false);
-    int best_D = 0;
+    int best_D = 0, best_what = 0;
     bool best_skip = false;
     Dry best_d;
     if (i_from == 1 && chains && may_fuse(c, ESQ_EPI_STAGE) &&
         (c->chain_caps & ESQ_CHAIN_CAP_FROM_STATE)) {
         for (int D = c->chain_depth; D >= 2; --D) {
-            if (1 + D >= i_to || crosses(1, 1 + D) || D + 1 > ESQ_CHAIN_MAX_DEPTH) continue;
+            if (1 + D >= i_to || crosses(0, 1 + D) || D + 1 > ESQ_CHAIN_MAX_DEPTH) continue;
+            const int what0 = (P && 1 + D == P) ? 3 : 0;
+            if (what0 == 3 && !may_fuse(c, ESQ_EPI_SOLERR)) continue;
+            const bool hands_on = what0 == 0 || c->pre.b_is_next;
             // (its last target unwritten where the chain behind it forms its own input)
-            for (int skip = (skip_cap && !greedy) ? 1 : 0; skip >= 0; --skip) {
+            for (int skip = (hands_on && skip_cap && !greedy) ? 1 : 0; skip >= 0; --skip) {
                 Dry d;
-                if (!ask_chain(0, D + 1, 0, lazy, false, skip != 0, d)) continue;
-                const double cst = step_cost(c, mk(OP_CHAIN, 0, d, D + 1, 0, lazy, false, skip != 0)) +
-                                   solve(D + 1, !skip, false, false, false, false);
-                if (greedy || cst < best) { best = cst; best_D = D; best_d = d; best_skip = skip != 0; }
+                if (!ask_chain(0, D + 1, what0, lazy, false, skip != 0, d)) continue;
+                const double cst = step_cost(c, mk(OP_CHAIN, 0, d, D + 1, what0, lazy, false, skip != 0)) +
+                                   solve(D + 1, hands_on && !skip, false, false, false, false);
+                if (greedy || cst < best) {
+                    best = cst; best_D = D; best_d = d; best_skip = skip != 0; best_what = what0;
+                }
             }
             if (greedy) break;
         }
     }
     if (best_D) {
-        plan.steps.push_back(mk(OP_CHAIN, 0, best_d, best_D + 1, 0, lazy, false, best_skip));
-        walk(best_D + 1, !best_skip, false, false);
+        plan.steps.push_back(mk(OP_CHAIN, 0, best_d, best_D + 1, best_what, lazy, false, best_skip));
+        walk(best_D + 1, (best_what == 0 || c->pre.b_is_next) && !best_skip, false, false);
     } else {
         plan.steps.push_back(k0);
         walk(i_from, false, false, true);
@@ -1028,11 +1163,17 @@ int run_step(esq_ctx *c, const PlanStep &st, double t, double h) {
             return r;
         }
         case OP_CHAIN: {
-            const int r = sweep_chain(c, i, st.depth, t, h, st.what, st.lazy, st.from_rows,
-                                      st.skip_out);
+            int r = sweep_chain(c, i, st.depth, t, h, st.what, st.lazy, st.from_rows,
+                                st.skip_out);
             if (r == 0 && i == 0) { ++c->end_fused; c->k0_missing = false; }
+            // the early estimate rode on the sweep: its sum to the estimate's slot
+            if (r == 0 && st.what == 3) {
+                ++c->pre.fused;
+                r = publish_pre(c, c->partials, c->red_count);
+            }
             return r;
         }
+        case OP_PRE_KERNEL: return pre_kernel(c, h);
         case OP_SRC_STAGE: return sweep_next_stage(c, 1, t, h, true);
         case OP_ACCUM: return esq_rk_stage_accumulate(c, i, h);
         case OP_LINCOMB: return lincomb_stage(c, i, h);
@@ -1118,7 +1259,11 @@ void launch_ahead(esq_ctx *c, double t_new, double h) {
     a.ystage = c->ystage; a.work = c->work;
     a.tail_missing = c->tail_missing; a.missing_rows = c->missing_rows;
     a.k0_done = k0_next && !c->k0_missing;
-    a.wrote_ynew = st.op == OP_CHAIN && st.what >= 1;
+    a.wrote_ynew = st.op == OP_CHAIN && (st.what == 1 || st.what == 2 || st.what == 4);
+    // (a first launch that IS the step -- Ts5's chain through the end -- leaves the
+    // error partial sums behind; one that carries the early estimate has published it)
+    a.red_count = c->red_count;
+    a.pre_seq = (st.op == OP_CHAIN && st.what == 3) ? c->pre_last_seq : 0;
     c->kmap = kmap_now;
     static_cast<StepState &>(*c) = sv;
     if (r != 0) {                        // refused at run time: the plans learn it
@@ -1192,6 +1337,19 @@ int esqi::restore_rows(esq_ctx *c) {
     if (c->accepted_steps - c->last_restore_at <= 4) c->keep_rows = true;
     c->last_restore_at = c->accepted_steps;
     return 0;
+}
+
+// is the early estimate's y_pre the argument of the stage that follows it (CFMR7osc:
+// calvo.py:257)?  Depends on the blocked-accumulation plan: with a boundary, stage
+// `rows` resumes a stored partial sum, the estimate's y_pre runs the whole chain --
+// bit-identical values, but not the same rows, so the two are kept apart then
+static void update_pre(esq_ctx *c) {
+    c->pre.b_is_next = false;
+    const int rows = c->pre.rows;
+    if (!rows || !c->have_tab || rows >= c->s || (int)c->stage_init.size() <= rows) return;
+    bool same = true;
+    for (int j = 0; j < rows; ++j) same = same && c->pre.b[j] == c->A[(size_t)rows * c->s + j];
+    c->pre.b_is_next = same && c->stage_init[rows] < 0;
 }
 
 extern "C" {
@@ -1293,6 +1451,7 @@ int esq_replan(esq_ctx *c) {
             ++c->stage_nnz[i];
             if (j >= c->stage_from[i]) c->stage_terms[i].push_back(Term{j, a});
         }
+    update_pre(c);
     return 0;
 }
 
@@ -1328,6 +1487,7 @@ int esq_rk_set_tableau(esq_ctx *c, int s, const double *A, const double *B,
     c->C.assign(C, C + s);
     c->E.assign(E, E + s + 1);
     c->have_tab = true;
+    if (c->pre.rows > s - 1) c->pre.rows = 0;      // (an estimate of another tableau)
     return esq_replan(c);
 }
 
@@ -1405,6 +1565,7 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
     c->missing_rows = 0;
     c->ynew_ready = false;
     c->solerr_ready = false;
+    c->pre_last_seq = 0;
     // (the plan that launch belongs to: K[0] was still to come then)
     const bool k0_then = skip_first ? ahead.k0_next : c->k0_missing;
     if (skip_first && plan_key(i_from, i_to, false, k0_then, c->lazy_rows && !c->keep_rows) !=
@@ -1421,6 +1582,8 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
         // the launch ended in y_new: that buffer is this step's YNEW now (the old one
         // -- the state before the last step, dead from here on -- is the spare)
         if (c->ahead.wrote_ynew) std::swap(c->ynew, c->spare_vec);
+        c->red_count = c->ahead.red_count;
+        c->pre_last_seq = c->ahead.pre_seq;
         ++c->ahead_used;
     } else if (ahead.committed) {
         ++c->ahead_dropped;
@@ -1445,7 +1608,13 @@ int esq_rk_stages(esq_ctx *c, int i_from, int i_to, double t, double h) {
             c->k0_missing = false;
             i0 = 1;
         }
+        const int P = pre_at(c, i_from, i_to);
         for (int i = i0; i < i_to; ++i) {
+            if (P && i == P && i0 < P) {
+                // (the estimate has not been published by this attempt yet)
+                const int rq = pre_kernel(c, h);
+                if (rq) return rq;
+            }
             int rp = esq_rk_stage_accumulate(c, i, h);
             if (rp) return rp;
             rp = call_rhs(c, t + c->C[i] * h, c->ystage, c->krow[c->kmap[i]]);
@@ -1527,6 +1696,15 @@ int esq_plan_describe(const char *plugin, int N, int s, const double *A, const d
                       const double *C, const double *E, int fsal, int chain_caps,
                       int fuse_mask, int lazy_rows, int chain_depth, int src_pays, char *buf,
                       size_t buflen) {
+    return esq_plan_describe_pre(plugin, N, s, A, B, C, E, fsal, chain_caps, fuse_mask,
+                                 lazy_rows, chain_depth, src_pays, nullptr, nullptr, 0, buf,
+                                 buflen);
+}
+int esq_plan_describe_pre(const char *plugin, int N, int s, const double *A, const double *B,
+                          const double *C, const double *E, int fsal, int chain_caps,
+                          int fuse_mask, int lazy_rows, int chain_depth, int src_pays,
+                          const double *e_pre, const double *b_pre, int pre_rows, char *buf,
+                          size_t buflen) {
     if (!plugin || !A || !B || !C || !E || !buf || buflen < 2 || s < 1 || N < 1) return ESQ_EINVAL;
     esq_ctx ctx;
     esq_ctx *c = &ctx;
@@ -1534,10 +1712,11 @@ int esq_plan_describe(const char *plugin, int N, int s, const double *A, const d
     int r = make_detached(c, &user, plugin, N, s, A, B, C, E, fsal, chain_caps, fuse_mask,
                           lazy_rows, chain_depth, src_pays);
     if (r && !user) return r;
+    if (!r && pre_rows) r = esq_rk_set_pre(c, e_pre, b_pre, pre_rows);
     size_t used = 0;
     buf[0] = 0;
     static const char *kOp[] = {"k0", "chain", "src", "accum", "lincomb", "stage", "block",
-                                "ynew", "solerr", "rhs"};
+                                "ynew", "solerr", "rhs", "pre"};
     const struct { const char *label; bool ready, k0; } keys[] = {
         {"first", false, false}, {"deferred", false, true}, {"prelaunched", true, false}};
     for (const auto &k : keys) {
@@ -1588,19 +1767,29 @@ int esq_plan_describe(const char *plugin, int N, int s, const double *A, const d
 // found them.  tests/test_step_plans.py (also under the sanitizer build).
 namespace {
 bool same_state(const StepState &a, const StepState &b) {
-    static_assert(sizeof(StepState) == 104, "a new field of StepState: compare it below");
+    static_assert(sizeof(StepState) == 112, "a new field of StepState: compare it below");
     return a.y == b.y && a.ynew == b.ynew && a.ystage == b.ystage && a.work == b.work &&
            a.ynew_ready == b.ynew_ready && a.solerr_ready == b.solerr_ready &&
            a.red_count == b.red_count && a.tail_missing == b.tail_missing &&
            a.tail_accepted == b.tail_accepted && a.missing_rows == b.missing_rows &&
            a.tail_t == b.tail_t && a.tail_h == b.tail_h && a.k0_missing == b.k0_missing &&
-           a.k0_t == b.k0_t && a.end_fused == b.end_fused && a.end_plain == b.end_plain;
+           a.k0_t == b.k0_t && a.end_fused == b.end_fused && a.end_plain == b.end_plain &&
+           a.pre_last_seq == b.pre_last_seq;
 }
 }  // namespace
 int esq_step_dry_run(const char *plugin, int N, int s, const double *A, const double *B,
                      const double *C, const double *E, int fsal, int chain_caps,
                      int fuse_mask, int lazy_rows, int chain_depth, int src_pays,
                      const int *script, int n_attempts, char *buf, size_t buflen) {
+    return esq_step_dry_run_pre(plugin, N, s, A, B, C, E, fsal, chain_caps, fuse_mask, lazy_rows,
+                                chain_depth, src_pays, nullptr, nullptr, 0, script, n_attempts,
+                                buf, buflen);
+}
+int esq_step_dry_run_pre(const char *plugin, int N, int s, const double *A, const double *B,
+                         const double *C, const double *E, int fsal, int chain_caps,
+                         int fuse_mask, int lazy_rows, int chain_depth, int src_pays,
+                         const double *e_pre, const double *b_pre, int pre_rows,
+                         const int *script, int n_attempts, char *buf, size_t buflen) {
     if (!plugin || !A || !B || !C || !E || !buf || buflen < 2 || s < 1 || N < 1 || !script ||
         n_attempts < 1)
         return ESQ_EINVAL;
@@ -1611,6 +1800,8 @@ int esq_step_dry_run(const char *plugin, int N, int s, const double *A, const do
     int r = make_detached(c, &user, plugin, N, s, A, B, C, E, fsal, chain_caps, fuse_mask,
                           lazy_rows, chain_depth, src_pays);
     if (r && !user) return r;
+    if (!r && pre_rows) r = esq_rk_set_pre(c, e_pre, b_pre, pre_rows);
+    c->ahead_on = true;
     size_t used = 0;
     buf[0] = 0;
     double t = 0.0, h = 1.0 / 64;
@@ -1639,6 +1830,14 @@ int esq_step_dry_run(const char *plugin, int N, int s, const double *A, const do
         const double h_guess = (code == 0 || code == 5) ? h : 0.0;
         r = esq_rk_solution_error_ahead(c, t, h, h_guess, &sumsq);
         if (r) break;
+        unsigned long long pre_seq = 0;
+        if (c->pre.rows) {
+            // every whole-step attempt carries exactly one early estimate of its own
+            double pre_sum = 0.0;
+            r = esq_rk_pre_result(c, &pre_sum);
+            if (r) break;
+            pre_seq = c->pre_last_seq;
+        }
         if (code == 2) {                                   // rejected
             h *= 0.5;
         } else {
@@ -1661,12 +1860,16 @@ int esq_step_dry_run(const char *plugin, int N, int s, const double *A, const do
             std::set<int> sp(c->spare_rows.begin(), c->spare_rows.end());
             ok = ok && sp.size() == c->spare_rows.size();
         }
-        char line[200];
-        snprintf(line, sizeof(line),
-                 "%d: state_ok=%d used=%ld dropped=%ld missing=%d k0=%d fused=%ld plain=%ld\n",
+        char line[240];
+        int w = snprintf(line, sizeof(line),
+                 "%d: state_ok=%d used=%ld dropped=%ld missing=%d k0=%d fused=%ld plain=%ld",
                  code, ok ? 1 : 0, c->ahead_used, c->ahead_dropped,
                  c->tail_missing ? __builtin_popcountll(c->missing_rows) : 0,
                  c->k0_missing ? 1 : 0, c->end_fused, c->end_plain);
+        if (c->pre.rows)
+            w += snprintf(line + w, sizeof(line) - (size_t)w, " pre=%llu/%llu fused=%ld plain=%ld",
+                          pre_seq, c->pre.seq, c->pre.fused, c->pre.plain);
+        snprintf(line + w, sizeof(line) - (size_t)w, "\n");
         const size_t len = strlen(line);
         if (used + len + 1 > buflen) { r = ESQ_EINVAL; break; }
         memcpy(buf + used, line, len + 1);
@@ -1722,6 +1925,8 @@ int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
     ENTER(c);
     c->ynew_ready = c->solerr_ready = false;
     if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    if (c->fsal && solerr_ready)       // the chain ran through the end of the step
+        return finish_reduction(c, sumsq_out, false, c->partials, c->red_count);
     if (c->fsal) {
         int r = 0;
         if (!ynew_ready) r = esq_rk_solution(c, h);
@@ -1791,6 +1996,51 @@ int esq_rk_pre_error(esq_ctx *c, double h, const double *e_pre,
         if (r) return r;
     }
     return finish_reduction(c, sumsq_out);
+}
+
+int esq_rk_set_pre(esq_ctx *c, const double *e_pre, const double *b_scale_pre, int rows) {
+    if (!c) return ESQ_EINVAL;
+    ENTER(c);
+    drop_plans(c);
+    c->pre.rows = 0;
+    c->pre.e.clear();
+    c->pre.b.clear();
+    c->pre.b_is_next = false;
+    if (rows == 0) return 0;
+    if (!c->have_tab) return fail(c, ESQ_ESTATE, "no tableau set");
+    if (!e_pre || !b_scale_pre || rows < 2 || rows > c->s - 1)
+        return fail(c, ESQ_EINVAL, "early estimate over %d rows of a %d-stage pair", rows, c->s);
+    c->pre.e.assign(e_pre, e_pre + rows);
+    c->pre.b.assign(b_scale_pre, b_scale_pre + rows);
+    c->pre.rows = rows;
+    update_pre(c);
+    return 0;
+}
+int esq_rk_pre_result(esq_ctx *c, double *sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    const unsigned long long seq = c->pre_last_seq;
+    if (!seq) return fail(c, ESQ_ESTATE, "no early estimate in flight (esq_rk_set_pre, then "
+                          "esq_rk_stages over the whole step)");
+    if (c->detached) { *sumsq_out = 0.0; return 0; }
+    // the attempt's final reduction has been waited for: the estimate, published by an
+    // earlier kernel of the same stream, is there -- the spin is for its visibility only
+    const auto &slot = c->h_slot->pre[seq % kPreSlots];
+    for (unsigned long spins = 1;; ++spins) {
+        if (__atomic_load_n(&slot.seq, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0xfff) == 0) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(&slot.seq, __ATOMIC_ACQUIRE) == seq) break;
+                return fail(c, ESQ_ESTATE, "early estimate %llu finished without a result", seq);
+            }
+            if (q != hipErrorNotReady)
+                return fail(c, (int)q, "stream failed while waiting for the early estimate: %s",
+                            hipGetErrorString(q));
+        }
+    }
+    *sumsq_out = slot.value;
+    return 0;
 }
 
 int esq_rk_custom_sol_err(esq_ctx *c, double h, const double *b, const double *e,

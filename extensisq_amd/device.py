@@ -345,9 +345,15 @@ class DeviceContext:
         # for the remaining single stages); ESQ_CHAIN_DEPTH=1 switches it off
         chain = rhs._chain_entry(self.lib)
         if chain is not None and fused is not None and use:
+            caps = int(rhs._chain_caps)
+            # A/B switches of the round-6 chain kinds: the FSAL end-point stage and the
+            # error norm inside the chain / an early estimate whose y_pre is not stored
+            if os.environ.get("ESQ_CHAIN_ERRNORM", "1") == "0":
+                caps &= ~_lib.CHAIN_CAP_ERRNORM
+            if os.environ.get("ESQ_CHAIN_PRE", "1") == "0":
+                caps &= ~_lib.CHAIN_CAP_PRE
             self._chk(self.lib.esq_set_rhs_chain(self.handle,
-                                                 C.cast(chain, C.c_void_p),
-                                                 int(rhs._chain_caps)),
+                                                 C.cast(chain, C.c_void_p), caps),
                       "esq_set_rhs_chain")
         # RKC entry: derivative + Chebyshev recursion in one sweep
         rkc = rhs._rkc_entry(self.lib)
@@ -381,6 +387,17 @@ class DeviceContext:
                                 "esq_rk_solution_error_ahead", t, h, h_next)
         return self._scalar(self.lib.esq_rk_solution_error,
                             "esq_rk_solution_error", t, h)
+
+    def rk_set_pre(self, e_pre, b_scale_pre):
+        """register the early error estimate (weights over K[0..len)): from then on
+        `esq_rk_stages(1, s, ...)` runs the whole attempt, the estimate inside it"""
+        e = np.ascontiguousarray(e_pre, dtype=np.float64)
+        b = np.ascontiguousarray(b_scale_pre, dtype=np.float64)
+        self._chk(self.lib.esq_rk_set_pre(self.handle, as_ptr(e), as_ptr(b), len(e)),
+                  "esq_rk_set_pre")
+
+    def rk_pre_result_sumsq(self):
+        return self._scalar(self.lib.esq_rk_pre_result, "esq_rk_pre_result")
 
     def rk_pre_error_sumsq(self, h, e_pre, b_scale_pre):
         e = np.ascontiguousarray(e_pre, dtype=np.float64)
@@ -540,8 +557,11 @@ class _Builtin(DeviceRHS):
     _symbol_rkc_chain = None
     _rkc_chain_depth = 4              # Chebyshev stages per chain sweep (ESQ_RKC_MAXDEPTH)
     _rkc_chain_forms = _lib.RKC_CHAIN_FIRST | _lib.RKC_CHAIN_LAST
-    _chain_caps = 31                  # the built-in sweeps handle every form and
-    _fuse_query = True                # answer the planner's queries
+    # the built-in 2-D sweeps handle every form (incl. round 6's: an unstored early
+    # estimate, the FSAL end-point stage inside the chain) and answer the planner's
+    # queries
+    _chain_caps = 31 | _lib.CHAIN_CAP_PRE | _lib.CHAIN_CAP_ERRNORM
+    _fuse_query = True
 
     def _rkc_chain_entry(self, lib):
         if not self._symbol_rkc_chain:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ESQ_ABI_VERSION 7
+#define ESQ_ABI_VERSION 8
 
 /* error codes (negative = misuse) */
 #define ESQ_EINVAL   (-1)   /* bad argument (row/slot out of range, NULL, ...) */
@@ -174,6 +174,19 @@ typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
  *   kind_last == ESQ_EPI_SOLERR  y_new with the solution weights, and
  *       err = h*(sum_u eu[u]*rows[u] + sum_k ek[k]*K_{i+k}), partial sums of
  *       |err/(atol + rtol*max(|y|,|y_new|))|^2            (common.py:341-351)
+ *       The same kind carries the EARLY error estimate of BS5 / CFMR7osc
+ *       (bogacki.py:340-346, calvo.py:255-261; esq_rk_set_pre): the weights are the
+ *       estimate's, the target is y_pre -- stored (out: CFMR7osc's y_pre IS the
+ *       argument of the next stage) or, out == NULL, only the partner of y in the
+ *       scale (ESQ_CHAIN_CAP_PRE).
+ *   kind_last == ESQ_EPI_ERRNORM (ESQ_CHAIN_CAP_ERRNORM)  FSAL pairs: the chain's LAST
+ *       stage is the end-point evaluation K_s = fun(t + h, y_new).  Its argument
+ *       T_{depth-1} = y_new (solution weights in cu/ck[depth-2]) is handed on in
+ *       registers AND stored to `out`; "target depth" is no vector but the error sum
+ *       err = h*(sum_u cu[depth-1][u]*rows[u] + sum_k ck[depth-1][k]*K_{i+k}) with the
+ *       error weights E in the last row of cu / ck (K_s = the chain's last derivative
+ *       included), partial sums of |err/(atol + rtol*max(|y|,|y_new|))|^2.
+ *       common.py:341-351 in one sweep with the stages before it.
  * The intermediate arguments never touch memory; y and the K rows the sums share
  * are read once for the whole chain.  rows[] is the union of the K rows any
  * target reads from memory, in ascending column order; bit u of umask[e] (bit k
@@ -192,7 +205,7 @@ typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
 #define ESQ_CHAIN_MAX_ROWS 10
 typedef struct esq_chain {
     int depth;                               /* 2 .. ESQ_CHAIN_MAX_DEPTH        */
-    int kind_last;                           /* ESQ_EPI_STAGE or ESQ_EPI_SOLERR */
+    int kind_last;                           /* ESQ_EPI_STAGE, _SOLERR or _ERRNORM */
     int nu;                                  /* K rows read from memory         */
     const double *rows[ESQ_CHAIN_MAX_ROWS];
     double cu[ESQ_CHAIN_MAX_DEPTH][ESQ_CHAIN_MAX_ROWS];
@@ -218,7 +231,7 @@ typedef struct esq_chain {
     double *f_out[ESQ_CHAIN_MAX_DEPTH];      /* NULL: do not store K_{i+k} (the library
                                               * re-evaluates the row for whoever reads
                                               * it, esq_rk_lazy_rows)             */
-    double *out;                             /* ESQ_EPI_STAGE: NULL = not wanted */
+    double *out;                             /* ESQ_EPI_STAGE, _SOLERR: NULL = not wanted */
     int f_store_nt;
     /* cache policy of the loads, a hint (bit 0: y_in, bit 1: y, bit 8 + u: rows[u]):
      * set = nothing in this step reads the vector again (non-temporal load),
@@ -434,6 +447,12 @@ int  esq_set_rhs_fused(esq_ctx *ctx, esq_rhs_fused_fn fn, int fuse_mask);
  *               this chain?"): the library then plans a step from the answers; without
  *               it a refused launch is remembered and the step finished the plain way */
 #define ESQ_CHAIN_CAP_QUERY      16
+/*   PRE         ESQ_EPI_SOLERR with chain->out == NULL (an early error estimate whose
+ *               y_pre nothing reads)
+ *   ERRNORM     kind_last == ESQ_EPI_ERRNORM (the FSAL end-point stage and the error
+ *               norm inside the chain) */
+#define ESQ_CHAIN_CAP_PRE        32
+#define ESQ_CHAIN_CAP_ERRNORM    64
 int  esq_set_rhs_chain(esq_ctx *ctx, esq_rhs_chain_fn fn, int caps);
 /* register (or clear) the optional RKC entry: esq_rkc_stages then issues ONE
  * kernel per Chebyshev stage (RHS + recursion) instead of two */
@@ -500,6 +519,23 @@ int  esq_rk_solution_error_ahead(esq_ctx *ctx, double t, double h, double h_next
  * Synchronises. */
 int  esq_rk_pre_error(esq_ctx *ctx, double h, const double *e_pre,
                       const double *b_scale_pre, int rows, double *sumsq_out);
+/* WHOLE STEPS of the pairs that test an early estimate (BS5, bogacki.py:238-338;
+ * CFMR7osc, calvo.py:152-253).  esq_rk_set_pre registers the estimate -- weights
+ * e_pre / b_scale_pre over K[0..rows), tested after stage rows - 1 -- and from then
+ * on esq_rk_stages(1, s, t, h) runs the WHOLE attempt: the stages before the
+ * estimate, the estimate (as the last target of the chain sweep that evaluates stage
+ * rows - 1 where the plugin takes it: no pass of its own; its sum goes to a slot of
+ * its own, nobody waits for it), and -- speculatively, as if the estimate had
+ * passed -- the remaining stages.  esq_rk_solution_error then waits ONCE;
+ * esq_rk_pre_result returns the early estimate's sum of that attempt (no wait of
+ * its own beyond a visibility spin).  A caller that finds it > tolerance rejects the
+ * attempt exactly as the piecewise sequence would have and counts the discarded
+ * stages itself; K rows and states are bit-identical to esq_rk_stages(1, rows) +
+ * esq_rk_pre_error + esq_rk_stages(rows, s).  rows == 0 clears.  ESQ_EINVAL unless
+ * 2 <= rows <= s - 1. */
+int  esq_rk_set_pre(esq_ctx *ctx, const double *e_pre, const double *b_scale_pre,
+                    int rows);
+int  esq_rk_pre_result(esq_ctx *ctx, double *sumsq_out);
 /* Same pass with caller-supplied weights over K[0..rows): the embedded pairs of
  * the variable-order CKdisc (`_comp_sol_err_tol`, cash.py:397-401):
  *   sol = Y + h*sum b[j] K[j];  err = h*sum e[j] K[j];
@@ -540,6 +576,13 @@ int  esq_plan_describe(const char *plugin, int N, int s, const double *A,
                        const double *B, const double *C, const double *E, int fsal,
                        int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
                        int src_pays, char *buf, size_t buflen);
+/* the same with an early estimate registered (esq_rk_set_pre): the whole-step program
+ * of BS5 / CFMR7osc; pre_rows == 0: none */
+int  esq_plan_describe_pre(const char *plugin, int N, int s, const double *A,
+                           const double *B, const double *C, const double *E, int fsal,
+                           int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
+                           int src_pays, const double *e_pre, const double *b_scale_pre,
+                           int pre_rows, char *buf, size_t buflen);
 /* Whole steps on a context WITHOUT a device: the host side of the step -- plans, row
  * maps, the first launch ahead of time and what it saves and restores, rows left
  * unwritten, the deferred end-point derivative -- with every launch replaced by the
@@ -562,6 +605,15 @@ int  esq_step_dry_run(const char *plugin, int N, int s, const double *A,
                       int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
                       int src_pays, const int *script, int n_attempts, char *buf,
                       size_t buflen);
+/* the same with an early estimate registered: every attempt then also reads its
+ * estimate (esq_rk_pre_result); the lines end in
+ *   pre=<this attempt's number>/<published so far> fused=<n> plain=<n> */
+int  esq_step_dry_run_pre(const char *plugin, int N, int s, const double *A,
+                          const double *B, const double *C, const double *E, int fsal,
+                          int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
+                          int src_pays, const double *e_pre, const double *b_scale_pre,
+                          int pre_rows, const int *script, int n_attempts, char *buf,
+                          size_t buflen);
 /* Rows of K that only the solution / error sums of their own sweep read (the
  * stages of a step's last chain sweep, non-FSAL pairs: `self.K[s] = f` of
  * common.py:355 for rows nothing in `_step_impl` reads again) are NOT written

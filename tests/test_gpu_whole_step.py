@@ -1,0 +1,237 @@
+"""Round 6: whole-step device plans of the pairs that test an EARLY error estimate
+(BS5, reference bogacki.py:238-346; CFMR7osc, calvo.py:152-261) and chain sweeps that
+run THROUGH the end of an FSAL step (y_new, the end-point stage K_s = f(t + h, y_new)
+and the error norm inside the sweep; common.py:341-351).
+
+* the whole-step attempt (`esq_rk_set_pre`: stages, early estimate as the last target
+  of a chain sweep, the rest of the attempt enqueued behind it, ONE host wait) takes
+  bit for bit the steps of the round-5 sequence of pieces (`ESQ_PRE_WHOLE=0`): K, y,
+  nfev, NFS, accepted and rejected attempts -- with early rejections on the way;
+* the chain through the end of the step equals the chain + end-point sweep pair
+  (`ESQ_CHAIN_ERRNORM=0`) bit for bit in K and y;
+* BS5 / CFMR7osc / Pr7 at the BASELINE grid against the ORACLE;
+* the reference's golden traces (Duffing nfev 212, README t-grid) run in host-RHS
+  mode and are covered by tests/test_gpu_parity.py::test_trajectory_golden.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_equal
+
+import extensisq_amd as esq
+from oracle import problems as pb
+from oracle import rk_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _plugin(plugin, N):
+    if plugin == "bruss":
+        return (lambda: esq.Brusselator2D(N)), pb.bruss2d_y0(N), pb.bruss2d_rho(N)
+    return (lambda: esq.Heat2D(N)), pb.heat2d_y0(N), pb.heat2d_rho(N)
+
+
+def _labels(solver):
+    return sorted(row[0] for row in solver._dev.profile_kernels())
+
+
+def _pre_stats(solver):
+    """(accepted launches ahead used, dropped)"""
+    used, dropped = C.c_long(), C.c_long()
+    solver._chk(solver._lib.esq_rk_launch_ahead_stats(solver._ctx, C.byref(used),
+                                                      C.byref(dropped)),
+                "esq_rk_launch_ahead_stats")
+    return used.value, dropped.value
+
+
+@pytest.mark.parametrize("name,plugin,N,rows", [
+    ("BS5", "bruss", 48, 12), ("BS5", "bruss", 130, 9), ("BS5", "heat", 130, 30),
+    ("BS5", "heat", 258, 7), ("BS5", "bruss", 512, 0), ("BS5", "heat", 700, 0),
+    ("CFMR7osc", "bruss", 36, 8), ("CFMR7osc", "bruss", 124, 30),
+    ("CFMR7osc", "heat", 250, 11), ("CFMR7osc", "bruss", 512, 0),
+    ("CFMR7osc", "heat", 700, 0)])
+def test_whole_step_attempts_equal_the_pieces_bit_for_bit(monkeypatch, name, plugin, N,
+                                                          rows):
+    """fixed step (every attempt accepted): whole-step attempts against the sequence of
+    pieces; rows > 0 forces the tile height (and lifts the small-grid rule), rows == 0
+    is the library's own choice on a grid the chains take by themselves"""
+    mk, y0, rho = _plugin(plugin, N)
+    h = 0.4 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7, nfev_stiff_detect=0)
+    cls = getattr(esq, name)
+    if rows:
+        monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    whole = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_PRE_WHOLE", "0")
+    pieces = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_PRE_WHOLE")
+    assert whole._pre_whole and not pieces._pre_whole
+    whole._dev.profile_enable([0, 1, 2])
+    for _ in range(4):
+        assert whole.step() is None and pieces.step() is None
+        assert whole.t == pieces.t
+        assert_allclose(whole.error_norm_old, pieces.error_norm_old, rtol=1e-11)
+        assert_equal(whole.y, pieces.y)
+        assert_equal(whole.K, pieces.K)
+    assert whole.nfev == pieces.nfev and whole.pre_discards == 0
+    labels = _labels(whole)
+    # the estimate rode on a chain sweep: no pass of its own
+    assert any("+pre" in lab for lab in labels), labels
+    assert not any(lab.startswith("k_pre_error") for lab in labels), labels
+    if name == "BS5":       # ... and the FSAL end of the step is one more chain sweep
+        assert any("+errnorm" in lab for lab in labels), labels
+        assert not any(lab.startswith("rhs+errnorm") for lab in labels), labels
+
+
+@pytest.mark.parametrize("name,plugin,N", [
+    ("BS5", "bruss", 130), ("BS5", "heat", 258), ("CFMR7osc", "bruss", 124),
+    ("CFMR7osc", "heat", 250), ("BS5", "bruss", 512)])
+def test_whole_step_controller_with_early_rejections_equals_the_pieces(monkeypatch, name,
+                                                                      plugin, N):
+    """the controller left alone from a first step far beyond the stability limit: the
+    early estimate rejects attempts (their speculative tails are thrown away and
+    counted), the final estimate rejects others; both runs take the same decisions"""
+    mk, y0, rho = _plugin(plugin, N)
+    kw = dict(first_step=60.0 / rho, rtol=1e-5, atol=1e-8, nfev_stiff_detect=0)
+    cls = getattr(esq, name)
+    if N < 500:
+        monkeypatch.setenv("ESQ_CHAIN_ROWS", "10")
+    whole = cls(mk(), 0.0, y0, 400.0 / rho, **kw)
+    nfs_whole = []
+    for _ in range(12):
+        if whole.status != "running":
+            break
+        assert whole.step() is None
+        nfs_whole.append(int(esq.NFS[()]))
+    monkeypatch.setenv("ESQ_PRE_WHOLE", "0")
+    pieces = cls(mk(), 0.0, y0, 400.0 / rho, **kw)
+    monkeypatch.delenv("ESQ_PRE_WHOLE")
+    nfs_pieces = []
+    for _ in range(len(nfs_whole)):
+        assert pieces.step() is None
+        nfs_pieces.append(int(esq.NFS[()]))
+    assert nfs_whole == nfs_pieces and nfs_whole[-1] >= 1
+    assert whole.pre_discards >= 1              # an EARLY rejection was among them
+    assert whole.nfev == pieces.nfev
+    assert_allclose(whole.t, pieces.t, rtol=1e-12)
+    assert_allclose(whole.h_abs, pieces.h_abs, rtol=1e-9)
+    assert_allclose(whole.y, pieces.y, rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["BS5", "CFMR7osc"])
+def test_whole_step_controller_matches_the_oracle(monkeypatch, name):
+    """... and the ORACLE's decisions: accepted steps, rejected attempts (early and
+    final), RHS evaluations, times"""
+    N = 130
+    mk, y0, rho = _plugin("bruss", N)
+    kw = dict(first_step=60.0 / rho, rtol=1e-5, atol=1e-8, nfev_stiff_detect=0)
+    monkeypatch.setenv("ESQ_CHAIN_ROWS", "10")
+    d = getattr(esq, name)(mk(), 0.0, y0, 400.0 / rho, **kw)
+    o = rk_oracle.METHODS[name](pb.bruss2d_rhs(N), 0.0, y0, 400.0 / rho, **kw)
+    steps = 0
+    while o.status == "running" and steps < 10:
+        assert o.step() is None
+        steps += 1
+    nfs_ref = int(rk_oracle.NFS[()])
+    for _ in range(steps):
+        assert d.step() is None
+    assert d._pre_whole and int(esq.NFS[()]) == nfs_ref and nfs_ref >= 1
+    assert d.nfev == o.nfev
+    assert_allclose(d.t, o.t, rtol=1e-9)
+    assert_allclose(d.h_abs, o.h_abs, rtol=1e-6)
+    assert_allclose(d.y, o.y, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,plugin,N,rows", [
+    ("Ts5", "heat", 258, 7), ("Ts5", "heat", 130, 30), ("Ts5", "bruss", 48, 12),
+    ("Ts5", "bruss", 130, 9), ("Ts5", "heat", 1000, 0), ("Ts5", "bruss", 512, 0),
+    ("BS5", "heat", 130, 8), ("BS5", "bruss", 512, 0)])
+def test_chain_through_the_end_of_an_fsal_step_is_bit_identical(monkeypatch, name, plugin,
+                                                               N, rows):
+    """ESQ_CHAIN_ERRNORM=0 (the chain ends in y_new, the end-point sweep carries the
+    error norm: round 5) against the chain that runs through the end of the step"""
+    mk, y0, rho = _plugin(plugin, N)
+    h = 0.4 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-4, atol=1e-7, nfev_stiff_detect=0)
+    cls = getattr(esq, name)
+    if rows:
+        monkeypatch.setenv("ESQ_CHAIN_ROWS", str(rows))
+    through = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.setenv("ESQ_CHAIN_ERRNORM", "0")
+    pair = cls(mk(), 0.0, y0, 1.0, **kw)
+    monkeypatch.delenv("ESQ_CHAIN_ERRNORM")
+    through._dev.profile_enable([0, 1, 2])
+    pair._dev.profile_enable([0, 1, 2])
+    for _ in range(4):
+        assert through.step() is None and pair.step() is None
+        assert through.t == pair.t
+        assert_allclose(through.error_norm_old, pair.error_norm_old, rtol=1e-11)
+        assert_equal(through.y, pair.y)
+        assert_equal(through.f, pair.f)            # K_s, the next step's K_0
+    assert_equal(through.K, pair.K)                # (rows left unwritten: restored)
+    assert through.nfev == pair.nfev
+    assert any("+errnorm" in lab for lab in _labels(through))
+    assert any(lab.startswith("rhs+errnorm") for lab in _labels(pair))
+    assert not any(lab.startswith("chain") and "+errnorm" in lab for lab in _labels(pair))
+
+
+def test_ts5_whole_step_is_one_launch_and_runs_ahead():
+    """config 2's step (Ts5, heat, N = 1000): ONE chain sweep from K[0] through the
+    error norm + the final sum; at max_step it is enqueued behind the previous step's
+    error norm (launch ahead) and taken over by the next step"""
+    N = 1000
+    mk, y0, rho = _plugin("heat", N)
+    h = 1.0 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+    d = esq.Ts5(mk(), 0.0, y0, 1.0, **kw)
+    o = rk_oracle.Ts5(pb.heat2d_rhs(N), 0.0, y0, 1.0, **kw)
+    d._dev.profile_enable([0, 1, 2])
+    for _ in range(5):
+        assert d.step() is None and o.step() is None
+        assert d.t == o.t
+        assert_allclose(d.error_norm_old, o.error_norm_old, rtol=1e-6)
+    labels = _labels(d)
+    assert labels == ["chain6+errnorm-K<1>"] or labels == ["chain6+errnorm<1>"], labels
+    used, dropped = _pre_stats(d)
+    assert used >= 3 and dropped == 0, (used, dropped)
+    kmax = np.abs(o.K).max()
+    assert_allclose(d.y, o.y, rtol=1e-11, atol=1e-13)
+    assert_allclose(d.K, o.K, rtol=0, atol=1e-10 * kmax)
+
+
+@pytest.mark.parametrize("name,plugin,N,plan", [
+    ("BS5", "bruss", 2236, ["chain2+errnorm-K<6>", "chain5+pre<1>"]),
+    ("BS5", "heat", 2236, None),
+    ("CFMR7osc", "bruss", 2236, None),
+    ("Pr7", "bruss", 2236, None)])
+def test_full_size_three_steps_match_oracle_early_estimate_pairs(name, plugin, N, plan):
+    """the BASELINE grid (n = 9 999 392 / 4 999 696), THREE steps against the oracle
+    with nothing read in between: the launch sequence tools/method_sweep.py times for
+    the pairs with an early estimate (and Pr7), the plan by name"""
+    mk, y0, rho = _plugin(plugin, N)
+    cpu = pb.bruss2d_rhs(N) if plugin == "bruss" else pb.heat2d_rhs(N)
+    h = 1.0 / rho
+    rtol, atol = (1e-6, 1e-9) if plugin == "bruss" else (1e-3, 1e-6)
+    kw = dict(first_step=h, max_step=h, rtol=rtol, atol=atol, nfev_stiff_detect=0)
+    d = getattr(esq, name)(mk(), 0.0, y0, 1.0, **kw)
+    o = rk_oracle.METHODS[name](cpu, 0.0, y0, 1.0, **kw)
+    errs = []
+    for k in range(3):
+        if k == 2:
+            d._dev.profile_reset()
+            d._dev.profile_enable([0, 1, 2])
+        assert d.step() is None and o.step() is None
+        assert d.t == o.t
+        errs.append((d.error_norm_old, o.error_norm_old))
+    d._dev.profile_enable(None)
+    labels = _labels(d)
+    assert d.nfev == o.nfev and int(esq.NFS[()]) == 0
+    kmax, ymax = np.abs(o.K).max(), np.abs(o.y).max()
+    k_atol = 10 * (2e-13 * kmax + 8 * np.finfo(float).eps * rho * ymax)
+    assert_allclose(d.y, o.y, rtol=1e-11, atol=h * k_atol)
+    assert_allclose(d.K, o.K, rtol=0, atol=k_atol)
+    for got, ref in errs:
+        assert_allclose(got, ref, rtol=1e-5)
+    if plan is not None:
+        assert labels == plan, labels
