@@ -51,6 +51,14 @@ REQUIRED = {
     "test_gpu_parity.py::test_nan_propagates_to_failure": 1,
     "test_gpu_scipy_surface.py::test_events": 1,
     "test_gpu_scipy_surface.py::test_t_eval": 1,
+    # round 6: whole-step attempts of the pairs with an early estimate, chains through
+    # the end of an FSAL step
+    "test_gpu_whole_step.py::test_whole_step_attempts_equal_the_pieces_bit_for_bit": 11,
+    "test_gpu_whole_step.py::test_whole_step_controller_with_early_rejections_equals_the_pieces": 5,
+    "test_gpu_whole_step.py::test_whole_step_controller_matches_the_oracle": 2,
+    "test_gpu_whole_step.py::test_chain_through_the_end_of_an_fsal_step_is_bit_identical": 8,
+    "test_gpu_whole_step.py::test_ts5_whole_step_is_one_launch_and_runs_ahead": 1,
+    "test_gpu_whole_step.py::test_full_size_three_steps_match_oracle_early_estimate_pairs": 4,
     # bit-identical restructurings, each with its on/off switch
     "test_gpu_parity.py::test_blocked_accumulation_is_bit_identical": 18,
     "test_gpu_parity.py::test_chained_stages_are_bit_identical": 45,

@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_step_plans as gsp  # noqa: E402
 
 CAP_FROM_STATE, CAP_SKIP_ROWS, CAP_FROM_ROWS, CAP_SKIP_OUT = 1, 2, 4, 8
+CAP_PRE, CAP_ERRNORM = gsp.CAP_PRE, gsp.CAP_ERRNORM
 
 
 @pytest.fixture(scope="module")
@@ -55,16 +56,21 @@ def test_every_plan_evaluates_each_stage_once_and_uses_only_declared_forms(plans
     stages = {m: getattr(esq, m).n_stages for m in gsp.METHODS}
     stages["Heun"] = 2
     for key, lines in plans.items():
-        name, plugin, caps, lazy = key.split("/")
+        name, plugin, caps, lazy = key.split("/")[:4]
+        pre = key.endswith("/pre")        # the whole step of a pair with an early estimate
         caps, lazy, s = int(caps[4:]), int(lazy[4:]), stages[name]
+        cls = getattr(esq, name, None)
+        P = len(gsp.early_estimate(cls)[0]) if pre else 0
         for line in lines:
             label, steps, launches, tail = _parse(line)
             assert launches == len(steps)
             done = []                     # stages whose derivative this plan evaluates
+            estimates = []                # ... and after which stage the estimate ran
             have_arg = label == "prelaunched"
             for op, i, depth, what, flags in steps:
                 if op == "chain":
-                    done += list(range(i, i + depth))
+                    # (what 4: the chain's last stage is the end-point evaluation)
+                    done += list(range(i, i + depth - (1 if what == 4 else 0)))
                     if i == 0:
                         assert label == "deferred" and caps & CAP_FROM_STATE, (key, line)
                     if "L" in flags:
@@ -76,6 +82,20 @@ def test_every_plan_evaluates_each_stage_once_and_uses_only_declared_forms(plans
                     # an argument must exist unless the chain makes it itself
                     assert have_arg or "F" in flags or i == 0, (key, line)
                     have_arg = what == 0 and "S" not in flags
+                    if what == 3:
+                        # the estimate rides on the chain that ends right before stage P;
+                        # its y_pre is the next argument only for CFMR7osc (calvo.py:257)
+                        assert pre and i + depth == P, (key, line)
+                        estimates.append(done[-1])
+                        have_arg = name == "CFMR7osc" and "S" not in flags
+                        if name == "BS5":
+                            assert caps & CAP_PRE, (key, line)
+                    if what == 4:
+                        assert caps & CAP_ERRNORM and i + depth == s + 1, (key, line)
+                        assert " ynew solerr" in tail, (key, line)
+                elif op == "pre":
+                    assert pre and i == P, (key, line)
+                    estimates.append(done[-1])
                 elif op == "k0":
                     assert label == "deferred" and i == 0
                     done.append(0)
@@ -97,6 +117,8 @@ def test_every_plan_evaluates_each_stage_once_and_uses_only_declared_forms(plans
                     have_arg = nxt not in ("lincomb", "accum")
             first = 0 if label == "deferred" else 1
             assert done == list(range(first, s)), (key, line, done)
+            # exactly one early estimate, right behind stage P - 1
+            assert estimates == ([P - 1] if pre else []), (key, line, estimates)
             # the last launch of a whole step forms y_new where the plugin fuses
             if plugin.startswith(("bruss2d", "heat2d", "diff3d")):
                 assert " ynew" in tail, (key, line)
@@ -134,13 +156,43 @@ def test_more_capabilities_never_cost_more(plans):
     def cost(line):
         return float(re.search(r"cost=([\d.]+)", line).group(1))
     for key, lines in plans.items():
-        if "/caps15/" not in key:
+        if "/caps15/" not in key or key.endswith("/pre"):
             continue
         for caps in range(15):
             other = plans[key.replace("/caps15/", f"/caps{caps}/")]
             for a, b in zip(lines, other):
                 if a.split(":")[0] == b.split(":")[0]:
                     assert cost(a) <= cost(b) + 0.011, (key, caps, a, b)
+
+
+def test_round6_chain_forms_only_ever_save_launches_and_words(plans):
+    """a chain through the end of an FSAL step / an early estimate on a chain sweep: the
+    plans with the new capabilities have no more launches and move no more words than
+    the plans without them (the planner's cost of an FSAL plan does not include the
+    end-point sweep that follows it, so costs are compared through launches and words:
+    the plan through the end of the step has the end-point sweep's 1 launch and
+    ne + 2 + 1 words in hand)"""
+    import extensisq_amd as esq
+
+    def words(line):
+        m = re.search(r"launches=(\d+) words=([\d.]+)\+([\d.]+)", line)
+        return int(m.group(1)), float(m.group(2)) + float(m.group(3))
+    seen = 0
+    for key, lines in plans.items():
+        parts = key.split("/")
+        if parts[2] != f"caps{15 | CAP_PRE | CAP_ERRNORM}":
+            continue
+        base = plans[key.replace(parts[2], "caps15")]
+        cls = getattr(esq, parts[0], None)
+        for a, b in zip(lines, base):
+            assert a.split(":")[0] == b.split(":")[0]
+            (la, wa), (lb, wb) = words(a), words(b)
+            if " solerr" in a and " solerr" not in b:      # (the end-point sweep: above)
+                ne = int((cls.E[:cls.n_stages] != 0).sum())
+                lb, wb = lb + 1, wb + ne + 3
+            assert la <= lb and wa <= wb + 1, (key, a, b)
+            seen += 1
+    assert seen > 60
 
 
 def _rkc_plan(m, depth, forms=0, end_slots=5):
@@ -218,7 +270,15 @@ LINE = re.compile(r"(\d+): state_ok=(\d) used=(\d+) dropped=(\d+) missing=(\d+) 
                   r"fused=(\d+) plain=(\d+)")
 
 
-def _dry(cls, plugin, N, script=SCRIPT, caps=15 | gsp.CAP_QUERY, lazy=1, depth=4, src=0):
+PRE_TAIL = re.compile(r" pre=(\d+)/(\d+) fused=(\d+) plain=(\d+)$")
+
+
+def _dry(cls, plugin, N, script=SCRIPT, caps=15 | gsp.CAP_QUERY, lazy=1, depth=4, src=0,
+         pre=None):
+    """rows (code, state_ok, used, dropped, missing, k0, end_fused, end_plain); with an
+    early estimate registered four more columns: the attempt's estimate number, the
+    estimates published so far, how many of them rode on a chain sweep / ran as a pass
+    of their own"""
     import ctypes as C
     import numpy as np
     from extensisq_amd import _lib
@@ -228,12 +288,24 @@ def _dry(cls, plugin, N, script=SCRIPT, caps=15 | gsp.CAP_QUERY, lazy=1, depth=4
     fsal = int(arrs[3][s] != 0)
     sc = np.asarray(script, dtype=np.int32)
     buf = C.create_string_buffer(1 << 15)
-    r = lib.esq_step_dry_run(plugin.encode(), N, s, *[_lib.as_ptr(a) for a in arrs], fsal, caps,
-                             gsp.FUSE_ALL | gsp.FUSE_SRC | gsp.FUSE_QUERY, lazy, depth, src,
-                             sc.ctypes.data_as(C.c_void_p), len(sc), buf, len(buf))
+    fuse = gsp.FUSE_ALL | gsp.FUSE_SRC | gsp.FUSE_QUERY
+    if pre is not None:
+        e, b = [np.ascontiguousarray(x, dtype=float) for x in pre]
+        r = lib.esq_step_dry_run_pre(plugin.encode(), N, s, *[_lib.as_ptr(a) for a in arrs],
+                                     fsal, caps, fuse, lazy, depth, src, _lib.as_ptr(e),
+                                     _lib.as_ptr(b), len(e), sc.ctypes.data_as(C.c_void_p),
+                                     len(sc), buf, len(buf))
+    else:
+        r = lib.esq_step_dry_run(plugin.encode(), N, s, *[_lib.as_ptr(a) for a in arrs], fsal,
+                                 caps, fuse, lazy, depth, src, sc.ctypes.data_as(C.c_void_p),
+                                 len(sc), buf, len(buf))
     assert r == 0, r
-    rows = [tuple(int(g) for g in LINE.match(ln).groups())
-            for ln in buf.value.decode().strip().split("\n")]
+    rows = []
+    for ln in buf.value.decode().strip().split("\n"):
+        row = tuple(int(g) for g in LINE.match(ln).groups())
+        if pre is not None:
+            row += tuple(int(g) for g in PRE_TAIL.search(ln).groups())
+        rows.append(row)
     assert [row[0] for row in rows] == list(script)
     return rows
 
@@ -249,7 +321,7 @@ def test_launch_ahead_leaves_the_step_state_as_it_found_it(plugin, N):
     classes = [getattr(esq, m) for m in gsp.METHODS] + [gsp.heun()]
     has_chain = plugin in ("bruss2d", "heat2d", "diff3d")
     for cls in classes:
-        for caps in (range(16) if plugin != "diff3d" and has_chain else
+        for caps in (list(range(16)) + gsp.CAPS_R6 if plugin != "diff3d" and has_chain else
                      [0, 1, 2, 3] if has_chain else [0]):
             for lazy in (0, 1):
                 rows = _dry(cls, plugin, N, caps=caps | gsp.CAP_QUERY, lazy=lazy)
@@ -281,3 +353,55 @@ def test_launch_ahead_script_of_the_metric_configuration():
     assert [r[2] for r in rows] == [0, 1, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9]
     assert [r[3] for r in rows] == [0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2]
     assert all(r[4] == 0 and r[5] == 0 and r[6] == 0 for r in rows)
+
+
+@pytest.mark.parametrize("plugin,N", gsp.PLUGINS)
+def test_whole_steps_with_an_early_estimate_on_a_detached_context(plugin, N):
+    """BS5 / CFMR7osc with their early estimate registered (esq_rk_set_pre), every
+    capability set incl. round 6's: every attempt -- accepted, rejected, launched ahead,
+    guessed wrong, with a reader in between -- carries exactly ONE estimate of its own
+    (a number no other attempt has), the speculation leaves the context as it found it,
+    and with the chain forms declared no estimate runs as a pass of its own"""
+    import extensisq_amd as esq
+    has_chain = plugin in ("bruss2d", "heat2d", "diff3d")
+    all_caps = ([0, 3, 15] + gsp.CAPS_R6 if plugin in ("bruss2d", "heat2d")
+                else [0, 3] if plugin == "diff3d" else [0])
+    for cls in (esq.BS5, esq.CFMR7osc):
+        pre = gsp.early_estimate(cls)
+        for caps in all_caps:
+            for lazy in (0, 1):
+                rows = _dry(cls, plugin, N, caps=caps | gsp.CAP_QUERY, lazy=lazy, pre=pre)
+                what = (cls.__name__, plugin, caps, lazy, rows)
+                assert all(row[1] == 1 for row in rows), what
+                mine = [row[8] for row in rows]
+                assert all(m > 0 for m in mine) and len(set(mine)) == len(mine), what
+                assert mine == sorted(mine), what
+                # (published: this attempt's, the dry run's own probe of launch_ahead,
+                # at most two launches ahead)
+                assert all(row[8] <= row[9] <= row[8] + 3 for row in rows), what
+                fused, plain = rows[-1][10], rows[-1][11]
+                assert fused + plain == rows[-1][9], what
+                full = caps & 15 == 15 and has_chain
+                if full and (cls is esq.CFMR7osc or caps & CAP_PRE):
+                    assert plain == 0, what
+                if not has_chain:
+                    assert fused == 0, what
+
+
+def test_early_estimate_plans_of_the_method_sweep(plans):
+    """the whole-step programs tools/method_sweep.py times at N = 2236, spelled out"""
+    caps = 15 | CAP_PRE | CAP_ERRNORM
+    bs5 = plans[f"BS5/bruss2d2236/caps{caps}/lazy1/pre"]
+    # stages 1-5 from K[0] with the estimate as last target (y_pre not stored), then
+    # stage 6 from the rows, y_new, the FSAL stage and the error norm: 2 launches
+    assert bs5[0].startswith("first: chain[1,5,3]LF chain[6,2,4]LF | launches=2 words=9+7 ")
+    cf = plans[f"CFMR7osc/bruss2d2236/caps{caps}/lazy1/pre"]
+    # y_pre of CFMR7osc IS stage 8's argument: stored, the last stage's sweep reads it
+    assert cf[1].startswith("deferred: chain[0,4,0]LS chain[4,4,3]LF solerr[8] "
+                            "| launches=3 words=13+10 ")
+    # without the round-6 forms BS5's estimate is a pass of its own
+    old = plans["BS5/bruss2d2236/caps15/lazy1/pre"]
+    assert " pre[6] " in old[0]
+    # config 2: the whole Ts5 step is one sweep, y and K[0] in, y_new and K[6] out
+    ts5 = plans[f"Ts5/heat2d1000/caps{caps}/lazy1"]
+    assert ts5[0].startswith("first: chain[1,6,4]LF | launches=1 words=2+2 ")
