@@ -474,9 +474,12 @@ struct Stencil2D {
                                   kSplit, kFrom>;
             const unsigned block = kSplit ? 64u * NF : (unsigned)kBlock;
             static const int wpc = chain_waves_per_cu(kern, block);   // per instantiation
+            // (min_rows < 0, light one-field rows: tiles down to `depth` rows, five at
+            // depth 6 -- Ts5's whole-step chain at N = 1000, tools/r06_ts5_rows.sh:
+            // 5-row tiles 34.7 us, 6 37.2, 4 48.7, 7 39.3)
             const GeoChain g = geo_chain(N, CA::kD, wpc, kSplit ? 1 : kBlock / 64,
                                          kSplit ? NF : 1, tall_tiles,
-                                         min_rows < 0 ? CA::kD : min_rows);
+                                         min_rows < 0 ? (CA::kD < 5 ? CA::kD : 5) : min_rows);
             if (decltype(kind)::value == ESQ_EPI_SOLERR ||
                 decltype(kind)::value == ESQ_EPI_ERRNORM) {
                 if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
