@@ -916,8 +916,7 @@ def solve_ivp_figure(w, device, steps=24):
         out["t_eval_end"] = {k: ev[k] for k in ("ms_per_step", "ms_per_step_mean", "steps",
                                                 "value", "assembly_ms")}
     try:
-        # how the downloads were made: by the DMA engines, or -- after an engine copy at
-        # half the link's rate -- by the copy kernel (csrc/esq_core.hip, lane_copy)
+        # the record of the process's download stream (csrc/esq_core.hip, lane_copy)
         from extensisq_amd._lib import copy_lane_info
         out["download_stream"] = copy_lane_info(device)
     except Exception:                                          # noqa: BLE001

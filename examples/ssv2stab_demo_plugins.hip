@@ -117,11 +117,11 @@ extern "C" int aniso3d_chain(void *user, const double *y_in, const esq_chain *ch
                              void *stream, void *e0, void *e1) {
     const User<AnisoFn> *u = (const User<AnisoFn> *)user;
     if (!u || n != Aniso::points(u->N)) return ESQ_EINVAL;
-    return Aniso::chain(u->fn, u->N, y_in, chain, stream, e0, e1, esq::stencil3d_tuning_from_env());
+    return Aniso::chain(u->fn, u->N, y_in, chain, stream, e0, e1, esq::stencil3d_tuning_default());
 }
 extern "C" int aniso3d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void *stream,
                                  void *e0, void *e1) {
     const User<AnisoFn> *u = (const User<AnisoFn> *)user;
     if (!u || n != Aniso::points(u->N)) return ESQ_EINVAL;
-    return Aniso::rkc_chain(u->fn, u->N, ch, stream, e0, e1, esq::stencil3d_tuning_from_env());
+    return Aniso::rkc_chain(u->fn, u->N, ch, stream, e0, e1, esq::stencil3d_tuning_default());
 }

@@ -42,6 +42,10 @@ SIGNATURES = {
     "esq_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "esq_create": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int]),
     "esq_create2": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    "esq_create3": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                              C.c_char_p]),
+    "esq_option_level": (C.c_int, [C.c_char_p]),
+    "esq_rhs_set_options": (C.c_int, [_vp, C.c_char_p]),
     "esq_destroy": (C.c_int, [_vp]),
     "esq_last_error": (C.c_char_p, [_vp]),
     "esq_synchronize": (C.c_int, [_vp]),
@@ -51,7 +55,7 @@ SIGNATURES = {
     "esq_snapshot_begin": (C.c_int, [_vp, C.c_int, C.c_int, _vpp]),
     "esq_snapshot_copy": (C.c_int, [_vp, _vp, C.c_int]),
     "esq_release_cached_memory": (C.c_int, [_vp]),
-    "esq_copy_lane_info": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "esq_copy_lane_info": (C.c_int, [C.c_int, _vp, _vp, _vp]),
     "esq_host_pin": (C.c_int, [_vp, C.c_size_t]),
     "esq_host_unpin": (C.c_int, [_vp]),
     "esq_copy": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -192,15 +196,70 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.esq_abi_version()
-    if ver == -ABI_VERSION and os.environ.get("ESQ_LIB_EXPERIMENT") == "1":
-        pass        # a what-if build (ESQ_CHAIN_EXP): timing only, results wrong by design
-    elif ver != ABI_VERSION:
-        raise DeviceError(
-            "libextensisq_amd.so ABI version mismatch" if ver != -ABI_VERSION else
-            f"{LIB_PATH} is a what-if build of the chain sweeps (ESQ_CHAIN_EXP): its "
-            "results are wrong by design; ESQ_LIB_EXPERIMENT=1 loads it for timing runs")
+    if ver != ABI_VERSION:
+        raise DeviceError(f"{LIB_PATH}: ABI version {ver}, this package binds {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+class Options:
+    """The tuning switches of ONE solver (`esq_options=` of a constructor, and so of
+    `solve_ivp(..., method=Pr8, esq_options={"chain_depth": 1})`): the `ESQ_*` switches of
+    DESIGN.md §3.4, lower case without the prefix.  Nothing here writes the process
+    environment (until round 5 the keyword did, for the duration of the constructor):
+    the library's own switches travel as an options string to `esq_create3` /
+    `esq_rhs_set_options`, the package's are looked up with `get`.  A key that is
+    neither is refused.  A switch the caller does not give takes the process default
+    `ESQ_<KEY>` -- read, never written."""
+
+    # switches this package reads itself (the library does not know them)
+    PACKAGE_KEYS = frozenset((
+        "chain", "fuse", "rkc_chain", "rkc_maxdepth", "host_slab", "lazy_y", "prelaunch",
+        "launch_ahead", "pre_whole", "chain_errnorm", "chain_pre", "lockstep_debug"))
+
+    def __init__(self, options=None):
+        if isinstance(options, Options):
+            options = options.values
+        self.values = {}
+        for key, value in dict(options or {}).items():
+            if not isinstance(key, str) or not key.replace("_", "").isalnum():
+                raise ValueError(f"esq_options: bad key {key!r}")
+            k = key.lower()
+            k = k[4:] if k.startswith("esq_") else k
+            if isinstance(value, bool):
+                value = int(value)
+            self.values[k] = str(value)
+        lib = None
+        self._level = {}
+        for k in self.values:
+            if k in self.PACKAGE_KEYS:
+                self._level[k] = 0
+                continue
+            lib = lib or load()
+            level = lib.esq_option_level(k.encode())
+            if level == 0:
+                raise ValueError(f"esq_options: unknown switch {k!r}")
+            self._level[k] = level
+
+    def get(self, key, default=None):
+        """a switch of this package: the explicit value, else ESQ_<KEY>, else default"""
+        if key in self.values:
+            return self.values[key]
+        return os.environ.get("ESQ_" + key.upper(), default)
+
+    def _string(self, level):
+        return ";".join(f"{k}={v}" for k, v in sorted(self.values.items())
+                        if self._level[k] == level).encode()
+
+    @property
+    def context_string(self):
+        """the switches of an `esq_ctx` (esq_create3)"""
+        return self._string(1)
+
+    @property
+    def plugin_string(self):
+        """the switches of a built-in plugin object (esq_rhs_set_options)"""
+        return self._string(2)
 
 
 def check(code, ctx=None, what=""):
@@ -239,16 +298,13 @@ def release_cached_memory():
 
 
 def copy_lane_info(device=0):
-    """the record of the large downloads of `device` (esq_copy_lane_info): the fastest
-    timed first piece, the copy kernel's reference piece and the latest whole download
-    (GB/s), downloads finished by the DMA engines / by the copy kernel"""
-    best, ref, last = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
-    eng, ker = C.c_long(0), C.c_long(0)
-    if load().esq_copy_lane_info(int(device), C.byref(best), C.byref(ref), C.byref(last),
-                                 C.byref(eng), C.byref(ker)) != 0:
+    """the record of the large downloads of `device` (esq_copy_lane_info): the fastest and
+    the latest one (GB/s), and how many the DMA engines have made"""
+    best, last, count = C.c_double(0.0), C.c_double(0.0), C.c_long(0)
+    if load().esq_copy_lane_info(int(device), C.byref(best), C.byref(last),
+                                 C.byref(count)) != 0:
         return None
-    return {"best_probe_gbs": best.value, "kernel_ref_gbs": ref.value, "last_gbs": last.value,
-            "engine_copies": eng.value, "kernel_copies": ker.value}
+    return {"best_gbs": best.value, "last_gbs": last.value, "engine_copies": count.value}
 
 
 def as_ptr(arr):

@@ -24,56 +24,26 @@ from scipy.integrate._ivp.common import (validate_first_step,
                                          validate_max_step, warn_extraneous)
 
 from ._lib import (SLOT_K, SLOT_WORK, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, VEC_NONE,
-                   VEC_Y, DeviceError, as_ptr)
-from .device import DeviceContext, DeviceRHS
+                   VEC_Y, DeviceError, Options, as_ptr)
+from .device import DeviceContext, DeviceRHS, _dense_dead, drain_dense
 from .lazy import LazyState
 
 LAZY_MIN_BYTES = 8 << 20       # states below this are downloaded at once
 
 
-class _EsqOptions:
-    """`esq_options={"chain_depth": 3, "lazy_y": "always", ...}` of a solver constructor
-    (and so of `solve_ivp(..., method=Pr8, esq_options=...)`): the library's tuning
-    switches -- the `ESQ_*` environment variables of DESIGN.md §3.4, lower case without
-    the prefix -- for THIS solver only.  The switches are read when a context, a plugin
-    object or a plan is made, all of which happens inside the constructor: they are put
-    into the environment for its duration and taken out again."""
-
-    def __init__(self, options):
-        self.options = dict(options or {})
-        for key in self.options:
-            if not isinstance(key, str) or not key.replace("_", "").isalnum():
-                raise ValueError(f"esq_options: bad key {key!r}")
-        self._saved = {}
-
-    def __enter__(self):
-        for key, value in self.options.items():
-            name = "ESQ_" + key.upper()
-            self._saved[name] = os.environ.get(name)
-            if isinstance(value, bool):
-                value = int(value)
-            os.environ[name] = str(value)
-        return self
-
-    def __exit__(self, *exc):
-        for name, old in self._saved.items():
-            if old is None:
-                os.environ.pop(name, None)
-            else:
-                os.environ[name] = old
-        return False
-
-
 def _with_esq_options(init):
-    """constructor decorator: the `esq_options=` keyword (see `_EsqOptions`)"""
+    """constructor decorator: the `esq_options=` keyword -- this solver's tuning switches
+    (`_lib.Options`: the ESQ_* switches of DESIGN.md §3.4, lower case without the
+    prefix).  They travel as ARGUMENTS -- to `esq_create3`, to `esq_rhs_set_options`, to
+    this package's own decisions -- and nothing writes the process environment (until
+    round 5 the keyword did, for the duration of the constructor: switches read later
+    had no effect, two threads constructing solvers raced).  Unknown keys: ValueError."""
     import functools
 
     @functools.wraps(init)
     def wrapper(self, *args, esq_options=None, **kwargs):
-        if esq_options is None:
-            return init(self, *args, **kwargs)
-        with _EsqOptions(esq_options):
-            return init(self, *args, **kwargs)
+        self._esq_options = Options(esq_options)
+        return init(self, *args, **kwargs)
     return wrapper
 
 
@@ -201,9 +171,12 @@ class DeviceHornerDenseOutput(DenseOutput):
         return np.stack([self._eval(xi) for xi in x], axis=1)
 
     def __del__(self):
+        # (a finalizer: esq_dense_destroy synchronises a stream and may free device
+        # memory -- parked like contexts, destroyed at the next well-defined point)
         handle, self._handle = getattr(self, "_handle", None), None
         if handle:
-            self._lib.esq_dense_destroy(handle)
+            from .device import _dense_dead
+            _dense_dead.append((self._lib.esq_dense_destroy, handle))
 
 
 class CubicDenseOutput(DenseOutput):
@@ -320,7 +293,7 @@ class _LazyStateMixin:
         # large device-resident states: `solver.y` READ BY scipy's solve_ivp loop is a
         # deferred mirror; every other caller gets the ndarray it always got.
         # ESQ_LAZY_Y=0: never; ESQ_LAZY_Y=always: for every caller
-        mode = os.environ.get("ESQ_LAZY_Y", "1")
+        mode = self._esq_options.get("lazy_y", "1")
         self._lazy_on = (self._device_rhs is not None and not host_slab
                          and nbytes >= LAZY_MIN_BYTES and mode != "0")
         self._lazy_always = mode == "always"
@@ -485,9 +458,11 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
             raise TypeError('dtypes of solution and derivative do not match')
         # at least 5 K rows: rows 1..4 are the work vectors of the device
         # starting-step estimate (they are free until the first step)
+        opts = self._esq_options
         self._dev = DeviceContext(
             self.n, max(self.n_stages + 1 + self._extra_rows, 5), is_cplx, device,
-            host_rhs=self._device_rhs is None and lockstep is None)
+            host_rhs=self._device_rhs is None and lockstep is None, options=opts)
+        self._prelaunch = opts.get("prelaunch", "1") != "0"
         self._lib = self._dev.lib
         self._ctx = self._dev.handle
         self._dev.set_tableau(self.A, self.B, self.C, self.E, self.FSAL)
@@ -501,18 +476,18 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
         # steps too where the state lives on the device: the estimate rides on the
         # chain sweep that completes its last stage, the rest of the attempt is
         # enqueued behind it as if it had passed, ONE wait per attempt
-        # (esq_rk_set_pre; ESQ_PRE_WHOLE=0: the piecewise sequence of round 5)
+        # (esq_rk_set_pre; pre_whole=0: the piecewise sequence of round 5)
         pre = self._early_estimate()
         self._pre_whole = (pre is not None and self._device_rhs is not None
                            and not is_cplx and not self._dev.host_slab
-                           and os.environ.get("ESQ_PRE_WHOLE", "1") != "0")
+                           and opts.get("pre_whole", "1") != "0")
         if self._pre_whole:
             self._dev.rk_set_pre(*pre)
         self.pre_discards = 0        # attempts whose speculative tail was thrown away
         self._launch_ahead = (self._device_rhs is not None
                               and (type(self)._step_impl is RungeKutta._step_impl
                                    or self._pre_whole)
-                              and os.environ.get("ESQ_LAUNCH_AHEAD", "1") != "0")
+                              and opts.get("launch_ahead", "1") != "0")
         self._dev._chk(self._lib.esq_rk_set_launch_ahead(self._ctx,
                                                          int(self._launch_ahead)),
                        "esq_rk_set_launch_ahead")
@@ -717,6 +692,8 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
 
     def step(self):
         self._retire_lazy_states()
+        if _dense_dead:
+            drain_dense()
         return super().step()
 
     @property
@@ -896,8 +873,6 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
             sumsq = self._dev.rk_solution_error_sumsq(t, h)
         return self._rms_from_sumsq(sumsq)
 
-    _prelaunch = os.environ.get("ESQ_PRELAUNCH", "1") != "0"
-
     def _finish_step(self, t_new, h, h_abs_next=None):
         """end-point derivative of non-FSAL pairs, then pointer rotation on the
         device (ref common.py:289-303).  `h_abs_next`: the step size the
@@ -1073,6 +1048,7 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
         current state (BS5 'best'), else at the pre-step state"""
         import ctypes
         P = np.ascontiguousarray(P, dtype=np.float64)
+        drain_dense()
         handle = ctypes.c_void_p()
         self._chk(self._lib.esq_dense_create(
             self._ctx, as_ptr(P), P.shape[0], P.shape[1], float(t_b - t_a),

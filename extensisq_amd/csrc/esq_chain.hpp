@@ -38,19 +38,10 @@
 
 #include "../../include/extensisq_amd.h"
 #include "esq_epilogue.hpp"
+#include "esq_options.hpp"
 #include "esq_terms.hpp"
 
-#ifndef ESQ_CHAIN_EXP
-#define ESQ_CHAIN_EXP 0
-#endif
 namespace esq {
-#if ESQ_CHAIN_EXP == 1 || ESQ_CHAIN_EXP == 3   // what-if timing: no loads at all (results wrong)
-#define ESQ_XLD(P, K) make_double2(1e-3 * (double)(threadIdx.x & 63), 2e-3)
-#define ESQ_XLDNT(P, K) make_double2(1e-3 * (double)(threadIdx.x & 63), 2e-3)
-#else
-#define ESQ_XLD(P, K) ld2(P, K)
-#define ESQ_XLDNT(P, K) ld2_nt(P, K)
-#endif
 
 // Register budget of the two-field (Brusselator) instantiations, from
 // `hipcc -Rpass-analysis=kernel-resource-usage`: the largest number of memory
@@ -58,60 +49,24 @@ namespace esq {
 // chains drop to one wave per SIMD and lose more than they save (measured:
 // chain3+solerr<6> at one wave per SIMD took 590 us where a two-wave chain2 +
 // a single sweep take 360).  The block planner (esq_step.hip) uses the same
-// table.  ESQ_CHAIN_CAPS="s2,e2,s3,e3,s4,e4" overrides it (tuning).
+// table.
 struct ChainCaps {
     int stage[7], solerr[7];
 };
-// The chain sweeps' tuning knobs, read from the environment ONCE -- when a context or
-// a built-in plugin object is made (chain_tuning_refresh; a separately compiled
-// plugin reads them at its first launch) -- never on the launch path:
-//   ESQ_CHAIN_CAPS="s2,e2,s3,e3,..."  register budget table below
-//   ESQ_CHAIN_ROWS=R                  tile height of every chain sweep (tests: also lifts
-//                                     the small-grid rule)
-//   ESQ_CHAIN_SERPENTINE=0            all tile rows march downwards
-//   ESQ_CHAIN_TALL_WAVES=w            waves per SIMD the tall one-field tiles may use
+// Tile height of a plugin object's chain sweeps: forced (tests: small tiles put the halo
+// rows everywhere and lift the small-grid rule) or 0 = the library's rules
+// (esq_stencil2d.hpp, geo_chain).  Part of the plugin OBJECT (option CHAIN_ROWS of
+// esq_rhs_set_options; a user plugin passes its own to Stencil2D::chain): until round 5
+// a process-wide table that one solver's options leaked through to the next.
 struct ChainTuning {
-    bool caps_set = false;
-    int caps[10] = {0};
-    int caps_n = 0;
     int rows = 0;
     bool rows_set = false;
-    unsigned serpentine = 1;
-    int tall_waves = 2;
 };
-inline ChainTuning read_chain_tuning() {
+// the process default (ESQ_CHAIN_ROWS), for plugin objects that were given no option
+inline ChainTuning chain_tuning_default() {
     ChainTuning t;
-    if (const char *env = getenv("ESQ_CHAIN_CAPS")) {
-        t.caps_set = true;
-        t.caps_n = sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", &t.caps[0], &t.caps[1],
-                          &t.caps[2], &t.caps[3], &t.caps[4], &t.caps[5], &t.caps[6],
-                          &t.caps[7], &t.caps[8], &t.caps[9]);
-    }
-    if (const char *env = getenv("ESQ_CHAIN_ROWS")) { t.rows_set = true; t.rows = atoi(env); }
-    if (const char *env = getenv("ESQ_CHAIN_SERPENTINE")) t.serpentine = atoi(env) == 0 ? 0u : 1u;
-    if (const char *env = getenv("ESQ_CHAIN_TALL_WAVES")) t.tall_waves = atoi(env);
+    if (const char *env = env_get("CHAIN_ROWS")) { t.rows_set = true; t.rows = atoi(env); }
     return t;
-}
-// (contexts may be made and driven from any thread: the table is copied in and out
-// under a lock)
-struct ChainTuningBox {
-    std::mutex mu;
-    ChainTuning t = read_chain_tuning();
-};
-inline ChainTuningBox &chain_tuning_box() {
-    static ChainTuningBox b;
-    return b;
-}
-inline ChainTuning chain_tuning() {
-    ChainTuningBox &b = chain_tuning_box();
-    std::lock_guard<std::mutex> g(b.mu);
-    return b.t;
-}
-inline void chain_tuning_refresh() {
-    const ChainTuning fresh = read_chain_tuning();
-    ChainTuningBox &b = chain_tuning_box();
-    std::lock_guard<std::mutex> g(b.mu);
-    b.t = fresh;
 }
 // compute units of the device the calling thread has selected (the tile-height rules
 // fill "one round of resident waves"); 256 where there is no device (detached
@@ -137,16 +92,8 @@ inline int device_cus() {
 // split = one field per wave (k_chain2d<..., SPLIT = true>): the budget of a
 // one-field kernel.  Depth 5 and 6 are instantiated with up to 6 memory rows.
 inline ChainCaps chain_caps(bool split = true) {
-    ChainCaps c = split ? ChainCaps{{0, 0, 9, 9, 9, 6, 6}, {0, 0, 9, 9, 9, 6, 6}}
-                        : ChainCaps{{0, 0, 8, 5, 1, -1, -1}, {0, 0, 7, 2, -1, -1, -1}};
-    const ChainTuning t = chain_tuning();
-    if (t.caps_set) {
-        const int *v = t.caps;
-        for (int d = 2; d <= 6; ++d) {
-            if (t.caps_n >= 2 * (d - 1)) { c.stage[d] = v[2 * (d - 2)]; c.solerr[d] = v[2 * (d - 2) + 1]; }
-        }
-    }
-    return c;
+    return split ? ChainCaps{{0, 0, 9, 9, 9, 6, 6}, {0, 0, 9, 9, 9, 6, 6}}
+                 : ChainCaps{{0, 0, 8, 5, 1, -1, -1}, {0, 0, 7, 2, -1, -1, -1}};
 }
 inline bool chain_within_caps(int depth, bool solerr, int nu, bool split = true) {
     if (depth < 2 || depth > 6) return false;
@@ -259,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         auto ld_ys = [&](int r, int f) -> double2 {
             if (!PERIODIC && (!live || !row_ok(r))) return make_double2(0.0, 0.0);
             const size_t k_ = (size_t)(fbase + f) * fstride + (size_t)wrap(r) * npairs + pwl;
-            return (ca.ld_nt & 1u) ? ESQ_XLDNT(ys, k_) : ESQ_XLD(ys, k_);
+            return (ca.ld_nt & 1u) ? ld2_nt(ys, k_) : ld2(ys, k_);
         };
         const double2 zero = make_double2(0.0, 0.0);
         // every weight as a scalar of its own: taken straight from the argument
@@ -268,18 +215,6 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         // row in chain4+solerr<8>, half of its vector instructions)
         double w_cu[D][ChainArgs<D, NU>::NUa], w_eu[ChainArgs<D, NU>::NUa], w_ck[D][D],
             w_ek[D];
-#if ESQ_CHAIN_EXP >= 2
-#pragma unroll
-        for (int e = 0; e < D; ++e) {
-#pragma unroll
-            for (int j = 0; j < NU; ++j) w_cu[e][j] = 0.25 + 0.01 * (e + j);
-#pragma unroll
-            for (int k = 0; k < D; ++k) w_ck[e][k] = 0.125 + 0.01 * (e + k);
-            w_ek[e] = 0.03 * e;
-        }
-#pragma unroll
-        for (int j = 0; j < NU; ++j) w_eu[j] = 0.01 * j;
-#else
 #pragma unroll
         for (int e = 0; e < D; ++e) {
 #pragma unroll
@@ -296,16 +231,11 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         for (int j = 0; j < NU; ++j) {
             asm("s_mov_b64 %0, %1" : "=s"(w_eu[j]) : "s"(ca.eu[j]));
         }
-#endif
         double w_c0[ChainArgs<D, NU>::NUa];
         if constexpr (FROMROWS) {
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
-#if ESQ_CHAIN_EXP >= 2
-                w_c0[j] = 0.2 + 0.01 * j;
-#else
                 asm("s_mov_b64 %0, %1" : "=s"(w_c0[j]) : "s"(ca.c0[j]));
-#endif
             }
         }
         // windows of the D stages: rows rho_k - 1, rho_k, rho_k + 1 of T_k
@@ -344,20 +274,16 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             const size_t k2_ = (size_t)(fbase + f) * fstride + base_;              \
             _Pragma("unroll") for (int j = 0; j < NU; ++j)                         \
                 u[j][f] = !act_ ? zero : ((ca.ld_nt >> (8 + j)) & 1u)                 \
-                              ? ESQ_XLDNT(ca.rows[j], k2_) : ESQ_XLD(ca.rows[j], k2_);       \
+                              ? ld2_nt(ca.rows[j], k2_) : ld2(ca.rows[j], k2_);       \
             yrow[f] = zero;                                                        \
             if (ca.y)                                                              \
-                yrow[f] = !act_ ? zero : (ca.ld_nt & 2u) ? ESQ_XLDNT(ca.y, k2_)        \
-                                                         : ESQ_XLD(ca.y, k2_);     \
+                yrow[f] = !act_ ? zero : (ca.ld_nt & 2u) ? ld2_nt(ca.y, k2_)        \
+                                                         : ld2(ca.y, k2_);     \
         }                                                                          \
     }
         // FROMROWS: T_0 of the row a set belongs to (same ascending FMA chain, the
         // same two roundings as the sweep that would have written it)
-#if ESQ_CHAIN_EXP >= 2
-#define ESQ_XBIT(M, J) true
-#else
 #define ESQ_XBIT(M, J) (((M) >> (J)) & 1u)
-#endif
 #define ESQ_CHAIN_FORM_T0(IT, U_, Y_, DST)                                                 \
     {                                                                              \
         const int rho_ = rbase + dirn * ((IT) + 1);                                \
@@ -610,5 +536,6 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
 #undef ESQ_CHAIN_LOAD_ROW
 #undef ESQ_CHAIN_FORM_T0
 #undef ESQ_CHAIN_ROW_SUMS
+#undef ESQ_XBIT
 
 }  // namespace esq

@@ -414,18 +414,33 @@ constexpr size_t kCacheMaxBlocks = 8;
 int block_rank_locked(const Block &b) {         // 2 known fast, 1 unknown, 0 known slow
     return b.gbs == 0.0 ? 1 : b.gbs >= 0.6 * g_best_gbs ? 2 : 0;
 }
-size_t cache_cap_bytes() {
-    // (the switch is read per release -- they are rare: tests and esq_options change it)
-    const char *e = getenv("ESQ_SLAB_CACHE_MB");
+// cap of the bytes cached PER DEVICE: ESQ_SLAB_CACHE_MB, else a quarter of that device's
+// memory (asked once per device, with that device selected)
+size_t cache_cap_bytes(int device) {
+    // (the switch is read per release -- they are rare: tests change it)
+    const char *e = env_get("SLAB_CACHE_MB");
     if (e && *e) return (size_t)strtoull(e, nullptr, 10) << 20;
-    static const size_t dflt = [] {
+    static size_t dflt[64] = {0};
+    static bool known[64] = {false};
+    if (device < 0 || device >= 64) return 0;
+    if (!known[device]) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)0; }
-        return total_b / 4;
-    }();
-    return dflt;
+        if (hipSetDevice(device) == hipSuccess &&
+            hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            dflt[device] = total_b / 4;
+        else
+            (void)hipGetLastError();
+        if (cur >= 0) (void)hipSetDevice(cur);
+        known[device] = true;
+    }
+    return dflt[device];
 }
+// (the calling thread's current device is what it was afterwards)
 void drop_cached_locked(int device_or_all) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
     for (size_t k = 0; k < g_blocks.size();) {
         if (device_or_all < 0 || g_blocks[k].device == device_or_all) {
             (void)hipSetDevice(g_blocks[k].device);
@@ -435,6 +450,7 @@ void drop_cached_locked(int device_or_all) {
             ++k;
         }
     }
+    if (cur >= 0) (void)hipSetDevice(cur);
 }
 // the best cached block of that size (newest among equals) leaves the cache; false: none
 bool take_cached_locked(int device, size_t bytes, int min_rank, Block *out) {
@@ -497,23 +513,31 @@ void dev_release(int device, void *ptr, size_t bytes) {
                 break;
             }
     }
-    const size_t cap = cache_cap_bytes();
+    std::lock_guard<std::mutex> lk(g_block_mu);      // (also guards cache_cap_bytes' table)
+    const size_t cap = cache_cap_bytes(device);
     if (bytes >= kCacheMinBytes && bytes <= cap) {
-        std::lock_guard<std::mutex> lk(g_block_mu);
         g_blocks.push_back({device, (char *)ptr, bytes, gbs});
-        size_t held = 0;
-        for (const auto &b : g_blocks) held += b.bytes;
-        while (!g_blocks.empty() && (held > cap || g_blocks.size() > kCacheMaxBlocks)) {
+        // what THIS device holds against ITS cap; at most kCacheMaxBlocks per device
+        auto held_of = [&](size_t *count) {
+            size_t held = 0;
+            *count = 0;
+            for (const auto &b : g_blocks)
+                if (b.device == device) { held += b.bytes; ++*count; }
+            return held;
+        };
+        size_t count = 0, held = held_of(&count);
+        while (count > 0 && (held > cap || count > kCacheMaxBlocks)) {
             // out: a block known to be slow before any other, the oldest among equals
-            size_t out = 0;
-            for (size_t k = 1; k < g_blocks.size(); ++k)
-                if (block_rank_locked(g_blocks[k]) < block_rank_locked(g_blocks[out])) out = k;
-            held -= g_blocks[out].bytes;
-            (void)hipSetDevice(g_blocks[out].device);
-            (void)hipFree(g_blocks[out].ptr);
-            g_blocks.erase(g_blocks.begin() + (long)out);
+            long out = -1;
+            for (size_t k = 0; k < g_blocks.size(); ++k) {
+                if (g_blocks[k].device != device) continue;
+                if (out < 0 || block_rank_locked(g_blocks[k]) < block_rank_locked(g_blocks[(size_t)out]))
+                    out = (long)k;
+            }
+            (void)hipFree(g_blocks[(size_t)out].ptr);       // (the current device is `device`)
+            g_blocks.erase(g_blocks.begin() + out);
+            held = held_of(&count);
         }
-        (void)hipSetDevice(device);
         return;
     }
     (void)hipFree(ptr);
@@ -534,56 +558,21 @@ void note_block_rate(int device, const void *dev, double gbs) {
 // once, never destroyed), by hipMemcpyAsync -- the device's DMA engines -- into a
 // page-locked destination: 56 GB/s from memory that was allocated for the first time,
 // 25-30 GB/s from memory that has been freed and allocated again (above: why the
-// contexts' memory is cached, not freed).
-//
-// EXPERIMENTAL, opt-in (ESQ_D2H_MODE=auto | kernel): a copy by a KERNEL into the
-// page-locked destination runs at 53-55 GB/s whatever memory it reads (4 to 512
-// workgroups), at a price -- its stores over the link hold up the stores of a sweep that
-// runs beside it (the step's first chain sweep 0.10 -> 1.4 ms: plain solve_ivp 1.86
-// ms/step beside kernel copies of 8 workgroups, 2.05 with 128, 1.44 beside fast engine
-// copies, 2.8 beside slow ones).  `auto`: the engines copy the first kProbeBytes of a
-// download of >= 16 MiB and are timed; if that piece was slower than 0.8 x the fastest
-// such piece seen so far (a process whose first download already meets slow memory:
-// than 0.72 x what the kernel made of the second 8 MiB, timed once), the kernel copies
-// the rest.  NOT the default: with `auto`, two of seven runs of the whole GPU test suite
-// died of "Memory access fault by GPU ... Write access to a read-only page" at a host
-// address (six of six runs with the engines alone did not) -- a kernel's store through
-// hipHostGetDevicePointer of freshly registered memory is evidently not always backed
-// by a writable mapping, and three attempts to reproduce it in isolation (registrations
-// sharing a page, the runtime's own pin of an upload's source in the same pages, huge
-// pages) did not (profiles/r05_experiments.md, section 5).
+// contexts' memory is cached, not freed).  (Round 5 carried an opt-in copy KERNEL for
+// the slow case here; it faulted in two of seven suite runs, was never root-caused,
+// and went in round 6 -- the block cache is what keeps downloads fast.)
 constexpr int kLaneDevices = 64;
-constexpr size_t kLaneMinBytes = (size_t)8 << 20, kProbeBytes = (size_t)8 << 20;
+constexpr size_t kLaneMinBytes = (size_t)8 << 20;
 struct CopyLane {
     hipStream_t stream = nullptr;
     bool failed = false;
-    double best_probe_gbs = 0.0;   // fastest timed first piece
-    double kernel_ref_gbs = 0.0;   // a piece of the same size by the kernel, timed once
-    double last_gbs = 0.0;         // the latest whole download
-    long engine_copies = 0, kernel_copies = 0;
+    double best_gbs = 0.0;         // fastest download so far
+    double last_gbs = 0.0;         // the latest one
+    long copies = 0;
+    int busy = 0;                  // downloads in flight on the lane right now
 };
 std::mutex g_lane_mu;
 CopyLane g_lane[kLaneDevices];
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// dst: device-visible address of pinned host memory; 16-byte pieces + one double
-__global__ __launch_bounds__(256) void k_d2h(const u32x4 *__restrict__ src,
-                                             u32x4 *__restrict__ dst, size_t n16,
-                                             int tail) {
-    const size_t stride = (size_t)gridDim.x * 256u;
-    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    // four loads in flight per thread, then four stores over the link
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const u32x4 a = __builtin_nontemporal_load(src + i);
-        const u32x4 b = __builtin_nontemporal_load(src + i + stride);
-        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride);
-        const u32x4 d = __builtin_nontemporal_load(src + i + 3 * stride);
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
-    if (tail && blockIdx.x == 0 && threadIdx.x == 0)
-        ((double *)(dst + n16))[0] = ((const double *)(src + n16))[0];
-}
 
 // the process's download stream of `device` (the current device); nullptr: none
 hipStream_t copy_lane(int device) {
@@ -592,9 +581,6 @@ hipStream_t copy_lane(int device) {
     CopyLane &ln = g_lane[device];
     if (!ln.stream && !ln.failed &&
         hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess) {
-        // (a stream of the highest priority was tried for the kernel copies' sake: the
-        // kernel trace shows them in a hardware queue of their own either way, and the
-        // sweeps beside them as slow)
         (void)hipGetLastError();
         ln.stream = nullptr;
         ln.failed = true;
@@ -603,87 +589,35 @@ hipStream_t copy_lane(int device) {
 }
 
 // One large copy on `stream` (everything it depends on has been waited for); blocks
-// until the bytes are in `host`.  `pinned`: the destination is page-locked (a kernel
-// cannot write to any other, and a staged pageable copy says nothing about the engines)
+// until the bytes are in `host`.  `pinned`: the destination is page-locked (a staged
+// pageable copy says nothing about the engines: not timed)
 hipError_t lane_copy(int device, hipStream_t stream, void *host, const void *dev, size_t bytes,
                      bool pinned) {
-    // (read per download -- they are milliseconds apart: tests switch it in one process)
-    const char *m = getenv("ESQ_D2H_MODE");          // default: the engines alone
-    const int mode = !m ? 1 : !strcmp(m, "auto") ? 0 : !strcmp(m, "kernel") ? 2 : 1;
-    const unsigned blocks = env_uint("ESQ_D2H_BLOCKS", 8);
     const bool lane_ok = device >= 0 && device < kLaneDevices && bytes >= kLaneMinBytes;
-    void *dst = nullptr;
-    bool can_kernel = lane_ok && pinned && mode != 1 && blocks > 0 && bytes % 8 == 0 &&
-                      bytes >= 2 * kProbeBytes && ((uintptr_t)dev & 15) == 0;
-    if (can_kernel && (hipHostGetDevicePointer(&dst, host, 0) != hipSuccess || !dst ||
-                       ((uintptr_t)dst & 15) != 0)) {
-        (void)hipGetLastError();
-        can_kernel = false;
+    bool alone = false;
+    if (lane_ok) {
+        std::lock_guard<std::mutex> lk(g_lane_mu);
+        alone = g_lane[device].busy++ == 0;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipSuccess;
-    size_t done = 0;
-    bool by_kernel = can_kernel && mode == 2;
-    if (can_kernel && mode == 0) {
-        e = hipMemcpyAsync(host, dev, kProbeBytes, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) return e;
-        done = kProbeBytes;
-        const double gbs = (double)kProbeBytes * 1e-9 /
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        bool want_ref;
-        {
-            std::lock_guard<std::mutex> lk(g_lane_mu);
-            want_ref = g_lane[device].kernel_ref_gbs == 0.0 && bytes >= 3 * kProbeBytes;
-        }
-        double ref = 0.0;
-        if (want_ref) {
-            // once per process: what the kernel makes of a piece of that size -- the
-            // yardstick for a process whose FIRST download finds the engines slow
-            hipLaunchKernelGGL(k_d2h, dim3(blocks), dim3(256), 0, stream, (const u32x4 *)dev,
-                               (u32x4 *)dst, (size_t)0, 0);               // (code object load)
-            (void)hipStreamSynchronize(stream);
-            const auto k0 = std::chrono::steady_clock::now();
-            hipLaunchKernelGGL(k_d2h, dim3(blocks), dim3(256), 0, stream,
-                               (const u32x4 *)((const char *)dev + done),
-                               (u32x4 *)((char *)dst + done), kProbeBytes / 16, 0);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) return e;
-            ref = (double)kProbeBytes * 1e-9 /
-                  std::chrono::duration<double>(std::chrono::steady_clock::now() - k0).count();
-            done += kProbeBytes;
-        }
-        std::lock_guard<std::mutex> lk(g_lane_mu);
-        CopyLane &ln = g_lane[device];
-        if (ref > 0.0) ln.kernel_ref_gbs = ref;
-        if (gbs > ln.best_probe_gbs) ln.best_probe_gbs = gbs;
-        // slow: against the engines' own best, or -- no fast piece seen yet -- the kernel's
-        const double bar = ln.best_probe_gbs > 0.9 * ln.kernel_ref_gbs ? ln.best_probe_gbs
-                                                                       : 0.9 * ln.kernel_ref_gbs;
-        by_kernel = gbs < 0.8 * bar;
-    }
-    if (by_kernel) {
-        const size_t rest = bytes - done;
-        hipLaunchKernelGGL(k_d2h, dim3(blocks), dim3(256), 0, stream,
-                           (const u32x4 *)((const char *)dev + done),
-                           (u32x4 *)((char *)dst + done), rest / 16, (int)((rest / 8) & 1));
-        e = hipGetLastError();
-    } else {
-        e = hipMemcpyAsync((char *)host + done, (const char *)dev + done, bytes - done,
-                           hipMemcpyDeviceToHost, stream);
-    }
+    hipError_t e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess || !lane_ok) return e;
+    if (!lane_ok) return e;
     const double gbs = (double)bytes * 1e-9 /
                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     {
         std::lock_guard<std::mutex> lk(g_lane_mu);
         CopyLane &ln = g_lane[device];
-        ln.last_gbs = gbs;
-        ++(by_kernel ? ln.kernel_copies : ln.engine_copies);
+        // (two downloads that shared the lane halved each other's rate: neither says
+        // anything about the memory it read from)
+        alone = alone && --ln.busy == 0;
+        if (e == hipSuccess) {
+            ln.last_gbs = gbs;
+            if (alone && gbs > ln.best_gbs) ln.best_gbs = gbs;
+            ++ln.copies;
+        }
     }
-    if (!by_kernel && pinned && done == 0) note_block_rate(device, dev, gbs);
+    if (e == hipSuccess && pinned && alone) note_block_rate(device, dev, gbs);
     return e;
 }
 
@@ -733,30 +667,15 @@ int h2d(esq_ctx *c, void *dev, const void *host, size_t bytes, bool was_idle) {
     return 0;
 }
 
-unsigned env_uint(const char *name, unsigned dflt) {
-    const char *s = getenv(name);
-    if (!s || !*s) return dflt;
-    char *end = nullptr;
-    long v = strtol(s, &end, 10);
-    return (end != s && v >= 0) ? (unsigned)v : dflt;
-}
-
-
 }  // namespace esqi
 
 using namespace esqi;
 
 extern "C" {
 
-// a what-if build of the chain sweeps (ESQ_CHAIN_EXP != 0, profiles/r04_experiments.md
-// §1: loads replaced by constants / weights made compile-time) computes WRONG results
-// by design: it reports a negative version, which the Python binding refuses unless
-// ESQ_LIB_EXPERIMENT=1 says the caller knows (timing runs only)
-#if defined(ESQ_CHAIN_EXP) && ESQ_CHAIN_EXP != 0
-int esq_abi_version(void) { return -ESQ_ABI_VERSION; }
-#else
 int esq_abi_version(void) { return ESQ_ABI_VERSION; }
-#endif
+
+int esq_option_level(const char *key) { return key ? esq::option_level(key) : 0; }
 
 int esq_device_count(int *count_out) {
     if (!count_out) return ESQ_EINVAL;
@@ -776,21 +695,30 @@ int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) 
 }
 int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
                 int flags) {
+    return esq_create3(out, device, n, n_rows, is_complex, flags, nullptr);
+}
+int esq_create3(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
+                int flags, const char *options) {
     if (!out || n_rows < 1 || n_rows > 64) return ESQ_EINVAL;
-    esq::chain_tuning_refresh();       // the chain sweeps' environment knobs: once per context
     esq_ctx *c = new (std::nothrow) esq_ctx();
     if (!c) return ESQ_ENOMEM;
     *out = c;   // returned even on failure so the caller can read the message
+    {
+        // this context's switches; a key the caller did not give falls back to the
+        // process default ESQ_<KEY> (esq_options.hpp)
+        std::string bad;
+        if (c->opts.parse(options, esq::kOptContext, &bad) != 0)
+            return fail(c, ESQ_EINVAL, "esq_create3: '%s' is not a context option "
+                        "(esq_option_level)", bad.c_str());
+    }
+    const esq::Options &o = c->opts;
     c->device = device;
     c->n = n;
     c->cplx = is_complex != 0;
     c->len = c->cplx ? 2 * n : n;
     c->len_pad = ((c->len + kPadDoubles - 1) / kPadDoubles) * kPadDoubles;
     if (c->len_pad == 0) c->len_pad = kPadDoubles;
-    // ESQ_ROW_STAGGER: extra bytes between consecutive vectors (HBM channel
-    // de-aliasing experiments); must be a multiple of 16
-    const size_t stagger = (env_uint("ESQ_ROW_STAGGER", 0) / 16) * 2;
-    c->stride = c->len_pad + stagger;
+    c->stride = c->len_pad;
     c->n_rows = n_rows;
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -826,26 +754,28 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     HIPCHK(c, hipHostMalloc((void **)&c->h_slot, 128,
                             hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->h_slot, 0, sizeof(HostSlot));
-    c->comm_timeout_s = (double)env_uint("ESQ_COMM_TIMEOUT_S", 120);
+    c->comm_timeout_s = (double)o.uint_or("COMM_TIMEOUT_S", 120);
     // K_i of the stage / block sweeps is streamed out (nobody re-reads it soon).
     // The last stage's and the end-point sweep's derivative is read again by the
     // next launches: kept cacheable while three vectors fit the Infinity Cache
     // (Pr9 at n = 5e6: plain 74 us vs streamed 80 us for the following chain),
     // streamed beyond (Pr8 at n = 1e7: end-point sweep 58 -> 48 us, step -2.5 %)
     const bool three_fit = 3 * c->len_pad * sizeof(double) <= ((size_t)160 << 20);
-    c->epi_nt = env_uint("ESQ_EPI_NT", three_fit ? 0x3 : 0xf);
-    c->lazy_rows = env_uint("ESQ_LAZY_ROWS", 1) != 0;
-    c->lazy_end = env_uint("ESQ_LAZY_END", 1) != 0;
+    c->epi_nt = o.uint_or("EPI_NT", three_fit ? 0x3 : 0xf);
+    c->lazy_rows = o.uint_or("LAZY_ROWS", 1) != 0;
+    c->lazy_end = o.uint_or("LAZY_END", 1) != 0;
     c->ahead_on = false;           // esq_rk_set_launch_ahead: callers that take whole steps
-    c->chain_from_rows = env_uint("ESQ_CHAIN_FROM_ROWS", 1) != 0;
-    if (const char *e = getenv("ESQ_CHAIN_LDNT")) {          // "first,middle,last" bit masks
+    c->chain_from_rows = o.uint_or("CHAIN_FROM_ROWS", 1) != 0;
+    c->plan_debug = o.has("PLAN_DEBUG");
+    c->block_acc = o.uint_or("BLOCK_ACC", 1) != 0;
+    if (const char *e = o.get("CHAIN_LDNT")) {          // "first,middle,last" bit masks
         unsigned a = 4, b = 4, d = 4;
         if (sscanf(e, "%u,%u,%u", &a, &b, &d) == 3) {
             c->chain_ld_nt[0] = a; c->chain_ld_nt[1] = b; c->chain_ld_nt[2] = d;
             c->chain_ld_nt_set = true;
         }
     }
-    c->chain_depth = (int)env_uint("ESQ_CHAIN_DEPTH", 4);     // 5 and 6 exist too
+    c->chain_depth = (int)o.uint_or("CHAIN_DEPTH", 4);     // 5 and 6 exist too
     if (c->chain_depth > ESQ_CHAIN_MAX_DEPTH) c->chain_depth = ESQ_CHAIN_MAX_DEPTH;
     // launch geometry: grid-stride kernels, a few resident blocks per CU
     hipDeviceProp_t prop;
@@ -863,15 +793,15 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     // window through L2.  Measured (profiles/r02_experiments.md): Ts5 at n = 1e6
     // 0.0834 -> 0.0778 ms/step, Pr8 at n = 1e7 unchanged, Pr9 at n = 5e6 +0.8 %:
     // used where the working set is cache-resident.  ESQ_SRC=0|1 overrides.
-    c->src_pays = env_uint("ESQ_SRC", fits_mall ? 1 : 0) != 0;
-    const unsigned per_cu = env_uint("ESQ_BLOCKS_PER_CU", fits_mall ? 8 : 2);
-    c->stage_policy = (int)env_uint("ESQ_STAGE_POLICY", fits_mall ? 0 : 10);
+    c->src_pays = o.uint_or("SRC", fits_mall ? 1 : 0) != 0;
+    const unsigned per_cu = o.uint_or("BLOCKS_PER_CU", fits_mall ? 8 : 2);
+    c->stage_policy = (int)o.uint_or("STAGE_POLICY", fits_mall ? 0 : 10);
     size_t g = (size_t)cus * per_cu;
     if (g > need) g = need;
     if (g < 1) g = 1;
     c->grid_stream = (unsigned)g;
     c->grid_reduce = (unsigned)(g > (size_t)kMaxPartials ? kMaxPartials : g);
-    size_t gb = (size_t)cus * env_uint("ESQ_BLOCK_BPC", 16);
+    size_t gb = (size_t)cus * 16;
     if (gb > need) gb = need;
     c->grid_block = (unsigned)(gb < 1 ? 1 : gb);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -884,6 +814,12 @@ int esq_destroy(esq_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &ev : c->prof_live) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
     for (auto &e : c->prof_pool) (void)hipEventDestroy(e);
+    // (a snapshot copy of a small vector may still read the slab: before it goes back
+    // to the cache -- where the next context could take and overwrite it)
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
     if (c->host_slab) {
         if (c->slab_host) (void)hipHostFree(c->slab_host);
     } else if (c->slab) {
@@ -891,10 +827,6 @@ int esq_destroy(esq_ctx *c) {
     }
     for (const auto &a : c->aux_slabs) dev_release(c->device, a.first, a.second);
     if (c->h_slot) (void)hipHostFree(c->h_slot);
-    if (c->copy_stream) {
-        (void)hipStreamSynchronize(c->copy_stream);
-        (void)hipStreamDestroy(c->copy_stream);
-    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -980,16 +912,14 @@ int esq_release_cached_memory(size_t *bytes_out) {
     if (bytes_out) *bytes_out = held;
     return 0;
 }
-int esq_copy_lane_info(int device, double *best_probe_gbs_out, double *kernel_ref_gbs_out,
-                       double *last_gbs_out, long *engine_copies_out, long *kernel_copies_out) {
+int esq_copy_lane_info(int device, double *best_gbs_out, double *last_gbs_out,
+                       long *copies_out) {
     if (device < 0 || device >= kLaneDevices) return ESQ_EINVAL;
     std::lock_guard<std::mutex> lk(g_lane_mu);
     const CopyLane &ln = g_lane[device];
-    if (best_probe_gbs_out) *best_probe_gbs_out = ln.best_probe_gbs;
-    if (kernel_ref_gbs_out) *kernel_ref_gbs_out = ln.kernel_ref_gbs;
+    if (best_gbs_out) *best_gbs_out = ln.best_gbs;
     if (last_gbs_out) *last_gbs_out = ln.last_gbs;
-    if (engine_copies_out) *engine_copies_out = ln.engine_copies;
-    if (kernel_copies_out) *kernel_copies_out = ln.kernel_copies;
+    if (copies_out) *copies_out = ln.copies;
     return 0;
 }
 int esq_host_pin(void *host, size_t bytes) {
@@ -1019,7 +949,7 @@ int esq_snapshot_copy(void *token, double *host, int host_is_pinned) {
                      hipSuccess;
             if (!pinned) (void)hipGetLastError();
         }
-        static const bool dbg = getenv("ESQ_SNAPSHOT_DEBUG") != nullptr;
+        static const bool dbg = env_get("SNAPSHOT_DEBUG") != nullptr;
         const auto t_a = std::chrono::steady_clock::now();
         e = hipEventSynchronize(tk->ready);              // (the copy itself is timed)
         const auto t_b = std::chrono::steady_clock::now();
@@ -1105,13 +1035,13 @@ int esq_set_rhs_rkc_chain(esq_ctx *c, esq_rhs_rkc_chain_fn fn, int max_depth) {
     ENTER(c);
     c->rhs_rkc_chain = fn;
     c->rkc_refused = 0;
-    c->rkc_first = fn && (max_depth & ESQ_RKC_CHAIN_FIRST) && env_uint("ESQ_RKC_FIRST", 1) != 0;
+    c->rkc_first = fn && (max_depth & ESQ_RKC_CHAIN_FIRST) && c->opts.uint_or("RKC_FIRST", 1) != 0;
     c->rkc_first_refused = false;
-    c->rkc_last = fn && (max_depth & ESQ_RKC_CHAIN_LAST) && env_uint("ESQ_RKC_LAST", 1) != 0;
+    c->rkc_last = fn && (max_depth & ESQ_RKC_CHAIN_LAST) && c->opts.uint_or("RKC_LAST", 1) != 0;
     c->rkc_last_refused = 0;
     max_depth &= 0xff;
     int d = fn ? max_depth : 1;
-    const int env = (int)env_uint("ESQ_RKC_DEPTH", 0);        // 0: the plugin's own
+    const int env = (int)c->opts.uint_or("RKC_DEPTH", 0);    // 0: the plugin's own
     if (env > 0 && env < d) d = env;
     if (d > ESQ_RKC_CHAIN_MAX_DEPTH) d = ESQ_RKC_CHAIN_MAX_DEPTH;
     c->rkc_depth = d < 1 ? 1 : d;

@@ -27,6 +27,7 @@
 
 #include "../../include/extensisq_amd.h"
 #include "esq_kernels.hpp"
+#include "esq_options.hpp"
 
 namespace esqi {
 
@@ -202,9 +203,12 @@ struct esq_ctx : esqi::StepState {
         unsigned long long seq = 0;       // estimates published so far
         long fused = 0, plain = 0;        // inside a chain sweep / by k_pre_error
     } pre;
+    esq::Options opts;                    // this context's switches (esq_create3)
+    bool plan_debug = false;              // PLAN_DEBUG: the planner's queries on stderr
+    bool block_acc = true;                // BLOCK_ACC=0: no blocked accumulation
     bool detached = false;                // no device behind the context (esq_plan_describe)
-    bool chain_from_rows = true;          // ESQ_CHAIN_FROM_ROWS=0: never
-    unsigned chain_ld_nt[3] = {4, 4, 4};  // ESQ_CHAIN_LDNT: forced load policy of the
+    bool chain_from_rows = true;          // CHAIN_FROM_ROWS=0: never
+    unsigned chain_ld_nt[3] = {4, 4, 4};  // CHAIN_LDNT: forced load policy of the
     bool chain_ld_nt_set = false;         // first / middle / last chain (tuning)
     // first stage argument of the NEXT step, formed at accept time
     bool pre_valid = false;
@@ -353,7 +357,8 @@ struct Prof {
 void prof_drain(esq_ctx *c);
 
 // ---- esq_core.hip ------------------------------------------------------------
-unsigned env_uint(const char *name, unsigned dflt);
+// (the process environment is read in ONE place: esq::env_get, esq_options.hpp)
+using esq::env_get;
 int wait_slot(esq_ctx *c, unsigned long long seq, double timeout_s);
 // partials -> one double on the host (all-reduced over the communicator if set)
 int finish_reduction(esq_ctx *c, double *out, bool take_min = false,

@@ -56,18 +56,14 @@ int esq_rhs_bruss2d(void *user, double t, const double *y, double *f, size_t n,
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != BRUSS2D || n != r->n) return ESQ_EINVAL;
     const double d = r->alpha * ((double)r->N * (double)r->N);
-    if (BrussSplit::grid_ok(r->N) && rhs_variant() != 1)
+    if (BrussSplit::grid_ok(r->N))
         return BrussSplit::rhs(fn_of(r), r->N, y, f, stream);
+    // odd grids: the scalar kernel
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;
     unsigned nblocks = bpr * (unsigned)r->N;
     const unsigned grid = ((nblocks + kXcd - 1) / kXcd) * kXcd;
-    static const bool nts = getenv("ESQ_RHS_STORE_NT") && atoi(getenv("ESQ_RHS_STORE_NT"));
-    if (nts)
-        hipLaunchKernelGGL(k_bruss2d<true>, dim3(grid), dim3(kBlock), 0,
-                           (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, bpr);
-    else
-        hipLaunchKernelGGL(k_bruss2d<false>, dim3(grid), dim3(kBlock), 0,
-                           (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, bpr);
+    hipLaunchKernelGGL(k_bruss2d<false>, dim3(grid), dim3(kBlock), 0,
+                       (hipStream_t)stream, y, f, r->N, d, r->a, r->b, grid, bpr);
     return (int)hipGetLastError();
 }
 

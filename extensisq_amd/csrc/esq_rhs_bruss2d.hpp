@@ -48,7 +48,8 @@ template <int LO, int HI>
 inline int bruss2d_chain_range(Rhs *r, const double *y_in, const esq_chain *chain,
                                void *stream, void *start_event, void *stop_event) {
     return BrussSplit::chain<LO, HI>(fn_of(r), r->N, y_in, chain, stream, start_event,
-                                     stop_event);
+                                     stop_event, /*tall_tiles=*/false, /*min_rows=*/0,
+                                     &r->tune);
 }
 
 }  // namespace

@@ -44,24 +44,33 @@ struct Rhs {
     double amp;
     double *lam_dev;
     size_t n;
-    // tuning / test knobs, read from the environment ONCE when the plugin object is
-    // made (ESQ_RKC_FORCE: chain sweeps on grids of any size; ESQ_RKC_PLANES:
-    // planes per tile of the 3-D chain sweeps, 0 = chosen by geo_rkc3d)
-    int rkc_force, rkc_planes, rkc_jt, rkc_nw, diff3d_r;
+    // tuning / test knobs of THIS plugin object (esq_rhs_set_options; defaults from the
+    // process environment when the object is made): RKC_FORCE chain sweeps on grids of
+    // any size, RKC_PLANES planes per tile of the 3-D chain sweeps (0 = chosen by
+    // geo_rkc3d), DIFF3D_R the 3-D plugin's marching sweep, CHAIN_ROWS the tile height
+    // of the 2-D chain sweeps
+    int rkc_force, rkc_planes, diff3d_r;
+    esq::ChainTuning tune;
 };
 
-// ESQ_RHS_VARIANT=1: scalar kernels instead of the vectorised sweeps (tests)
-inline int rhs_variant() {
-    static const int v = getenv("ESQ_RHS_VARIANT") ? atoi(getenv("ESQ_RHS_VARIANT")) : 0;
-    return v;
+// the plugin-level switches (esq_options.hpp) of a built-in plugin object
+inline void apply_options(Rhs *r, const esq::Options &o) {
+    r->rkc_force = o.int_or("RKC_FORCE", 0);
+    r->rkc_planes = o.int_or("RKC_PLANES", 0);
+    r->diff3d_r = o.int_or("DIFF3D_R", 0);
+    r->tune = esq::ChainTuning{};
+    if (const char *rows = o.get("CHAIN_ROWS")) {
+        r->tune.rows_set = true;
+        r->tune.rows = atoi(rows);
+    }
 }
 
 inline int make(void **out, Rhs proto) {
     if (!out) return ESQ_EINVAL;
-    esq::chain_tuning_refresh();       // the environment, once per plugin object
     Rhs *r = (Rhs *)malloc(sizeof(Rhs));
     if (!r) return ESQ_ENOMEM;
     *r = proto;
+    apply_options(r, esq::Options{});      // the process defaults (ESQ_<KEY>)
     *out = r;
     return 0;
 }

@@ -127,6 +127,14 @@ int esq_rhs_cdiag_create(void **user_out, int device, const double *lam_host,
     return diag_create(user_out, CDIAG, device, lam_host, 2 * n_complex, amp_re,
                        amp_im);
 }
+int esq_rhs_set_options(void *user, const char *options) {
+    if (!user) return ESQ_EINVAL;
+    esq::Options o;
+    std::string bad;
+    if (o.parse(options, esq::kOptPlugin, &bad) != 0) return ESQ_EINVAL;
+    apply_options((Rhs *)user, o);
+    return 0;
+}
 int esq_rhs_free(void *user) {
     if (!user) return 0;
     Rhs *r = (Rhs *)user;

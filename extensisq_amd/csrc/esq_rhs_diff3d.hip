@@ -11,9 +11,6 @@ int esq_rhs_diff3d_create(void **user_out, int N) {
     if (N < 1) return ESQ_EINVAL;
     Rhs r{};
     r.kind = DIFF3D; r.N = N; r.n = (size_t)N * N * N;
-    const esq::Stencil3dTuning t = esq::stencil3d_tuning_from_env();
-    r.rkc_force = t.force; r.rkc_planes = t.planes; r.rkc_jt = t.jt; r.rkc_nw = t.nw;
-    r.diff3d_r = t.march_r;
     return make(user_out, r);
 }
 
@@ -41,7 +38,7 @@ int esq_rhs_diff3d(void *user, double t, const double *y, double *f, size_t n,
                    void *stream) {
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != DIFF3D || n != r->n) return ESQ_EINVAL;
-    return Diff3d::rhs(fn_of(r), r->N, t, y, f, stream, tuning_of(r), rhs_variant() == 1);
+    return Diff3d::rhs(fn_of(r), r->N, t, y, f, stream, tuning_of(r), false);
 }
 
 }  // extern "C"

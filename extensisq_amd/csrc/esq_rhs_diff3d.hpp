@@ -31,7 +31,7 @@ inline Diff3dFn fn_of(const Rhs *r) {
 }
 inline esq::Stencil3dTuning tuning_of(const Rhs *r) {
     esq::Stencil3dTuning t;
-    t.force = r->rkc_force; t.planes = r->rkc_planes; t.jt = r->rkc_jt; t.nw = r->rkc_nw;
+    t.force = r->rkc_force; t.planes = r->rkc_planes;
     t.march_r = r->diff3d_r;
     return t;
 }

@@ -39,7 +39,7 @@ int esq_rhs_heat2d(void *user, double t, const double *y, double *f, size_t n,
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != HEAT2D || n != r->n) return ESQ_EINVAL;
     const double c = (double)(r->N + 1) * (double)(r->N + 1);
-    if (Heat::grid_ok(r->N) && rhs_variant() != 1)
+    if (Heat::grid_ok(r->N))
         return Heat::rhs(fn_of(r), r->N, y, f, stream);
     const unsigned bpr = (r->N + kBlock - 1) / kBlock;
     unsigned nblocks = bpr * (unsigned)r->N;
@@ -72,7 +72,7 @@ int esq_rhs_heat2d_rkc_chain(void *user, const esq_rkc_chain *ch, size_t n, void
                              void *start_event, void *stop_event) {
     Rhs *r = (Rhs *)user;
     if (!r || r->kind != HEAT2D || n != r->n || !ch) return ESQ_EINVAL;
-    return Heat::rkc_chain(fn_of(r), r->N, ch, stream, start_event, stop_event);
+    return Heat::rkc_chain(fn_of(r), r->N, ch, stream, start_event, stop_event, &r->tune);
 }
 
 // (the depths live in three translation units: esq_rhs_heat2d.hpp)

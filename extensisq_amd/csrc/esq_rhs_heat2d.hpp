@@ -31,7 +31,7 @@ template <int LO, int HI>
 inline int heat2d_chain_range(Rhs *r, const double *y_in, const esq_chain *chain,
                               void *stream, void *start_event, void *stop_event) {
     return Heat::chain<LO, HI>(fn_of(r), r->N, y_in, chain, stream, start_event, stop_event,
-                               /*tall_tiles=*/true, /*min_rows=*/-1);
+                               /*tall_tiles=*/true, /*min_rows=*/-1, &r->tune);
 }
 
 }  // namespace

@@ -229,24 +229,23 @@ inline int chain_waves_per_cu(Kernel kern, unsigned block) {
 // as fast or faster (tools/small_chain_sweep.py: Brusselator Pr8 at N = 316 78 us
 // unchained, 87 with depth-2 chains; at N = 500 100 against 87..98 chained; heat
 // Pr9 at N = 448 90 against 98); ESQ_CHAIN_ROWS (tests) lifts the rule
-inline bool chain_fits_grid(int N, int depth) {
-    if (chain_tuning().rows_set) return true;
+inline bool chain_fits_grid(int N, int depth, const ChainTuning &tune) {
+    if (tune.rows_set) return true;
     const int W = 64 - 2 * (depth - 1);
     const size_t tpr = ((size_t)N / 2 + W - 1) / W;
     return (size_t)N * tpr >= 2048;
 }
-// alternate tile rows march in opposite directions (esq_chain.hpp);
-// ESQ_CHAIN_SERPENTINE=0: all downwards
-inline unsigned chain_serpentine() { return chain_tuning().serpentine; }
+// alternate tile rows march in opposite directions (esq_chain.hpp: a tile and its
+// vertical neighbour read the halo rows they share at the same moment)
+inline unsigned chain_serpentine() { return 1u; }
 // tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
 // share one tile (the split sweeps: one per field)
 inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_block,
-                          int waves_per_tile, bool tall_if_one_round = false,
-                          int min_rows = 0) {
+                          int waves_per_tile, const ChainTuning &tune,
+                          bool tall_if_one_round = false, int min_rows = 0) {
     GeoChain g;
     const int W = 64 - 2 * (depth - 1);
     g.tpr = ((unsigned)N / 2 + W - 1) / W;
-    const ChainTuning tune = chain_tuning();
     const size_t cus = (size_t)device_cus();
     int R = tune.rows_set ? tune.rows : 0;                          // tuning / tests
     if (R <= 0) {
@@ -273,7 +272,7 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
         // chain5<0> 50 us, R = 44 0.540 with 65 us; R = 15, 18, 26 .. 36 -- three waves,
         // or a partial second round -- 0.549 .. 0.600)
         if (tall_if_one_round) {
-            const int tall_waves = tune.tall_waves;
+            const int tall_waves = 2;     // (tools/chain_rows_sweep.sh, round 4)
             for (int w = tall_waves < waves_per_cu / 4 ? tall_waves : waves_per_cu / 4;
                  w >= 1 && R <= 0; --w) {
                 const int cand = rows_for(cus * 4 * (size_t)w);
@@ -369,7 +368,10 @@ struct Stencil2D {
     // form -- it ends one: f(t_end, y) and the error estimate as one more stage slot --
     // included).  Depth 2 .. 6 (LAST: 2 .. 5).
     static int rkc_chain(const Fn &fn, int N, const esq_rkc_chain *ch, void *stream,
-                         void *start_event, void *stop_event) {
+                         void *start_event, void *stop_event,
+                         const ChainTuning *tuning = nullptr) {
+        // (a plugin object's own tile height, else the process default)
+        const ChainTuning tune = tuning ? *tuning : chain_tuning_default();
         if (!ch || !ch->yjm2 || !ch->yn || !ch->fn || !ch->out) return ESQ_EINVAL;
         if (!ch->yjm1 && ch->yjm2 != ch->yn) return ESQ_EINVAL;     // FIRST: y_{j-2} = y_n
         if constexpr (NF != 1) {
@@ -379,7 +381,7 @@ struct Stencil2D {
             if (ch->fy_out && (ch->out_prev || !ch->partials || !ch->yjm1)) return ESQ_EINVAL;
             const int slots = ch->depth + (ch->fy_out ? 1 : 0);
             if (ch->depth < 2 || slots > 6) return ESQ_ENOTSUP;
-            if (!chain_fits_grid(N, ch->depth + 1)) return ESQ_ENOTSUP;
+            if (!chain_fits_grid(N, ch->depth + 1, tune)) return ESQ_ENOTSUP;
             if ((unsigned long long)N * N * 8ull > 0xffffffffull - 16ull) return ESQ_ENOTSUP;
             int rc = ESQ_ENOTSUP;
             auto launch = [&](auto depth_c, auto first_c, auto last_c) {
@@ -390,7 +392,7 @@ struct Stencil2D {
                 static const int wpc = chain_waves_per_cu(kern, (unsigned)kBlock);
                 // (tile width: 64 - 2*ceil(D/2) pairs = geo_chain's rule for depth
                 // ceil(D/2) + 1; D - 1 run-in rows per side)
-                const GeoChain g = geo_chain(N, (DD + 1) / 2 + 1, wpc, kBlock / 64, 1,
+                const GeoChain g = geo_chain(N, (DD + 1) / 2 + 1, wpc, kBlock / 64, 1, tune,
                                              /*tall_if_one_round=*/true, /*min_rows=*/DD);
                 Rkc2dArgs<DD> a;
                 a.a = ch->yjm1; a.b = ch->yjm2; a.yn = ch->yn; a.fn = ch->fn;
@@ -446,11 +448,13 @@ struct Stencil2D {
     template <int LO = 2, int HI = 6>
     static int chain(const Fn &fn, int N, const double *y_in, const esq_chain *chain,
                      void *stream, void *start_event, void *stop_event,
-                     bool tall_tiles = false, int min_rows = 0) {
+                     bool tall_tiles = false, int min_rows = 0,
+                     const ChainTuning *tuning = nullptr) {
         constexpr bool split = SPLIT_CHAINS && NF > 1;
         if (!chain) return ESQ_EINVAL;
         if (N % 2 != 0 || N < 16) return ESQ_ENOTSUP;
-        if (!chain_fits_grid(N, chain->depth)) return ESQ_ENOTSUP;
+        const ChainTuning tune = tuning ? *tuning : chain_tuning_default();
+        if (!chain_fits_grid(N, chain->depth, tune)) return ESQ_ENOTSUP;
         // register budget (esq_chain.hpp, ChainCaps)
         if (NF > 1 && !chain_within_caps(chain->depth, chain->kind_last == ESQ_EPI_SOLERR,
                                          chain->nu, split))
@@ -478,7 +482,7 @@ struct Stencil2D {
             // depth 6 -- Ts5's whole-step chain at N = 1000, tools/r06_ts5_rows.sh:
             // 5-row tiles 34.7 us, 6 37.2, 4 48.7, 7 39.3)
             const GeoChain g = geo_chain(N, CA::kD, wpc, kSplit ? 1 : kBlock / 64,
-                                         kSplit ? NF : 1, tall_tiles,
+                                         kSplit ? NF : 1, tune, tall_tiles,
                                          min_rows < 0 ? (CA::kD < 5 ? CA::kD : 5) : min_rows);
             if (decltype(kind)::value == ESQ_EPI_SOLERR ||
                 decltype(kind)::value == ESQ_EPI_ERRNORM) {

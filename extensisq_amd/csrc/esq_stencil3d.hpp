@@ -274,21 +274,21 @@ __global__ __launch_bounds__(kBlock) void k_stencil3d_pairs(
     if (Epi::kReduce) block_partial(local, epi.red.partials);
 }
 
-// tuning / test knobs of a 3-D plugin object, read from the environment ONCE when the
-// object is made (stencil3d_tuning_from_env): ESQ_RKC_FORCE chain sweeps on grids of
-// any size, ESQ_RKC_PLANES planes per tile of the chain sweeps (0: chosen),
-// ESQ_RKC_CFG="JT,NW" shape of the Chebyshev chain sweeps, ESQ_DIFF3D_R 0 = the
-// 16-byte pair sweep (default), 1 / 2 / 4 / 8 = the marching sweep with that many
-// planes per workgroup
+// tuning / test knobs of a 3-D plugin OBJECT (the built-in plugin: options RKC_FORCE,
+// RKC_PLANES, DIFF3D_R of esq_rhs_set_options, defaults from the environment when the
+// object is made -- stencil3d_tuning_default; a user plugin fills the struct itself):
+// `force` chain sweeps on grids of any size, `planes` per tile of the chain sweeps
+// (0: chosen), `march_r` 0 = the 16-byte pair sweep (default), 1 / 2 / 4 / 8 = the
+// marching sweep with that many planes per workgroup.  (jt, nw: shape of the Chebyshev
+// chain sweeps, 0 = the measured one -- tools/rkc_shape_sweep.sh, round 4)
 struct Stencil3dTuning {
     int force = 0, planes = 0, jt = 0, nw = 0, march_r = 0;
 };
-inline Stencil3dTuning stencil3d_tuning_from_env() {
+inline Stencil3dTuning stencil3d_tuning_default() {
     Stencil3dTuning t;
-    if (const char *e = getenv("ESQ_RKC_FORCE")) t.force = atoi(e);
-    if (const char *e = getenv("ESQ_RKC_PLANES")) t.planes = atoi(e);
-    if (const char *e = getenv("ESQ_DIFF3D_R")) t.march_r = atoi(e);
-    if (const char *e = getenv("ESQ_RKC_CFG")) sscanf(e, "%d,%d", &t.jt, &t.nw);
+    if (const char *e = env_get("RKC_FORCE")) t.force = atoi(e);
+    if (const char *e = env_get("RKC_PLANES")) t.planes = atoi(e);
+    if (const char *e = env_get("DIFF3D_R")) t.march_r = atoi(e);
     return t;
 }
 

@@ -81,8 +81,7 @@ static int run_block(esq_ctx *c, const esq_ctx::Block &b, double h,
     a.h = h;
     double alg = 0.0;
     *made_ystage = false;
-    static const bool fold = env_uint("ESQ_BLOCK_FOLD", 1) != 0;
-    if (fold && no > 0 && b.stages[0] == b.J && c->stage_init[b.J] == b.out_vec[0] &&
+    if (no > 0 && b.stages[0] == b.J && c->stage_init[b.J] == b.out_vec[0] &&
         c->stage_from[b.J] == b.J) {
         a.y = c->y;
         a.out[0] = c->ystage;
@@ -629,10 +628,9 @@ double plan_units_chained(const esq_ctx *c, const std::vector<int> &bounds) {
     const std::vector<double> &A = c->A;
     auto nz = [&](int i, int j) { return A[(size_t)i * s + j] != 0.0; };
     static const double kHalo[7] = {1.0, 1.0, 1.10, 1.20, 1.31, 1.38, 1.46};
-    // cost of a written word in read words (tuning: ESQ_PLAN_WRITE_COST=1.5)
-    const char *wenv = getenv("ESQ_PLAN_WRITE_COST");
-    const double kW = wenv ? atof(wenv) : 2.0;
-    const double kWide = getenv("ESQ_PLAN_WIDE") ? atof(getenv("ESQ_PLAN_WIDE")) : 1.12;
+    // cost of a written word in read words; chains with more than six memory rows run
+    // below the request-rate ceiling (profiles/r03_experiments.md §18)
+    const double kW = 2.0, kWide = 1.12;
     std::vector<int> from(s, 0);
     std::vector<char> has_init(s, 0), cur(s, 0);
     struct Blk { int J, nt, no, ninit; std::vector<int> cols; };
@@ -809,9 +807,6 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
     const int s = c->s;
     const double t = 0.0, h = 1.0;             // queries do not depend on them
     const bool chains = c->rhs_chain && c->rhs_fused && !c->cplx && c->chain_depth >= 2;
-    // ESQ_PLAN_GREEDY=1: the first option in order of preference (round 3's rule:
-    // the longest chain first) instead of the cheapest sequence
-    static const bool greedy = env_uint("ESQ_PLAN_GREEDY", 0) != 0;
     // whole steps of the pairs with an early estimate: it is tested before stage P
     const int P = pre_at(c, i_from, i_to);
     auto crosses = [&](int lo, int hi) {       // a boundary J with lo < J <= hi
@@ -840,8 +835,7 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
         if (it == asked.end()) {
             Dry q;
             const int r = sweep_chain(c, i, D, t, h, what, lazy, from_rows, skip_out, &q);
-            static const bool dbg = getenv("ESQ_PLAN_DEBUG") != nullptr;
-            if (dbg)
+            if (c->plan_debug)
                 fprintf(stderr, "[esq plan] chain(i=%d, D=%d, what=%d%s%s%s) -> %d  words %g+%g\n",
                         i, D, what, lazy ? ", lazy" : "", from_rows ? ", from rows" : "",
                         skip_out ? ", no out" : "", r, q.reads, q.writes);
@@ -866,8 +860,6 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
     const bool lazy = lazy_ok && c->rhs && i_to == s && (c->chain_caps & ESQ_CHAIN_CAP_SKIP_ROWS);
     const bool from_cap = c->chain_from_rows && (c->chain_caps & ESQ_CHAIN_CAP_FROM_ROWS);
     const bool skip_cap = from_cap && (c->chain_caps & ESQ_CHAIN_CAP_SKIP_OUT) && i_to == s;
-    // ESQ_CHAIN_FROM_ROWS=2: only the chains that end or start a step (round 3)
-    static const bool from_anywhere = env_uint("ESQ_CHAIN_FROM_ROWS", 1) != 2;
     // the argument of stage i by the library's own kernel (after a block sweep that
     // left only the partial sums: the stage kernel alone)
     auto argument = [&](int i, bool block_done) {
@@ -949,7 +941,6 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
                     // leave that argument unwritten)
                     Dry d;
                     if (from_cap && (i_to == s || first_from) &&
-                        (from_anywhere || what == 2 || first_from) &&
                         ask_chain(i, D, what, lazy, true, skip != 0, d))
                         push({mk(OP_CHAIN, i, d, D, what, lazy, true, skip != 0)}, i + D,
                              hands_on && !skip, false, what == 1 || what == 2, what == 2);
@@ -969,15 +960,7 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
             Dry d;
             const PlanStep st = mk(OP_SRC_STAGE, 1, d);
             if (!refused(st) && sweep_next_stage(c, 1, t, h, true, &d) == 0) {
-                // (round 3's order: before any chain that does not form its input)
                 push({mk(OP_SRC_STAGE, 1, d)}, 2, true);
-                if (greedy) {
-                    // keep it in front of the plain chains, behind the from-rows ones
-                    std::stable_partition(out.begin(), out.end(), [](const PlanOption &x) {
-                        return x.steps.size() == 1 && (x.steps[0].from_rows ||
-                                                       x.steps[0].op == OP_SRC_STAGE);
-                    });
-                }
             }
         }
         auto with_arg = [&](PlanStep st) {
@@ -1055,21 +1038,6 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
             const double cst = o[q].cost +
                                solve(o[q].next, o[q].ready, o[q].block_done, false, o[q].ynew,
                                      o[q].solerr);
-            if (greedy) {
-                // round 3's rule: the first option in order of preference; a chain
-                // leaves its last target unwritten only if the launch that follows
-                // is a chain that forms its own input
-                const PlanStep &last = o[q].steps.back();
-                if (last.op == OP_CHAIN && last.skip_out) {
-                    const unsigned kn = key_of(o[q].next, false, false, false);
-                    const bool ok = o[q].next < i_to && memo[kn].pick >= 0 &&
-                                    opts[kn][memo[kn].pick].steps[0].op == OP_CHAIN &&
-                                    opts[kn][memo[kn].pick].steps[0].from_rows;
-                    if (!ok) continue;
-                }
-                best.cost = cst; best.pick = q;
-                break;
-            }
             if (best.pick < 0 || cst < best.cost) { best.cost = cst; best.pick = q; }
         }
         memo[k] = best;
@@ -1109,16 +1077,15 @@ Plan build_plan(esq_ctx *c, int i_from, int i_to, bool ready0, bool k0_missing, 
             if (what0 == 3 && !may_fuse(c, ESQ_EPI_SOLERR)) continue;
             const bool hands_on = what0 == 0 || c->pre.b_is_next;
             // (its last target unwritten where the chain behind it forms its own input)
-            for (int skip = (hands_on && skip_cap && !greedy) ? 1 : 0; skip >= 0; --skip) {
+            for (int skip = (hands_on && skip_cap) ? 1 : 0; skip >= 0; --skip) {
                 Dry d;
                 if (!ask_chain(0, D + 1, what0, lazy, false, skip != 0, d)) continue;
                 const double cst = step_cost(c, mk(OP_CHAIN, 0, d, D + 1, what0, lazy, false, skip != 0)) +
                                    solve(D + 1, hands_on && !skip, false, false, false, false);
-                if (greedy || cst < best) {
+                if (cst < best) {
                     best = cst; best_D = D; best_d = d; best_skip = skip != 0; best_what = what0;
                 }
             }
-            if (greedy) break;
         }
     }
     if (best_D) {
@@ -1361,8 +1328,7 @@ int esq_replan(esq_ctx *c) {
     if (!c || !c->have_tab) return ESQ_EINVAL;
     const int s = c->s;
     drop_plans(c);
-    const bool chained = c->rhs_chain && c->chain_depth >= 2 &&
-                         env_uint("ESQ_PLAN_CHAINED", 1) != 0;
+    const bool chained = c->rhs_chain && c->chain_depth >= 2;
     auto cost = [&](const std::vector<int> &bounds) -> double {
         if (chained) return plan_units_chained(c, bounds);
         return (double)plan_words(c->A, s, bounds, nullptr);
@@ -1371,12 +1337,12 @@ int esq_replan(esq_ctx *c) {
     c->blocks.clear();
     c->stage_init.assign(s, -1);
     c->stage_from.assign(s, 0);
-    if (env_uint("ESQ_BLOCK_ACC", 1) != 0 && s >= 4) {
+    if (c->block_acc && s >= 4) {
         std::vector<int> best;
         double best_words = cost(best);
         // fewest boundaries first: a plan with more boundaries must be strictly
         // better (every boundary is one more launch)
-        const bool dbg = getenv("ESQ_PLAN_DEBUG") != nullptr;
+        const bool dbg = c->plan_debug;
         if (dbg) fprintf(stderr, "[esq plan] no boundary: %.2f\n", best_words);
         for (int b1 = 2; b1 < s; ++b1) {
             const double w = cost({b1});
@@ -1395,18 +1361,6 @@ int esq_replan(esq_ctx *c) {
                         const double w = cost({b1, b2, b3});
                         if (w >= 0 && w < best_words) { best_words = w; best = {b1, b2, b3}; }
                     }
-        // ESQ_BLOCK_BOUNDS="6,10": override the boundaries (tuning experiments)
-        if (const char *ov = getenv("ESQ_BLOCK_BOUNDS")) {
-            std::vector<int> forced;
-            for (const char *q = ov; *q;) {
-                char *end = nullptr;
-                const long v = strtol(q, &end, 10);
-                if (end == q) break;
-                if (v >= 2 && v < s) forced.push_back((int)v);
-                q = *end ? end + 1 : end;
-            }
-            if (plan_words(c->A, s, forced, nullptr) >= 0) best = forced;
-        }
         if (!best.empty()) {
             std::vector<esq_ctx::Block> blocks;
             plan_words(c->A, s, best, &blocks);

@@ -169,7 +169,28 @@ _graveyard = __import__("collections").deque()     # (append / popleft: atomic, 
                                                    # a finalizer may run inside ANY allocation)
 
 
+# interpolants (esq_dense_*) of collected DeviceHornerDenseOutput objects: they own their
+# device memory and no state download reads from them, so they need not wait for the copy
+# worker -- destroyed by the next step / interpolant / context of the thread that drives
+# solvers (a t_eval run drops one interpolant per step: they must not pile up until the
+# next context is made)
+_dense_dead = __import__("collections").deque()
+
+
+def drain_dense():
+    while _dense_dead:
+        try:
+            free, handle = _dense_dead.popleft()
+        except IndexError:
+            break
+        try:
+            free(handle)
+        except Exception:                                     # noqa: BLE001
+            pass
+
+
 def _drain_graveyard(timeout=60.0):
+    drain_dense()
     dead = []
     while True:
         try:
@@ -178,9 +199,14 @@ def _drain_graveyard(timeout=60.0):
             break
     if dead:
         from . import lazy
-        lazy._worker.wait_idle(timeout)  # no state download may still read from them
+        # no state download may still read from them: a copy still in flight after the
+        # timeout keeps its source alive -- the entries go back (at exit: they are left
+        # to the process's teardown rather than freed under a running copy)
+        if not lazy._worker.wait_idle(timeout):
+            _graveyard.extend(dead)
+            return
     for free, what in dead:             # (esq_destroy, context) / (esq_rhs_free, plugin data)
-        try:
+        try:                            # / (esq_dense_destroy, interpolant)
             free(what)
         except Exception:                                     # noqa: BLE001
             pass
@@ -196,9 +222,12 @@ class DeviceContext:
     # in pinned, device-mapped host memory (ESQ_HOST_SLAB=0 switches it off)
     HOST_SLAB_MAX_DOUBLES = 8192
 
-    def __init__(self, n, n_rows, is_complex=False, device=0, host_rhs=False):
+    def __init__(self, n, n_rows, is_complex=False, device=0, host_rhs=False,
+                 options=None):
         self.lib = _lib.load()
         _drain_graveyard()              # contexts of collected solvers: freed here
+        # this context's switches (`esq_options=` of the solver that owns it)
+        self.options = options if isinstance(options, _lib.Options) else _lib.Options(options)
         self.n = int(n)
         self.n_rows = int(n_rows)
         self.is_complex = bool(is_complex)
@@ -206,11 +235,12 @@ class DeviceContext:
         self.device = int(device)
         doubles = self.n * (2 if is_complex else 1)
         self.host_slab = (bool(host_rhs) and doubles <= self.HOST_SLAB_MAX_DOUBLES
-                          and os.environ.get("ESQ_HOST_SLAB", "1") != "0")
+                          and self.options.get("host_slab", "1") != "0")
         handle = C.c_void_p()
-        code = self.lib.esq_create2(
+        code = self.lib.esq_create3(
             C.byref(handle), self.device, self.n, self.n_rows,
-            int(self.is_complex), _lib.CREATE_HOST_SLAB if self.host_slab else 0)
+            int(self.is_complex), _lib.CREATE_HOST_SLAB if self.host_slab else 0,
+            self.options.context_string)
         self.handle = handle
         if code != 0:
             msg = self.lib.esq_last_error(handle) if handle else b""
@@ -318,14 +348,14 @@ class DeviceContext:
         # subset, default all) selects the epilogue kinds for A/B runs ("src":
         # the first sweep of a step forms its own input from y and K[0]).
         fused = rhs._fused_entry(self.lib)
-        want = os.environ.get("ESQ_CHAIN", "")
+        want = self.options.get("chain", "")
         use = (want == "1") or (want != "0" and rhs._fuse_default)
         if fused is not None and use:
             kinds = {"stage": 1 << _lib.EPI_STAGE, "block": 1 << _lib.EPI_BLOCK,
                      "solerr": 1 << _lib.EPI_SOLERR,
                      "errnorm": 1 << _lib.EPI_ERRNORM,
                      "rkcerr": 1 << _lib.EPI_RKCERR, "src": _lib.FUSE_SRC}
-            sel = os.environ.get("ESQ_FUSE", "")
+            sel = self.options.get("fuse", "")
             mask = _lib.FUSE_ALL if rhs._fuse_mask is None else rhs._fuse_mask
             mask |= _lib.FUSE_SRC if rhs._fuse_src else 0
             supported = mask
@@ -348,22 +378,22 @@ class DeviceContext:
             caps = int(rhs._chain_caps)
             # A/B switches of the round-6 chain kinds: the FSAL end-point stage and the
             # error norm inside the chain / an early estimate whose y_pre is not stored
-            if os.environ.get("ESQ_CHAIN_ERRNORM", "1") == "0":
+            if self.options.get("chain_errnorm", "1") == "0":
                 caps &= ~_lib.CHAIN_CAP_ERRNORM
-            if os.environ.get("ESQ_CHAIN_PRE", "1") == "0":
+            if self.options.get("chain_pre", "1") == "0":
                 caps &= ~_lib.CHAIN_CAP_PRE
             self._chk(self.lib.esq_set_rhs_chain(self.handle,
                                                  C.cast(chain, C.c_void_p), caps),
                       "esq_set_rhs_chain")
         # RKC entry: derivative + Chebyshev recursion in one sweep
         rkc = rhs._rkc_entry(self.lib)
-        if rkc is not None and os.environ.get("ESQ_RKC_CHAIN", "1") != "0":
+        if rkc is not None and self.options.get("rkc_chain", "1") != "0":
             self._chk(self.lib.esq_set_rhs_rkc(self.handle,
                                                C.cast(rkc, C.c_void_p)),
                       "esq_set_rhs_rkc")
             # RKC chain entry: several Chebyshev stages per marching sweep
             # (ESQ_RKC_DEPTH=1 in the environment: one launch per stage)
-            rkc_chain = rhs._rkc_chain_entry(self.lib)
+            rkc_chain = rhs._rkc_chain_entry(self.lib, self.options)
             if rkc_chain is not None:
                 self._chk(self.lib.esq_set_rhs_rkc_chain(
                     self.handle, C.cast(rkc_chain[0], C.c_void_p),
@@ -469,7 +499,7 @@ class DeviceRHS:
     _owns_user = True          # the user pointers of _create are freed with esq_rhs_free
 
     def __init__(self):
-        self._bound = {}       # device -> (fn, user)
+        self._bound = {}       # (device, plugin switches) -> (fn, user)
         self._host_ctx = {}    # device -> DeviceContext of __call__
         self._last_device = 0
 
@@ -488,7 +518,7 @@ class DeviceRHS:
         """optional `esq_rhs_chain_fn` of this plugin"""
         return None
 
-    def _rkc_chain_entry(self, lib):
+    def _rkc_chain_entry(self, lib, options=None):
         """optional `esq_rhs_rkc_chain_fn` of this plugin and the deepest chain
         it runs: (entry, max_depth) or None"""
         return None
@@ -500,10 +530,19 @@ class DeviceRHS:
     def _bind(self, ctx):
         if ctx.n != self.n:
             raise ValueError(f"RHS is for n={self.n}, solver state has n={ctx.n}")
-        key = ctx.device
-        self._last_device = key
+        self._last_device = ctx.device
+        # one plugin object per device AND set of plugin switches: two solvers with
+        # different `esq_options` sharing this RHS do not share its tile geometry
+        opts = ctx.options.plugin_string
+        key = (ctx.device, opts)
         if key not in self._bound:
-            self._bound[key] = self._create(ctx.lib, ctx.device)
+            fn, user = self._create(ctx.lib, ctx.device)
+            if opts:
+                if not (self._owns_user and user):
+                    raise ValueError("esq_options: plugin switches "
+                                     f"({opts.decode()}) need a built-in plugin")
+                check(ctx.lib.esq_rhs_set_options(user, opts), None, "esq_rhs_set_options")
+            self._bound[key] = (fn, user)
         return self._bound[key]
 
     def __call__(self, t, y):
@@ -563,11 +602,12 @@ class _Builtin(DeviceRHS):
     _chain_caps = 31 | _lib.CHAIN_CAP_PRE | _lib.CHAIN_CAP_ERRNORM
     _fuse_query = True
 
-    def _rkc_chain_entry(self, lib):
+    def _rkc_chain_entry(self, lib, options=None):
         if not self._symbol_rkc_chain:
             return None
         # (the forms the built-in chain sweep takes: opening / ending a step)
-        depth = int(os.environ.get("ESQ_RKC_MAXDEPTH", self._rkc_chain_depth))
+        options = options or _lib.Options()
+        depth = int(options.get("rkc_maxdepth", self._rkc_chain_depth))
         return getattr(lib, self._symbol_rkc_chain), depth | self._rkc_chain_forms
 
     def _rkc_entry(self, lib):

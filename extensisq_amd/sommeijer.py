@@ -118,7 +118,8 @@ class SSV2stab(_LazyStateMixin, OdeSolver):
         # ---- device state: 8 rows, roles rotated by index
         self._dev = DeviceContext(
             self.n, self._N_ROWS, False, device,
-            host_rhs=self._device_rhs is None and lockstep is None)
+            host_rhs=self._device_rhs is None and lockstep is None,
+            options=self._esq_options)
         self._lib = self._dev.lib
         self._ctx = self._dev.handle
         self._dev.set_tol(self.rtol, self.atol)

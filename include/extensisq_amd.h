@@ -349,6 +349,17 @@ int  esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex)
 #define ESQ_CREATE_HOST_SLAB 1
 int  esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
                  int flags);
+/* ... with THIS context's tuning switches: `options` is
+ * "key=value;key=value" (keys in any case, with or without the ESQ_ prefix; NULL or ""
+ * for none), e.g. "chain_depth=1;lazy_rows=0".  A key the caller does not give takes the
+ * process default -- the environment variable ESQ_<KEY>, read now, on this thread -- so
+ * one solver's switches never reach another, and nothing writes the environment.  An
+ * unknown key, or one that steers a plugin object (esq_rhs_set_options), is refused:
+ * ESQ_EINVAL, the key in esq_last_error.  esq_option_level: 1 = a context's switch,
+ * 2 = a plugin object's, 0 = not a switch of the library. */
+int  esq_create3(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
+                 int flags, const char *options);
+int  esq_option_level(const char *key);
 int  esq_destroy(esq_ctx *ctx);
 const char *esq_last_error(const esq_ctx *ctx);
 int  esq_synchronize(esq_ctx *ctx);
@@ -387,16 +398,11 @@ int  esq_snapshot_copy(void *token, double *host, int host_is_pinned);
 int  esq_release_cached_memory(size_t *bytes_out);
 /* Downloads of 8 MiB and more (esq_download, esq_snapshot_copy) run on ONE stream per
  * device and process, through the device's DMA engines (hipMemcpyAsync) into a page-locked
- * destination.  ESQ_D2H_MODE=auto | kernel (experimental, see csrc/esq_core.hip: it has
- * crashed test runs) lets a small copy kernel take over from engines that read slow --
- * recycled -- memory: with `auto` the engines copy the first 8 MiB of a download of 16 MiB
- * and more and are timed, and the kernel copies the rest if that piece was slower than
- * 0.8 x the fastest seen.  This reports the record: the fastest first piece, the kernel's
- * reference piece (both 0 with the engines alone), the latest whole download (GB/s), and
- * how many downloads were finished either way. */
-int  esq_copy_lane_info(int device, double *best_probe_gbs_out, double *kernel_ref_gbs_out,
-                        double *last_gbs_out, long *engine_copies_out,
-                        long *kernel_copies_out);
+ * destination.  This reports the record: the fastest and the latest download (GB/s; the
+ * fastest among those that had the stream to themselves) and how many there were.
+ * (The opt-in copy kernel of ABI 7 -- ESQ_D2H_MODE -- is gone: it faulted.) */
+int  esq_copy_lane_info(int device, double *best_gbs_out, double *last_gbs_out,
+                        long *copies_out);
 /* page-lock / release a host buffer (hipHostRegister: mapped into the device's address
  * space, portable across devices) */
 int  esq_host_pin(void *host, size_t bytes);
@@ -803,6 +809,10 @@ int  esq_rhs_bruss2d_create(void **user_out, int N, double alpha, double a,
                             double b);                    /* n = 2*N*N          */
 int  esq_rhs_diff3d_create(void **user_out, int N);       /* n = N*N*N          */
 int  esq_rhs_free(void *user);
+/* the tuning switches of ONE built-in plugin object ("chain_rows=12;rkc_force=1": the
+ * keys of esq_option_level == 2; the process defaults ESQ_<KEY> applied when the object
+ * was made are replaced).  ESQ_EINVAL for any other key. */
+int  esq_rhs_set_options(void *user, const char *options);
 int  esq_rhs_diag(void *user, double t, const double *y, double *f, size_t n,
                   void *stream);
 int  esq_rhs_cdiag(void *user, double t, const double *y, double *f, size_t n,

@@ -180,26 +180,68 @@ def test_an_aborted_communicator_is_dropped_by_every_attached_context():
     assert grp.sync_aborted() is True and lib.cleared == [11]
 
 
-def test_esq_options_live_for_the_constructor_only(monkeypatch):
-    """`esq_options=` of a solver constructor: the library's ESQ_* switches for this
-    solver only -- in the environment while the constructor runs, gone (or back to what
-    they were) afterwards; a bad key is refused"""
+def test_esq_options_travel_as_arguments_not_through_the_environment(monkeypatch):
+    """`esq_options=` of a solver constructor (`_lib.Options`): this solver's switches.
+    The library's travel as strings to esq_create3 (a context's) / esq_rhs_set_options (a
+    plugin object's), the package's are looked up; a switch that was not given takes the
+    process default ESQ_<KEY> -- READ, never written: the environment is untouched, so
+    two threads may construct solvers with different switches.  A key that is not a
+    switch is refused (until round 5 it was silently put into the environment)."""
     import os
+    from extensisq_amd._lib import Options
     monkeypatch.setenv("ESQ_CHAIN_DEPTH", "3")
-    monkeypatch.delenv("ESQ_LAZY_Y", raising=False)
+    monkeypatch.setenv("ESQ_LAZY_Y", "0")
+    monkeypatch.delenv("ESQ_LAUNCH_AHEAD", raising=False)
+    before = dict(os.environ)
     seen = {}
 
     class Probe:
         @dev_common._with_esq_options
         def __init__(self, a, b=2):
-            seen.update(depth=os.environ.get("ESQ_CHAIN_DEPTH"), lazy=os.environ.get("ESQ_LAZY_Y"),
-                        ahead=os.environ.get("ESQ_LAUNCH_AHEAD"), a=a, b=b)
+            seen.update(opts=self._esq_options, a=a, b=b)
 
-    Probe(1, b=5, esq_options={"chain_depth": 1, "lazy_y": "always", "launch_ahead": False})
-    assert seen == dict(depth="1", lazy="always", ahead="0", a=1, b=5)
-    assert os.environ["ESQ_CHAIN_DEPTH"] == "3" and "ESQ_LAZY_Y" not in os.environ
-    assert "ESQ_LAUNCH_AHEAD" not in os.environ
-    Probe(7)                                      # no options: the environment as it is
-    assert seen["depth"] == "3" and seen["lazy"] is None and seen["a"] == 7
-    with pytest.raises(ValueError):
-        Probe(1, esq_options={"chain depth; rm": 1})
+    Probe(1, b=5, esq_options={"chain_depth": 1, "ESQ_LAZY_ROWS": False, "lazy_y": "always",
+                               "launch_ahead": False, "chain_rows": 12, "rkc_force": True})
+    o = seen["opts"]
+    assert (seen["a"], seen["b"]) == (1, 5)
+    assert dict(os.environ) == before                       # nothing written
+    # library switches by the object they steer, package switches by lookup
+    assert o.context_string == b"chain_depth=1;lazy_rows=0"
+    assert o.plugin_string == b"chain_rows=12;rkc_force=1"
+    assert o.get("lazy_y") == "always" and o.get("launch_ahead") == "0"
+    assert o.get("pre_whole", "1") == "1"                   # not given, not in the environment
+    Probe(7)                                                # no options: the process defaults
+    o = seen["opts"]
+    assert o.context_string == b"" and o.plugin_string == b"" and seen["a"] == 7
+    assert o.get("lazy_y", "1") == "0"                      # ESQ_LAZY_Y, read
+    for bad in ({"chain depth; rm": 1}, {"chian_depth": 1}, {"d2h_mode": "auto"},
+                {"plan_greedy": 1}, {3: 1}):
+        with pytest.raises(ValueError):
+            Probe(1, esq_options=bad)
+    assert isinstance(Options(o), Options) and Options(o).values == o.values
+
+
+def test_option_keys_are_known_to_the_library_by_level():
+    """esq_option_level: 1 = a context's switch, 2 = a plugin object's, 0 = unknown;
+    keys in any case, with or without the prefix"""
+    from extensisq_amd import _lib
+    lib = _lib.load()
+    for key in (b"chain_depth", b"CHAIN_DEPTH", b"ESQ_CHAIN_DEPTH", b"lazy_rows", b"lazy_end",
+                b"src", b"block_acc", b"rkc_depth", b"rkc_first", b"rkc_last", b"epi_nt",
+                b"comm_timeout_s", b"chain_from_rows"):
+        assert lib.esq_option_level(key) == 1, key
+    for key in (b"chain_rows", b"rkc_force", b"rkc_planes", b"diff3d_r"):
+        assert lib.esq_option_level(key) == 2, key
+    # closed experiments (retired in round 6) and nonsense
+    for key in (b"d2h_mode", b"plan_greedy", b"chain_split", b"row_stagger", b"block_fold",
+                b"chain_caps", b"rhs_variant", b"plan_write_cost", b"", b"chain"):
+        assert lib.esq_option_level(key) == 0, key
+    # a plugin object takes its own switches only (-1: ESQ_EINVAL)
+    import ctypes
+    user = ctypes.c_void_p()
+    assert lib.esq_rhs_heat2d_create(ctypes.byref(user), 64) == 0
+    assert lib.esq_rhs_set_options(user, b"chain_rows=12;rkc_planes=3") == 0
+    assert lib.esq_rhs_set_options(user, b"chain_depth=1") == -1
+    assert lib.esq_rhs_set_options(user, b"no_such=1") == -1
+    assert lib.esq_rhs_set_options(user, None) == 0
+    assert lib.esq_rhs_free(user) == 0

@@ -3,7 +3,7 @@
     python tools/slab_probe.py [contexts]
 Makes Pr8-sized contexts (n = 1e7, 14 rows: a 1.2 GB slab each) one after the other, the
 previous one destroyed when the next is made (as consecutive solve_ivp calls do), and times
-engine copies (ESQ_D2H_MODE=engine) of the state and of three rows of K of each."""
+engine copies of the state and of three rows of K of each."""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,6 @@ import numpy as np
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, ROOT)
-os.environ["ESQ_D2H_MODE"] = "engine"
 from extensisq_amd import _lib                                   # noqa: E402
 from extensisq_amd.device import DeviceContext                   # noqa: E402
 
