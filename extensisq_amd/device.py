@@ -393,7 +393,11 @@ class DeviceContext:
                       "esq_set_rhs_rkc")
             # RKC chain entry: several Chebyshev stages per marching sweep
             # (ESQ_RKC_DEPTH=1 in the environment: one launch per stage)
-            rkc_chain = rhs._rkc_chain_entry(self.lib, self.options)
+            # (plugin classes written against round 5 take `lib` only)
+            import inspect
+            takes_options = len(inspect.signature(rhs._rkc_chain_entry).parameters) >= 2
+            rkc_chain = (rhs._rkc_chain_entry(self.lib, self.options) if takes_options
+                         else rhs._rkc_chain_entry(self.lib))
             if rkc_chain is not None:
                 self._chk(self.lib.esq_set_rhs_rkc_chain(
                     self.handle, C.cast(rkc_chain[0], C.c_void_p),

@@ -59,6 +59,7 @@ REQUIRED = {
     "test_gpu_whole_step.py::test_chain_through_the_end_of_an_fsal_step_is_bit_identical": 8,
     "test_gpu_whole_step.py::test_ts5_whole_step_is_one_launch_and_runs_ahead": 1,
     "test_gpu_whole_step.py::test_full_size_three_steps_match_oracle_early_estimate_pairs": 4,
+    "test_gpu_whole_step.py::test_eight_threads_construct_solvers_with_their_own_switches": 1,
     # bit-identical restructurings, each with its on/off switch
     "test_gpu_parity.py::test_blocked_accumulation_is_bit_identical": 18,
     "test_gpu_parity.py::test_chained_stages_are_bit_identical": 45,

@@ -242,3 +242,53 @@ def test_full_size_three_steps_match_oracle_early_estimate_pairs(name, plugin, N
         assert_allclose(got, ref, rtol=1e-5)
     if plan is not None:
         assert labels == plan, labels
+
+
+def test_eight_threads_construct_solvers_with_their_own_switches():
+    """`esq_options=` travels as arguments (esq_create3 / esq_rhs_set_options), not through
+    the process environment: eight threads construct and step solvers with DIFFERENT
+    chain depths and tile heights at the same moment, each gets the plan of its own
+    switches -- and all eight states are the same bits (ADVICE r05
+    medium: until round 5 the keyword wrote os.environ for the duration of the
+    constructor, two constructors with different options raced)"""
+    import os
+    import threading
+    N = 96
+    rho = esq.Brusselator2D(N).spectral_radius()
+    y0 = pb.bruss2d_y0(N)
+    h = 0.25 / rho
+    kw = dict(first_step=h, max_step=h, rtol=1e-6, atol=1e-9, nfev_stiff_detect=0)
+    cases = [(1, 12), (2, 12), (3, 9), (4, 12), (1, 9), (2, 7), (3, 12), (4, 8)]
+    env_before = dict(os.environ)
+    gate = threading.Barrier(len(cases))
+    out = [None] * len(cases)
+
+    def run(k):
+        depth, rows = cases[k]
+        try:
+            gate.wait(30)
+            s = esq.Pr8(esq.Brusselator2D(N), 0.0, y0, 1.0,
+                        esq_options={"chain_depth": depth, "chain_rows": rows}, **kw)
+            s._dev.profile_enable([0, 1, 2])
+            for _ in range(3):
+                assert s.step() is None
+            out[k] = (np.array(s.y), _labels(s))
+        except BaseException as exc:                          # noqa: BLE001
+            out[k] = exc
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(len(cases))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert dict(os.environ) == env_before
+    for k, (depth, rows) in enumerate(cases):
+        assert not isinstance(out[k], BaseException), (cases[k], out[k])
+        y, labels = out[k]
+        assert_equal(y, out[0][0])
+        depths = [int(lab[5]) for lab in labels if lab.startswith("chain")]
+        if depth == 1:
+            assert not depths, (cases[k], labels)
+        else:
+            # (one stage more where the end-point derivative rides in front)
+            assert depths and max(depths) in (depth, depth + 1), (cases[k], labels)
