@@ -102,6 +102,7 @@ SIGNATURES = {
                                    _vp, C.c_int, C.c_char_p, C.c_size_t]),
     "esq_dense_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int,
                                    _vpp]),
+    "esq_dense_create_vecs": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vpp]),
     "esq_dense_eval": (C.c_int, [_vp, C.c_double, _vp]),
     "esq_dense_download": (C.c_int, [_vp, _vp]),
     "esq_dense_destroy": (C.c_int, [_vp]),

@@ -24,7 +24,7 @@ from scipy.integrate._ivp.common import (validate_first_step,
                                          validate_max_step, warn_extraneous)
 
 from ._lib import (SLOT_K, SLOT_WORK, SLOT_Y, SLOT_YNEW, SLOT_YSTAGE, VEC_NONE,
-                   VEC_Y, DeviceError, Options, as_ptr)
+                   VEC_Y, VEC_YNEW, DeviceError, Options, as_ptr)
 from .device import DeviceContext, DeviceRHS, _dense_dead, drain_dense
 from .lazy import LazyState
 
@@ -54,11 +54,21 @@ def _read_by_solve_ivp(depth=2):
     frames between this function and the reader of the property"""
     import sys
     try:
-        code = sys._getframe(depth).f_code
+        frame = sys._getframe(depth)
     except ValueError:
         return False
-    return code.co_name == "solve_ivp" and code.co_filename.replace("\\", "/").endswith(
-        "scipy/integrate/_ivp/ivp.py")
+    code = frame.f_code
+    if not (code.co_name == "solve_ivp" and code.co_filename.replace("\\", "/").endswith(
+            "scipy/integrate/_ivp/ivp.py")):
+        return False
+    # with event functions scipy hands the `y` it read here to USER code (`event(t, y)`,
+    # ivp.py:680): that code gets the ndarray the reference gives it -- numba / Cython /
+    # torch.from_numpy callbacks need the buffer, `isinstance(y, np.ndarray)` holds
+    # (ADVICE r05)
+    try:
+        return frame.f_locals.get("events") is None
+    except Exception:                                         # noqa: BLE001
+        return True
 
 def _inside_solve_ivp(max_depth=16):
     """is scipy's `solve_ivp` among the callers (a solver constructed by it: ivp.py:590)?"""
@@ -195,6 +205,28 @@ class CubicDenseOutput(DenseOutput):
                + x ** 2 * (3.0 - 2.0 * x) * self.y[:, np.newaxis]
                + x ** 2 * (x - 1.0) * self.h * self.f[:, np.newaxis])
         return out if t.shape else out[:, 0]
+
+
+def _cubic_interpolant(solver, t_old, t, y_old, y, f_old, f):
+    """C1 cubic Hermite interpolant through (y_old, f_old), (y, f) -- vector ids of the
+    solver's context -- as a device-resident Horner form (esq_dense_create_vecs):
+    with d = y - y_old and x = (t - t_old) / h,
+        y(x) = y_old + x (h f_old) + x^2 (3 d - 2 h f_old - h f) + x^3 (-2 d + h f_old + h f)
+    (the expansion of ref common.py:812-821).  d is formed first -- 3 y - 3 y_old in one
+    rounding -- then the small h f terms are added."""
+    import ctypes
+    h = t - t_old
+    ids = (ctypes.c_int * 4)(y, y_old, f_old, f)
+    W = np.array([[0.0, 3.0, -2.0],
+                  [0.0, -3.0, 2.0],
+                  [h, -2.0 * h, h],
+                  [0.0, -h, h]])
+    handle = ctypes.c_void_p()
+    solver._chk(solver._lib.esq_dense_create_vecs(solver._ctx, ids, 4, as_ptr(W), 3, y_old,
+                                                  ctypes.byref(handle)),
+                "esq_dense_create_vecs")
+    return DeviceHornerDenseOutput(t_old, t, solver._lib, handle, solver.n,
+                                   solver._dev.dtype)
 
 
 class LockstepGroup:
@@ -1068,6 +1100,16 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
     def _dense_output_impl(self):
         if isinstance(self.P, np.ndarray):
             return self._horner_interpolant(self.P, self.t_old, self.t)
+        if self.n >= self._DEVICE_DENSE_MIN_N:
+            # tableaux without P: the cubic Hermite interpolant (ref common.py:366-368,
+            # 793-821) as a device-resident Horner form -- nothing is copied to the
+            # host until it is evaluated
+            rid = self._lib.esq_rk_row_id
+            f_old, f = rid(self._ctx, 0, 1), rid(self._ctx, 0, 0)
+            if f_old < 0 or f < 0:
+                raise DeviceError(f"esq_rk_row_id failed with code {min(f_old, f)}")
+            # (after the accept Y is the new state, YNEW the pre-step one)
+            return _cubic_interpolant(self, self.t_old, self.t, VEC_YNEW, VEC_Y, f_old, f)
         return CubicDenseOutput(self.t_old, self.t, self.y_old, self.y,
                                 self.f_old, self.f)
 

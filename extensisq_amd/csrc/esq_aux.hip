@@ -22,13 +22,11 @@ void launch_dense_n(esq_ctx *c, const DenseArgs &a, int np, double scale) {
                        c->stream, a, np, scale, c->len_pad / 2);
 }
 extern "C" {
-int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
-                     int from_end, esq_dense **out) {
-    if (!c || !P || !out) return ESQ_EINVAL;
-    ENTER_KEEP(c);
-    ENSURE_ROWS(c);
-    if (rows < 1 || rows > c->n_rows || p < 1 || p > kMaxCols)
-        return fail(c, ESQ_EINVAL, "bad interpolant shape (%d, %d)", rows, p);
+// Q_k = scale * sum_j W[j][k] * src[j]  (k < p, ascending j: one fused pass over the
+// sources for all columns), base = a copy of `base`: the interpolant owns its memory
+static int dense_build(esq_ctx *c, const double *const *src, int nsrc, const double *W, int p,
+                       double scale, const double *base, esq_dense **out) {
+    if (p < 1 || p > kMaxCols) return fail(c, ESQ_EINVAL, "bad interpolant width %d", p);
     esq_dense *d = new (std::nothrow) esq_dense();
     if (!d) return ESQ_ENOMEM;
     d->device = c->device;
@@ -47,13 +45,13 @@ int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
     if (e != hipSuccess) { dev_release(d->device, d->mem, d->mem_bytes); delete d; return fail(c, (int)e, "stream"); }
     DenseArgs a;
     int nt = 0;
-    for (int j = 0; j < rows; ++j) {
+    for (int j = 0; j < nsrc; ++j) {
         bool any = false;
-        for (int k = 0; k < p; ++k) any = any || P[(size_t)j * p + k] != 0.0;
+        for (int k = 0; k < p; ++k) any = any || W[(size_t)j * p + k] != 0.0;
         if (!any) continue;
         if (nt >= kMaxTerms) { esq_dense_destroy(d); return fail(c, ESQ_EINVAL, "too many rows"); }
-        a.p[nt] = c->krow[c->kmap_last[j]];
-        for (int k = 0; k < kMaxCols; ++k) a.w[nt][k] = k < p ? P[(size_t)j * p + k] : 0.0;
+        a.p[nt] = src[j];
+        for (int k = 0; k < kMaxCols; ++k) a.w[nt][k] = k < p ? W[(size_t)j * p + k] : 0.0;
         ++nt;
     }
     for (int j = nt; j < kMaxTerms; ++j) {
@@ -61,16 +59,14 @@ int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
         for (int k = 0; k < kMaxCols; ++k) a.w[j][k] = 0.0;
     }
     for (int k = 0; k < kMaxCols; ++k) a.q[k] = k < p ? d->mem + (size_t)k * d->len_pad : nullptr;
-    if (nt < 1) { esq_dense_destroy(d); return fail(c, ESQ_EINVAL, "P is all zero"); }
+    if (nt < 1) { esq_dense_destroy(d); return fail(c, ESQ_EINVAL, "the weights are all zero"); }
     switch (nt) {
-#define CASE(N) case N: launch_dense_n<N>(c, a, p, h); break;
+#define CASE(N) case N: launch_dense_n<N>(c, a, p, scale); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9)
         CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17)
         CASE(18) CASE(19) CASE(20)
 #undef CASE
     }
-    // base state: after esq_rk_accept, Y is the new state, YNEW the pre-step one
-    const double *base = from_end ? c->y : c->ynew;
     e = hipMemcpyAsync(d->mem + (size_t)p * d->len_pad, base,
                        d->len_pad * sizeof(double), hipMemcpyDefault, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -81,6 +77,40 @@ int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
     }
     *out = d;
     return 0;
+}
+static double *dense_vec(esq_ctx *c, int r);      // (vec_ptr, below)
+
+int esq_dense_create(esq_ctx *c, const double *P, int rows, int p, double h,
+                     int from_end, esq_dense **out) {
+    if (!c || !P || !out) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    ENSURE_ROWS(c);
+    if (rows < 1 || rows > c->n_rows || p < 1 || p > kMaxCols)
+        return fail(c, ESQ_EINVAL, "bad interpolant shape (%d, %d)", rows, p);
+    std::vector<const double *> src(rows);
+    for (int j = 0; j < rows; ++j) src[j] = c->krow[c->kmap_last[j]];
+    // base state: after esq_rk_accept, Y is the new state, YNEW the pre-step one
+    return dense_build(c, src.data(), rows, P, p, h, from_end ? c->y : c->ynew, out);
+}
+// The same interpolant object from ANY vectors of the context (ids as in esq_vec_*: a
+// physical K row >= 0, ESQ_VEC_Y ...):  Q_k = sum_j W[j][k] * vec_j,  base = vec(base_vec).
+// What the C1 cubic Hermite interpolant of the reference (common.py:793-821;
+// SSV2stab: sommeijer.py:400-406) becomes in Horner form -- with d = y - y_old,
+//     y(x) = y_old + x*(h f_old) + x^2*(3 d - 2 h f_old - h f) + x^3*(-2 d + h f_old + h f)
+// -- so that `dense_output()` of SSV2stab and of tableaux without P copies nothing to
+// the host until it is evaluated.
+int esq_dense_create_vecs(esq_ctx *c, const int *vec_ids, int nvec, const double *W, int p,
+                          int base_vec, esq_dense **out) {
+    if (!c || !vec_ids || !W || !out) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    ENSURE_ROWS(c);
+    if (nvec < 1 || nvec > kMaxTerms) return fail(c, ESQ_EINVAL, "bad vector count %d", nvec);
+    std::vector<const double *> src(nvec);
+    for (int j = 0; j < nvec; ++j)
+        if (!(src[j] = dense_vec(c, vec_ids[j]))) return fail(c, ESQ_EINVAL, "bad vector id");
+    const double *base = dense_vec(c, base_vec);
+    if (!base) return fail(c, ESQ_EINVAL, "bad base vector id");
+    return dense_build(c, src.data(), nvec, W, p, 1.0, base, out);
 }
 int esq_dense_eval(esq_dense *d, double x, double *host_out) {
     if (!d || !host_out) return ESQ_EINVAL;
@@ -134,6 +164,7 @@ static double *vec_ptr(esq_ctx *c, int r) {
     }
 }
 #define ROW(c, r) vec_ptr((c), (r))
+static double *dense_vec(esq_ctx *c, int r) { return vec_ptr(c, r); }
 // a vector id whose overwriting changes what the rows evaluated on demand
 // (esq_rk_lazy_rows) would be computed from: they are evaluated first
 #define ENSURE_ROWS_BEFORE_WRITE(c, id)                                   \

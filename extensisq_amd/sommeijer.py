@@ -451,9 +451,20 @@ class SSV2stab(_LazyStateMixin, OdeSolver):
         factor = num / den if num < 10.0 * den else 10.0     # den == 0: err == 0
         return max(0.1, factor) * absh
 
+    # below this size a host interpolant answers the many tiny evaluations of event
+    # root-finding faster than kernel launches do (as RungeKutta._DEVICE_DENSE_MIN_N)
+    _DEVICE_DENSE_MIN_N = 4096
+
     def _dense_output_impl(self):
-        """cubic Hermite through (y_old, f_old), (y, f)  (ref :400-406)"""
+        """cubic Hermite through (y_old, f_old), (y, f)  (ref :400-406); large states:
+        a device-resident Horner form of it (common._cubic_interpolant) -- nothing is
+        copied to the host until the interpolant is evaluated (round 5: four n-vectors
+        per call, 128 MB at N = 159 against a 1.2 ms step)"""
         r = self._r
+        if self.n >= self._DEVICE_DENSE_MIN_N:
+            from .common import _cubic_interpolant
+            return _cubic_interpolant(self, self.t_old, self.t, r["yold"], r["yn"],
+                                      r["fold"], r["fn"])
         dl = self._dev.download
         return CubicDenseOutput(self.t_old, self.t, dl(SLOT_K, r["yold"]),
                                 dl(SLOT_K, r["yn"]), dl(SLOT_K, r["fold"]),

@@ -659,6 +659,15 @@ int  esq_rk_launch_ahead_stats(esq_ctx *ctx, long *used_out, long *dropped_out);
 typedef struct esq_dense esq_dense;
 int  esq_dense_create(esq_ctx *ctx, const double *P, int rows, int p, double h,
                       int from_end, esq_dense **out);
+/* The same object from ANY vectors of the context (ids as in esq_vec_*: a physical K
+ * row >= 0 -- esq_rk_row_id -- or ESQ_VEC_Y ...):  Q_k = sum_j W[j*p + k] * vec_j
+ * (ascending j, one pass), base = vec(base_vec).  The C1 cubic Hermite interpolant of
+ * tableaux without P and of SSV2stab (common.py:793-821, sommeijer.py:400-406) in Horner
+ * form: with d = y - y_old,
+ *   y(x) = y_old + x (h f_old) + x^2 (3 d - 2 h f_old - h f) + x^3 (-2 d + h f_old + h f)
+ * so that their dense_output() copies nothing to the host until it is evaluated. */
+int  esq_dense_create_vecs(esq_ctx *ctx, const int *vec_ids, int nvec, const double *W,
+                           int p, int base_vec, esq_dense **out);
 /* host_out[n] = base + sum_c Qh[:,c] x^(c+1)  (Horner on the device, x scaled) */
 int  esq_dense_eval(esq_dense *d, double x, double *host_out);
 /* Qh as a (p, n) row-major host matrix (transpose of the reference's Q*h) */

@@ -19,6 +19,8 @@ import numpy as np
 import pytest
 from numpy.testing import assert_allclose, assert_equal
 
+from scipy.integrate import solve_ivp
+
 import extensisq_amd as esq
 from oracle import problems as pb
 from oracle import rk_oracle
@@ -292,3 +294,97 @@ def test_eight_threads_construct_solvers_with_their_own_switches():
         else:
             # (one stage more where the end-point derivative rides in front)
             assert depths and max(depths) in (depth, depth + 1), (cases[k], labels)
+
+
+# ------------------------------------------ device-resident cubic Hermite interpolant
+def _heun():
+    class Heun(esq.RungeKutta):       # a user tableau WITHOUT P (ref docs/Demo_own_RK.ipynb)
+        n_stages, order, order_secondary = 2, 2, 1
+        A = np.array([[0.0, 0.0], [1.0, 0.0]])
+        B = np.array([0.5, 0.5])
+        C = np.array([0.0, 1.0])
+        E = np.array([0.5, -0.5, 0.0])
+    return Heun
+
+
+@pytest.mark.parametrize("which", ["ssv2stab", "heun", "ssv2stab_small"])
+def test_cubic_interpolant_lives_on_the_device(which):
+    """dense_output() of SSV2stab (sommeijer.py:400-406) and of a tableau without P
+    (common.py:366-368, 793-821): large states get the cubic Hermite interpolant as a
+    device-resident Horner form (esq_dense_create_vecs) -- nothing is downloaded when it
+    is made; it equals the reference's formula on host copies of the four vectors to
+    rounding, and outlives the step and the solver"""
+    from extensisq_amd.common import CubicDenseOutput, DeviceHornerDenseOutput
+    N = 24 if which == "ssv2stab_small" else 96
+    rhs = esq.Heat2D(N)
+    y0 = pb.heat2d_y0(N, seed=3)
+    rho = rhs.spectral_radius()
+    if which == "heun":
+        s = _heun()(rhs, 0.0, y0, 1.0, first_step=0.2 / rho, max_step=0.2 / rho,
+                    rtol=1e-3, atol=1e-6)
+    else:
+        s = esq.SSV2stab(rhs, 0.0, y0, 1.0, rtol=1e-4, atol=1e-6,
+                         rho_jac=lambda t, y: rho, const_jac=True)
+    for _ in range(3):
+        assert s.step() is None
+    before = _lib_copies()
+    sol = s.dense_output()
+    if which == "ssv2stab_small":               # below the threshold: the host interpolant
+        assert isinstance(sol, CubicDenseOutput)
+        return
+    assert isinstance(sol, DeviceHornerDenseOutput)
+    assert _lib_copies() == before              # ... and nothing came to the host for it
+    # the reference's formula on host copies of the four vectors
+    if which == "heun":
+        y_old, y, f_old, f = s.y_old, s.y, s.f_old, s.f
+    else:
+        from extensisq_amd._lib import SLOT_K
+        r = s._r
+        y_old, y, f_old, f = (s._dev.download(SLOT_K, r[k]) for k in ("yold", "yn", "fold", "fn"))
+    ref = CubicDenseOutput(s.t_old, s.t, y_old, np.asarray(y), f_old, f)
+    tc = s.t_old + (s.t - s.t_old) * np.array([0.0, 0.125, 0.5, 0.9, 1.0])
+    scale = np.abs(y0).max()
+    assert_allclose(sol(tc), ref(tc), rtol=0, atol=4e-15 * scale)
+    assert_allclose(sol(s.t_old), y_old, rtol=0, atol=0)     # x = 0: the base itself
+    assert_allclose(sol(s.t), np.asarray(y), rtol=0, atol=4e-15 * scale)
+    # it owns its memory: the solver steps on, is closed, the interpolant still answers
+    want = sol(tc[2])
+    assert s.step() is None
+    s._dev.close()
+    assert_equal(sol(tc[2]), want)
+
+
+def _lib_copies():
+    """downloads so far (a spy on DeviceContext.download, below)"""
+    return _DOWNLOADS[0]
+
+
+_DOWNLOADS = [0]
+
+
+@pytest.fixture(autouse=True)
+def _count_downloads(monkeypatch):
+    from extensisq_amd.device import DeviceContext
+    real = DeviceContext.download
+
+    def counting(self, *a, **k):
+        _DOWNLOADS[0] += 1
+        return real(self, *a, **k)
+    monkeypatch.setattr(DeviceContext, "download", counting)
+    yield
+
+
+def test_solve_ivp_dense_output_of_ssv2stab_matches_the_oracle_on_a_large_state():
+    """the drop-in call with dense_output=True on a device-resident state: every
+    step's interpolant is the device-resident cubic; against the oracle's"""
+    from extensisq_amd.common import DeviceHornerDenseOutput
+    from oracle import rkc_oracle
+    N = 80
+    y0 = pb.heat2d_y0(N, seed=2)
+    kw = dict(rtol=1e-4, atol=1e-6, dense_output=True)
+    res = solve_ivp(esq.Heat2D(N), (0, 0.004), y0, method=esq.SSV2stab, **kw)
+    ref = solve_ivp(pb.heat2d_rhs(N), (0, 0.004), y0, method=rkc_oracle.SSV2stab, **kw)
+    assert res.success and len(res.t) == len(ref.t)
+    assert all(isinstance(i, DeviceHornerDenseOutput) for i in res.sol.interpolants)
+    tc = np.linspace(0, 0.004, 9)
+    assert_allclose(res.sol(tc), ref.sol(tc), rtol=1e-7, atol=1e-10)
