@@ -910,11 +910,11 @@ def solve_ivp_figure(w, device, steps=24):
     after every step there too (ivp.py:665) but uses only the interpolant of the
     last one; the deferred mirror (extensisq_amd/lazy.py) then copies nothing."""
     out = _solve_ivp_run(w, device, steps, {})
-    if "rho_jac" not in w["kw"]:
-        h = w["kw"]["max_step"]
-        ev = _solve_ivp_run(w, device, steps, {"t_eval": [steps * h]})
-        out["t_eval_end"] = {k: ev[k] for k in ("ms_per_step", "ms_per_step_mean", "steps",
-                                                "value", "assembly_ms")}
+    # (SSV2stab too since round 6: its cubic interpolant is device-resident as well)
+    h = w["kw"]["max_step"]
+    ev = _solve_ivp_run(w, device, steps, {"t_eval": [steps * h]})
+    out["t_eval_end"] = {k: ev[k] for k in ("ms_per_step", "ms_per_step_mean", "steps",
+                                            "value", "assembly_ms")}
     try:
         # the record of the process's download stream (csrc/esq_core.hip, lane_copy)
         from extensisq_amd._lib import copy_lane_info

@@ -399,6 +399,15 @@ class _LazyStateMixin:
         self._lazy_live.append(entry)
         return mirror
 
+    def _peek_lazy_state(self):
+        """a mirror of the current state for a callee that may well ignore it (a
+        user's `rho_jac(t, y)`): never copied ahead of its first use"""
+        eager, self._lazy_eager = self._lazy_eager, False
+        try:
+            return self._new_lazy_state()
+        finally:
+            self._lazy_eager = eager
+
     def _retire_lazy_states(self, everything=False):
         """Before a step starts: the device is about to overwrite the buffer of the
         state before the current one.  Mirrors of it that somebody still holds are

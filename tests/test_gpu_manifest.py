@@ -61,6 +61,7 @@ REQUIRED = {
     "test_gpu_whole_step.py::test_full_size_three_steps_match_oracle_early_estimate_pairs": 4,
     "test_gpu_whole_step.py::test_eight_threads_construct_solvers_with_their_own_switches": 1,
     "test_gpu_whole_step.py::test_cubic_interpolant_lives_on_the_device": 3,
+    "test_gpu_whole_step.py::test_state_dependent_spectral_radius_bound_downloads_only_if_it_looks": 1,
     "test_gpu_whole_step.py::test_solve_ivp_dense_output_of_ssv2stab_matches_the_oracle_on_a_large_state": 1,
     # bit-identical restructurings, each with its on/off switch
     "test_gpu_parity.py::test_blocked_accumulation_is_bit_identical": 18,

@@ -388,3 +388,39 @@ def test_solve_ivp_dense_output_of_ssv2stab_matches_the_oracle_on_a_large_state(
     assert all(isinstance(i, DeviceHornerDenseOutput) for i in res.sol.interpolants)
     tc = np.linspace(0, 0.004, 9)
     assert_allclose(res.sol(tc), ref.sol(tc), rtol=1e-7, atol=1e-10)
+
+
+def test_state_dependent_spectral_radius_bound_downloads_only_if_it_looks(monkeypatch):
+    """SSV2stab's `rho_jac(t, y)` (sommeijer.py:174-176) on a large device-resident state:
+    the function gets a deferred mirror -- a bound that ignores y costs no download, one
+    that reads y gets the state's values (and the run is the same run)"""
+    import extensisq_amd.common as cm
+    monkeypatch.setattr(cm, "LAZY_MIN_BYTES", 1 << 16)       # (a 96 x 96 state counts as large)
+    N = 96
+    rhs = esq.Heat2D(N)
+    rho = rhs.spectral_radius()
+    y0 = pb.heat2d_y0(N, seed=4)
+    seen = []
+
+    def ignores(t, y):
+        seen.append(type(y).__name__)
+        return rho
+
+    def looks(t, y):
+        return rho * (1.0 + 0.0 * float(np.abs(y).max()))
+
+    kw = dict(rtol=1e-4, atol=1e-6)
+    a = esq.SSV2stab(rhs, 0.0, y0, 1.0, rho_jac=ignores, **kw)
+    start = _lib_copies()
+    for _ in range(4):
+        assert a.step() is None
+    # (the constructor's check and the first step see the host copy of y0 that exists
+    # anyway; from then on the state is on the device only)
+    assert _lib_copies() == start and seen[-2:] == ["LazyState", "LazyState"], seen
+    b = esq.SSV2stab(esq.Heat2D(N), 0.0, y0, 1.0, rho_jac=looks, **kw)
+    start = _lib_copies()
+    for _ in range(4):
+        assert b.step() is None
+    assert _lib_copies() > start
+    assert a.t == b.t and a.nfev == b.nfev
+    assert_equal(np.asarray(a.y), np.asarray(b.y))
