@@ -24,10 +24,19 @@
 // never touch memory; y is read once per chain.
 //
 // Geometry.  One wave owns a tile of R rows x (64 - 2(D-1)) column pairs; lane l
-// holds pair  W*ct - (D-1) + l.  Stage k is valid on lanes [k, 63-k] and on
-// D-1-k halo rows above and below the tile, so every left/right neighbour comes
-// from a wave shuffle and NO single-lane fix-up loads exist.  Overhead: 2(D-1)/R
-// rows and 2(D-1)/64 lanes of loads and stage evaluations.
+// holds pair  W*ct - (D-1) + l.  Stage k is valid on lanes [k, 63-k], so every
+// left/right neighbour comes from a wave shuffle and NO single-lane fix-up loads
+// exist.  Vertically, tiles come in DIVERGING PAIRS (round 6): two tiles of one
+// workgroup start at the row boundary they share -- the upper one marches up, the
+// lower one down -- and hand each other the ONE value per stage the neighbour's
+// stencil reaches across that boundary (T_k of their first row, through LDS, in
+// the first D iterations), so a tile has no run-in rows at all; at its far end
+// stage k walks D-1-k halo rows of the next pair (which arrives there at the same
+// moment from the other side: the shared rows meet in L2).  Overhead: (D-1)/R rows
+// -- half of the independent tiles' 2(D-1)/R, and D-1 marching iterations per tile
+// less, which is what counts on the short tiles of latency-bound grids (Ts5 at
+// N = 1000: 10 instead of 15 iterations) -- and 2(D-1)/64 lanes of loads and stage
+// evaluations.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -156,44 +165,60 @@ struct ChainArgs {
 template <int NFT, bool PERIODIC, int D, int NU, int KINDLAST, class Fn,
           bool SPLIT = false, bool FROMROWS = false, bool PREFETCH = ESQ_CHAIN_PREFETCH>
 __global__ __launch_bounds__(kBlock) void k_chain2d(
-    const double *__restrict__ ys, ChainArgs<D, NU> ca, Fn fn, int N, int R,
-    unsigned tpr, unsigned ntiles, unsigned nblocks, unsigned xcd, unsigned serp) {
+    const double *__restrict__ ys, ChainArgs<D, NU> ca, Fn fn, int N, int npr,
+    unsigned tpr, unsigned ntiles, unsigned nblocks, unsigned xcd) {
     constexpr int NF = SPLIT ? 1 : NFT;            // fields per wave
     constexpr int H = D - 1;                       // halo rows / lanes per side
     constexpr int W = 64 - 2 * H;                  // last-stage pairs per tile
     constexpr bool SOLERR = KINDLAST == ESQ_EPI_SOLERR;
     constexpr bool ERRN = KINDLAST == ESQ_EPI_ERRNORM;
     static_assert(!ERRN || D >= 2, "the end-point stage follows at least one stage");
-    constexpr int WAVES = SPLIT ? NFT : kBlock / 64;    // waves per workgroup
+    // a workgroup works on whole PAIRS of vertically adjacent tiles: one pair (each
+    // tile NFT waves, one per field) or kBlock / 128 pairs (each tile one wave)
+    constexpr int TPB = SPLIT ? 2 : kBlock / 64;        // tiles per workgroup
+    constexpr int WAVES = SPLIT ? 2 * NFT : kBlock / 64;    // waves per workgroup
+    static_assert(WAVES * 64 <= kBlock && TPB % 2 == 0, "a workgroup holds whole pairs");
     // SPLIT: the centre rows of all D stages, double-buffered by iteration parity
-    __shared__ double2 xch[SPLIT ? 2 : 1][SPLIT ? D : 1][SPLIT ? NFT : 1][SPLIT ? 64 : 1];
+    __shared__ double2 xch[SPLIT ? 2 : 1][SPLIT ? D : 1][SPLIT ? 2 * NFT : 1][SPLIT ? 64 : 1];
+    // T_k (k = 1 .. D - 1) of each tile's FIRST row: what the pair's other tile needs
+    // from across the boundary they both start at
+    __shared__ double2 pairx[TPB][D > 1 ? D - 1 : 1][NFT][64];
     // XCD band remap as in the one-stage sweeps: XCD x takes a contiguous band
     const unsigned per = (nblocks + xcd - 1) / xcd;
     const unsigned lb = (blockIdx.x % xcd) * per + blockIdx.x / xcd;
     // wave-uniform by construction; said so, the tile, its row range and every
     // branch on them are scalar for the compiler too
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned tile = SPLIT ? lb : lb * (kBlock / 64) + wave;
-    const int fbase = SPLIT ? (int)wave : 0;       // first field of this wave
+    const unsigned tib = SPLIT ? wave / NFT : wave;          // tile within the workgroup
+    const unsigned tile = lb * TPB + tib;
+    const int fbase = SPLIT ? (int)(wave % NFT) : 0;   // first field of this wave
     double local = 0.0;
-    if (lb < nblocks && tile < ntiles) {                        // wave-uniform
+    const bool active = lb < nblocks && tile < ntiles;          // wave-uniform
+    if (active) {
         const int npairs = N / 2;
         const int lane = threadIdx.x & 63;
-        const int pc = W * (int)(tile % tpr) - H + lane;
+        // tile -> (pair, upper | lower half); pairs in row-major order of the grid
+        const unsigned pq = tile >> 1, half = tile & 1u;
+        const int pc = W * (int)(pq % tpr) - H + lane;
         const bool indom = pc >= 0 && pc < npairs;
         const bool live = PERIODIC ? (pc >= -H && pc < npairs + H) : indom;
         const int pw = PERIODIC ? (pc < 0 ? pc + npairs : (pc >= npairs ? pc - npairs : pc))
                                 : pc;
         const bool store_ok = indom && lane >= H && lane < 64 - H;
-        const int r0 = (int)(tile / tpr) * R;
-        const int Re = (N - r0) < R ? (N - r0) : R;
-        // Even tile rows march DOWN the grid, odd ones UP: a tile and its vertical
-        // neighbour then read the halo rows they share at the same moment (both
-        // start at, or both arrive at, their common boundary), i.e. one of the two
-        // reads hits in the XCD's L2.  The arithmetic does not see the direction
-        // (the Laplacian adds the rows above and below in one commutative add).
-        const int dirn = (serp && ((tile / tpr) & 1u)) ? -1 : 1;
-        const int rbase = dirn > 0 ? r0 - H : r0 + Re - 1 + H;   // stage 0's first row
+        // the pair's rows [p0, p1), split in the middle: the upper tile marches UP
+        // from the split, the lower one DOWN (the arithmetic does not see the
+        // direction: the Laplacian adds the rows above and below in one commutative
+        // add).  The pair below arrives at p1 from the other side at the same moment:
+        // the run-out rows the two share meet in the XCD's L2.
+        const int prow = (int)(pq / tpr);
+        const int p0 = (int)(((long long)N * prow) / npr);
+        const int p1 = (int)(((long long)N * (prow + 1)) / npr);
+        const int mid = p0 + (p1 - p0) / 2;
+        const int r0 = half ? mid : p0;
+        const int Re = half ? p1 - mid : mid - p0;
+        const int Re_max = (p1 - mid) > (mid - p0) ? (p1 - mid) : (mid - p0);
+        const int dirn = half ? 1 : -1;
+        const int rbase = dirn > 0 ? r0 : r0 + Re - 1;          // stage 0's first row
         const size_t fstride = (size_t)N * (size_t)npairs;     // pairs per field
         auto row_ok = [&](int r) { return PERIODIC || (r >= 0 && r < N); };
         auto wrap = [&](int r) {
@@ -209,6 +234,12 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             return (ca.ld_nt & 1u) ? ld2_nt(ys, k_) : ld2(ys, k_);
         };
         const double2 zero = make_double2(0.0, 0.0);
+        // the base of the targets' sums: y, or -- a chain from the state, ca.y == NULL --
+        // the chain's own input.  One pointer, always loaded through (the row is in
+        // cache: it was the window's next row an iteration ago): `ca.y ? yrow : wc[0]`
+        // on two double2 lvalues makes the compiler select an ADDRESS and send the
+        // windows through scratch
+        const double *__restrict__ ybase = ca.y ? ca.y : ys;
         // every weight as a scalar of its own: taken straight from the argument
         // struct, the compiler keeps whole 16-register load tuples alive and, out
         // of scalar registers, re-reads a TUPLE for every use (706 v_readlane per
@@ -258,7 +289,9 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                 wc[0][f] = ld_ys(rbase, f);
             }
         }
-        const int iters = Re + 2 * H;
+        // no run-in rows (the partner hands the boundary values over); SPLIT: the
+        // workgroup's barrier per row needs the same count in both tiles of the pair
+        const int iters = (SPLIT ? Re_max : Re) + H;
         // operands of stage 0's row: loaded ONE ITERATION AHEAD, so that a wave
         // always has a whole row set in flight behind the row it computes on
         // (the sweeps are latency-bound: few waves per SIMD at this register use).
@@ -275,10 +308,8 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             _Pragma("unroll") for (int j = 0; j < NU; ++j)                         \
                 u[j][f] = !act_ ? zero : ((ca.ld_nt >> (8 + j)) & 1u)                 \
                               ? ld2_nt(ca.rows[j], k2_) : ld2(ca.rows[j], k2_);       \
-            yrow[f] = zero;                                                        \
-            if (ca.y)                                                              \
-                yrow[f] = !act_ ? zero : (ca.ld_nt & 2u) ? ld2_nt(ca.y, k2_)        \
-                                                         : ld2(ca.y, k2_);     \
+            yrow[f] = !act_ ? zero : (ca.ld_nt & 2u) ? ld2_nt(ybase, k2_)           \
+                                                     : ld2(ybase, k2_);        \
         }                                                                          \
     }
         // FROMROWS: T_0 of the row a set belongs to (same ascending FMA chain, the
@@ -353,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             for (int f = 0; f < NF; ++f) {
                 if constexpr (!FROMROWS) {
                     wp[0][f] = ysn[f];
-                    yf[0][f] = ca.y ? yrow[f] : wc[0][f];
+                    yf[0][f] = yrow[f];
                 } else {
                     ycur[f] = yrow[f];
                 }
@@ -388,7 +419,14 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
 #pragma unroll
                 for (int k = 0; k < D; ++k) xch[it & 1][k][wave][lane] = wc[k][0];
                 __syncthreads();
+            } else {
+                // the pair's boundary values were written in the iteration before.  An
+                // LDS-only barrier: __syncthreads() would also drain vmcnt -- the row
+                // set requested one iteration ahead
+                if (it >= 1 && it < D) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
+            // stage `it` starts in this iteration, at the tile's first row: the row
+            // before it is the partner's first row
             // ---- the D targets' sums: of row rho0 (this set), or -- FROMROWS -- of
             // the row after it, held for one iteration
             if constexpr (!FROMROWS) {
@@ -421,26 +459,45 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
             // ---- the stages, each one row behind its predecessor
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                if (it >= 2 * k) {                                 // wave-uniform
+                if (it >= k) {                                     // wave-uniform
                     const int rho = rho0 - dirn * k;
                     const bool actk = live && row_ok(rho);
                     const bool own = rho >= r0 && rho < r0 + Re;
                     const size_t basek = (size_t)wrap(rho) * npairs + pw;
                     double2 cc[NF], lap[NF], fK[NF];
+                    // the window's row before this one -- as SCALARS (a conditional
+                    // overwrite of a double2 makes the compiler select an ADDRESS and
+                    // send the windows through scratch)
+                    double upx[NF], upy[NF];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) { upx[f] = wm[k][f].x; upy[f] = wm[k][f].y; }
+                    if (k >= 1 && it == k) {                       // wave-uniform
+                        // the stage's first row: the row before it is the partner's
+                        // first row (written an iteration ago, behind a barrier)
+                        asm volatile("");
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const double *pv = reinterpret_cast<const double *>(
+                                &pairx[tib ^ 1u][k >= 1 ? k - 1 : 0][fbase + f][lane]);
+                            upx[f] = pv[0];
+                            upy[f] = pv[1];
+                        }
+                    }
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
                         const double lf = lane_left(wc[k][f].y);
                         const double rt = lane_right(wc[k][f].x);
                         cc[f] = wc[k][f];
-                        lap[f].x = ((wm[k][f].x + wp[k][f].x) + (lf + wc[k][f].y)) -
+                        lap[f].x = ((upx[f] + wp[k][f].x) + (lf + wc[k][f].y)) -
                                    4.0 * wc[k][f].x;
-                        lap[f].y = ((wm[k][f].y + wp[k][f].y) + (wc[k][f].x + rt)) -
+                        lap[f].y = ((upy[f] + wp[k][f].y) + (wc[k][f].x + rt)) -
                                    4.0 * wc[k][f].y;
                     }
                     if constexpr (SPLIT) {
                         double2 call[NFT];
 #pragma unroll
-                        for (int g = 0; g < NFT; ++g) call[g] = xch[it & 1][k][g][lane];
+                        for (int g = 0; g < NFT; ++g)
+                            call[g] = xch[it & 1][k][tib * NFT + g][lane];
                         fK[0] = fn.eval_one(fbase, call, lap[0]);
                     } else {
                         fn.eval(cc, lap, fK);
@@ -473,6 +530,10 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                         if (k + 1 < D) {
                             wp[k + 1 < D ? k + 1 : k][f] =
                                 make_double2(actk ? t.x : 0.0, actk ? t.y : 0.0);
+                            // the tile's first row: the partner's stage k + 1 needs it
+                            if (it == k)
+                                pairx[tib][k][fbase + f][lane] =
+                                    make_double2(actk ? t.x : 0.0, actk ? t.y : 0.0);
                             // ERRNORM: the end-point stage's argument is y_new
                             if (ERRN && k == D - 2 && own && store_ok) st2(ca.out, k2, t);
                         } else if (ERRN) {
@@ -530,6 +591,10 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                 }
             }
         }
+    }
+    if (!SPLIT && !active) {
+        // (a wave without a tile keeps the workgroup's barrier count)
+        for (int it = 1; it < D; ++it) asm volatile("s_barrier" ::: "memory");
     }
     if (SOLERR || ERRN) block_partial_w<WAVES>(local, ca.red.partials);
 }

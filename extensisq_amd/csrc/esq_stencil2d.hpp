@@ -235,9 +235,6 @@ inline bool chain_fits_grid(int N, int depth, const ChainTuning &tune) {
     const size_t tpr = ((size_t)N / 2 + W - 1) / W;
     return (size_t)N * tpr >= 2048;
 }
-// alternate tile rows march in opposite directions (esq_chain.hpp: a tile and its
-// vertical neighbour read the halo rows they share at the same moment)
-inline unsigned chain_serpentine() { return 1u; }
 // tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
 // share one tile (the split sweeps: one per field)
 inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_block,
@@ -297,6 +294,35 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
     g.nblocks = (g.ntiles + tiles_per_block - 1) / tiles_per_block;
     g.grid = ((g.nblocks + kXcd - 1) / kXcd) * kXcd;
     return g;
+}
+
+// ... for the chain sweeps of the explicit pairs (k_chain2d): the tiles come in
+// DIVERGING PAIRS that split the rows [N prow / npr, N (prow + 1) / npr) between them
+// (esq_chain.hpp); R from the rules above, npr pair rows, both tiles of every pair
+// non-empty
+struct GeoPairs {
+    int R, npr;
+    unsigned tpr, ntiles, nblocks, grid;
+};
+inline GeoPairs geo_chain_pairs(int N, int depth, int waves_per_cu, int tiles_per_block,
+                                int waves_per_tile, const ChainTuning &tune,
+                                bool tall_if_one_round = false, int min_rows = 0) {
+    const GeoChain g = geo_chain(N, depth, waves_per_cu, tiles_per_block, waves_per_tile, tune,
+                                 tall_if_one_round, min_rows);
+    GeoPairs p;
+    p.R = g.R;
+    p.tpr = g.tpr;
+    // never MORE tiles than the independent tiles of that height would be: the rules
+    // above fill exactly one round of wave slots, and a tile beyond them costs a whole
+    // second round (first version: 52 instead of 51 tile rows at N = 2236 put 2080
+    // waves on 2048 slots -- chain5<0> 102 -> 162 us)
+    p.npr = ((N + g.R - 1) / g.R) / 2;
+    if (p.npr > N / 2) p.npr = N / 2;
+    if (p.npr < 1) p.npr = 1;
+    p.ntiles = 2u * p.tpr * (unsigned)p.npr;
+    p.nblocks = (p.ntiles + tiles_per_block - 1) / tiles_per_block;
+    p.grid = ((p.nblocks + kXcd - 1) / kXcd) * kXcd;
+    return p;
 }
 
 // ---------------------------------------------------------------------------
@@ -476,14 +502,17 @@ struct Stencil2D {
             if (decltype(from_c)::value && !kFrom) { rc_launch = ESQ_ENOTSUP; return; }
             auto kern = k_chain2d<NF, PERIODIC, CA::kD, CA::kNU, decltype(kind)::value, Fn,
                                   kSplit, kFrom>;
-            const unsigned block = kSplit ? 64u * NF : (unsigned)kBlock;
+            // (a workgroup holds whole pairs of tiles: one pair of NF-wave tiles, or
+            // kBlock / 128 pairs of one-wave tiles)
+            const unsigned block = kSplit ? 128u * NF : (unsigned)kBlock;
             static const int wpc = chain_waves_per_cu(kern, block);   // per instantiation
             // (min_rows < 0, light one-field rows: tiles down to `depth` rows, five at
             // depth 6 -- Ts5's whole-step chain at N = 1000, tools/r06_ts5_rows.sh:
             // 5-row tiles 34.7 us, 6 37.2, 4 48.7, 7 39.3)
-            const GeoChain g = geo_chain(N, CA::kD, wpc, kSplit ? 1 : kBlock / 64,
-                                         kSplit ? NF : 1, tune, tall_tiles,
-                                         min_rows < 0 ? (CA::kD < 5 ? CA::kD : 5) : min_rows);
+            const GeoPairs g = geo_chain_pairs(N, CA::kD, wpc, kSplit ? 2 : kBlock / 64,
+                                               kSplit ? NF : 1, tune, tall_tiles,
+                                               min_rows < 0 ? (CA::kD < 5 ? CA::kD : 5)
+                                                            : min_rows);
             if (decltype(kind)::value == ESQ_EPI_SOLERR ||
                 decltype(kind)::value == ESQ_EPI_ERRNORM) {
                 if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
@@ -491,12 +520,11 @@ struct Stencil2D {
             }
             if (chain->read_amplification)
                 *chain->read_amplification =
-                    (double)(g.R + 2 * (CA::kD - 1) + (kFrom ? 2 : 0)) / g.R * 64.0 /
+                    (double)(g.R + (CA::kD - 1) + (kFrom ? 2 : 0)) / g.R * 64.0 /
                     (64 - 2 * (CA::kD - 1));
             hipExtLaunchKernelGGL(kern, dim3(g.grid), dim3(block), 0, (hipStream_t)stream,
                                   (hipEvent_t)start_event, (hipEvent_t)stop_event, 0, y_in, ca,
-                                  fn, N, g.R, g.tpr, g.ntiles, g.nblocks, (unsigned)kXcd,
-                                  chain_serpentine());
+                                  fn, N, g.npr, g.tpr, g.ntiles, g.nblocks, (unsigned)kXcd);
         };
         // (several fields in one wave: the register budget ends at depth 4)
         constexpr int kDeepest = (split || NF == 1) ? 6 : 4;
