@@ -356,7 +356,7 @@ class SSV2stab(_LazyStateMixin, OdeSolver):
         # (lazy.py): a bound that does not look at y -- `lambda t, y: 12 (N + 1)^2` --
         # costs no download, one that does gets it on first use (round 5: one full
         # device-to-host copy per evaluation either way unless const_jac)
-        if self._lazy_on and self._y_host is None:
+        if getattr(self, "_lazy_on", False) and self._y_host is None:
             y_arg = self._peek_lazy_state()
             sprad = self.rho_jac(t, y_arg)
             if y_arg.materialized:
