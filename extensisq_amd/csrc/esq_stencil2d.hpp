@@ -285,7 +285,10 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
         // (the halo rows are recomputed: the Brusselator's heavier rows want depth + 2,
         // the heat sweeps fill the wave slots down to `depth` rows -- Ts5 at N = 1000:
         // chain5<1> 31 us on 7-row tiles, 27 on 5-row tiles, 36 on 4-row tiles)
-        if (min_rows <= 0) min_rows = depth + 2;
+        // (round 6, diverging pairs -- half the halo rows: five-row tiles at any depth from
+        // 3 on; Pr8 at N = 500, tools/r06_rows_sweep.sh: R = 5 0.069 ms/step, 6 0.075,
+        // 4 0.077, 8 0.091)
+        if (min_rows <= 0) min_rows = depth + 2 < 5 ? depth + 2 : 5;
         if (R < min_rows) R = min_rows;
     }
     if (R > N) R = N;
