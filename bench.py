@@ -480,6 +480,9 @@ def assemble(args, meta, world, n, timing, table, lockstep_on, rccl_nranks,
             "algorithmic_bytes_per_launch":
                 r["algorithmic_bytes"] / launches if launches else None,
             "gbs": r["floor_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            # this kernel's own fraction of the HBM peak on COMPULSORY bytes (VERDICT r05
+            # item 3: per kernel, not only for the dominant class)
+            "frac": r["floor_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
             "l2_side_gbs": r["moved_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else None}
     dom = [r for r in table.values() if r["class"] == meta["klass"]]
     ms = sum(r["total_ms"] for r in dom)

@@ -30,7 +30,7 @@ P = os.path.join(ROOT, "profiles")
 PEAK = 8.0e12
 
 STAGE = ("k_lincomb", "k_block_acc", "rhs+stage", "rhs1+stage", "rhs+block") + tuple(
-    f"chain{d}{suffix}" for d in range(2, 7) for suffix in ("", "+solerr"))
+    f"chain{d}{suffix}" for d in range(2, 7) for suffix in ("", "+solerr", "+errnorm", "+pre"))
 RKC = ("rhs_rkc", "k_rkc_first", "k_rkc_stage") + tuple(f"rkc_chain{d}" for d in range(2, 9))
 
 
@@ -39,7 +39,9 @@ def label(name):
     # marching chain sweeps (round 3): k_chain2d<NF, PERIODIC, D, NU, KINDLAST, Fn>
     m = re.search(r"k_chain2d<\d+, (?:true|false), (\d+), (\d+), (\d+)", name)
     if m:
-        sol = "+solerr" if m.group(3) == "3" else ""
+        # (kind 3 also carries an early estimate -- "+pre" for bench.py: folded below;
+        # kind 4, round 6: the chain runs through the end of an FSAL step)
+        sol = {"3": "+solerr", "4": "+errnorm"}.get(m.group(3), "")
         return f"chain{m.group(1)}{sol}<{m.group(2)}>"
     # 3-D chain sweeps of the explicit pairs (round 5): k_chain3d<D, NU, JT, NW, KINDLAST, St>
     m = re.search(r"k_chain3d<(\d+), (\d+), \d+, \d+, (\d+)", name)
@@ -133,7 +135,7 @@ def one(tag, cfg):
     # step's last Chebyshev chain "...-last"; each is the same kernel for rocprofv3
     events = {}
     for k, v in (bench or {}).get("roofline", {}).get("kernels", {}).items():
-        e = events.setdefault(k.replace("-K<", "<").replace("-last", ""),
+        e = events.setdefault(k.replace("-K<", "<").replace("-last", "").replace("+pre", "+solerr"),
                               {"launches": 0, "us": 0.0, "moved": 0.0, "floor": 0.0})
         e["launches"] += v["launches"]
         e["us"] += v["avg_us"] * v["launches"]
