@@ -58,20 +58,14 @@ def _read_by_solve_ivp(depth=2):
     except ValueError:
         return False
     code = frame.f_code
-    if not (code.co_name == "solve_ivp" and code.co_filename.replace("\\", "/").endswith(
-            "scipy/integrate/_ivp/ivp.py")):
-        return False
-    # with event functions scipy hands the `y` it read here to USER code (`event(t, y)`,
-    # ivp.py:680): that code gets the ndarray the reference gives it -- numba / Cython /
-    # torch.from_numpy callbacks need the buffer, `isinstance(y, np.ndarray)` holds
-    # 
-    try:
-        return frame.f_locals.get("events") is None
-    except Exception:                                         # noqa: BLE001
-        return True
+    return code.co_name == "solve_ivp" and code.co_filename.replace("\\", "/").endswith(
+        "scipy/integrate/_ivp/ivp.py")
 
-def _inside_solve_ivp(max_depth=16):
-    """is scipy's `solve_ivp` among the callers (a solver constructed by it: ivp.py:590)?"""
+def _inside_solve_ivp(max_depth=16, want_events=False):
+    """is scipy's `solve_ivp` among the callers (a solver constructed by it: ivp.py:590)?
+    want_events: ... and was it given event functions?  (Asked ONCE, by the constructor:
+    `frame.f_locals` is a snapshot the frame keeps -- read inside the loop it would hold
+    the previous step's `y` alive, and a mirror somebody still holds is downloaded)"""
     import sys
     try:
         frame = sys._getframe(1)
@@ -83,7 +77,12 @@ def _inside_solve_ivp(max_depth=16):
         code = frame.f_code
         if code.co_name == "solve_ivp" and code.co_filename.replace("\\", "/").endswith(
                 "scipy/integrate/_ivp/ivp.py"):
-            return True
+            if not want_events:
+                return True
+            try:
+                return frame.f_locals.get("events") is not None
+            except Exception:                                 # noqa: BLE001
+                return False
         frame = frame.f_back
     return False
 
@@ -329,6 +328,12 @@ class _LazyStateMixin:
         self._lazy_on = (self._device_rhs is not None and not host_slab
                          and nbytes >= LAZY_MIN_BYTES and mode != "0")
         self._lazy_always = mode == "always"
+        # with event functions scipy hands the `y` it reads after every step to USER code
+        # (`event(t, y)`, ivp.py:680): that code gets the ndarray the reference gives it
+        # -- numba / Cython / torch.from_numpy callbacks need the buffer,
+        # `isinstance(y, np.ndarray)` holds -- so no deferred mirrors then
+        if self._lazy_on and not self._lazy_always and _inside_solve_ivp(want_events=True):
+            self._lazy_on = False
         self._state_gen = 0          # accepted steps: which state the device holds
         self._lazy_live = []         # [weakref(mirror), generation, copy-done event]
         self._lazy_eager = False     # the caller stores its states: copy at once
