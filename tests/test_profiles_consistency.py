@@ -17,7 +17,7 @@ import pytest
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(__file__), ".."))
 P = os.path.join(ROOT, "profiles")
-TAG = "r05"
+TAG = "r06"
 
 
 @pytest.mark.parametrize("config", ["pr8", "ts5", "pr9", "rkc", "pr8_7070", "rkc_400", "pr8_diff3d",
