@@ -15,6 +15,15 @@
 //       T_{k+1}[rho_k] is complete now: it enters stage k+1's window (registers)
 //                      or, for the last stage, is stored (next argument / y_new)
 //
+// A row (or a chain member) that takes no part in a target enters it with weight
+// +0.0 (round 6; the 3-D sweeps since round 5): fma(0, v, s) == s for every finite v,
+// so the values are those of the skipping sums bit for bit, and a non-finite v
+// poisons the target exactly as NumPy's K[:i].T @ A[i, :i] over ALL rows does
+// (common.py:355).  Until round 5 every FMA pair sat behind a participation test
+// (one s_bitcmp + a real branch, i.e. its own basic block): without them the
+// Brusselator's whole-step Ts5 chain runs in 156 instead of 263 us, Pr8's heat chains
+// 11 % faster, the metric's 1-3 % (profiles/r06_experiments.md, section 6).
+//
 // Target e's sum for a row starts when stage 0 visits the row (the K rows read
 // from memory -- ONCE for all D targets; a leading partial sum of the blocked
 // accumulation is simply the first such row, with weight 1) and takes
@@ -118,12 +127,10 @@ struct ChainArgs {
     const double *rows[NUa];         // K rows read from memory (union over targets)
     double cu[D][NUa];               // cu[e][u]: weight of rows[u] in target e + 1
     double eu[NUa];                  // SOLERR: error weights of the last target
-    unsigned umask[D];               // rows that take part in target e + 1's chain
     double ck[D][D];                 // ck[e][k]: weight of K_k in target e + 1 (k <= e)
     double ek[D];                    // SOLERR: error weight of K_k
-    unsigned kmask[D];               // stages whose K takes part in target e + 1
     double c0[NUa];                  // FROMROWS: weights of rows[] in the chain's own
-    unsigned umask0;                 // input T_0 = y + h * sum_u c0[u] rows[u]
+                                     // input T_0 = y + h * sum_u c0[u] rows[u]
     const double *y;                 // base state; nullptr: the chain's own input
     double h;
     double *fk[D];                   // where K_k goes (nullptr: not stored)
@@ -159,7 +166,7 @@ struct ChainArgs {
 // becomes E + three chains.  Same arithmetic, bit-identical.
 // FROMROWS: the chain's input T_0 (the argument of its first stage) is not read from
 // memory but formed from y and the memory rows the chain loads anyway
-// (ca.c0, ca.umask0) -- the previous sweep then need not write it.  The row sets
+// (ca.c0) -- the previous sweep then need not write it.  The row sets
 // are requested one grid row further ahead (T_0's row must exist before stage 0's
 // window takes it) and the targets' sums over a row set wait one iteration.
 template <int NFT, bool PERIODIC, int D, int NU, int KINDLAST, class Fn,
@@ -314,7 +321,6 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
     }
         // FROMROWS: T_0 of the row a set belongs to (same ascending FMA chain, the
         // same two roundings as the sweep that would have written it)
-#define ESQ_XBIT(M, J) (((M) >> (J)) & 1u)
 #define ESQ_CHAIN_FORM_T0(IT, U_, Y_, DST)                                                 \
     {                                                                              \
         const int rho_ = rbase + dirn * ((IT) + 1);                                \
@@ -322,11 +328,8 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                           \
             double2 s0_ = zero;                                                    \
             _Pragma("unroll") for (int j = 0; j < NU; ++j) {                       \
-                if (ESQ_XBIT(um0, j)) {                                            \
-                    asm volatile("");                                              \
-                    s0_.x = fma(w_c0[j], U_[j][f].x, s0_.x);                       \
-                    s0_.y = fma(w_c0[j], U_[j][f].y, s0_.y);                       \
-                }                                                                  \
+                s0_.x = fma(w_c0[j], U_[j][f].x, s0_.x);                           \
+                s0_.y = fma(w_c0[j], U_[j][f].y, s0_.y);                           \
             }                                                                      \
             const double2 t0_ = make_double2(__dadd_rn(Y_[f].x, __dmul_rn(ca.h, s0_.x)), \
                                              __dadd_rn(Y_[f].y, __dmul_rn(ca.h, s0_.y))); \
@@ -341,14 +344,11 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
     _Pragma("unroll") for (int f = 0; f < NF; ++f) {                               \
         double2 s_ = zero, se_ = zero;                                             \
         _Pragma("unroll") for (int j = 0; j < NU; ++j) {                           \
-            if (ESQ_XBIT(um[e], j)) {                  /* uniform */               \
-                asm volatile("");    /* a real branch, not 2 selects per fma */    \
-                s_.x = fma(w_cu[e][j], uc[j][f].x, s_.x);                          \
-                s_.y = fma(w_cu[e][j], uc[j][f].y, s_.y);                          \
-                if (SOLERR && e == D - 1) {                                        \
-                    se_.x = fma(w_eu[j], uc[j][f].x, se_.x);                       \
-                    se_.y = fma(w_eu[j], uc[j][f].y, se_.y);                       \
-                }                                                                  \
+            s_.x = fma(w_cu[e][j], uc[j][f].x, s_.x);                              \
+            s_.y = fma(w_cu[e][j], uc[j][f].y, s_.y);                              \
+            if (SOLERR && e == D - 1) {                                            \
+                se_.x = fma(w_eu[j], uc[j][f].x, se_.x);                           \
+                se_.y = fma(w_eu[j], uc[j][f].y, se_.y);                           \
             }                                                                      \
         }                                                                          \
         S[e][f] = s_;                                                              \
@@ -357,9 +357,6 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
         // FROMROWS: sums and base row of the set that arrived one iteration ago
         double2 sh[D][NF], seh[NF], yh[NF];
         if constexpr (FROMROWS) {
-            unsigned um0 = ca.umask0, um[D];
-#pragma unroll
-            for (int e = 0; e < D; ++e) um[e] = ca.umask[e];
             ESQ_CHAIN_LOAD_ROW(-2)                       // row rbase - dirn
             ESQ_CHAIN_FORM_T0(-2, u, yrow, wm[0])
             ESQ_CHAIN_LOAD_ROW(-1)                       // row rbase
@@ -396,19 +393,7 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                 if (it + 1 < iters) ESQ_CHAIN_LOAD_ROW(it + 1)
             }
             if constexpr (FROMROWS) {
-                unsigned um0 = ca.umask0;
-                asm volatile("" : "+s"(um0));
                 ESQ_CHAIN_FORM_T0(it, uc, ycur, wp[0])
-            }
-            // the participation masks, opaque per row: tested where they are used
-            // (one scalar bit test) instead of 2 x 90 hoisted lane masks that live
-            // in spilled scalar registers
-            unsigned um[D], km[D];
-#pragma unroll
-            for (int e = 0; e < D; ++e) {
-                um[e] = ca.umask[e];
-                km[e] = ca.kmask[e];
-                asm volatile("" : "+s"(um[e]), "+s"(km[e]));
             }
             if constexpr (SPLIT) {
                 // the other fields' centre values, for ALL stages at once: a stage's
@@ -512,14 +497,11 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
                         // K_k enters the sums of the later targets
 #pragma unroll
                         for (int e = k; e < D; ++e) {
-                            if (ESQ_XBIT(km[e], k)) {              // uniform
-                                asm volatile("");
-                                acc[e][k][f].x = fma(w_ck[e][k], fK[f].x, acc[e][k][f].x);
-                                acc[e][k][f].y = fma(w_ck[e][k], fK[f].y, acc[e][k][f].y);
-                                if (SOLERR && e == D - 1) {
-                                    acce[k][f].x = fma(w_ek[k], fK[f].x, acce[k][f].x);
-                                    acce[k][f].y = fma(w_ek[k], fK[f].y, acce[k][f].y);
-                                }
+                            acc[e][k][f].x = fma(w_ck[e][k], fK[f].x, acc[e][k][f].x);
+                            acc[e][k][f].y = fma(w_ck[e][k], fK[f].y, acc[e][k][f].y);
+                            if (SOLERR && e == D - 1) {
+                                acce[k][f].x = fma(w_ek[k], fK[f].x, acce[k][f].x);
+                                acce[k][f].y = fma(w_ek[k], fK[f].y, acce[k][f].y);
                             }
                         }
                         // target k + 1 is complete for this row
@@ -601,6 +583,5 @@ __global__ __launch_bounds__(kBlock) void k_chain2d(
 #undef ESQ_CHAIN_LOAD_ROW
 #undef ESQ_CHAIN_FORM_T0
 #undef ESQ_CHAIN_ROW_SUMS
-#undef ESQ_XBIT
 
 }  // namespace esq

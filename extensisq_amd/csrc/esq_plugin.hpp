@@ -207,16 +207,15 @@ ChainArgs<D, NU> make_chain_args(const esq_chain *c) {
         a.eu[j] = on ? c->eu[j] : 0.0;
         for (int e = 0; e < D; ++e) a.cu[e][j] = on ? c->cu[e][j] : 0.0;
     }
+    // (umask / kmask of the descriptor: who takes part in which target.  These sweeps do
+    // not test them -- a row that takes no part has weight +0.0, esq_chain.hpp)
     for (int e = 0; e < D; ++e) {
-        a.umask[e] = c->umask[e];
-        a.kmask[e] = c->kmask[e];
         a.ek[e] = c->ek[e];
         a.fk[e] = c->f_out[e];
         for (int k = 0; k < D; ++k) a.ck[e][k] = c->ck[e][k];
     }
     for (int j = 0; j < ChainArgs<D, NU>::NUa; ++j)
         a.c0[j] = (c->from_rows && j < NU && j < c->nu) ? c->c0[j] : 0.0;
-    a.umask0 = c->from_rows ? c->umask0 : 0u;
     a.y = c->y; a.h = c->h; a.out = c->out; a.f_nt = c->f_store_nt;
     a.ld_nt = (unsigned)c->load_nt;
     a.red.atol_vec = c->atol_vec; a.red.atol_s = c->atol_s; a.red.rtol = c->rtol;

@@ -191,7 +191,10 @@ typedef int (*esq_rhs_fused_fn)(void *user, double t, const double *y_in,
  * are read once for the whole chain.  rows[] is the union of the K rows any
  * target reads from memory, in ascending column order; bit u of umask[e] (bit k
  * of kmask[e]) says whether rows[u] (K_{i+k}) takes part in target e+1's sum --
- * a row that does not is skipped, not multiplied by zero.  A leading partial
+ * the weight of one that does not is +0.0, so a plugin may skip it or multiply
+ * through (fma(0, v, s) == s for finite v; a non-finite v then poisons the target as
+ * NumPy's K[:i].T @ A[i,:i] over all rows does, common.py:355; the built-in sweeps
+ * multiply through since ABI 8: no test per term).  A leading partial
  * sum of the blocked accumulation is passed as the FIRST row of its target with
  * weight 1 (fma(1, p, 0) == p).  Every sum runs over ascending column index
  * (rows, then the chain's own K in order), each
