@@ -610,7 +610,8 @@ hipError_t lane_copy(int device, hipStream_t stream, void *host, const void *dev
         CopyLane &ln = g_lane[device];
         // (two downloads that shared the lane halved each other's rate: neither says
         // anything about the memory it read from)
-        alone = alone && --ln.busy == 0;
+        const bool last_out = --ln.busy == 0;
+        alone = alone && last_out;
         if (e == hipSuccess) {
             ln.last_gbs = gbs;
             if (alone && gbs > ln.best_gbs) ln.best_gbs = gbs;
