@@ -41,8 +41,7 @@ SIGNATURES = {
     "esq_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "esq_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "esq_create": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int]),
-    "esq_create2": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]),
-    "esq_create3": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int,
+    "esq_create2": (C.c_int, [_vpp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int,
                               C.c_char_p]),
     "esq_option_level": (C.c_int, [C.c_char_p]),
     "esq_rhs_set_options": (C.c_int, [_vp, C.c_char_p]),
@@ -89,17 +88,11 @@ SIGNATURES = {
     "esq_rk_lazy_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "esq_plan_describe": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                    C.c_char_p, C.c_size_t]),
-    "esq_plan_describe_pre": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
-                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                        _vp, _vp, C.c_int, C.c_char_p, C.c_size_t]),
-    "esq_step_dry_run_pre": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
-                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                       _vp, _vp, C.c_int, _vp, C.c_int, C.c_char_p,
-                                       C.c_size_t]),
+                                    _vp, _vp, C.c_int, C.c_char_p, C.c_size_t]),
     "esq_step_dry_run": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                   _vp, C.c_int, C.c_char_p, C.c_size_t]),
+                                   _vp, _vp, C.c_int, _vp, C.c_int, C.c_char_p,
+                                   C.c_size_t]),
     "esq_dense_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int,
                                    _vpp]),
     "esq_dense_create_vecs": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vpp]),
@@ -208,7 +201,7 @@ class Options:
     `solve_ivp(..., method=Pr8, esq_options={"chain_depth": 1})`): the `ESQ_*` switches of
     DESIGN.md §3.4, lower case without the prefix.  Nothing here writes the process
     environment (until round 5 the keyword did, for the duration of the constructor):
-    the library's own switches travel as an options string to `esq_create3` /
+    the library's own switches travel as an options string to `esq_create2` /
     `esq_rhs_set_options`, the package's are looked up with `get`.  A key that is
     neither is refused.  A switch the caller does not give takes the process default
     `ESQ_<KEY>` -- read, never written."""
@@ -254,7 +247,7 @@ class Options:
 
     @property
     def context_string(self):
-        """the switches of an `esq_ctx` (esq_create3)"""
+        """the switches of an `esq_ctx` (esq_create2)"""
         return self._string(1)
 
     @property

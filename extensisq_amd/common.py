@@ -34,7 +34,7 @@ LAZY_MIN_BYTES = 8 << 20       # states below this are downloaded at once
 def _with_esq_options(init):
     """constructor decorator: the `esq_options=` keyword -- this solver's tuning switches
     (`_lib.Options`: the ESQ_* switches of DESIGN.md §3.4, lower case without the
-    prefix).  They travel as ARGUMENTS -- to `esq_create3`, to `esq_rhs_set_options`, to
+    prefix).  They travel as ARGUMENTS -- to `esq_create2`, to `esq_rhs_set_options`, to
     this package's own decisions -- and nothing writes the process environment (until
     round 5 the keyword did, for the duration of the constructor: switches read later
     had no effect, two threads constructing solvers raced).  Unknown keys: ValueError."""

@@ -692,13 +692,9 @@ int esq_device_pci_bus_id(int device, char *buf, size_t buflen) {
 }
 
 int esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex) {
-    return esq_create2(out, device, n, n_rows, is_complex, 0);
+    return esq_create2(out, device, n, n_rows, is_complex, 0, nullptr);
 }
 int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
-                int flags) {
-    return esq_create3(out, device, n, n_rows, is_complex, flags, nullptr);
-}
-int esq_create3(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
                 int flags, const char *options) {
     if (!out || n_rows < 1 || n_rows > 64) return ESQ_EINVAL;
     esq_ctx *c = new (std::nothrow) esq_ctx();
@@ -709,7 +705,7 @@ int esq_create3(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
         // process default ESQ_<KEY> (esq_options.hpp)
         std::string bad;
         if (c->opts.parse(options, esq::kOptContext, &bad) != 0)
-            return fail(c, ESQ_EINVAL, "esq_create3: '%s' is not a context option "
+            return fail(c, ESQ_EINVAL, "esq_create2: '%s' is not a context option "
                         "(esq_option_level)", bad.c_str());
     }
     const esq::Options &o = c->opts;

@@ -203,7 +203,7 @@ struct esq_ctx : esqi::StepState {
         unsigned long long seq = 0;       // estimates published so far
         long fused = 0, plain = 0;        // inside a chain sweep / by k_pre_error
     } pre;
-    esq::Options opts;                    // this context's switches (esq_create3)
+    esq::Options opts;                    // this context's switches (esq_create2)
     bool plan_debug = false;              // PLAN_DEBUG: the planner's queries on stderr
     bool block_acc = true;                // BLOCK_ACC=0: no blocked accumulation
     bool detached = false;                // no device behind the context (esq_plan_describe)

@@ -6,7 +6,7 @@
 // one solver to the next, and setenv raced with getenv in worker threads (ADVICE
 // r05).  Now a switch is a (key, value) pair of the object it steers:
 //
-//   esq_create3(..., "chain_depth=3;lazy_rows=0")        the context's switches
+//   esq_create2(..., "chain_depth=3;lazy_rows=0")        the context's switches
 //   esq_rhs_set_options(user, "chain_rows=12")           a built-in plugin object's
 //
 // and the process environment (ESQ_<KEY>) is only the DEFAULT of a key the caller did
@@ -30,7 +30,7 @@ inline const char *env_get(const char *key) {
     return getenv(name);
 }
 
-// which object a key steers: 1 = a context (esq_create3), 2 = a plugin object
+// which object a key steers: 1 = a context (esq_create2), 2 = a plugin object
 // (esq_rhs_set_options), 0 = not a switch of the library
 constexpr int kOptContext = 1, kOptPlugin = 2;
 struct OptionKey {

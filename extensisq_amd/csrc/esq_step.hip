@@ -1647,14 +1647,6 @@ static int make_detached(esq_ctx *c, void **user_out, const char *plugin, int N,
 }
 
 int esq_plan_describe(const char *plugin, int N, int s, const double *A, const double *B,
-                      const double *C, const double *E, int fsal, int chain_caps,
-                      int fuse_mask, int lazy_rows, int chain_depth, int src_pays, char *buf,
-                      size_t buflen) {
-    return esq_plan_describe_pre(plugin, N, s, A, B, C, E, fsal, chain_caps, fuse_mask,
-                                 lazy_rows, chain_depth, src_pays, nullptr, nullptr, 0, buf,
-                                 buflen);
-}
-int esq_plan_describe_pre(const char *plugin, int N, int s, const double *A, const double *B,
                           const double *C, const double *E, int fsal, int chain_caps,
                           int fuse_mask, int lazy_rows, int chain_depth, int src_pays,
                           const double *e_pre, const double *b_pre, int pre_rows, char *buf,
@@ -1732,14 +1724,6 @@ bool same_state(const StepState &a, const StepState &b) {
 }
 }  // namespace
 int esq_step_dry_run(const char *plugin, int N, int s, const double *A, const double *B,
-                     const double *C, const double *E, int fsal, int chain_caps,
-                     int fuse_mask, int lazy_rows, int chain_depth, int src_pays,
-                     const int *script, int n_attempts, char *buf, size_t buflen) {
-    return esq_step_dry_run_pre(plugin, N, s, A, B, C, E, fsal, chain_caps, fuse_mask, lazy_rows,
-                                chain_depth, src_pays, nullptr, nullptr, 0, script, n_attempts,
-                                buf, buflen);
-}
-int esq_step_dry_run_pre(const char *plugin, int N, int s, const double *A, const double *B,
                          const double *C, const double *E, int fsal, int chain_caps,
                          int fuse_mask, int lazy_rows, int chain_depth, int src_pays,
                          const double *e_pre, const double *b_pre, int pre_rows,

@@ -237,7 +237,7 @@ class DeviceContext:
         self.host_slab = (bool(host_rhs) and doubles <= self.HOST_SLAB_MAX_DOUBLES
                           and self.options.get("host_slab", "1") != "0")
         handle = C.c_void_p()
-        code = self.lib.esq_create3(
+        code = self.lib.esq_create2(
             C.byref(handle), self.device, self.n, self.n_rows,
             int(self.is_complex), _lib.CREATE_HOST_SLAB if self.host_slab else 0,
             self.options.context_string)

@@ -350,9 +350,7 @@ int  esq_create(esq_ctx **out, int device, size_t n, int n_rows, int is_complex)
  * removes two copy-engine round trips per stage.  Meant for vectors of at most
  * a few thousand doubles: kernels then read their operands over PCIe. */
 #define ESQ_CREATE_HOST_SLAB 1
-int  esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
-                 int flags);
-/* ... with THIS context's tuning switches: `options` is
+/* ... and THIS context's tuning switches (since ABI 8): `options` is
  * "key=value;key=value" (keys in any case, with or without the ESQ_ prefix; NULL or ""
  * for none), e.g. "chain_depth=1;lazy_rows=0".  A key the caller does not give takes the
  * process default -- the environment variable ESQ_<KEY>, read now, on this thread -- so
@@ -360,7 +358,7 @@ int  esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex
  * unknown key, or one that steers a plugin object (esq_rhs_set_options), is refused:
  * ESQ_EINVAL, the key in esq_last_error.  esq_option_level: 1 = a context's switch,
  * 2 = a plugin object's, 0 = not a switch of the library. */
-int  esq_create3(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
+int  esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
                  int flags, const char *options);
 int  esq_option_level(const char *key);
 int  esq_destroy(esq_ctx *ctx);
@@ -579,19 +577,14 @@ int  esq_rk_download_last_K(esq_ctx *ctx, int row, double *host);
  * library's queries on the host).  One line per starting state of a step:
  *   first / deferred / prelaunched: <launch> ... | launches=<n> words=<r>+<w> cost=<c>
  * (designed 8-byte words per element read + written, halo re-reads not counted; the
- * planner's cost of the sequence, which it minimises).
+ * planner's cost of the sequence, which it minimises).  pre_rows != 0: with that early
+ * estimate registered (esq_rk_set_pre) -- the whole-step program of BS5 / CFMR7osc.
  * tests/test_step_plans.py pins the plans of every tableau with it. */
 int  esq_plan_describe(const char *plugin, int N, int s, const double *A,
                        const double *B, const double *C, const double *E, int fsal,
                        int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
-                       int src_pays, char *buf, size_t buflen);
-/* the same with an early estimate registered (esq_rk_set_pre): the whole-step program
- * of BS5 / CFMR7osc; pre_rows == 0: none */
-int  esq_plan_describe_pre(const char *plugin, int N, int s, const double *A,
-                           const double *B, const double *C, const double *E, int fsal,
-                           int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
-                           int src_pays, const double *e_pre, const double *b_scale_pre,
-                           int pre_rows, char *buf, size_t buflen);
+                       int src_pays, const double *e_pre, const double *b_scale_pre,
+                       int pre_rows, char *buf, size_t buflen);
 /* Whole steps on a context WITHOUT a device: the host side of the step -- plans, row
  * maps, the first launch ahead of time and what it saves and restores, rows left
  * unwritten, the deferred end-point derivative -- with every launch replaced by the
@@ -612,17 +605,9 @@ int  esq_plan_describe_pre(const char *plugin, int N, int s, const double *A,
 int  esq_step_dry_run(const char *plugin, int N, int s, const double *A,
                       const double *B, const double *C, const double *E, int fsal,
                       int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
-                      int src_pays, const int *script, int n_attempts, char *buf,
+                      int src_pays, const double *e_pre, const double *b_scale_pre,
+                      int pre_rows, const int *script, int n_attempts, char *buf,
                       size_t buflen);
-/* the same with an early estimate registered: every attempt then also reads its
- * estimate (esq_rk_pre_result); the lines end in
- *   pre=<this attempt's number>/<published so far> fused=<n> plain=<n> */
-int  esq_step_dry_run_pre(const char *plugin, int N, int s, const double *A,
-                          const double *B, const double *C, const double *E, int fsal,
-                          int chain_caps, int fuse_mask, int lazy_rows, int chain_depth,
-                          int src_pays, const double *e_pre, const double *b_scale_pre,
-                          int pre_rows, const int *script, int n_attempts, char *buf,
-                          size_t buflen);
 /* Rows of K that only the solution / error sums of their own sweep read (the
  * stages of a step's last chain sweep, non-FSAL pairs: `self.K[s] = f` of
  * common.py:355 for rows nothing in `_step_impl` reads again) are NOT written

@@ -247,7 +247,7 @@ def test_full_size_three_steps_match_oracle_early_estimate_pairs(name, plugin, N
 
 
 def test_eight_threads_construct_solvers_with_their_own_switches():
-    """`esq_options=` travels as arguments (esq_create3 / esq_rhs_set_options), not through
+    """`esq_options=` travels as arguments (esq_create2 / esq_rhs_set_options), not through
     the process environment: eight threads construct and step solvers with DIFFERENT
     chain depths and tile heights at the same moment, each gets the plan of its own
     switches -- and all eight states are the same bits (ADVICE r05

@@ -182,7 +182,7 @@ def test_an_aborted_communicator_is_dropped_by_every_attached_context():
 
 def test_esq_options_travel_as_arguments_not_through_the_environment(monkeypatch):
     """`esq_options=` of a solver constructor (`_lib.Options`): this solver's switches.
-    The library's travel as strings to esq_create3 (a context's) / esq_rhs_set_options (a
+    The library's travel as strings to esq_create2 (a context's) / esq_rhs_set_options (a
     plugin object's), the package's are looked up; a switch that was not given takes the
     process default ESQ_<KEY> -- READ, never written: the environment is untouched, so
     two threads may construct solvers with different switches.  A key that is not a

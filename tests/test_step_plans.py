@@ -289,16 +289,12 @@ def _dry(cls, plugin, N, script=SCRIPT, caps=15 | gsp.CAP_QUERY, lazy=1, depth=4
     sc = np.asarray(script, dtype=np.int32)
     buf = C.create_string_buffer(1 << 15)
     fuse = gsp.FUSE_ALL | gsp.FUSE_SRC | gsp.FUSE_QUERY
-    if pre is not None:
-        e, b = [np.ascontiguousarray(x, dtype=float) for x in pre]
-        r = lib.esq_step_dry_run_pre(plugin.encode(), N, s, *[_lib.as_ptr(a) for a in arrs],
-                                     fsal, caps, fuse, lazy, depth, src, _lib.as_ptr(e),
-                                     _lib.as_ptr(b), len(e), sc.ctypes.data_as(C.c_void_p),
-                                     len(sc), buf, len(buf))
-    else:
-        r = lib.esq_step_dry_run(plugin.encode(), N, s, *[_lib.as_ptr(a) for a in arrs], fsal,
-                                 caps, fuse, lazy, depth, src, sc.ctypes.data_as(C.c_void_p),
-                                 len(sc), buf, len(buf))
+    e, b = ([np.ascontiguousarray(x, dtype=float) for x in pre] if pre is not None
+            else (np.zeros(1), np.zeros(1)))
+    r = lib.esq_step_dry_run(plugin.encode(), N, s, *[_lib.as_ptr(a) for a in arrs], fsal, caps,
+                             fuse, lazy, depth, src, _lib.as_ptr(e), _lib.as_ptr(b),
+                             len(e) if pre is not None else 0, sc.ctypes.data_as(C.c_void_p),
+                             len(sc), buf, len(buf))
     assert r == 0, r
     rows = []
     for ln in buf.value.decode().strip().split("\n"):

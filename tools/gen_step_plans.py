@@ -54,14 +54,11 @@ def describe(lib, as_ptr, cls, plugin, N, caps, fuse, lazy, depth=4, src=0, pre=
     arrs = [np.ascontiguousarray(getattr(cls, k), dtype=float) for k in "ABCE"]
     fsal = int(arrs[3][s] != 0)
     buf = C.create_string_buffer(1 << 15)
-    if pre is not None:
-        e, b = [np.ascontiguousarray(x, dtype=float) for x in pre]
-        r = lib.esq_plan_describe_pre(plugin.encode(), N, s, *[as_ptr(a) for a in arrs], fsal,
-                                      caps, fuse, lazy, depth, src, as_ptr(e), as_ptr(b),
-                                      len(e), buf, len(buf))
-    else:
-        r = lib.esq_plan_describe(plugin.encode(), N, s, *[as_ptr(a) for a in arrs], fsal,
-                                  caps, fuse, lazy, depth, src, buf, len(buf))
+    e, b = ([np.ascontiguousarray(x, dtype=float) for x in pre] if pre is not None
+            else (np.zeros(1), np.zeros(1)))
+    r = lib.esq_plan_describe(plugin.encode(), N, s, *[as_ptr(a) for a in arrs], fsal, caps,
+                              fuse, lazy, depth, src, as_ptr(e), as_ptr(b),
+                              len(e) if pre is not None else 0, buf, len(buf))
     if r:
         raise RuntimeError(f"esq_plan_describe({cls}, {plugin}) -> {r}")
     return buf.value.decode().strip().split("\n")
