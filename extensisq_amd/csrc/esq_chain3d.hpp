@@ -302,6 +302,9 @@ __global__ __launch_bounds__(64 * NW) void k_chain3d(const double *__restrict__ 
 // Shapes (rows per thread x waves per workgroup) by depth: the windows, the targets'
 // travelling sums, the base-state delay line and one plane of operands in flight
 // are (2 D + D (D + 1) / 2 + D [+ D] + NU + 2) JT doubles per thread.
+// (round 6: the 1024-thread workgroup caps these kernels at 128 VGPRs -- the wide ones
+// spill, chain3+solerr<9>: 108 scalar and 2 vector registers -- but 4 x 8 and 3 x 8, which
+// do not, are 8-12 % slower at N = 159 and 5 % at N = 400: profiles/r06_experiments.md, 7)
 template <int D>
 struct Chain3dShape {
     static constexpr int JT = 2, NW = 16;
