@@ -77,6 +77,7 @@ SIGNATURES = {
     "esq_rk_set_launch_ahead": (C.c_int, [_vp, C.c_int]),
     "esq_rk_launch_ahead_stats": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "esq_rk_pre_error": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, _dp]),
+    "esq_rk_attempt": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, _dp, _dp]),
     "esq_rk_set_pre": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "esq_rk_pre_result": (C.c_int, [_vp, _dp]),
     "esq_rk_custom_sol_err": (C.c_int, [_vp, C.c_double, _vp, _vp, C.c_int, C.c_int,

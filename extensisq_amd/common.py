@@ -13,6 +13,7 @@ attempt.
 There is no CPU implementation of the step in this package: without the built
 library and a GPU the constructor raises `DeviceError`.
 """
+import ctypes
 import logging
 import os
 from math import copysign, sqrt
@@ -903,6 +904,17 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
             y_stage = self._dev.download(SLOT_YSTAGE)
             self._dev.upload(SLOT_K, i, self.fun(t + self.C[i] * h, y_stage))
 
+    def _attempt(self, t, h, h_next=0.0, want_pre=False):
+        """stages 1 .. s - 1, the solution and the error estimate(s) of one attempt with
+        a device RHS, ONE call into the library: -> (sumsq, pre_sumsq or None); counts the
+        evaluations of a full attempt"""
+        out, pre = ctypes.c_double(), ctypes.c_double()
+        self._chk(self._lib.esq_rk_attempt(self._ctx, t, h, h_next, ctypes.byref(out),
+                                           ctypes.byref(pre) if want_pre else None),
+                  "esq_rk_attempt")
+        self.nfev += self.n_stages - 1 + self.FSAL
+        return out.value, (pre.value if want_pre else None)
+
     def _solution_and_error(self, t, h, h_next=0.0):
         """`_comp_sol_err` (ref common.py:341-351): returns the error norm,
         leaves y_new in the YNEW slot.  `h_next`: the next step size if this
@@ -983,15 +995,14 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
             if self._pre_whole:
                 if self._lockstep is not None:
                     self._lockstep.check_identical(self._dev, "(t, h)", (t, h))
-                self._chk(self._lib.esq_rk_stages(self._ctx, 1, s, t, h), "esq_rk_stages")
-                sumsq = self._dev.rk_solution_error_sumsq(
-                    t, h, self._guess_next_step(t_new, h_abs))
-                pre = self._rms_from_sumsq(self._dev.rk_pre_result_sumsq())
-                self.nfev += s - 2
+                sumsq, pre_sq = self._attempt(t, h, self._guess_next_step(t_new, h_abs),
+                                              want_pre=True)
+                pre = self._rms_from_sumsq(pre_sq)
                 if not pre > 1:
-                    self.nfev += 1 + self.FSAL
                     error_norm = self._rms_from_sumsq(sumsq)
                 else:
+                    # (the speculative tail: thrown away, not counted)
+                    self.nfev -= 1 + self.FSAL
                     self.pre_discards += 1
             else:
                 self._run_stages(1, s - 1, t, h)
@@ -1039,8 +1050,13 @@ class RungeKutta(_LazyStateMixin, OdeSolver):
             t_new = t + h
             if self._lockstep is not None:
                 self._lockstep.check_identical(self._dev, "(t, h)", (t, h))
-            self._run_stages(1, self.n_stages, t, h)
-            error_norm = self._solution_and_error(t, h, self._guess_next_step(t_new, h_abs))
+            if self._device_rhs is not None:
+                # the whole attempt in one call (esq_rk_attempt)
+                error_norm = self._rms_from_sumsq(
+                    self._attempt(t, h, self._guess_next_step(t_new, h_abs))[0])
+            else:
+                self._run_stages(1, self.n_stages, t, h)
+                error_norm = self._solution_and_error(t, h)
             if error_norm < 1:
                 h_abs *= self._accept_factor(error_norm, h, rejected)
                 break

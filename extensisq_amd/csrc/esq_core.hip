@@ -32,6 +32,19 @@ __global__ __launch_bounds__(1024) void k_final_sum(
         publish(rs, t);
     }
 }
+// few partials (the sweeps of small grids, where a step is bound by its launches:
+// config 2's whole-step chain has 504): ONE wave, lane-strided sums and the wave64 tree --
+// no LDS, no workgroup barrier, a quarter of the 1024-thread kernel's time.  The order
+// of the sum is fixed (lane l takes partials l, l + 64, ...), as the big kernel's is.
+__global__ __launch_bounds__(64) void k_final_sum_small(
+    const double *__restrict__ partials, int count, ResultSink rs) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += 64) s += partials[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) publish(rs, s);
+}
+constexpr int kSmallSumMax = 2048;
+
 // after the lock-step all-reduce: device double -> host slot
 __global__ void k_publish(const double *__restrict__ src, ResultSink rs) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -241,6 +254,9 @@ int finish_reduction(esq_ctx *c, double *out, bool take_min, const double *parti
     if (take_min)
         hipLaunchKernelGGL(k_final_min, dim3(1), dim3(1024), 0, c->stream,
                            partials, count, rs);
+    else if (count <= kSmallSumMax)
+        hipLaunchKernelGGL(k_final_sum_small, dim3(1), dim3(64), 0, c->stream,
+                           partials, count, rs);
     else
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(1024), 0, c->stream,
                            partials, count, rs);
@@ -290,7 +306,11 @@ int publish_pre(esq_ctx *c, const double *partials, int count) {
     rs.host_value = c->comm ? nullptr : &slot.value;
     double *dev = c->d_result + 8 + (seq % kPreSlots);
     rs.dev = c->comm ? dev : nullptr;
-    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(1024), 0, c->stream, partials, count, rs);
+    if (count <= kSmallSumMax)
+        hipLaunchKernelGGL(k_final_sum_small, dim3(1), dim3(64), 0, c->stream, partials, count,
+                           rs);
+    else
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(1024), 0, c->stream, partials, count, rs);
     HIPCHK(c, hipGetLastError());
     if (c->comm) {
         const int r = g_rccl.AllReduce(dev, dev, 1, kNcclFloat64, kNcclSum, c->comm, c->stream);

@@ -1857,6 +1857,21 @@ int esq_rk_solution_error_ahead(esq_ctx *c, double t, double h, double h_next,
     c->ahead_ask_h = 0.0;
     return r;
 }
+// one call for a whole attempt of a device-RHS step: esq_rk_stages(1, s, t, h), then
+// esq_rk_solution_error_ahead(t, h, h_next) -- on small grids a step is bound by the
+// host's share (config 2: 23 us of kernel, 33 us of step), and every call through the
+// binding is a microsecond of it.  pre_sumsq_out (may be NULL): the early estimate of
+// the attempt where one is registered (esq_rk_set_pre), else untouched.
+int esq_rk_attempt(esq_ctx *c, double t, double h, double h_next, double *sumsq_out,
+                   double *pre_sumsq_out) {
+    if (!c || !sumsq_out) return ESQ_EINVAL;
+    int r = esq_rk_stages(c, 1, c->s, t, h);
+    if (r) return r;
+    r = esq_rk_solution_error_ahead(c, t, h, h_next, sumsq_out);
+    if (r) return r;
+    if (pre_sumsq_out && c->pre.rows && c->pre_last_seq) r = esq_rk_pre_result(c, pre_sumsq_out);
+    return r;
+}
 int esq_rk_solution_error(esq_ctx *c, double t, double h, double *sumsq_out) {
     if (!c || !sumsq_out) return ESQ_EINVAL;
     const bool ynew_ready = c->ynew_ready, solerr_ready = c->solerr_ready;

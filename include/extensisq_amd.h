@@ -521,6 +521,12 @@ int  esq_rk_solution_error(esq_ctx *ctx, double t, double h, double *sumsq_out);
  * and the first launch is enqueued (~17 us per step).  Needs esq_rk_set_launch_ahead. */
 int  esq_rk_solution_error_ahead(esq_ctx *ctx, double t, double h, double h_next,
                                  double *sumsq_out);
+/* A whole attempt of a step in ONE call: esq_rk_stages(ctx, 1, s, t, h) followed by
+ * esq_rk_solution_error_ahead(ctx, t, h, h_next, sumsq_out) (h_next == 0: no launch ahead)
+ * -- and, pre_sumsq_out != NULL with an early estimate registered, esq_rk_pre_result.  On
+ * small grids the host's share bounds the step; this saves two trips through the binding. */
+int  esq_rk_attempt(esq_ctx *ctx, double t, double h, double h_next, double *sumsq_out,
+                    double *pre_sumsq_out);
 /* BS5's early estimate (bogacki.py:340-346) over K[0..rows): YSTAGE-free,
  * y_pre = Y + h*sum b_scale_pre[j] K[j] is formed in registers only.
  * Synchronises. */
