@@ -224,16 +224,17 @@ inline int chain_waves_per_cu(Kernel kern, unsigned block) {
     if (waves > 32) waves = 32;
     return waves;
 }
-// a chain of depth D carries 2(D-1) halo rows per tile and marches row by row: on
-// grids below ~450 x 450 a step is bound by its launches and D single sweeps are
-// as fast or faster (tools/small_chain_sweep.py: Brusselator Pr8 at N = 316 78 us
-// unchained, 87 with depth-2 chains; at N = 500 100 against 87..98 chained; heat
-// Pr9 at N = 448 90 against 98); ESQ_CHAIN_ROWS (tests) lifts the rule
+// Until round 5 a chain tile carried 2(D-1) halo rows and the plugins refused chains on
+// grids below ~450 x 450, where D single sweeps were as fast (Pr8 at N = 316: 78 us
+// unchained, 87 chained).  With diverging pairs (no run-in rows), no test per FMA pair and
+// four-row tiles the chains win down to N = 96 -- Pr8 on the Brusselator 0.066 -> 0.050
+// ms/step there, 0.095 -> 0.056 at N = 448; Ts5 on the heat plugin 0.033 -> 0.023 at
+// N = 128 (tools/r06_small_grids.sh): round 2's "65 us launch floor" of small device-RHS
+// states was a floor of thirteen launches.  Below N = 64 the single sweeps stay
+// (ESQ_CHAIN_ROWS / the chain_rows option lifts the rule: tests).
 inline bool chain_fits_grid(int N, int depth, const ChainTuning &tune) {
-    if (tune.rows_set) return true;
-    const int W = 64 - 2 * (depth - 1);
-    const size_t tpr = ((size_t)N / 2 + W - 1) / W;
-    return (size_t)N * tpr >= 2048;
+    (void)depth;
+    return tune.rows_set || N >= 64;
 }
 // tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
 // share one tile (the split sweeps: one per field)
@@ -285,10 +286,11 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
         // (the halo rows are recomputed: the Brusselator's heavier rows want depth + 2,
         // the heat sweeps fill the wave slots down to `depth` rows -- Ts5 at N = 1000:
         // chain5<1> 31 us on 7-row tiles, 27 on 5-row tiles, 36 on 4-row tiles)
-        // (round 6, diverging pairs -- half the halo rows: five-row tiles at any depth from
-        // 3 on; Pr8 at N = 500, tools/r06_rows_sweep.sh: R = 5 0.069 ms/step, 6 0.075,
-        // 4 0.077, 8 0.091)
-        if (min_rows <= 0) min_rows = depth + 2 < 5 ? depth + 2 : 5;
+        // (independent tiles with run-in rows -- the Chebyshev chains: depth + 2 unless
+        // the caller says otherwise; the diverging pairs of the explicit chains: four-row
+        // tiles where the grid does not fill the wave slots -- Pr8 at N = 448,
+        // tools/r06_small_grids.sh: R = 4 0.056 ms/step, 5 0.060, 6 0.069, 8 0.075)
+        if (min_rows <= 0) min_rows = depth + 2;
         if (R < min_rows) R = min_rows;
     }
     if (R > N) R = N;
@@ -320,6 +322,14 @@ inline GeoPairs geo_chain_pairs(int N, int depth, int waves_per_cu, int tiles_pe
     // second round (first version: 52 instead of 51 tile rows at N = 2236 put 2080
     // waves on 2048 slots -- chain5<0> 102 -> 162 us)
     p.npr = ((N + g.R - 1) / g.R) / 2;
+    {
+        // ... unless there is room: then pairs of at most 2R rows, so that no tile is
+        // taller than R (N = 500, R = 4: 63 pairs of 7.9 rows instead of 62 of 8.1, whose
+        // five-row tiles set the pace of every workgroup)
+        const int up = (N + 2 * g.R - 1) / (2 * g.R);
+        const size_t slots = (size_t)device_cus() * (size_t)waves_per_cu;
+        if ((size_t)2 * up * g.tpr * (size_t)waves_per_tile <= slots) p.npr = up;
+    }
     if (p.npr > N / 2) p.npr = N / 2;
     if (p.npr < 1) p.npr = 1;
     p.ntiles = 2u * p.tpr * (unsigned)p.npr;
@@ -509,13 +519,10 @@ struct Stencil2D {
             // kBlock / 128 pairs of one-wave tiles)
             const unsigned block = kSplit ? 128u * NF : (unsigned)kBlock;
             static const int wpc = chain_waves_per_cu(kern, block);   // per instantiation
-            // (min_rows < 0, light one-field rows: tiles down to `depth` rows, five at
-            // depth 6 -- Ts5's whole-step chain at N = 1000, tools/r06_ts5_rows.sh:
-            // 5-row tiles 34.7 us, 6 37.2, 4 48.7, 7 39.3)
             const GeoPairs g = geo_chain_pairs(N, CA::kD, wpc, kSplit ? 2 : kBlock / 64,
                                                kSplit ? NF : 1, tune, tall_tiles,
-                                               min_rows < 0 ? (CA::kD < 5 ? CA::kD : 5)
-                                                            : min_rows);
+                                               /*min_rows=*/4);
+            (void)min_rows;
             if (decltype(kind)::value == ESQ_EPI_SOLERR ||
                 decltype(kind)::value == ESQ_EPI_ERRNORM) {
                 if ((int)g.grid > chain->partials_cap) { rc_launch = ESQ_ENOTSUP; return; }
