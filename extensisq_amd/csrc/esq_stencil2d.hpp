@@ -230,11 +230,12 @@ inline int chain_waves_per_cu(Kernel kern, unsigned block) {
 // four-row tiles the chains win down to N = 96 -- Pr8 on the Brusselator 0.066 -> 0.050
 // ms/step there, 0.095 -> 0.056 at N = 448; Ts5 on the heat plugin 0.033 -> 0.023 at
 // N = 128 (tools/r06_small_grids.sh): round 2's "65 us launch floor" of small device-RHS
-// states was a floor of thirteen launches.  Below N = 64 the single sweeps stay
-// (ESQ_CHAIN_ROWS / the chain_rows option lifts the rule: tests).
+// states was a floor of thirteen launches.  With two-row tiles (where the grid leaves wave
+// slots free) the chains win from the smallest grid the kernels take, N = 16: Pr8 0.069 ->
+// 0.040 ms/step, Ts5 0.035 -> 0.020.
 inline bool chain_fits_grid(int N, int depth, const ChainTuning &tune) {
-    (void)depth;
-    return tune.rows_set || N >= 64;
+    (void)depth; (void)tune;
+    return N >= 16;
 }
 // tiles_per_block: wave tiles a workgroup works on; waves_per_tile: waves that
 // share one tile (the split sweeps: one per field)
@@ -287,9 +288,9 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
         // the heat sweeps fill the wave slots down to `depth` rows -- Ts5 at N = 1000:
         // chain5<1> 31 us on 7-row tiles, 27 on 5-row tiles, 36 on 4-row tiles)
         // (independent tiles with run-in rows -- the Chebyshev chains: depth + 2 unless
-        // the caller says otherwise; the diverging pairs of the explicit chains: four-row
-        // tiles where the grid does not fill the wave slots -- Pr8 at N = 448,
-        // tools/r06_small_grids.sh: R = 4 0.056 ms/step, 5 0.060, 6 0.069, 8 0.075)
+        // the caller says otherwise; the diverging pairs of the explicit chains: down to
+        // two-row tiles where the grid does not fill the wave slots -- Pr8 at N = 128,
+        // tools/r06_small_grids.sh: R = 2 0.041 ms/step, 3 0.047, 4 0.052, 6 0.064)
         if (min_rows <= 0) min_rows = depth + 2;
         if (R < min_rows) R = min_rows;
     }
@@ -521,7 +522,7 @@ struct Stencil2D {
             static const int wpc = chain_waves_per_cu(kern, block);   // per instantiation
             const GeoPairs g = geo_chain_pairs(N, CA::kD, wpc, kSplit ? 2 : kBlock / 64,
                                                kSplit ? NF : 1, tune, tall_tiles,
-                                               /*min_rows=*/4);
+                                               /*min_rows=*/2);
             (void)min_rows;
             if (decltype(kind)::value == ESQ_EPI_SOLERR ||
                 decltype(kind)::value == ESQ_EPI_ERRNORM) {
