@@ -213,6 +213,7 @@ inline Geo2d geo2d(int N) {
 struct GeoChain {
     int R;
     unsigned tpr, ntiles, nblocks, grid;
+    bool clamped = false;     // R is the minimum height: the grid leaves wave slots free
 };
 template <class Kernel>
 inline int chain_waves_per_cu(Kernel kern, unsigned block) {
@@ -292,7 +293,7 @@ inline GeoChain geo_chain(int N, int depth, int waves_per_cu, int tiles_per_bloc
         // two-row tiles where the grid does not fill the wave slots -- Pr8 at N = 128,
         // tools/r06_small_grids.sh: R = 2 0.041 ms/step, 3 0.047, 4 0.052, 6 0.064)
         if (min_rows <= 0) min_rows = depth + 2;
-        if (R < min_rows) R = min_rows;
+        if (R < min_rows) { R = min_rows; g.clamped = true; }
     }
     if (R > N) R = N;
     g.R = R;
@@ -327,9 +328,12 @@ inline GeoPairs geo_chain_pairs(int N, int depth, int waves_per_cu, int tiles_pe
         // ... unless there is room: then pairs of at most 2R rows, so that no tile is
         // taller than R (N = 500, R = 4: 63 pairs of 7.9 rows instead of 62 of 8.1, whose
         // five-row tiles set the pace of every workgroup)
+        // (only where R is the minimum height: a height chosen to fill exactly one round
+        // -- Pr9 on the heat plugin at N = 2236: 107 tile rows of 21 on 2048 slots -- must
+        // not get a 108th)
         const int up = (N + 2 * g.R - 1) / (2 * g.R);
         const size_t slots = (size_t)device_cus() * (size_t)waves_per_cu;
-        if ((size_t)2 * up * g.tpr * (size_t)waves_per_tile <= slots) p.npr = up;
+        if (g.clamped && (size_t)2 * up * g.tpr * (size_t)waves_per_tile <= slots) p.npr = up;
     }
     if (p.npr > N / 2) p.npr = N / 2;
     if (p.npr < 1) p.npr = 1;

@@ -245,3 +245,11 @@ def test_option_keys_are_known_to_the_library_by_level():
     assert lib.esq_rhs_set_options(user, b"no_such=1") == -1
     assert lib.esq_rhs_set_options(user, None) == 0
     assert lib.esq_rhs_free(user) == 0
+    # ... and so does a context: refused before anything touches a device (no GPU here),
+    # the offending key in the message
+    ctx = ctypes.c_void_p()
+    for bad in (b"chain_rows=12", b"no_such=1", b"chain_depth=1;d2h_mode=auto"):
+        assert lib.esq_create2(ctypes.byref(ctx), 0, 100, 3, 0, 0, bad) == -1
+        msg = lib.esq_last_error(ctx).decode()
+        assert "not a context option" in msg and bad.split(b"=")[-2].split(b";")[-1].decode().upper() in msg, msg
+        lib.esq_destroy(ctx)
