@@ -784,6 +784,9 @@ int esq_create2(esq_ctx **out, int device, size_t n, int n_rows, int is_complex,
     c->ahead_on = false;           // esq_rk_set_launch_ahead: callers that take whole steps
     c->chain_from_rows = o.uint_or("CHAIN_FROM_ROWS", 1) != 0;
     c->plan_debug = o.has("PLAN_DEBUG");
+    if (c->plan_debug)
+        fprintf(stderr, "esq: slab at %p (%zu doubles, row stride %zu)\n", (void *)c->slab,
+                c->slab_doubles, c->stride);
     c->block_acc = o.uint_or("BLOCK_ACC", 1) != 0;
     if (const char *e = o.get("CHAIN_LDNT")) {          // "first,middle,last" bit masks
         unsigned a = 4, b = 4, d = 4;

@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 out=gpurun_out/r06_variance.log
 : > $out
 for rep in 1 2 3 4 5 6; do
-  python tools/variance_probe.py 1 30 >> $out 2>&1
+  ESQ_PLAN_DEBUG=1 python tools/variance_probe.py 1 30 2>&1 | grep "slab at\|instance" >> $out
 done
-python tools/variance_probe.py 6 30 >> $out 2>&1
+ESQ_PLAN_DEBUG=1 python tools/variance_probe.py 10 30 2>&1 | grep "slab at\|instance" >> $out
 cat $out

@@ -51,7 +51,7 @@ for k in range(inst):
         assert s.step() is None
     rows = s._dev.profile_kernels()
     print("pid %d instance %d: %.4f ms/step  " % (os.getpid(), k, 1e3 * wall)
-          + "  ".join("%s=%.1f" % (r[0], 1e3 * r[3] / r[2]) for r in rows) + "  " + clocks(), flush=True)
+          + "  ".join("%s=%.1f" % (r[0], 1e3 * r[3] / r[2]) for r in rows), flush=True)
     dev = s._dev
     del s
     dev.close()
