@@ -194,15 +194,26 @@ void prof_drain(esq_ctx *c) {
 // Wait until the reduction numbered `seq` has landed in the pinned host slot.
 // The GPU writes the slot itself (no copy engine, no stream-sync wake-up: the
 // 8-byte D2H copy + hipStreamSynchronize pair cost ~15 us of every step), the
-// host spins on it.  The stream is queried now and then so that a faulted
-// kernel surfaces as an error instead of a hang; `timeout_s` > 0 bounds the
-// wait (lock-step: a peer that died never arrives at the all-reduce).
+// host spins on it.  The stream is queried so that a faulted kernel surfaces as an
+// error instead of a hang -- but only once the wait has lasted 2 ms, then every
+// millisecond: a hipStreamQuery makes the runtime put a marker behind the last
+// command of the stream (here: the next step's first sweep, launched ahead), and that
+// marker's system-scope release holds the following sweep back by 5.5-6 us while the
+// XCDs' L2s write back (seen in the kernel trace of every step while the query came
+// every 4096 spins, i.e. 20-40 us: profiles/r06_experiments.md section 16).
+// `timeout_s` > 0 bounds the wait (lock-step: a peer that died never arrives at the
+// all-reduce).
 int wait_slot(esq_ctx *c, unsigned long long seq, double timeout_s) {
     volatile unsigned long long *flag = &c->h_slot->seq;
     const auto t0 = std::chrono::steady_clock::now();
+    double next_query_s = 2e-3;
     for (unsigned long spins = 1;; ++spins) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
-        if ((spins & 0xfff) == 0) {
+        if ((spins & 0x3ff) == 0) {
+            const double el = std::chrono::duration<double>(
+                std::chrono::steady_clock::now() - t0).count();
+            if (el < next_query_s) continue;
+            next_query_s = el + 1e-3;
             const hipError_t q = hipStreamQuery(c->stream);
             if (q == hipSuccess) {
                 // everything on the stream has finished: the slot is written
@@ -212,11 +223,7 @@ int wait_slot(esq_ctx *c, unsigned long long seq, double timeout_s) {
             if (q != hipErrorNotReady)
                 return fail(c, (int)q, "stream failed while waiting for a reduction: %s",
                             hipGetErrorString(q));
-            if (timeout_s > 0.0) {
-                const double el = std::chrono::duration<double>(
-                    std::chrono::steady_clock::now() - t0).count();
-                if (el > timeout_s) return ESQ_ETIMEOUT;
-            }
+            if (timeout_s > 0.0 && el > timeout_s) return ESQ_ETIMEOUT;
         }
     }
 }
