@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # `make VARIANT=...` in csrc/); must sit next to the package like the default one
 LIB_PATH = os.environ.get("ESQ_LIB") or os.path.join(_HERE, "libextensisq_amd.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2
 EPI_STAGE, EPI_BLOCK, EPI_SOLERR, EPI_ERRNORM = 1, 2, 3, 4
 EPI_RKCERR = 6
@@ -110,6 +110,7 @@ SIGNATURES = {
     "esq_rkc_error_norm": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, _dp]),
     "esq_rkc_stages_end": (C.c_int, [_vp] + [C.c_int] * 6 + [C.c_double, C.c_int, _vp,
                                     C.c_double, C.c_double, _vp, _vp, _vp]),
+    "esq_rkc_guess_next": (C.c_int, [_vp, C.c_double, C.c_int, _vp]),
     "esq_rkc_plan_describe": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]),
     "esq_rkc_end_error": (C.c_int, [_vp] + [C.c_int] * 4 + [C.c_double, C.c_double,
                                                             _dp]),

@@ -227,6 +227,71 @@ struct RkcTail {
 int rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3, double hmus1,
                int m, const double *scalars, int *y_row_out, RkcTail *tail);
 }  // namespace
+// The next step's opening chain sweep (FIRST form: y_1 formed on the fly from y_{n+1} and
+// its derivative), into the two free work rows -- behind the final sum of the step being
+// finished, before the host waits for it.  Exactly the launch the next esq_rkc_stages_end
+// would make first (rkc_stages below), only earlier.
+extern "C++" bool esqi::rkc_launch_ahead_if_asked(esq_ctx *c) {
+    esq_ctx::RkcAhead &ah = c->rkc_ahead;
+    if (!ah.ask || !ah.armed) return false;
+    ah.ask = ah.armed = false;
+    ah.valid = false;
+    const int m = ah.ask_m;
+    if (!c->rhs_rkc_chain || !c->rkc_first || c->rkc_first_refused || c->rkc_depth < 2 ||
+        m < 3 || c->comm || c->cplx)
+        return false;
+    const int d = rkc_chain_len(m - 1, c->rkc_depth, c->rkc_refused);
+    if (d < 2 || 2 + d > m) return false;              // (not the chain that ends the step)
+    if (ah.free_a == ESQ_VEC_NONE || ah.free_b == ESQ_VEC_NONE) return false;
+    esq_rkc_chain ch;
+    memset(&ch, 0, sizeof(ch));
+    ch.depth = d;
+    ch.yjm1 = nullptr;
+    ch.hmus_first = ah.ask_hmus1;
+    ch.yjm2 = ROW(c, ah.at_y);
+    ch.yn = ROW(c, ah.at_y);
+    ch.fn = ROW(c, ah.at_f);
+    for (int k = 0; k < d; ++k) {
+        const double *s5 = ah.ask_sc + 5 * (size_t)k;
+        ch.mu[k] = s5[0]; ch.nu[k] = s5[1];
+        ch.omn[k] = (1.0 - s5[0]) - s5[1];
+        ch.hmus[k] = s5[2]; ch.ajm1[k] = s5[3]; ch.t[k] = s5[4];
+    }
+    ch.out = ROW(c, ah.free_a);
+    ch.out_prev = ROW(c, ah.free_b);
+    if (!ch.yn || !ch.fn || !ch.out || !ch.out_prev) return false;
+    double amp = 1.0;
+    ch.read_amplification = &amp;
+    char label[24];
+    snprintf(label, sizeof(label), "rkc_chain%d-first", d);
+    Prof p(c, ESQ_PROF_RKC, label, -1, 64.0 * d * (double)c->len, false, 0.0);
+    const int r = c->rhs_rkc_chain(c->rhs_user, &ch, c->len, (void *)c->stream,
+                                   (void *)p.start(), (void *)p.stop());
+    if (r != 0) {                          // declined: the next call finds it out again
+        p.cancel();
+        return false;
+    }
+    p.ev.moved = (2.0 * amp + 2.0) * 8.0 * (double)c->len;
+    p.ev.floor = 4.0 * 8.0 * (double)c->len;
+    ah.valid = true;
+    ah.yn = ah.at_y; ah.fn = ah.at_f;
+    ah.out = ah.free_a; ah.outp = ah.free_b;
+    ah.d = d; ah.m = m; ah.hmus1 = ah.ask_hmus1;
+    memcpy(ah.sc, ah.ask_sc, sizeof(double) * 5 * (size_t)d);
+    return true;
+}
+int esq_rkc_guess_next(esq_ctx *c, double hmus1_next, int m_next, const double *scalars_next) {
+    if (!c || m_next < 1 || (m_next > 1 && !scalars_next)) return ESQ_EINVAL;
+    ENTER_KEEP(c);
+    esq_ctx::RkcAhead &ah = c->rkc_ahead;
+    ah.ask = true;
+    ah.armed = false;
+    ah.ask_m = m_next;
+    ah.ask_hmus1 = hmus1_next;
+    const int rows = m_next - 1 < ESQ_RKC_CHAIN_MAX_DEPTH ? m_next - 1 : ESQ_RKC_CHAIN_MAX_DEPTH;
+    if (rows > 0) memcpy(ah.ask_sc, scalars_next, sizeof(double) * 5 * (size_t)rows);
+    return 0;
+}
 int esq_rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3,
                    double hmus1, int m, const double *scalars, int *y_row_out) {
     if (!c || !y_row_out || m < 1 || (m > 1 && !scalars)) return ESQ_EINVAL;
@@ -238,11 +303,15 @@ int esq_rkc_stages_end(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w
                        int *y_row_out, int *fy_row_out, double *sumsq_out) {
     if (!c || !y_row_out || !fy_row_out || !sumsq_out || m < 1 || (m > 1 && !scalars))
         return ESQ_EINVAL;
+    // (the opening sweep of this step may be in the queue already: esq_rkc_guess_next)
+    const bool ahead_valid = c->rkc_ahead.valid;
     ENTER(c);
+    c->rkc_ahead.valid = ahead_valid;
     RkcTail tail;
     tail.t_end = t_end;
     tail.h = h;
     int r = rkc_stages(c, yn, fn, w0, w1, w2, w3, hmus1, m, scalars, y_row_out, &tail);
+    c->rkc_ahead.ask = c->rkc_ahead.armed = false;
     if (r) return r;
     if (!tail.done) {
         // f(t_end, y) into a work row that does not hold y, and the estimate
@@ -287,6 +356,31 @@ int rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3, doubl
     };
     int jm1 = w0, jm2 = yn;
     int j = 2;
+    // the step's opening chain sweep was launched behind the previous step's final sum
+    // (esq_rkc_guess_next): taken up if this call asks for exactly that recursion on
+    // exactly those rows, dropped otherwise (it wrote two work rows)
+    if (c->rkc_ahead.valid) {
+        esq_ctx::RkcAhead &ah = c->rkc_ahead;
+        bool in_work_a = false, in_work_b = false;
+        for (int a = 0; a < nwork; ++a) {
+            in_work_a |= work[a] == ah.out;
+            in_work_b |= work[a] == ah.outp;
+        }
+        const bool take = tail && first_pending && yn == ah.yn && fn == ah.fn && m == ah.m &&
+                          hmus1 == ah.hmus1 && in_work_a && in_work_b && ah.d >= 2 &&
+                          2 + ah.d <= m &&
+                          memcmp(scalars, ah.sc, sizeof(double) * 5 * (size_t)ah.d) == 0;
+        ah.valid = false;
+        if (take) {
+            ++c->ahead_used;
+            first_pending = false;
+            jm1 = ah.out;
+            jm2 = ah.outp;
+            j = 2 + ah.d;
+        } else {
+            ++c->ahead_dropped;
+        }
+    }
     while (j <= m) {
         const double *sc = scalars + 5 * (size_t)(j - 2);
         // ---- a chain of d stages: y_{j-1}, y_{j-2} in, y_{j+d-1}, y_{j+d-2} out
@@ -352,6 +446,15 @@ int rkc_stages(esq_ctx *c, int yn, int fn, int w0, int w1, int w2, int w3, doubl
                         tail->done = true;
                         tail->fy_row = o2;
                         *y_row_out = o1;
+                        if (c->rkc_ahead.ask) {
+                            // (two work rows that hold neither y_{n+1} nor its derivative)
+                            esq_ctx::RkcAhead &ah = c->rkc_ahead;
+                            ah.at_y = o1;
+                            ah.at_f = o2;
+                            ah.free_a = free_row(o1, o2, ESQ_VEC_NONE);
+                            ah.free_b = free_row(o1, o2, ah.free_a);
+                            ah.armed = true;
+                        }
                         return finish_reduction(c, &tail->sumsq, false, c->partials,
                                                 c->red_count);
                     }

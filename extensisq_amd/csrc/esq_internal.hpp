@@ -245,6 +245,22 @@ struct esq_ctx : esqi::StepState {
         unsigned long long pre_seq = 0;   // its early estimate (0: none)
     } ahead;
     long ahead_used = 0, ahead_dropped = 0;
+    // the opening chain sweep of the next Chebyshev step, launched behind this step's final
+    // sum (esq_rkc_guess_next)
+    struct RkcAhead {
+        bool valid = false;               // launched, not yet taken up
+        int yn = 0, fn = 0, out = 0, outp = 0, d = 0, m = 0;
+        double hmus1 = 0.0;
+        double sc[5 * ESQ_RKC_CHAIN_MAX_DEPTH];
+        // the request (cleared by the esq_rkc_stages_end that follows it)
+        bool ask = false;
+        bool armed = false;               // ... and the step's end chain has named the rows
+        int ask_m = 0;
+        double ask_hmus1 = 0.0;
+        double ask_sc[5 * ESQ_RKC_CHAIN_MAX_DEPTH];
+        // where the step being enqueued leaves y_{n+1}, f(y_{n+1}) and two free work rows
+        int at_y = 0, at_f = 0, free_a = 0, free_b = 0;
+    } rkc_ahead;
     // which sweeps stream the fresh derivative out with non-temporal stores
     // (ESQ_EPI_NT bits: 0 stage, 1 block, 2 solerr, 3 end-point, 4 FSAL errnorm)
     unsigned epi_nt = 0x3;
@@ -336,6 +352,7 @@ double *slot_ptr(esq_ctx *c, int slot, int row, bool logical = true);
         (c)->self_valid = false;             \
         (c)->ahead.valid = false;            \
         (c)->ahead.committed = false;        \
+        (c)->rkc_ahead.valid = false;        \
     } while (0)
 
 // ---- profiling -------------------------------------------------------------
@@ -384,6 +401,9 @@ void drop_plans(esq_ctx *c);
 // calls it before it waits, if esq_rk_solution_error_ahead asked for it)
 // -> whether a launch went into the queue
 bool launch_ahead_if_asked(esq_ctx *c);
+// ---- esq_aux.hip: the opening chain sweep of the next Chebyshev step (esq_rkc_guess_next),
+// called by launch_ahead_if_asked -> whether a launch went into the queue
+bool rkc_launch_ahead_if_asked(esq_ctx *c);
 // ---- esq_core.hip ------------------------------------------------------------
 // sink of the next reduction / completion signal (bumps red_seq)
 ResultSink next_sink(esq_ctx *c, bool to_host_value);

@@ -1258,7 +1258,8 @@ bool esqi::launch_ahead_if_asked(esq_ctx *c) {
     const double h = c->ahead_ask_h, t = c->ahead_ask_t;
     c->ahead_ask_h = 0.0;
     if (h != 0.0) launch_ahead(c, t, h);
-    return h != 0.0 && c->ahead.valid;
+    const bool rkc = rkc_launch_ahead_if_asked(c);
+    return (h != 0.0 && c->ahead.valid) || rkc;
 }
 
 // The rows `missing_rows` of the step in flight (or of the step just accepted) exist

@@ -11,6 +11,7 @@ the H211-type controller and the power-iteration control flow are host scalar
 code below; norms come back as one double per call.
 """
 import ctypes as C
+from collections import OrderedDict
 from math import cosh, log, sinh, sqrt
 from warnings import warn
 
@@ -30,10 +31,11 @@ nfesig = np.array(0)          # RHS evaluations spent on spectral-radius estimat
 maxm = np.array(0)            # largest stage count used
 
 
-def chebyshev_scalars(m, t, h):
-    """Coefficients of the m-stage second-order Chebyshev recursion
-    (ref sommeijer.py:278-314).  Returns (h*mus_1, table) where table is an
-    (m-1, 5) array of (mu, nu, h*mus, ajm1, t + h*theta_{j-1}) for j = 2..m."""
+def _chebyshev_base(m):
+    """The part of the m-stage recursion's coefficients that depends on m alone
+    (ref sommeijer.py:278-314): (mus_1, base) with base an (m-1, 5) array of
+    (mu, nu, mus, ajm1, theta_{j-1}) for j = 2..m.  A Python loop of m - 1 rounds
+    (~1 us each: 0.1 ms at the hundred stages of BASELINE config 4)."""
     w0 = 1.0 + 2.0 / (13.0 * m ** 2)
     sq = w0 ** 2 - 1.0
     rt = sqrt(sq)
@@ -45,7 +47,7 @@ def chebyshev_scalars(m, t, h):
     z_prev, z_prev2 = w0, 1.0
     dz_prev, dz_prev2 = 1.0, 0.0
     d2z_prev, d2z_prev2 = 0.0, 0.0
-    table = np.empty((max(m - 1, 0), 5))
+    base = np.empty((max(m - 1, 0), 5))
     for j in range(2, m + 1):
         z = 2.0 * w0 * z_prev - z_prev2
         dz = 2.0 * w0 * dz_prev - dz_prev2 + 2.0 * z_prev
@@ -55,13 +57,43 @@ def chebyshev_scalars(m, t, h):
         mu = 2.0 * w0 * b / b_prev
         nu = -b / b_prev2
         mus = mu * w1 / w0
-        table[j - 2] = (mu, nu, h * mus, a_prev, t + h * th_prev)
+        base[j - 2] = (mu, nu, mus, a_prev, th_prev)
         th = mu * th_prev + nu * th_prev2 + mus * (1.0 - a_prev)
         th_prev2, th_prev = th_prev, th
         b_prev2, b_prev = b_prev, b
         z_prev2, z_prev = z_prev, z
         dz_prev2, dz_prev = dz_prev, dz
         d2z_prev2, d2z_prev = d2z_prev, d2z
+    base.setflags(write=False)
+    return mus1, base
+
+
+# the last stage counts used (an adaptive run moves through a handful of them; a run
+# at a fixed step -- every step of the benchmark -- uses one).  Without it the GPU waited
+# 0.12 ms of every 1.22 ms step at N = 159 for this loop (profiles/r06_experiments.md
+# section 17).
+_CHEB_CACHE = OrderedDict()
+_CHEB_CACHE_MAX = 32
+
+
+def chebyshev_scalars(m, t, h):
+    """Coefficients of the m-stage second-order Chebyshev recursion
+    (ref sommeijer.py:278-314).  Returns (h*mus_1, table) where table is an
+    (m-1, 5) array of (mu, nu, h*mus, ajm1, t + h*theta_{j-1}) for j = 2..m
+    (the same products and sums, element by element, as the scalar loop's)."""
+    hit = _CHEB_CACHE.get(m)
+    if hit is None:
+        hit = _chebyshev_base(m)
+        _CHEB_CACHE[m] = hit
+        while len(_CHEB_CACHE) > _CHEB_CACHE_MAX:
+            _CHEB_CACHE.popitem(last=False)
+    else:
+        _CHEB_CACHE.move_to_end(m)
+    mus1, base = hit
+    table = base.copy()
+    table[:, 2] *= h                    # h * mus
+    table[:, 4] *= h                    # t + h * theta_{j-1}
+    table[:, 4] += t
     return h * mus1, table
 
 
@@ -128,6 +160,10 @@ class SSV2stab(_LazyStateMixin, OdeSolver):
         self._have_V = False
         self._n_norm = self.n
         self._lockstep = lockstep
+        # the next step's opening sweep ahead of time (esq_rkc_guess_next; the package
+        # switch launch_ahead=0 turns it off, as for the explicit pairs)
+        self._launch_ahead = (self._device_rhs is not None
+                              and self._esq_options.get("launch_ahead", "1") != "0")
         if lockstep is not None:
             self._dev._chk(self._lib.esq_set_comm(self._ctx, lockstep.comm),
                            "esq_set_comm")
@@ -270,7 +306,7 @@ class SSV2stab(_LazyStateMixin, OdeSolver):
             jm2, jm1 = jm1, free
         return jm1
 
-    def _stages_end(self, t, h, m, out):
+    def _stages_end(self, t, h, m, out, guess_next=False):
         """device RHS: all m stages, f(t + h, y_{n+1}) and the sum of squares of the
         weighted error estimate (into `out`); returns the rows of y_{n+1} and of
         its derivative"""
@@ -279,6 +315,13 @@ class SSV2stab(_LazyStateMixin, OdeSolver):
         w = r["w"]
         yrow, fyrow = C.c_int(), C.c_int()
         tab = np.ascontiguousarray(table)
+        if guess_next:
+            # a run that sits at max_step with a constant spectral radius takes the same
+            # step again if this one is accepted: its opening chain sweep goes into the
+            # queue behind this step's final sum, before the host waits for the norm
+            hmus1_n, table_n = chebyshev_scalars(m, t + h, h)
+            self._chk(self._lib.esq_rkc_guess_next(self._ctx, hmus1_n, m, as_ptr(table_n)),
+                      "esq_rkc_guess_next")
         self._chk(self._lib.esq_rkc_stages_end(
             self._ctx, r["yn"], r["fn"], w[0], w[1], w[2], w[3], hmus1, m, as_ptr(tab),
             float(t + h), h, C.byref(yrow), C.byref(fyrow), C.byref(out)),
@@ -404,7 +447,7 @@ class SSV2stab(_LazyStateMixin, OdeSolver):
                 # the stages, f(t + h, y) and the error estimate (ref
                 # sommeijer.py:273-329, 214-220) in one call: with a chain entry the
                 # end of the step rides in the last chain sweep
-                yrow, fyrow = self._stages_end(t, h, m, out)
+                yrow, fyrow = self._stages_end(t, h, m, out, self._guess_next(t, h, absh))
             else:
                 yrow = self._stages(t, h, m)
                 fyrow = next(w for w in r["w"] if w != yrow)
@@ -426,6 +469,19 @@ class SSV2stab(_LazyStateMixin, OdeSolver):
 
         self._advance(t + h, h, absh, hmin, err, yrow, fyrow)
         return True, None
+
+    def _guess_next(self, t, h, absh):
+        """whether the step AFTER the attempt (t, h) is known before its error norm: the
+        run sits at max_step (an accepted step then keeps it: the controller's answer is
+        clipped to max_step and only err >= 1 shrinks it), the spectral radius is not
+        looked at again (const_jac) and the end of the interval is not near.  Then the
+        library launches the next step's opening sweep ahead (esq_rkc_guess_next); a
+        wrong guess costs one discarded sweep."""
+        if (not self._launch_ahead or self._lockstep is not None or not self.const_jac
+                or absh != self.max_step or self.newspc):
+            return False
+        t_next = t + h
+        return 1.1 * absh < abs(self.t_bound - t_next)
 
     def _advance(self, t_new, h, absh, hmin, err, yrow, fyrow):
         """book-keeping of an accepted step (ref sommeijer.py:245-270)"""

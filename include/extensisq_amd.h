@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ESQ_ABI_VERSION 8
+#define ESQ_ABI_VERSION 9
 
 /* error codes (negative = misuse) */
 #define ESQ_EINVAL   (-1)   /* bad argument (row/slot out of range, NULL, ...) */
@@ -716,6 +716,19 @@ int  esq_rkc_error_norm(esq_ctx *ctx, int y, int yn, int fn, int fy, double h,
 int  esq_rkc_stages_end(esq_ctx *ctx, int yn, int fn, int w0, int w1, int w2, int w3,
                         double hmus1, int m, const double *scalars, double t_end,
                         double h, int *y_row_out, int *fy_row_out, double *sumsq_out);
+/* The recursion of the NEXT step if this attempt is accepted and the controller keeps the
+ * step (a run that sits at max_step): called right before esq_rkc_stages_end, which then
+ * enqueues that step's opening chain sweep (FIRST form; y_{n+1} and its derivative are the
+ * rows it has just produced) behind its own final sum, BEFORE the host waits for the error
+ * norm -- the device does not idle while the host digests the step (35 us of a 1.17 ms
+ * step at N = 159).  The next esq_rkc_stages_end skips that sweep if it is asked for
+ * exactly this recursion on exactly those rows; anything else (a rejection, another step
+ * size, any other call on the context) discards it: the sweep only wrote work rows
+ * (counted by esq_rk_launch_ahead_stats).  scalars: the first 5 * min(m_next - 1,
+ * ESQ_RKC_CHAIN_MAX_DEPTH) doubles of the table are read.  Plugins without an RKC chain
+ * entry that opens a step: nothing is launched.                  (as esq_rk_set_launch_ahead:
+ * common.py:222-308 has no counterpart, the results are those of the plain sequence) */
+int  esq_rkc_guess_next(esq_ctx *ctx, double hmus1_next, int m_next, const double *scalars_next);
 /* The launch sequence esq_rkc_stages_end runs for m stages with a chain entry of the
  * given depth and forms (ESQ_RKC_CHAIN_FIRST / _LAST or-ed into max_depth, as for
  * esq_set_rhs_rkc_chain) that takes the LAST form with up to end_slots_max stage

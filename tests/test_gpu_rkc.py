@@ -760,3 +760,92 @@ def test_solve_ivp_with_deferred_states_rkc(monkeypatch, mode):
     s = esq.SSV2stab(esq.Diffusion3D(N), 0.0, y0, tf, **{k: v for k, v in kw.items()
                                                         if k not in ("t_eval", "dense_output")})
     assert s.step() is None and isinstance(s.y, np.ndarray) and not isinstance(s.y, LazyState)
+
+
+def _ahead_stats(solver):
+    used, dropped = C.c_long(), C.c_long()
+    solver._chk(solver._lib.esq_rk_launch_ahead_stats(solver._ctx, C.byref(used),
+                                                      C.byref(dropped)),
+                "esq_rk_launch_ahead_stats")
+    return used.value, dropped.value
+
+
+@pytest.mark.parametrize("plugin,N", [("diff3d", 57), ("heat", 130)])
+def test_rkc_opening_sweep_launched_ahead_is_bit_identical(plugin, N):
+    """A run at max_step with a constant spectral radius: the next step's opening chain
+    sweep goes into the queue behind the step's final sum (esq_rkc_guess_next) and the
+    next esq_rkc_stages_end takes it up -- same states, same counters as with
+    launch_ahead=0 (ref sommeijer.py:162-271: the reference has no such thing, the
+    results are the plain sequence's).  Then a step that does NOT follow the guess (the
+    state replaced, a smaller step): the sweep is dropped, the result is the plain one."""
+    from extensisq_amd import workloads as wl
+    rhs = esq.Diffusion3D(N) if plugin == "diff3d" else esq.Heat2D(N)
+    if plugin == "diff3d":                            # smooth data: no rejections
+        y0 = wl.diff3d_y0(N)
+    else:
+        x = (np.arange(N) + 1.0) / (N + 1.0)
+        y0 = np.outer(np.sin(np.pi * x), np.sin(np.pi * x)).ravel()
+    rho = rhs.spectral_radius()
+    h = 400.0 / rho                                   # about 25 stages
+
+    def make(**kw):
+        return esq.SSV2stab(rhs, 0.0, y0, 1.0, first_step=h, max_step=h, rtol=1e-2, atol=1e-2,
+                            rho_jac=lambda t, y: rho, const_jac=True, **kw)
+
+    a, b = make(), make(esq_options={"launch_ahead": 0})
+    for _ in range(6):
+        assert a.step() is None and b.step() is None
+        assert a.t == b.t
+        assert np.array_equal(np.asarray(a.y), np.asarray(b.y))
+    used, dropped = _ahead_stats(a)
+    assert used >= 4 and dropped == 0, (used, dropped)
+    assert _ahead_stats(b) == (0, 0)
+    assert a.nfev == b.nfev
+    # the guess fails: another state arrives between the steps
+    y1 = np.asarray(a.y) * 0.5
+    a.y = y1
+    b.y = y1
+    assert a.step() is None and b.step() is None
+    assert np.array_equal(np.asarray(a.y), np.asarray(b.y))
+    # ... and a step size below max_step (no guess is made, none is taken)
+    c = esq.SSV2stab(rhs, 0.0, y0, 1.0, first_step=0.5 * h, max_step=h, rtol=1e-2, atol=1e-2,
+                     rho_jac=lambda t, y: rho, const_jac=True)
+    d = esq.SSV2stab(rhs, 0.0, y0, 1.0, first_step=0.5 * h, max_step=h, rtol=1e-2, atol=1e-2,
+                     rho_jac=lambda t, y: rho, const_jac=True, esq_options={"launch_ahead": 0})
+    for _ in range(5):
+        assert c.step() is None and d.step() is None
+        assert c.t == d.t and np.array_equal(np.asarray(c.y), np.asarray(d.y))
+
+
+def test_rkc_opening_sweep_ahead_survives_a_rejection():
+    """an attempt at max_step that is REJECTED after its successor's opening sweep went
+    into the queue: the retry runs from (y_n, f_n) as if nothing had been launched"""
+    from extensisq_amd import workloads as wl
+    N = 57
+    rhs = esq.Diffusion3D(N)
+    y0 = wl.diff3d_y0(N)
+    rho = rhs.spectral_radius()
+    h = 400.0 / rho
+    rough = np.random.default_rng(4).standard_normal(rhs.n) * 50.0
+
+    def run(**kw):
+        s = esq.SSV2stab(rhs, 0.0, y0, 1.0, first_step=h, max_step=h, rtol=1e-2, atol=1e-2,
+                         rho_jac=lambda t, y: rho, const_jac=True, **kw)
+        for _ in range(3):                            # smooth data: the run sits at max_step
+            assert s.step() is None
+        assert s.absh == s.max_step
+        s.y = rough                                   # ... and now the next attempt fails
+        before = int(dev_rkc.nrejct)
+        for _ in range(3):
+            assert s.step() is None
+        return s, int(dev_rkc.nrejct) - before
+
+    a, rej_a = run()
+    ta, ya = a.t, np.asarray(a.y).copy()
+    b, rej_b = run(esq_options={"launch_ahead": 0})
+    assert rej_a == rej_b and rej_a >= 1
+    assert ta == b.t and np.array_equal(ya, np.asarray(b.y))
+    assert a.nfev == b.nfev
+    used, dropped = _ahead_stats(a)
+    assert used >= 1 and dropped >= 1, (used, dropped)    # the rejected attempt's successor
+    assert _ahead_stats(b) == (0, 0)

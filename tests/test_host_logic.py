@@ -253,3 +253,47 @@ def test_option_keys_are_known_to_the_library_by_level():
         msg = lib.esq_last_error(ctx).decode()
         assert "not a context option" in msg and bad.split(b"=")[-2].split(b";")[-1].decode().upper() in msg, msg
         lib.esq_destroy(ctx)
+
+
+def test_chebyshev_scalars_cached_base_is_bit_identical():
+    """sommeijer.chebyshev_scalars keeps the m-dependent part of the coefficients of the
+    last stage counts; the table of a step must equal the scalar loop's (ref
+    sommeijer.py:278-314: h*mus and t + h*theta formed per stage) bit for bit"""
+    from math import cosh, log, sinh, sqrt
+
+    from extensisq_amd.sommeijer import chebyshev_scalars
+
+    def scalar_loop(m, t, h):
+        w0 = 1.0 + 2.0 / (13.0 * m ** 2)
+        sq = w0 ** 2 - 1.0
+        rt = sqrt(sq)
+        arg = m * log(w0 + rt)
+        w1 = sinh(arg) * sq / (cosh(arg) * m * rt - w0 * sinh(arg))
+        bj1 = bj2 = 1.0 / (2.0 * w0) ** 2
+        mus1 = w1 * bj1
+        thj2, thj1 = 0.0, mus1
+        zj1, zj2, dzj1, dzj2, d2zj1, d2zj2 = w0, 1.0, 1.0, 0.0, 0.0, 0.0
+        rows = []
+        for _ in range(2, m + 1):
+            zj = 2.0 * w0 * zj1 - zj2
+            dzj = 2.0 * w0 * dzj1 - dzj2 + 2.0 * zj1
+            d2zj = 2.0 * w0 * d2zj1 - d2zj2 + 4.0 * dzj1
+            bj = d2zj / dzj ** 2
+            ajm1 = 1.0 - zj1 * bj1
+            mu = 2.0 * w0 * bj / bj1
+            nu = -bj / bj2
+            mus = mu * w1 / w0
+            rows.append((mu, nu, h * mus, ajm1, t + h * thj1))
+            thj = mu * thj1 + nu * thj2 + mus * (1.0 - ajm1)
+            thj2, thj1, bj2, bj1 = thj1, thj, bj1, bj
+            zj2, zj1, dzj2, dzj1, d2zj2, d2zj1 = zj1, zj, dzj1, dzj, d2zj1, d2zj
+        return h * mus1, np.array(rows).reshape(-1, 5)
+
+    rng = np.random.default_rng(5)
+    for m in (1, 2, 3, 17, 99, 100, 431):
+        for _ in range(3):                       # (second and third call: from the cache)
+            t, h = rng.normal() * 10.0, rng.normal() * 10.0 ** rng.uniform(-6, 1)
+            want, got = scalar_loop(m, t, h), chebyshev_scalars(m, t, h)
+            assert want[0] == got[0]
+            assert want[1].shape == got[1].shape
+            assert np.array_equal(want[1].view(np.uint64), got[1].view(np.uint64)), (m, t, h)
