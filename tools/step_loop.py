@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """plain solver.step() loop of one method on a built-in plugin at fixed steps (for kernel
 traces: `rocprofv3 --kernel-trace -- python3 tools/step_loop.py Pr8 bruss 2236 40`)
-    python tools/step_loop.py [method] [bruss|heat|diff3d] [N] [steps]"""
+    python tools/step_loop.py [method] [bruss|heat|diff3d] [N] [steps] [fixed|adaptive|ivp|ivp_dense]
+adaptive: the controller is free (first_step = h/4, max_step = inf); ivp / ivp_dense:
+scipy's solve_ivp over `steps` stability-limited steps with t_eval=[t_end] / dense_output"""
 import os
 import sys
 import time
@@ -14,6 +16,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "Pr8"
 plug = sys.argv[2] if len(sys.argv) > 2 else "bruss"
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 2236
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 40
+mode = sys.argv[5] if len(sys.argv) > 5 else "fixed"
 if plug == "bruss":
     rhs, y0 = esq.Brusselator2D(N), wl.bruss2d_y0(N)
 elif plug == "heat":
@@ -25,6 +28,20 @@ if name == "SSV2stab":
     h = 6490.0 / rho
     s = esq.SSV2stab(rhs, 0.0, y0, 1e9, first_step=h, max_step=h, rtol=1e-3, atol=1e-3,
                      rho_jac=lambda t, y: rho, const_jac=True)
+elif mode in ("ivp", "ivp_dense"):
+    from scipy.integrate import solve_ivp
+    h = 1.0 / rho
+    kw = dict(t_eval=[steps * h]) if mode == "ivp" else dict(dense_output=True)
+    t0 = time.perf_counter()
+    sol = solve_ivp(rhs, (0.0, steps * h), y0, method=getattr(esq, name), first_step=h, max_step=h,
+                    rtol=0.1, atol=1e3, nfev_stiff_detect=0, **kw)
+    print("%s %s N=%d %s: %.4f ms/step over %d steps" % (
+        name, plug, N, mode, 1e3 * (time.perf_counter() - t0) / max(1, sol.nfev // 13), sol.nfev // 13))
+    sys.exit(0)
+elif mode == "adaptive":
+    h = 1.0 / rho
+    s = getattr(esq, name)(rhs, 0.0, y0, 1e9, first_step=h / 4, rtol=1e-6, atol=1e-9,
+                           nfev_stiff_detect=0)
 else:
     h = 1.0 / rho
     s = getattr(esq, name)(rhs, 0.0, y0, 1e9, first_step=h, max_step=h, rtol=0.1, atol=1e3,
